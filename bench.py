@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- aggregated edges/s of the GCN SpMM hot path (feat = 128) on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (one aggregation Y = A.X) over the whole synthetic input, inputs
+resident in HBM.  N = 1: BASELINE.json configs[1], arxiv-shaped CSR (169 343 x 1 166 243, seed 123),
+GCN sum with explicit unit weights (Figure7/our.py:78), fp32, loaded with the locality reorder
+applied like src/data.cu:96-133 (the un-reordered number is reported beside it).  N > 1: weak
+scaling -- the global graph is N x arxiv-shaped, 1-D row-partitioned; every step pulls the halo
+feature rows with one RCCL all-to-all and then runs the same kernel (gnn_computing_amd/dist.py).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FEAT = 128
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes(V, E, F, explicit_val=True):
+    """SURVEY.md 8d gather model: E*(4F + 4 [idx] + 4 [val]) + V*4F [Y] + (V+1)*4 [ptr]."""
+    return E * (4 * F + 4 + (4 if explicit_val else 0)) + V * 4 * F + (V + 1) * 4
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def time_steps(step_fn, steps, warmup, barrier):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides.
+    Returns (wall seconds for K steps, avg device seconds per step from HIP events on the launch stream)."""
+    for _ in range(warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(steps):
+        step_fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev = evs[0].elapsed_time(evs[steps]) * 1e-3 / steps
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e-3 for i in range(steps))
+    return wall, dev, per[len(per) // 2]
+
+
+def cpu_baseline(ptr, idx, val, x, budget_s=10.0):
+    """The oracle (port of aggr_gcn.h:13-35) timed on the host cores: whole arxiv passes until ~budget_s."""
+    from oracle import oracle as orc
+    orc.gcn_seq(ptr, idx, val, x)  # warm-up (page-in, thread pool)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 200:
+        t0 = time.perf_counter()
+        orc.gcn_seq(ptr, idx, val, x)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": len(idx) / med, "unit": "edges/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "%d full passes of the same arxiv-shaped workload (median %.2f ms), OpenMP over rows"
+                      % (len(times), med * 1e3)}
+
+
+def run_single(args, dev):
+    import gnn_computing_amd as gnc
+    mode = os.environ.get("BENCH_MODE", "balanced")
+    ptr_t, idx_t = gnc.graph.dataset("arxiv")
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    V, E = len(ptr) - 1, len(idx)
+    rng = np.random.default_rng(123)
+    x = rng.standard_normal((V, FEAT), dtype=np.float32)
+    val = np.ones(E, np.float32)
+
+    def build(p, i):
+        dp, di, dv = torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev), torch.from_numpy(val).to(dev)
+        agg = gnc.Aggregator_GCN(dp, di, dv, FEAT, FEAT)
+        if mode == "balanced":
+            agg.schedule_balanced(0)
+        elif mode == "scheduled":
+            agg.schedule(gnc.Schedule.neighbor_grouping, [int(os.environ.get("BENCH_NG", "32"))])
+        return agg
+
+    dx = torch.from_numpy(x).to(dev)
+    y = torch.empty((V, FEAT), dtype=torch.float32, device=dev)
+    results = {}
+    # without reorder
+    agg0 = build(ptr, idx)
+    results["no_reorder"] = time_steps(lambda: agg0.run(dx, y, 512, mode), args.steps, args.warmup, lambda: None)
+    # with the locality reorder applied on load (reference: load_graph(..., "_thres_0.2"), our.py:79)
+    t0 = time.perf_counter()
+    rows = gnc.graph.locality_order(ptr, idx)
+    nptr, nidx, rev = gnc.reorder_csr(ptr, idx, rows)
+    t_reorder = time.perf_counter() - t0
+    agg1 = build(nptr, nidx)
+    dx1 = torch.from_numpy(np.ascontiguousarray(x[rows])).to(dev)
+    results["reorder"] = time_steps(lambda: agg1.run(dx1, y, 512, mode), args.steps, args.warmup, lambda: None)
+    # sanity: the timed kernel's output matches the oracle on this very input (outside the timed region)
+    from oracle import oracle as orc
+    ps, ix, tg = agg1.get_schedule(mode) if mode != "rows" else (None, None, None)
+    ref = orc.gcn_seq(nptr, nidx, val, x[rows]) if mode == "rows" else orc.gcn_grouped(ps, tg, nidx, val, x[rows], V)
+    assert np.array_equal(y.cpu().numpy(), ref), "bench output differs from the oracle"
+
+    which = os.environ.get("BENCH_HEADLINE", "reorder")
+    wall, dev_s, med_s = results[which]
+    ms = wall / args.steps * 1e3
+    B = algorithmic_bytes(V, E, FEAT)
+    achieved = B / dev_s / 1e9
+    pmc = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+    other = "no_reorder" if which == "reorder" else "reorder"
+    out = {
+        "metric": "aggregated edges/sec, GCN SpMM feat=128", "value": E / (wall / args.steps), "unit": "edges/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "arxiv-shaped power-law CSR 169343x1166243 (seed 123), GCN sum, feat=128, "
+                               "explicit unit weights, %s, mode=%s" % (
+                                   "locality reorder applied on load" if which == "reorder" else "no reorder", mode),
+                   "num_v": V, "num_e": E, "feat": FEAT},
+        "achieved_gbps": achieved,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
+                     "kernel": "k_gcn_items (+k_combine)", "algorithmic_bytes": B,
+                     "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6},
+        other: {"value": E / (results[other][0] / args.steps), "avg_launch_us": results[other][1] * 1e6,
+                "achieved_gbps": B / results[other][1] / 1e9},
+        "reorder_prep_s": t_reorder,
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(nptr, nidx, val, x[rows], args.cpu_budget)
+    return out
+
+
+def run_multi(args, dev, rank, world):
+    import torch.distributed as dist
+    import gnn_computing_amd as gnc
+    from gnn_computing_amd.dist import PartitionedGCN
+    V1, E1 = gnc.graph.SHAPES["arxiv"]
+    Vg, Eg = V1 * world, E1 * world
+    # every rank generates the same global graph on its GPU (seeded), in community order: this is the
+    # "locality reorder applied on load" input; rows are then split into nnz-balanced blocks
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(Vg, Eg, seed=123, device=dev, community_order=True)
+    ptr, idx = ptr_t.cpu().numpy(), idx_t.cpu().numpy()
+    del ptr_t, idx_t
+    val = np.ones(Eg, np.float32)
+    pg = PartitionedGCN(ptr, idx, val, FEAT, device=dev, mode=os.environ.get("BENCH_MODE", "balanced"))
+    g = torch.Generator(device=dev)
+    g.manual_seed(123 + rank)
+    pg.set_local_x(torch.randn((pg.hx.n_local, FEAT), generator=g, device=dev))
+    wall, dev_s, med_s = time_steps(pg.step, args.steps, args.warmup, dist.barrier)
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    halo = torch.tensor([pg.hx.halo_bytes(FEAT), pg.num_e_local], dtype=torch.float64, device=dev)
+    dist.all_reduce(halo, op=dist.ReduceOp.SUM)
+    wall = float(t.item())
+    if rank != 0:
+        return None
+    B = algorithmic_bytes(Vg, Eg, FEAT)
+    return {
+        "metric": "aggregated edges/sec, GCN SpMM feat=128", "value": Eg / (wall / args.steps), "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%d x arxiv-shaped power-law CSR (%dx%d, seed 123, community order), GCN sum, "
+                               "feat=128, 1-D row partition + RCCL all-to-all halo pull per step" % (world, Vg, Eg),
+                   "num_v": Vg, "num_e": Eg, "feat": FEAT, "halo_bytes_per_step_all_ranks": float(halo[0].item())},
+        "achieved_gbps": B / (wall / args.steps) / 1e9,
+        "roofline": {"bound": "hbm", "achieved": B / (wall / args.steps) / 1e9 / world, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": B / (wall / args.steps) / 1e9 / world / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "per-GPU share of the step (halo exchange included)", "algorithmic_bytes": B},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-budget", type=float, default=10.0)
+    args = ap.parse_args()
+
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "gnn_computing_amd", "libgnnagg.so")):
+        ge.build()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        out = run_multi(args, dev, rank, world)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        if args.gpus != 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many processes" % args.gpus)
+        out = run_single(args, dev)
+    if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,692 @@
+// api.hip -- the C-ABI of libgnnagg.so (include/gnnagg.h): handle objects, schedules, dispatch.
+//
+// Mirrors the reference's Aggregator / Aggregator_GCN / Aggregator_GAT life cycle
+// (include/aggregator.h:25-151, aggr_gcn.h:362-550, aggr_gat.h:299-441) behind plain C entry points.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <vector>
+
+#include "common.h"
+
+namespace gnnagg {
+
+static thread_local std::string g_last_error;
+static bool g_abort_on_error = true;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(GNNAGG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {  // owning device array
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int upload(const std::vector<T> &h)
+    {
+        release();
+        n = h.size();
+        if (n == 0) return GNNAGG_OK;
+        HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+        HIP_TRY(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+        return GNNAGG_OK;
+    }
+    int reserve(size_t want)  // grow-only scratch
+    {
+        if (want <= n) return GNNAGG_OK;
+        release();
+        HIP_TRY(hipMalloc((void **)&p, want * sizeof(T)));
+        n = want;
+        return GNNAGG_OK;
+    }
+};
+
+// One schedule = the reference's (d_ptr_scheduled, d_idx_scheduled, d_target_scheduled,
+// d_val_scheduled, num_target) of aggregator.h:130-133 plus what the deterministic combine needs.
+struct Schedule {
+    bool valid = false;
+    int kind = GNNAGG_SCHED_NOP;
+    int num_target = 0;
+    bool permuted = false;  // locality schedules permute idx/val; neighbor grouping aliases them
+    std::vector<int> h_ptr_s, h_target, h_idx_s;
+    std::vector<float> h_val_s;
+    DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s;
+    DevBuf<float> val_s;
+    int n_empty = 0, n_mrows = 0, n_slots = 0;
+
+    void reset()
+    {
+        valid = false;
+        ptr_s.release(); target.release(); slot.release(); empty_rows.release();
+        mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release();
+        h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear();
+        num_target = n_empty = n_mrows = n_slots = 0;
+        permuted = false;
+    }
+    WorkList worklist() const
+    {
+        WorkList w;
+        w.ptr = ptr_s.p; w.target = target.p; w.slot = slot.p; w.empty_rows = empty_rows.p;
+        w.n_items = num_target; w.n_empty = n_empty;
+        w.mrow_id = mrow_id.p; w.mrow_ptr = mrow_ptr.p; w.n_mrows = n_mrows; w.n_slots = n_slots;
+        return w;
+    }
+};
+
+struct Ctx {
+    enum Kind { GCN, GAT } kind;
+    int V = 0, E = 0;
+    const int *d_ptr = nullptr;
+    const int *d_idx = nullptr;
+    const float *d_val = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<int> h_ptr;  // host mirror, fetched on first schedule (reference ctor: aggregator.h:50)
+    Schedule sched[2];       // [0] user schedule (MODE_SCHEDULED), [1] balanced (MODE_BALANCED)
+    DevBuf<float> partial, partial_den;
+    DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
+    DevBuf<int> diffbuf;
+    int xcd_remap = 1;
+    int variant = 0;
+    int avg_deg() const { return V > 0 ? (int)((long)E / V) : 0; }
+};
+
+static std::mutex g_mu;
+static std::set<Ctx *> g_live;
+
+static Ctx *lookup(gnnagg_handle h)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    Ctx *c = reinterpret_cast<Ctx *>(h);
+    return g_live.count(c) ? c : nullptr;
+}
+
+static int fetch_host_ptr(Ctx *c)
+{
+    if (!c->h_ptr.empty()) return GNNAGG_OK;
+    c->h_ptr.resize((size_t)c->V + 1);
+    HIP_TRY(hipMemcpy(c->h_ptr.data(), c->d_ptr, ((size_t)c->V + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (c->h_ptr[0] != 0 || c->h_ptr[c->V] != c->E) {
+        c->h_ptr.clear();
+        return fail(GNNAGG_ERR_ARG, "CSR ptr[0] != 0 or ptr[num_v] != num_e");
+    }
+    return GNNAGG_OK;
+}
+
+// From (ptr_s, target): which groups own a whole row, which rows are split, which rows have no
+// group at all; then upload everything.
+static int finalize_schedule(Ctx *c, Schedule &s)
+{
+    const int V = c->V, G = (int)s.h_target.size();
+    s.num_target = G;
+    std::vector<int> groups_of(V, 0);
+    for (int g = 0; g < G; ++g) groups_of[s.h_target[g]]++;
+    std::vector<int> base(V, -1), mrow_id, mrow_ptr(1, 0), empty;
+    int nslots = 0;
+    for (int r = 0; r < V; ++r) {
+        if (groups_of[r] == 0) empty.push_back(r);
+        if (groups_of[r] > 1) {
+            base[r] = nslots;
+            nslots += groups_of[r];
+            mrow_id.push_back(r);
+            mrow_ptr.push_back(nslots);
+        }
+    }
+    std::vector<int> slot(G), cursor(V, 0);
+    for (int g = 0; g < G; ++g) {
+        const int r = s.h_target[g];
+        slot[g] = base[r] < 0 ? -1 : base[r] + cursor[r]++;
+    }
+    s.n_empty = (int)empty.size();
+    s.n_mrows = (int)mrow_id.size();
+    s.n_slots = nslots;
+    int rc;
+    if ((rc = s.ptr_s.upload(s.h_ptr_s))) return rc;
+    if ((rc = s.target.upload(s.h_target))) return rc;
+    if ((rc = s.slot.upload(slot))) return rc;
+    if ((rc = s.empty_rows.upload(empty))) return rc;
+    if ((rc = s.mrow_id.upload(mrow_id))) return rc;
+    if ((rc = s.mrow_ptr.upload(mrow_ptr))) return rc;
+    if (s.permuted) {
+        if ((rc = s.idx_s.upload(s.h_idx_s))) return rc;
+        if (!s.h_val_s.empty() && (rc = s.val_s.upload(s.h_val_s))) return rc;
+    }
+    s.valid = true;
+    return GNNAGG_OK;
+}
+
+static int build_grouping(Ctx *c, Schedule &s, int ng, int kind)
+{
+    if (ng <= 0) return fail(GNNAGG_ERR_ARG, "neighbor group size must be >= 1");
+    int rc = fetch_host_ptr(c);
+    if (rc) return rc;
+    s.reset();
+    s.kind = kind;
+    const int G = neighbor_grouping(c->h_ptr.data(), ng, c->V, nullptr, nullptr);
+    s.h_ptr_s.resize((size_t)G + 1);
+    s.h_target.resize((size_t)G);
+    neighbor_grouping(c->h_ptr.data(), ng, c->V, s.h_ptr_s.data(), s.h_target.data());
+    return finalize_schedule(c, s);
+}
+
+static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind)
+{
+    if (par_num <= 0) return fail(GNNAGG_ERR_ARG, "locality partition count must be >= 1");
+    int rc = fetch_host_ptr(c);
+    if (rc) return rc;
+    std::vector<int> h_idx((size_t)c->E);
+    std::vector<float> h_val;
+    if (c->E > 0) HIP_TRY(hipMemcpy(h_idx.data(), c->d_idx, (size_t)c->E * sizeof(int), hipMemcpyDeviceToHost));
+    if (c->d_val && c->E > 0) {
+        h_val.resize((size_t)c->E);
+        HIP_TRY(hipMemcpy(h_val.data(), c->d_val, (size_t)c->E * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    s.reset();
+    s.kind = kind;
+    s.permuted = true;
+    std::vector<int> ptr_s((size_t)c->E + 2), tgt((size_t)c->E + 1);
+    s.h_idx_s.resize((size_t)c->E);
+    if (!h_val.empty()) s.h_val_s.resize((size_t)c->E);
+    const int G = locality_schedule(c->h_ptr.data(), h_idx.data(), h_val.empty() ? nullptr : h_val.data(), par_num, ng,
+                                    c->V, total_v, ptr_s.data(), s.h_idx_s.data(),
+                                    h_val.empty() ? nullptr : s.h_val_s.data(), tgt.data());
+    ptr_s.resize((size_t)G + 1);
+    tgt.resize((size_t)G);
+    const int kept = ptr_s[G];
+    s.h_idx_s.resize((size_t)kept);
+    if (!s.h_val_s.empty()) s.h_val_s.resize((size_t)kept);
+    s.h_ptr_s.swap(ptr_s);
+    s.h_target.swap(tgt);
+    return finalize_schedule(c, s);
+}
+
+static int pick_chunk(const Ctx *c)
+{
+    // long rows become work items of <= chunk edges: small enough that the hub rows of a
+    // power-law graph spread over many wavefronts, large enough that partial-sum traffic
+    // (2 * F * 4 bytes per extra item) stays a few percent of the gather traffic.
+    int chunk = 32;
+    while (chunk < 512 && chunk < 2 * c->avg_deg()) chunk <<= 1;
+    return chunk;
+}
+
+static int get_sched(Ctx *c, int mode, Schedule **out)
+{
+    if (mode == GNNAGG_MODE_SCHEDULED) {
+        if (!c->sched[0].valid)
+            return fail(GNNAGG_ERR_STATE, "scheduled run without schedule() (reference: assert aggr_gcn.h:392)");
+        *out = &c->sched[0];
+    } else if (mode == GNNAGG_MODE_BALANCED) {
+        if (!c->sched[1].valid) {
+            int rc = build_grouping(c, c->sched[1], pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
+            if (rc) return rc;
+        }
+        *out = &c->sched[1];
+    } else {
+        *out = nullptr;
+    }
+    return GNNAGG_OK;
+}
+
+static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce)
+{
+    if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
+    if (!x || !y) return fail(GNNAGG_ERR_ARG, "null feature pointer");
+    if (reduce < GNNAGG_REDUCE_SUM || reduce > GNNAGG_REDUCE_MAX) return fail(GNNAGG_ERR_ARG, "bad reduce");
+    if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
+    Schedule *s = nullptr;
+    int rc = get_sched(c, mode, &s);
+    if (rc) return rc;
+    GcnLaunch L;
+    L.row_ptr = c->d_ptr; L.x = x; L.y = y; L.feat = feat; L.reduce = reduce;
+    L.xcd_remap = c->xcd_remap; L.variant = c->variant;
+    if (!s) {
+        L.wl.ptr = c->d_ptr;
+        L.wl.n_items = c->V;
+        L.idx = c->d_idx;
+        L.val = c->d_val;
+    } else {
+        L.wl = s->worklist();
+        L.idx = s->permuted ? s->idx_s.p : c->d_idx;
+        L.val = s->permuted ? s->val_s.p : c->d_val;
+        if (s->n_slots > 0) {
+            if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
+            L.partial = c->partial.p;
+        }
+    }
+    return launch_gcn(L, c->stream);
+}
+
+static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat, int heads, float slope, int mode,
+                   float *newval)
+{
+    if (c->kind != Ctx::GAT) return fail(GNNAGG_ERR_ARG, "handle is not a GAT aggregator");
+    if (!x || !y || !att) return fail(GNNAGG_ERR_ARG, "null feature/attention pointer");
+    if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
+    Schedule *s = nullptr;
+    int rc = get_sched(c, mode, &s);
+    if (rc) return rc;
+    GatLaunch L;
+    L.att = att; L.x = x; L.y = y; L.feat = feat; L.heads = heads; L.slope = slope; L.newval = newval;
+    L.xcd_remap = c->xcd_remap;
+    if (!s) {
+        L.wl.ptr = c->d_ptr;
+        L.wl.n_items = c->V;
+        L.idx = c->d_idx;
+    } else {
+        L.wl = s->worklist();
+        L.idx = s->permuted ? s->idx_s.p : c->d_idx;
+        if (s->permuted && newval)
+            return fail(GNNAGG_ERR_ARG, "newval output is defined for CSR edge order only (not locality schedules)");
+        if (s->n_slots > 0) {
+            if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
+            if ((rc = c->partial_den.reserve((size_t)s->n_slots * heads))) return rc;
+            L.partial = c->partial.p;
+            L.partial_den = c->partial_den.p;
+        }
+    }
+    return launch_gat(L, c->stream);
+}
+
+static int do_schedule(Ctx *c, int kind, const int *param, int total_v)
+{
+    if (!param) return fail(GNNAGG_ERR_ARG, "null schedule parameter array");
+    switch (kind) {
+        case GNNAGG_SCHED_NEIGHBOR_GROUPING:
+            return build_grouping(c, c->sched[0], param[0], kind);
+        case GNNAGG_SCHED_LOCALITY:
+            return build_locality(c, c->sched[0], param[0], 0, total_v, kind);
+        case GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING:
+            if (param[1] <= 0) return fail(GNNAGG_ERR_ARG, "neighbor group size must be >= 1");
+            return build_locality(c, c->sched[0], param[0], param[1], total_v, kind);
+        case GNNAGG_SCHED_NOP:
+            c->sched[0].reset();
+            return GNNAGG_OK;
+        default:
+            return fail(GNNAGG_ERR_ARG, "unknown schedule kind");
+    }
+}
+
+static void die_if_abort(int rc, const char *where)
+{
+    if (rc == GNNAGG_OK || !g_abort_on_error) return;
+    // reference FatalError, include/util.h:82-92
+    fprintf(stderr, "gnnagg failure in %s: %s\nAborting...\n", where, g_last_error.c_str());
+    (void)hipDeviceReset();
+    exit(1);
+}
+
+}  // namespace gnnagg
+
+using namespace gnnagg;
+
+#define GET_CTX(h)                                                      \
+    Ctx *c = lookup(h);                                                 \
+    if (!c) return fail(GNNAGG_ERR_ARG, "invalid or destroyed handle")
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char *gnnagg_last_error(void) { return g_last_error.c_str(); }
+int gnnagg_version(void) { return 100; }
+void gnnagg_set_abort_on_error(int on) { g_abort_on_error = on != 0; }
+
+// ------------------------------------------------------------------------------- Section B
+static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const float *d_val, int V, int E,
+                  gnnagg_handle *out)
+{
+    if (!out) return fail(GNNAGG_ERR_ARG, "null output handle");
+    *out = 0;
+    if (V < 0 || E < 0) return fail(GNNAGG_ERR_ARG, "negative graph size");
+    if (!d_ptr || (E > 0 && !d_idx)) return fail(GNNAGG_ERR_ARG, "null CSR pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(GNNAGG_ERR_HIP, "no HIP device available: libgnnagg has no CPU fallback");
+    Ctx *c = new Ctx;
+    c->kind = kind; c->V = V; c->E = E; c->d_ptr = d_ptr; c->d_idx = d_idx; c->d_val = d_val;
+    if (const char *e = getenv("GNNAGG_XCD_REMAP")) c->xcd_remap = atoi(e);
+    if (const char *e = getenv("GNNAGG_VARIANT")) c->variant = atoi(e);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_live.insert(c);
+    }
+    *out = reinterpret_cast<gnnagg_handle>(c);
+    return GNNAGG_OK;
+}
+
+int gnnagg_gcn_create(const int *d_ptr, const int *d_idx, const float *d_val, int num_v, int num_e,
+                      gnnagg_handle *out)
+{
+    return create(Ctx::GCN, d_ptr, d_idx, d_val, num_v, num_e, out);
+}
+
+int gnnagg_gat_create(const int *d_ptr, const int *d_idx, int num_v, int num_e, gnnagg_handle *out)
+{
+    return create(Ctx::GAT, d_ptr, d_idx, nullptr, num_v, num_e, out);
+}
+
+int gnnagg_destroy(gnnagg_handle h)
+{
+    Ctx *c;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        c = reinterpret_cast<Ctx *>(h);
+        if (!g_live.count(c)) return fail(GNNAGG_ERR_ARG, "invalid or destroyed handle");
+        g_live.erase(c);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    delete c;
+    return GNNAGG_OK;
+}
+
+int gnnagg_set_stream(gnnagg_handle h, void *hip_stream)
+{
+    GET_CTX(h);
+    c->stream = (hipStream_t)hip_stream;
+    return GNNAGG_OK;
+}
+
+int gnnagg_update_val(gnnagg_handle h, const float *d_val)
+{
+    GET_CTX(h);
+    if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
+    c->d_val = d_val;  // aliases, like aggr_gcn.h:540-544
+    return GNNAGG_OK;
+}
+
+int gnnagg_schedule(gnnagg_handle h, int kind, const int *param, int total_num_v)
+{
+    GET_CTX(h);
+    return do_schedule(c, kind, param, total_num_v);
+}
+
+int gnnagg_schedule_balanced(gnnagg_handle h, int chunk)
+{
+    GET_CTX(h);
+    if (chunk < 0) return fail(GNNAGG_ERR_ARG, "chunk must be >= 0");
+    return build_grouping(c, c->sched[1], chunk > 0 ? chunk : pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
+}
+
+int gnnagg_num_target(gnnagg_handle h, int mode, int *out)
+{
+    GET_CTX(h);
+    if (!out) return fail(GNNAGG_ERR_ARG, "null output");
+    if (mode == GNNAGG_MODE_ROWS) {
+        *out = c->V;
+        return GNNAGG_OK;
+    }
+    Schedule *s = nullptr;
+    int rc = get_sched(c, mode, &s);
+    if (rc) return rc;
+    *out = s->num_target;
+    return GNNAGG_OK;
+}
+
+int gnnagg_get_schedule(gnnagg_handle h, int mode, int *h_ptr_s, int *h_idx_s, int *h_target, float *h_val_s)
+{
+    GET_CTX(h);
+    Schedule *s = nullptr;
+    int rc = get_sched(c, mode, &s);
+    if (rc) return rc;
+    if (!s) return fail(GNNAGG_ERR_ARG, "MODE_ROWS has no schedule");
+    // read back from the device: this is what the kernels consume
+    const int G = s->num_target;
+    if (h_ptr_s) HIP_TRY(hipMemcpy(h_ptr_s, s->ptr_s.p, ((size_t)G + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (h_target && G > 0) HIP_TRY(hipMemcpy(h_target, s->target.p, (size_t)G * sizeof(int), hipMemcpyDeviceToHost));
+    const size_t ne = s->permuted ? s->h_idx_s.size() : (size_t)c->E;
+    if (h_idx_s && ne > 0)
+        HIP_TRY(hipMemcpy(h_idx_s, s->permuted ? s->idx_s.p : c->d_idx, ne * sizeof(int), hipMemcpyDeviceToHost));
+    if (h_val_s && ne > 0) {
+        const float *src = s->permuted ? s->val_s.p : c->d_val;
+        if (!src) return fail(GNNAGG_ERR_STATE, "aggregator has no edge values");
+        HIP_TRY(hipMemcpy(h_val_s, src, ne * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return GNNAGG_OK;
+}
+
+int gnnagg_gcn_run(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce)
+{
+    GET_CTX(h);
+    return gcn_run(c, d_x, d_y, feat, mode, reduce);
+}
+
+int gnnagg_csr2edgelist(gnnagg_handle h, int *d_edgelist)
+{
+    GET_CTX(h);
+    if (!d_edgelist && c->E > 0) return fail(GNNAGG_ERR_ARG, "null edge list");
+    return launch_csr2edgelist(c->d_ptr, c->d_idx, d_edgelist, c->V, c->avg_deg(), c->stream);
+}
+
+int gnnagg_gcn_run_edgewise(gnnagg_handle h, const float *d_x, float *d_y, int feat)
+{
+    GET_CTX(h);
+    if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
+    if (!d_x || !d_y || feat <= 0) return fail(GNNAGG_ERR_ARG, "bad edge-wise arguments");
+    int rc;
+    if (c->edgelist.n < (size_t)2 * c->E || c->edgelist.p == nullptr) {
+        if ((rc = c->edgelist.reserve((size_t)2 * std::max(c->E, 1)))) return rc;
+        if ((rc = launch_csr2edgelist(c->d_ptr, c->d_idx, c->edgelist.p, c->V, c->avg_deg(), c->stream))) return rc;
+    }
+    return launch_edgewise(c->edgelist.p, c->d_val, d_x, d_y, c->E, c->V, feat, c->stream);
+}
+
+int gnnagg_gat_run(gnnagg_handle h, const float *d_x, const float *d_att, float *d_y, int feat, int heads,
+                   float slope, int mode, float *d_newval)
+{
+    GET_CTX(h);
+    return gat_run(c, d_x, d_att, d_y, feat, heads, slope, mode, d_newval);
+}
+
+int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, int heads, float slope)
+{
+    GET_CTX(h);
+    if (!d_att || (!d_out_val && c->E > 0) || heads <= 0) return fail(GNNAGG_ERR_ARG, "bad run_att arguments");
+    return launch_gat_att(c->d_ptr, c->d_idx, d_att, d_out_val, c->V, heads, slope, c->avg_deg(), c->stream);
+}
+
+int gnnagg_gat_run_u_add_v(gnnagg_handle h, const float *d_att, float *d_out_val)
+{
+    GET_CTX(h);
+    if (!d_att || (!d_out_val && c->E > 0)) return fail(GNNAGG_ERR_ARG, "bad u_add_v arguments");
+    return launch_u_add_v(c->d_ptr, c->d_idx, d_att, d_out_val, c->V, c->avg_deg(), c->stream);
+}
+
+int gnnagg_gat_run_add_to_center(gnnagg_handle h, const float *d_in_val, float *d_out_att)
+{
+    GET_CTX(h);
+    if ((!d_in_val && c->E > 0) || !d_out_att) return fail(GNNAGG_ERR_ARG, "bad add_to_center arguments");
+    return launch_add_to_center(c->d_ptr, d_in_val, d_out_att, c->V, c->avg_deg(), c->stream);
+}
+
+int gnnagg_gat_run_div_each(gnnagg_handle h, const float *d_in_att, float *d_inout_val)
+{
+    GET_CTX(h);
+    if (!d_in_att || (!d_inout_val && c->E > 0)) return fail(GNNAGG_ERR_ARG, "bad div_each arguments");
+    return launch_div_each(c->d_ptr, d_in_att, d_inout_val, c->V, c->avg_deg(), c->stream);
+}
+
+int gnnagg_spmm_naive(const int *d_ptr, const int *d_idx, const float *d_val, const float *d_x, float *d_y,
+                      int num_v, int feat, void *hip_stream)
+{
+    if (!d_ptr || !d_val || !d_x || !d_y || feat <= 0 || num_v < 0) return fail(GNNAGG_ERR_ARG, "bad spmm arguments");
+    return launch_spmm_naive(d_ptr, d_idx, d_val, d_x, d_y, num_v, feat, hip_stream);
+}
+
+static int count_result(int *d_diff, int *h_diff, void *stream)
+{
+    HIP_TRY(hipMemcpyAsync(h_diff, d_diff, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    (void)hipFree(d_diff);
+    return GNNAGG_OK;
+}
+
+int gnnagg_validate(const float *d_ref, const float *d_ans, int num, int *h_diff, void *hip_stream)
+{
+    if (!d_ref || !d_ans || !h_diff || num < 0) return fail(GNNAGG_ERR_ARG, "bad validate arguments");
+    int *d_diff = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_diff, sizeof(int)));
+    int rc = launch_validate(d_ref, d_ans, num, d_diff, hip_stream);
+    if (rc) { (void)hipFree(d_diff); return rc; }
+    return count_result(d_diff, h_diff, hip_stream);
+}
+
+int gnnagg_validate_reordered(const float *d_ref, const float *d_ans, const int *d_map, int num_v, int feat,
+                              int *h_diff, void *hip_stream)
+{
+    if (!d_ref || !d_ans || !d_map || !h_diff || num_v < 0 || feat <= 0)
+        return fail(GNNAGG_ERR_ARG, "bad validate_reordered arguments");
+    int *d_diff = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_diff, sizeof(int)));
+    int rc = launch_validate_reordered(d_ref, d_ans, d_map, num_v, feat, d_diff, hip_stream);
+    if (rc) { (void)hipFree(d_diff); return rc; }
+    return count_result(d_diff, h_diff, hip_stream);
+}
+
+// ------------------------------------------------------------------------------- Section A
+int64_t GCN_init_impl(int *ptr, int *idx, float *val, int num_v, int num_e)
+{
+    gnnagg_handle h = 0;
+    die_if_abort(gnnagg_gcn_create(ptr, idx, val, num_v, num_e, &h), "GCN_init_impl");
+    return h;
+}
+
+void GCN_update_val_impl(int64_t at, float *val) { die_if_abort(gnnagg_update_val(at, val), "GCN_update_val_impl"); }
+
+void GCN_run_impl(int64_t at, float *feat, float *out_feat, int blocksize, int scheduled, int featlen)
+{
+    (void)blocksize;
+    die_if_abort(gnnagg_gcn_run(at, feat, out_feat, featlen, scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS,
+                                GNNAGG_REDUCE_SUM),
+                 "GCN_run_impl");
+}
+
+static int schedule_ng(int64_t at, int *arr)
+{
+    GET_CTX(at);
+    return do_schedule(c, GNNAGG_SCHED_NEIGHBOR_GROUPING, arr, c->V);
+}
+
+void GCN_schedule_impl(int64_t at, int *arr) { die_if_abort(schedule_ng(at, arr), "GCN_schedule_impl"); }
+
+int64_t GAT_init_impl(int *ptr, int *idx, int num_v, int num_e)
+{
+    gnnagg_handle h = 0;
+    die_if_abort(gnnagg_gat_create(ptr, idx, num_v, num_e, &h), "GAT_init_impl");
+    return h;
+}
+
+void GAT_run_impl(int64_t at, float *feat, float *att, float *out_feat, int blocksize, int scheduled, int featlen)
+{
+    (void)blocksize;
+    die_if_abort(gnnagg_gat_run(at, feat, att, out_feat, featlen, 1, 0.2f,
+                                scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS, nullptr),
+                 "GAT_run_impl");
+}
+
+void GAT_run_u_add_v_impl(int64_t at, float *att, float *outval, int blocksize)
+{
+    (void)blocksize;
+    die_if_abort(gnnagg_gat_run_u_add_v(at, att, outval), "GAT_run_u_add_v_impl");
+}
+
+void GAT_run_add_to_center_impl(int64_t at, float *inval, float *outatt, int blocksize)
+{
+    (void)blocksize;
+    die_if_abort(gnnagg_gat_run_add_to_center(at, inval, outatt), "GAT_run_add_to_center_impl");
+}
+
+void GAT_run_div_each_impl(int64_t at, float *inatt, float *inoutval, int blocksize)
+{
+    (void)blocksize;
+    die_if_abort(gnnagg_gat_run_div_each(at, inatt, inoutval), "GAT_run_div_each_impl");
+}
+
+void GAT_schedule_impl(int64_t at, int *arr) { die_if_abort(schedule_ng(at, arr), "GAT_schedule_impl"); }
+
+// ------------------------------------------------------------------------------- Section C
+int gnnagg_load_graph(const char *datadir, const char *dset, const char *reorder_suffix, int shuffle, int *num_v,
+                      int *num_e, int **h_ptr, int **h_idx, int **h_rows, int **h_reverse_rows)
+{
+    if (!dset || !num_v || !num_e || !h_ptr || !h_idx) return fail(GNNAGG_ERR_ARG, "bad load_graph arguments");
+    if (h_rows) *h_rows = nullptr;
+    if (h_reverse_rows) *h_reverse_rows = nullptr;
+    return load_graph(datadir, dset, reorder_suffix, shuffle, num_v, num_e, h_ptr, h_idx, h_rows, h_reverse_rows);
+}
+
+void gnnagg_free_host(void *p) { free(p); }
+
+int gnnagg_reorder_csr(const int *h_ptr, const int *h_idx, const int *h_map, const int *h_reverse_map, int num_v,
+                       int num_e, int *h_newptr, int *h_newidx)
+{
+    if (!h_ptr || !h_map || !h_reverse_map || !h_newptr || num_v < 0 || num_e < 0 || (num_e > 0 && (!h_idx || !h_newidx)))
+        return fail(GNNAGG_ERR_ARG, "bad reorder_csr arguments");
+    reorder_csr(h_ptr, h_idx, h_map, h_reverse_map, num_v, h_newptr, h_newidx);
+    return GNNAGG_OK;
+}
+
+int gnnagg_neighbor_grouping_schedule(const int *h_ptr, int neighbor_num, int num_v, int *h_ptr_out,
+                                      int *h_target_out, int *num_groups)
+{
+    if (!h_ptr || neighbor_num <= 0 || num_v < 0 || !num_groups)
+        return fail(GNNAGG_ERR_ARG, "bad neighbor_grouping_schedule arguments");
+    *num_groups = neighbor_grouping(h_ptr, neighbor_num, num_v, h_ptr_out, h_target_out);
+    return GNNAGG_OK;
+}
+
+int gnnagg_locality_schedule(const int *h_ptr, const int *h_idx, const float *h_val, int par_num, int neighbor_num,
+                             int num_v, int total_num_v, int *h_ptr_out, int *h_idx_out, float *h_val_out,
+                             int *h_target_out, int *num_groups)
+{
+    if (!h_ptr || !h_idx || par_num <= 0 || num_v < 0 || !h_ptr_out || !h_idx_out || !h_target_out || !num_groups)
+        return fail(GNNAGG_ERR_ARG, "bad locality_schedule arguments");
+    *num_groups = locality_schedule(h_ptr, h_idx, h_val, par_num, neighbor_num, num_v, total_num_v, h_ptr_out,
+                                    h_idx_out, h_val_out, h_target_out);
+    return GNNAGG_OK;
+}
+
+// ------------------------------------------------------------------------------- Section D
+int gnnagg_partition_rows(const int *h_ptr, int num_v, int nparts, int *h_bounds)
+{
+    if (!h_ptr || !h_bounds || nparts <= 0 || num_v < 0) return fail(GNNAGG_ERR_ARG, "bad partition_rows arguments");
+    partition_rows(h_ptr, num_v, nparts, h_bounds);
+    return GNNAGG_OK;
+}
+
+int gnnagg_halo_plan(const int *h_ptr, const int *h_idx, int num_v, const int *h_bounds, int nparts, int rank,
+                     int *h_local_ptr, int *h_local_idx, int **h_halo_ids, int *h_halo_counts, int *num_halo)
+{
+    if (!h_ptr || !h_idx || !h_bounds || nparts <= 0 || rank < 0 || rank >= nparts || !h_local_ptr || !h_local_idx ||
+        !h_halo_ids || !h_halo_counts || !num_halo)
+        return fail(GNNAGG_ERR_ARG, "bad halo_plan arguments");
+    return halo_plan(h_ptr, h_idx, num_v, h_bounds, nparts, rank, h_local_ptr, h_local_idx, h_halo_ids, h_halo_counts,
+                     num_halo);
+}
+
+int gnnagg_pack_rows(const float *d_x, const int *d_ids, int n, int feat, float *d_out, void *hip_stream)
+{
+    if (n < 0 || feat <= 0 || (n > 0 && (!d_x || !d_ids || !d_out))) return fail(GNNAGG_ERR_ARG, "bad pack_rows arguments");
+    return launch_pack_rows(d_x, d_ids, n, feat, d_out, hip_stream);
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,92 @@
+// common.h -- internal declarations shared by the translation units of libgnnagg.so.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/gnnagg.h"
+
+namespace gnnagg {
+
+// records the message for gnnagg_last_error() and returns `code`
+int fail(int code, const std::string &msg);
+
+// ---- host_graph.cpp
+void reorder_csr(const int *ptr, const int *idx, const int *map, const int *rmap, int V, int *newptr, int *newidx);
+int neighbor_grouping(const int *ptr, int ng, int V, int *ptr_out, int *target_out);
+int locality_schedule(const int *ptr, const int *idx, const float *val, int par_num, int ng, int V, int total_v,
+                      int *ptr_out, int *idx_out, float *val_out, int *target_out);
+int load_graph(const char *datadir, const char *dset, const char *suffix, int shuffle, int *num_v, int *num_e,
+               int **ptr_o, int **idx_o, int **rows_o, int **rrows_o);
+void partition_rows(const int *ptr, int V, int nparts, int *bounds);
+int halo_plan(const int *ptr, const int *idx, int V, const int *bounds, int nparts, int rank, int *lptr, int *lidx,
+              int **halo_ids_o, int *halo_counts, int *num_halo);
+
+// ---- kernels.hip : launch descriptors (all pointers are device pointers)
+
+// A work list: item g covers edges [ptr[g], ptr[g+1]) of output row (target ? target[g] : g).
+//   slot == nullptr : every item owns its whole row -> direct store.
+//   slot[g] <  0    : item owns the whole row -> direct store
+//   slot[g] >= 0    : row is split over several items -> partial sums go to scratch row slot[g]
+// Items [n_items, n_items + n_empty) zero-fill the rows listed in empty_rows (rows with no item).
+struct WorkList {
+    const int *ptr = nullptr;
+    const int *target = nullptr;
+    const int *slot = nullptr;
+    const int *empty_rows = nullptr;
+    int n_items = 0;
+    int n_empty = 0;
+    // multi-item rows: row mrow_id[m] sums scratch rows [mrow_ptr[m], mrow_ptr[m+1]) in order
+    const int *mrow_id = nullptr;
+    const int *mrow_ptr = nullptr;
+    int n_mrows = 0;
+    int n_slots = 0;
+};
+
+struct GcnLaunch {
+    WorkList wl;
+    const int *row_ptr = nullptr;  // original CSR ptr (degrees for mean)
+    const int *idx = nullptr;
+    const float *val = nullptr;  // nullptr => implicit 1
+    const float *x = nullptr;
+    float *y = nullptr;
+    float *partial = nullptr;  // [n_slots, F] scratch
+    int feat = 0;
+    int reduce = GNNAGG_REDUCE_SUM;
+    int xcd_remap = 1;
+    int variant = 0;  // tuning knob: 0 = default lane geometry
+};
+
+struct GatLaunch {
+    WorkList wl;
+    const int *idx = nullptr;
+    const float *att = nullptr;  // [V,H,2]
+    const float *x = nullptr;
+    float *y = nullptr;
+    float *partial = nullptr;      // [n_slots, F]
+    float *partial_den = nullptr;  // [n_slots, H]
+    float *newval = nullptr;       // optional [E,H] un-normalised weights
+    int feat = 0;
+    int heads = 1;
+    float slope = 0.2f;
+    int xcd_remap = 1;
+};
+
+int launch_gcn(const GcnLaunch &a, void *stream);
+int launch_gat(const GatLaunch &a, void *stream);
+int launch_gat_att(const int *ptr, const int *idx, const float *att, float *out, int V, int heads, float slope,
+                   int avg_deg, void *stream);
+int launch_u_add_v(const int *ptr, const int *idx, const float *att, float *out, int V, int avg_deg, void *stream);
+int launch_add_to_center(const int *ptr, const float *in, float *out, int V, int avg_deg, void *stream);
+int launch_div_each(const int *ptr, const float *in, float *inout, int V, int avg_deg, void *stream);
+int launch_csr2edgelist(const int *ptr, const int *idx, int *edgelist, int V, int avg_deg, void *stream);
+int launch_edgewise(const int *edgelist, const float *val, const float *x, float *y, int E, int V, int feat,
+                    void *stream);
+int launch_spmm_naive(const int *ptr, const int *idx, const float *val, const float *x, float *y, int V, int feat,
+                      void *stream);
+int launch_validate(const float *ref, const float *ans, int num, int *d_diff, void *stream);
+int launch_validate_reordered(const float *ref, const float *ans, const int *map, int V, int feat, int *d_diff,
+                              void *stream);
+int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out, void *stream);
+
+}  // namespace gnnagg

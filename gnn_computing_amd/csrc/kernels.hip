@@ -1,0 +1,732 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels of the neighbor-aggregation hot path.
+//
+// Design (wave64, HBM/L2-bound integer+fp32 gather work; no MFMA -- 0.25 flop/B):
+//  * A "lane group" of GROUP = 8/16/32/64 lanes owns one work item (a CSR row, or a chunk of a
+//    long row) and one column tile of GROUP*VEC floats; each lane keeps VEC accumulators and
+//    loads VEC*4 bytes per neighbor, so a group reads a contiguous GROUP*VEC*4-byte segment of
+//    the neighbor's feature row (512 B for F=128: four 128-B lines, one dwordx4 per lane).
+//    GROUP < 64 packs several short rows into one wavefront (avg degree of arxiv is 6.9), which
+//    is what keeps lanes busy where the reference's warp-per-row scheme idles.
+//  * The FMA chain of an item runs in CSR order (bit-exact against the oracle); memory-level
+//    parallelism comes from issuing the U=8 neighbor gathers of a chunk before the first FMA and
+//    from prefetching the next chunk's (idx,val) while the current gathers are in flight.
+//  * Long rows are split into several items by the schedule; their partial sums go to a scratch
+//    slab and a second kernel adds them in ascending order (deterministic; the reference uses
+//    fp32 atomics in arbitrary order, aggr_gcn.h:112).
+//  * Workgroup -> item-block mapping is XCD-aware: consecutive item blocks (which share
+//    neighbors after the locality reorder) are placed on the same XCD / L2 (8 XCDs, block b runs
+//    on XCD b % 8), using the bijective remap so any grid size works.
+//  * Wide feature rows (F > GROUP*VEC) are covered by several column tiles; tiles of one item
+//    block are adjacent in the remapped block order so they hit the same DRAM pages / L2 lines.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "common.h"
+
+namespace gnnagg {
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(GNNAGG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+static constexpr int kBlock = 256;  // 4 wavefronts
+static constexpr int kUnroll = 8;   // neighbor gathers in flight per lane group
+
+// ---------------------------------------------------------------------------------- helpers
+template <int VEC>
+struct Pack {
+    float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ Pack<VEC> load_pack(const float *p)
+{
+    Pack<VEC> r;
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else if constexpr (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        r.v[0] = t.x; r.v[1] = t.y;
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_pack(float *p, const float (&a)[VEC])
+{
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(a[0], a[1], a[2], a[3]);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(a[0], a[1]);
+    } else {
+        *p = a[0];
+    }
+}
+
+// Block b runs on XCD b % 8 (observed dispatch rule).  Give every XCD a contiguous range of
+// logical blocks; bijective for any nb (q = nb/8, r = nb%8: the first r XCDs get q+1 blocks).
+__device__ __forceinline__ int xcd_remap(int b, int nb)
+{
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+struct GcnArgs {
+    const int *ptr, *target, *slot, *empty_rows;
+    const int *row_ptr;
+    const int *idx;
+    const float *val;
+    const float *x;
+    float *y;
+    float *partial;
+    int n_items, n_total, feat, ntiles, nblocks, mean, remap;
+};
+
+// ------------------------------------------------------------------------- GCN / SAGE items
+// LIST = false: item g is CSR row g (reference aggr_gcn, aggr_gcn.h:5-36).
+// LIST = true : item g is a group of the schedule (reference aggr_gcn_target, aggr_gcn.h:78-114).
+template <int VEC, int GROUP, bool IS_MAX, bool LIST>
+__global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
+{
+    constexpr int ITEMS = kBlock / GROUP;
+    const int b = a.remap ? xcd_remap(blockIdx.x, a.nblocks) : (int)blockIdx.x;
+    const int tile = b % a.ntiles;
+    const int item = (b / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int col = (tile * GROUP + lane) * VEC;
+    if (item >= a.n_total || col >= a.feat) return;
+    const int F = a.feat;
+
+    if (LIST && item >= a.n_items) {  // rows without any group: the reference memsets vout (:393)
+        const float z[VEC] = {};
+        store_pack<VEC>(a.y + (size_t)a.empty_rows[item - a.n_items] * F + col, z);
+        return;
+    }
+
+    const int beg = a.ptr[item], end = a.ptr[item + 1];
+    const int *__restrict__ idx = a.idx;
+    const float *__restrict__ val = a.val;
+    const float *__restrict__ xcol = a.x + col;
+
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+
+    int s[kUnroll];
+    float w[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u)
+        if (beg + u < end) {
+            s[u] = idx[beg + u];
+            w[u] = val ? val[beg + u] : 1.0f;
+        }
+
+    for (int e = beg; e < end; e += kUnroll) {
+        Pack<VEC> xv[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (e + u < end) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+        // next chunk's neighbor ids / weights travel while the gathers above are in flight
+        int sn[kUnroll];
+        float wn[kUnroll];
+        const int en = e + kUnroll;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (en + u < end) {
+                sn[u] = idx[en + u];
+                wn[u] = val ? val[en + u] : 1.0f;
+            }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (e + u < end) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (IS_MAX) {
+                        const float p = xv[u].v[k] * w[u];
+                        acc[k] = p > acc[k] ? p : acc[k];
+                    } else {
+                        acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
+                    }
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            s[u] = sn[u];
+            w[u] = wn[u];
+        }
+    }
+
+    const int sl = (LIST && a.slot) ? a.slot[item] : -1;
+    if (sl >= 0) {
+        store_pack<VEC>(a.partial + (size_t)sl * F + col, acc);
+        return;
+    }
+    const int row = (LIST && a.target) ? a.target[item] : item;
+    if (beg == end) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    } else if (a.mean) {
+        const float d = (float)(end - beg);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
+    }
+    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+}
+
+struct CombineArgs {
+    const int *mrow_id, *mrow_ptr, *row_ptr;
+    const float *partial;
+    const float *partial_den;  // GAT only
+    float *y;
+    int n_mrows, feat, ntiles, heads, dhead, mean;
+};
+
+// Adds the partial rows of every split row in ascending slot order (deterministic counterpart of
+// the reference's atomicAdd, aggr_gcn.h:112) and applies mean / softmax normalisation.
+template <int VEC, int GROUP, bool IS_MAX, bool IS_GAT>
+__global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
+{
+    constexpr int ITEMS = kBlock / GROUP;
+    const int tile = blockIdx.x % a.ntiles;
+    const int m = (blockIdx.x / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int col = (tile * GROUP + lane) * VEC;
+    if (m >= a.n_mrows || col >= a.feat) return;
+    const int F = a.feat;
+    const int s0 = a.mrow_ptr[m], s1 = a.mrow_ptr[m + 1];
+    const int row = a.mrow_id[m];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+    float den = 0.0f;
+    const int h = IS_GAT ? col / a.dhead : 0;
+    for (int s = s0; s < s1; ++s) {
+        const Pack<VEC> p = load_pack<VEC>(a.partial + (size_t)s * F + col);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            if (IS_MAX)
+                acc[k] = p.v[k] > acc[k] ? p.v[k] : acc[k];
+            else
+                acc[k] += p.v[k];
+        }
+        if (IS_GAT) den += a.partial_den[(size_t)s * a.heads + h];
+    }
+    if (IS_GAT) {
+        if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+        }
+    } else if (a.mean) {
+        const float d = (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
+    }
+    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+}
+
+// ------------------------------------------------------------------------------- GAT items
+struct GatArgs {
+    const int *ptr, *target, *slot, *empty_rows;
+    const int *idx;
+    const float *att;
+    const float *x;
+    float *y;
+    float *partial, *partial_den, *newval;
+    int n_items, n_total, feat, ntiles, nblocks, heads, dhead, remap;
+    float slope;
+};
+
+__device__ __forceinline__ float edge_weight(float a_dst, float a_src, float slope)
+{
+    // reference aggr_gat.h:138-143: exp(max(s, s*slope)), no max-subtraction
+    const float sc = a_dst + a_src;
+    const float l = sc * slope;
+    return expf(sc > l ? sc : l);
+}
+
+// LIST = false: reference aggr_gat (aggr_gat.h:116-164); LIST = true: aggr_gat_fine (:167-205).
+template <int VEC, int GROUP, bool LIST>
+__global__ __launch_bounds__(kBlock) void k_gat_items(const GatArgs a)
+{
+    constexpr int ITEMS = kBlock / GROUP;
+    const int b = a.remap ? xcd_remap(blockIdx.x, a.nblocks) : (int)blockIdx.x;
+    const int tile = b % a.ntiles;
+    const int item = (b / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int col = (tile * GROUP + lane) * VEC;
+    if (item >= a.n_total || col >= a.feat) return;
+    const int F = a.feat, H = a.heads;
+
+    if (LIST && item >= a.n_items) {
+        const float z[VEC] = {};
+        store_pack<VEC>(a.y + (size_t)a.empty_rows[item - a.n_items] * F + col, z);
+        return;
+    }
+    const int beg = a.ptr[item], end = a.ptr[item + 1];
+    const int row = (LIST && a.target) ? a.target[item] : item;
+    const int h = col / a.dhead;
+    const bool head_leader = (col % a.dhead) == 0;
+    const int *__restrict__ idx = a.idx;
+    const float *__restrict__ att_src = a.att + (size_t)h * 2 + 1;
+    const float *__restrict__ xcol = a.x + col;
+    const float a_dst = a.att[((size_t)row * H + h) * 2];
+
+    float acc[VEC] = {};
+    float den = 0.0f;
+    for (int e = beg; e < end; e += kUnroll) {
+        int s[kUnroll];
+        float as[kUnroll];
+        Pack<VEC> xv[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (e + u < end) s[u] = idx[e + u];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (e + u < end) {
+                as[u] = att_src[(size_t)s[u] * H * 2];
+                xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+            }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (e + u < end) {
+                const float w = edge_weight(a_dst, as[u], a.slope);
+                if (a.newval && head_leader) a.newval[(size_t)(e + u) * H + h] = w;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
+                den += w;
+            }
+    }
+    const int sl = (LIST && a.slot) ? a.slot[item] : -1;
+    if (sl >= 0) {
+        store_pack<VEC>(a.partial + (size_t)sl * F + col, acc);
+        if (head_leader) a.partial_den[(size_t)sl * H + h] = den;
+        return;
+    }
+    if (beg == end) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    } else if (!LIST || den != 0.0f) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+    }
+    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+}
+
+// --------------------------------------------------------------------- geometry + dispatch
+struct Geometry {
+    int vec, group, ntiles;
+};
+
+static Geometry pick_geometry(int F, const void *p0, const void *p1, const void *p2, int dhead, int variant)
+{
+    auto aligned = [](const void *p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; };
+    int vec = 1;
+    if (F % 4 == 0 && dhead % 4 == 0 && aligned(p0, 16) && aligned(p1, 16) && aligned(p2, 16))
+        vec = 4;
+    else if (F % 2 == 0 && dhead % 2 == 0 && aligned(p0, 8) && aligned(p1, 8) && aligned(p2, 8))
+        vec = 2;
+    if (variant == 1 && vec == 4) vec = 2;  // wave-per-row flavour for F=128 (A/B knob)
+    if (variant == 2 && vec == 4) vec = 2;
+    const int lanes = (F + vec - 1) / vec;
+    int group = 8;
+    while (group < 64 && group < lanes) group <<= 1;
+    if (variant == 2 && group > 8) group >>= 1;  // half-width groups, two column tiles
+    const int ntiles = (lanes + group - 1) / group;
+    return {vec, group, ntiles};
+}
+
+#define DISPATCH_GEOM(g, KERNEL_CALL)                                            \
+    switch ((g).vec * 100 + (g).group) {                                         \
+        case 108: { constexpr int VEC = 1, GROUP = 8;  KERNEL_CALL; } break;     \
+        case 116: { constexpr int VEC = 1, GROUP = 16; KERNEL_CALL; } break;     \
+        case 132: { constexpr int VEC = 1, GROUP = 32; KERNEL_CALL; } break;     \
+        case 164: { constexpr int VEC = 1, GROUP = 64; KERNEL_CALL; } break;     \
+        case 208: { constexpr int VEC = 2, GROUP = 8;  KERNEL_CALL; } break;     \
+        case 216: { constexpr int VEC = 2, GROUP = 16; KERNEL_CALL; } break;     \
+        case 232: { constexpr int VEC = 2, GROUP = 32; KERNEL_CALL; } break;     \
+        case 264: { constexpr int VEC = 2, GROUP = 64; KERNEL_CALL; } break;     \
+        case 408: { constexpr int VEC = 4, GROUP = 8;  KERNEL_CALL; } break;     \
+        case 416: { constexpr int VEC = 4, GROUP = 16; KERNEL_CALL; } break;     \
+        case 432: { constexpr int VEC = 4, GROUP = 32; KERNEL_CALL; } break;     \
+        case 464: { constexpr int VEC = 4, GROUP = 64; KERNEL_CALL; } break;     \
+        default: return fail(GNNAGG_ERR_ARG, "unsupported lane geometry");       \
+    }
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+int launch_gcn(const GcnLaunch &L, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (L.feat <= 0) return fail(GNNAGG_ERR_ARG, "feature length must be >= 1");
+    const bool list = L.wl.target != nullptr || L.wl.slot != nullptr || L.wl.n_empty > 0;
+    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, L.feat, L.variant);
+    const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
+    GcnArgs a;
+    a.ptr = L.wl.ptr; a.target = L.wl.target; a.slot = L.wl.slot; a.empty_rows = L.wl.empty_rows;
+    a.row_ptr = L.row_ptr; a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
+    a.n_items = L.wl.n_items; a.n_total = L.wl.n_items + L.wl.n_empty; a.feat = L.feat; a.ntiles = g.ntiles;
+    a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap;
+    if (a.n_total > 0) {
+        const int items_per_block = kBlock / g.group;
+        a.nblocks = ceil_div(a.n_total, items_per_block) * g.ntiles;
+        if (a.remap && a.nblocks < 64) a.remap = 0;
+#define CALL_GCN                                                                                            \
+        if (list) {                                                                                         \
+            if (is_max) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, true, true>), dim3(a.nblocks), dim3(kBlock), 0, stream, a);  \
+            else        hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, false, true>), dim3(a.nblocks), dim3(kBlock), 0, stream, a); \
+        } else {                                                                                            \
+            if (is_max) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, true, false>), dim3(a.nblocks), dim3(kBlock), 0, stream, a); \
+            else        hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, false, false>), dim3(a.nblocks), dim3(kBlock), 0, stream, a);\
+        }
+        DISPATCH_GEOM(g, CALL_GCN)
+#undef CALL_GCN
+        HIP_TRY(hipGetLastError());
+    }
+    if (L.wl.n_mrows > 0) {
+        CombineArgs c;
+        c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = L.row_ptr; c.partial = L.partial;
+        c.partial_den = nullptr; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
+        c.heads = 1; c.dhead = L.feat; c.mean = a.mean;
+        const int nb = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
+#define CALL_COMB                                                                                           \
+        if (is_max) hipLaunchKernelGGL((k_combine<VEC, GROUP, true, false>), dim3(nb), dim3(kBlock), 0, stream, c);  \
+        else        hipLaunchKernelGGL((k_combine<VEC, GROUP, false, false>), dim3(nb), dim3(kBlock), 0, stream, c);
+        DISPATCH_GEOM(g, CALL_COMB)
+#undef CALL_COMB
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
+int launch_gat(const GatLaunch &L, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (L.feat <= 0 || L.heads <= 0 || L.feat % L.heads != 0)
+        return fail(GNNAGG_ERR_ARG, "GAT needs feat >= 1 and feat % heads == 0");
+    const bool list = L.wl.target != nullptr || L.wl.slot != nullptr || L.wl.n_empty > 0;
+    const int dhead = L.feat / L.heads;
+    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, dhead, 0);
+    GatArgs a;
+    a.ptr = L.wl.ptr; a.target = L.wl.target; a.slot = L.wl.slot; a.empty_rows = L.wl.empty_rows;
+    a.idx = L.idx; a.att = L.att; a.x = L.x; a.y = L.y; a.partial = L.partial; a.partial_den = L.partial_den;
+    a.newval = L.newval; a.n_items = L.wl.n_items; a.n_total = L.wl.n_items + L.wl.n_empty; a.feat = L.feat;
+    a.ntiles = g.ntiles; a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope;
+    if (a.n_total > 0) {
+        a.nblocks = ceil_div(a.n_total, kBlock / g.group) * g.ntiles;
+        if (a.remap && a.nblocks < 64) a.remap = 0;
+#define CALL_GAT                                                                                             \
+        if (list) hipLaunchKernelGGL((k_gat_items<VEC, GROUP, true>), dim3(a.nblocks), dim3(kBlock), 0, stream, a);  \
+        else      hipLaunchKernelGGL((k_gat_items<VEC, GROUP, false>), dim3(a.nblocks), dim3(kBlock), 0, stream, a);
+        DISPATCH_GEOM(g, CALL_GAT)
+#undef CALL_GAT
+        HIP_TRY(hipGetLastError());
+    }
+    if (L.wl.n_mrows > 0) {
+        CombineArgs c;
+        c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = nullptr; c.partial = L.partial;
+        c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
+        c.heads = L.heads; c.dhead = dhead; c.mean = 0;
+        const int nb = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
+#define CALL_COMB hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true>), dim3(nb), dim3(kBlock), 0, stream, c);
+        DISPATCH_GEOM(g, CALL_COMB)
+#undef CALL_COMB
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
+// ----------------------------------------------------------- per-row edge kernels (GAT adapter)
+// A lane group strides over the edges of one row; group size follows the average degree so short
+// rows do not idle a whole wavefront.
+static int edge_group(int avg_deg)
+{
+    int g = 8;
+    while (g < 64 && g < avg_deg) g <<= 1;
+    return g;
+}
+
+template <int GROUP>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int m = GROUP / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, GROUP);
+    return v;
+}
+
+// reference attGat, aggr_gat.h:5-31; item = (row, head)
+template <int GROUP>
+__global__ __launch_bounds__(kBlock) void k_gat_att(const int *__restrict__ ptr, const int *__restrict__ idx,
+                                                   const float *__restrict__ att, float *__restrict__ out, int V,
+                                                   int H, float slope)
+{
+    const long item = (long)blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (item >= (long)V * H) return;
+    const int row = (int)(item / H), h = (int)(item % H);
+    const int beg = ptr[row], end = ptr[row + 1];
+    const float a_dst = att[((size_t)row * H + h) * 2];
+    float part = 0.0f;
+    for (int e = beg + lane; e < end; e += GROUP) {
+        const float w = edge_weight(a_dst, att[((size_t)idx[e] * H + h) * 2 + 1], slope);
+        out[(size_t)e * H + h] = w;
+        part += w;
+    }
+    const float sum = group_sum<GROUP>(part);
+    for (int e = beg + lane; e < end; e += GROUP) out[(size_t)e * H + h] /= sum;
+}
+
+// reference u_add_v, aggr_gat.h:33-48
+template <int GROUP>
+__global__ __launch_bounds__(kBlock) void k_u_add_v(const int *__restrict__ ptr, const int *__restrict__ idx,
+                                                   const float *__restrict__ att, float *__restrict__ out, int V)
+{
+    const int row = blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (row >= V) return;
+    const float a_dst = att[(size_t)row * 2];
+    for (int e = ptr[row] + lane; e < ptr[row + 1]; e += GROUP) out[e] = a_dst + att[(size_t)idx[e] * 2 + 1];
+}
+
+// reference add_to_center, aggr_gat.h:50-74 (stride-1 output, :71)
+template <int GROUP>
+__global__ __launch_bounds__(kBlock) void k_add_to_center(const int *__restrict__ ptr, const float *__restrict__ in,
+                                                         float *__restrict__ out, int V)
+{
+    const int row = blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (row >= V) return;
+    float part = 0.0f;
+    for (int e = ptr[row] + lane; e < ptr[row + 1]; e += GROUP) part += in[e];
+    const float sum = group_sum<GROUP>(part);
+    if (lane == 0) out[row] = sum;
+}
+
+// reference each_div, aggr_gat.h:76-92
+template <int GROUP>
+__global__ __launch_bounds__(kBlock) void k_div_each(const int *__restrict__ ptr, const float *__restrict__ in,
+                                                    float *__restrict__ inout, int V)
+{
+    const int row = blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (row >= V) return;
+    const float d = in[row];
+    for (int e = ptr[row] + lane; e < ptr[row + 1]; e += GROUP) inout[e] /= d;
+}
+
+// reference convertCSRToEdgelist, aggregator.h:11-23 ((src,dst) written as one 8-byte store)
+template <int GROUP>
+__global__ __launch_bounds__(kBlock) void k_csr2edgelist(const int *__restrict__ ptr, const int *__restrict__ idx,
+                                                        int2 *__restrict__ edgelist, int V)
+{
+    const int row = blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (row >= V) return;
+    for (int e = ptr[row] + lane; e < ptr[row + 1]; e += GROUP) edgelist[e] = make_int2(idx[e], row);
+}
+
+#define DISPATCH_EDGE_GROUP(G, CALL)                      \
+    switch (G) {                                          \
+        case 8:  { constexpr int GROUP = 8;  CALL; } break;  \
+        case 16: { constexpr int GROUP = 16; CALL; } break;  \
+        case 32: { constexpr int GROUP = 32; CALL; } break;  \
+        default: { constexpr int GROUP = 64; CALL; } break;  \
+    }
+
+int launch_gat_att(const int *ptr, const int *idx, const float *att, float *out, int V, int heads, float slope,
+                   int avg_deg, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (V <= 0) return GNNAGG_OK;
+    const int G = edge_group(avg_deg);
+    const int nb = ceil_div((long)V * heads, kBlock / G);
+    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_gat_att<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, idx, att,
+                                              out, V, heads, slope))
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_u_add_v(const int *ptr, const int *idx, const float *att, float *out, int V, int avg_deg, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (V <= 0) return GNNAGG_OK;
+    const int G = edge_group(avg_deg);
+    const int nb = ceil_div(V, kBlock / G);
+    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_u_add_v<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, idx, att,
+                                              out, V))
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_add_to_center(const int *ptr, const float *in, float *out, int V, int avg_deg, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (V <= 0) return GNNAGG_OK;
+    const int G = edge_group(avg_deg);
+    const int nb = ceil_div(V, kBlock / G);
+    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_add_to_center<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, in,
+                                              out, V))
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_div_each(const int *ptr, const float *in, float *inout, int V, int avg_deg, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (V <= 0) return GNNAGG_OK;
+    const int G = edge_group(avg_deg);
+    const int nb = ceil_div(V, kBlock / G);
+    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_div_each<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, in,
+                                              inout, V))
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_csr2edgelist(const int *ptr, const int *idx, int *edgelist, int V, int avg_deg, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (V <= 0) return GNNAGG_OK;
+    const int G = edge_group(avg_deg);
+    const int nb = ceil_div(V, kBlock / G);
+    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_csr2edgelist<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, idx,
+                                              reinterpret_cast<int2 *>(edgelist), V))
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// ------------------------------------------------------------------------ edge-wise variant
+// reference aggr_gcn_edgewise, aggr_gcn.h:291-302 (which covers only 32 columns and reads one edge
+// past the end, :296); here one 64-lane wavefront per edge strides over all F columns.
+__global__ __launch_bounds__(kBlock) void k_edgewise(const int2 *__restrict__ edgelist, const float *__restrict__ val,
+                                                    const float *__restrict__ x, float *__restrict__ y, int E,
+                                                    int F)
+{
+    const int e = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const int2 sd = edgelist[e];
+    const float w = val ? val[e] : 1.0f;
+    for (int c = lane; c < F; c += 64) atomicAdd(&y[(size_t)sd.y * F + c], x[(size_t)sd.x * F + c] * w);
+}
+
+int launch_edgewise(const int *edgelist, const float *val, const float *x, float *y, int E, int V, int feat,
+                    void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(y, 0, (size_t)V * feat * sizeof(float), stream));  // aggr_gcn.h:448
+    if (E <= 0) return GNNAGG_OK;
+    hipLaunchKernelGGL(k_edgewise, dim3(ceil_div(E, kBlock / 64)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const int2 *>(edgelist), val, x, y, E, feat);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// --------------------------------------------------------------------- naive SpMM + validators
+// reference spmm<L>, spmm.h:223-265: thread per row, first edge a plain product, the rest FMAs,
+// empty rows left untouched.  Columns are walked in register tiles of 8 (any F, not a template).
+__global__ __launch_bounds__(128) void k_spmm_naive(const int *__restrict__ ptr, const int *__restrict__ idx,
+                                                   const float *__restrict__ val, const float *__restrict__ x,
+                                                   float *__restrict__ y, int V, int F)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= V) return;
+    const int beg = ptr[r], end = ptr[r + 1];
+    if (beg == end) return;
+    for (int c0 = 0; c0 < F; c0 += 8) {
+        float ans[8];
+        const int n = F - c0 < 8 ? F - c0 : 8;
+        {
+            const float v = val[beg];
+            const float *xr = x + (size_t)idx[beg] * F + c0;
+            for (int j = 0; j < n; ++j) ans[j] = v * xr[j];
+        }
+        for (int e = beg + 1; e < end; ++e) {
+            const float v = val[e];
+            const float *xr = x + (size_t)idx[e] * F + c0;
+            for (int j = 0; j < n; ++j) ans[j] = __builtin_fmaf(v, xr[j], ans[j]);
+        }
+        for (int j = 0; j < n; ++j) y[(size_t)r * F + c0 + j] = ans[j];
+    }
+}
+
+int launch_spmm_naive(const int *ptr, const int *idx, const float *val, const float *x, float *y, int V, int feat,
+                      void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (V <= 0) return GNNAGG_OK;
+    hipLaunchKernelGGL(k_spmm_naive, dim3(ceil_div(V, 128)), dim3(128), 0, stream, ptr, idx, val, x, y, V, feat);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// reference validate2, spmm.h:11-21
+__global__ void k_validate(const float *__restrict__ ref, const float *__restrict__ ans, int num, int *diff)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < num && fabsf((ref[t] - ans[t]) / ref[t]) > 1e-2f) atomicAdd(diff, 1);
+}
+
+// reference validateReordered, spmm.h:23-33
+__global__ void k_validate_reordered(const float *__restrict__ ref, const float *__restrict__ ans,
+                                     const int *__restrict__ map, int V, int F, int *diff)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (long)V * F && fabsf(ref[t] - ans[(size_t)map[t / F] * F + t % F]) > 1e-2f) atomicAdd(diff, 1);
+}
+
+int launch_validate(const float *ref, const float *ans, int num, int *d_diff, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(d_diff, 0, sizeof(int), stream));
+    if (num > 0) hipLaunchKernelGGL(k_validate, dim3(ceil_div(num, 256)), dim3(256), 0, stream, ref, ans, num, d_diff);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_validate_reordered(const float *ref, const float *ans, const int *map, int V, int feat, int *d_diff,
+                              void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(d_diff, 0, sizeof(int), stream));
+    if ((long)V * feat > 0)
+        hipLaunchKernelGGL(k_validate_reordered, dim3(ceil_div((long)V * feat, 256)), dim3(256), 0, stream, ref, ans,
+                           map, V, feat, d_diff);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// ----------------------------------------------------------------------------- halo packing
+// out[i,:] = x[ids[i],:]  -- send buffer of the halo all-to-all (gnnagg.h Section D)
+template <int VEC, int GROUP>
+__global__ __launch_bounds__(kBlock) void k_pack_rows(const float *__restrict__ x, const int *__restrict__ ids, int n,
+                                                     int F, int ntiles, float *__restrict__ out)
+{
+    const int tile = blockIdx.x % ntiles;
+    const int i = (blockIdx.x / ntiles) * (kBlock / GROUP) + threadIdx.x / GROUP;
+    const int col = (tile * GROUP + (threadIdx.x & (GROUP - 1))) * VEC;
+    if (i >= n || col >= F) return;
+    const Pack<VEC> p = load_pack<VEC>(x + (size_t)ids[i] * F + col);
+    store_pack<VEC>(out + (size_t)i * F + col, p.v);
+}
+
+int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (n <= 0) return GNNAGG_OK;
+    const Geometry g = pick_geometry(feat, x, out, nullptr, feat, 0);
+    const int nb = ceil_div(n, kBlock / g.group) * g.ntiles;
+#define CALL_PACK hipLaunchKernelGGL((k_pack_rows<VEC, GROUP>), dim3(nb), dim3(kBlock), 0, stream, x, ids, n, feat, g.ntiles, out);
+    DISPATCH_GEOM(g, CALL_PACK)
+#undef CALL_PACK
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+}  // namespace gnnagg

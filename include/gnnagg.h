@@ -1,0 +1,181 @@
+/*
+ * gnnagg.h -- C-ABI of libgnnagg.so, the MI355X-native neighbor-aggregation library.
+ *
+ * This is the drop-in boundary for the hot path of xxcclong/GNN-Computing
+ * (include/aggregator.h, aggr_gcn.h, aggr_gat.h, spmm.h, graph_schedule.h, src/data.cu).
+ * Plain pointers and sizes only; every `d_*` / "device" pointer is HIP device memory owned by
+ * the caller, every `h_*` / "host" pointer is host memory.  No torch / C++ types cross it.
+ *
+ * Section A mirrors, name for name, the flat API the reference's own PyTorch binding is written
+ * against (reference Figure7/kernel.cpp:15-35, defined in Figure7/kernel_generated.cu:15-74);
+ * a reference-side binding only has to link this library instead of compiling the CUDA headers.
+ * Section B is the same functionality with status codes, streams, reductions and heads.
+ * Section C is the host graph preparation (reference src/data.cu, include/graph_schedule.h).
+ * Section D is the 1-D row-partition / halo-exchange support (no reference counterpart:
+ * the reference asserts GPUNUM == 1, Figure9/main.cu:19).
+ *
+ * Error model: Section A keeps the reference's abort-on-error behaviour (include/util.h:82-104:
+ * message with the failing call, then exit(1)) unless gnnagg_set_abort_on_error(0) was called, in
+ * which case the error is recorded and the call returns (0 for the *_init functions).
+ * Sections B-D return GNNAGG_OK or an error code; gnnagg_last_error() gives the text.
+ * All `run` entry points are asynchronous on the handle's stream (reference: run() never
+ * synchronises, aggr_gcn.h:396,407); schedule / create are synchronous.
+ */
+#ifndef GNNAGG_H
+#define GNNAGG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNAGG_OK 0
+#define GNNAGG_ERR_ARG 1    /* bad argument / contract violation (reference: assert) */
+#define GNNAGG_ERR_HIP 2    /* HIP runtime failure (reference: checkCudaErrors) */
+#define GNNAGG_ERR_STATE 3  /* e.g. scheduled run without a schedule (reference: assert aggr_gcn.h:392) */
+#define GNNAGG_ERR_IO 4     /* graph files missing / malformed (reference: assert(fexist), data.cu:40) */
+
+/* enum Schedule, reference include/graph_schedule.h:8-14 (same values) */
+#define GNNAGG_SCHED_LOCALITY 0
+#define GNNAGG_SCHED_NEIGHBOR_GROUPING 1
+#define GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING 2
+#define GNNAGG_SCHED_NOP 3
+
+/* reduction over a row's neighbors */
+#define GNNAGG_REDUCE_SUM 0  /* reference aggr_gcn.h:13-35; val == NULL means weight 1 */
+#define GNNAGG_REDUCE_MEAN 1 /* sum then / deg   (reference: caller passes val = 1/deg) */
+#define GNNAGG_REDUCE_MAX 2  /* max_e val*x, 0 for an empty row (no reference kernel) */
+
+/* run modes */
+#define GNNAGG_MODE_ROWS 0      /* `scheduled = 0`: one work item per CSR row, sequential FMA chain in CSR order */
+#define GNNAGG_MODE_SCHEDULED 1 /* `scheduled = 1`: work items = groups of the last schedule() call */
+#define GNNAGG_MODE_BALANCED 2  /* library-chosen chunking of long rows (gnnagg_schedule_balanced) */
+
+typedef int64_t gnnagg_handle; /* opaque; same width as the reference's `int64_t at` (kernel.cpp:15) */
+
+const char *gnnagg_last_error(void);
+int gnnagg_version(void);
+void gnnagg_set_abort_on_error(int on);
+
+/* ---------------------------------------------------------------------------------------------
+ * A. Flat API -- one-to-one with reference Figure7/kernel.cpp:15-35
+ * ------------------------------------------------------------------------------------------- */
+/* kernel.cpp:15 / kernel_generated.cu:15-19.  ptr[num_v+1], idx[num_e], val[num_e] on device,
+ * borrowed for the life of the handle (the reference's torch path never frees them either). */
+int64_t GCN_init_impl(int *ptr, int *idx, float *val, int num_v, int num_e);
+/* kernel.cpp:17 / kernel_generated.cu:21-24 (Aggregator_GCN::updateval, aggr_gcn.h:540-544) */
+void GCN_update_val_impl(int64_t at, float *val);
+/* kernel.cpp:19 / kernel_generated.cu:26-32 (run_with_feat, aggr_gcn.h:411-444).  `blocksize` is a
+ * CUDA block-geometry hint in the reference; accepted and ignored. */
+void GCN_run_impl(int64_t at, float *feat, float *out_feat, int blocksize, int scheduled, int featlen);
+/* kernel.cpp:21 / kernel_generated.cu:34-39: schedule(neighbor_grouping, arr), arr[0] = NG */
+void GCN_schedule_impl(int64_t at, int *arr);
+/* kernel.cpp:23 / kernel_generated.cu:41-45 */
+int64_t GAT_init_impl(int *ptr, int *idx, int num_v, int num_e);
+/* kernel.cpp:25 / kernel_generated.cu:47-50 (Aggregator_GAT::run_with_feat, aggr_gat.h:355-394);
+ * att is [V,2]; leaky slope 0.2 (aggr_gat.h:347) */
+void GAT_run_impl(int64_t at, float *feat, float *att, float *out_feat, int blocksize, int scheduled, int featlen);
+/* kernel.cpp:27-31 / kernel_generated.cu:52-65 (aggr_gat.h:402-425) */
+void GAT_run_u_add_v_impl(int64_t at, float *att, float *outval, int blocksize);
+void GAT_run_add_to_center_impl(int64_t at, float *inval, float *outatt, int blocksize);
+void GAT_run_div_each_impl(int64_t at, float *inatt, float *inoutval, int blocksize);
+/* kernel.cpp:35 / kernel_generated.cu:69-74 */
+void GAT_schedule_impl(int64_t at, int *arr);
+
+/* ---------------------------------------------------------------------------------------------
+ * B. Status-returning API (streams, reductions, heads, lifetime)
+ * ------------------------------------------------------------------------------------------- */
+/* Aggregator_GCN ctor, aggr_gcn.h:365-374.  d_val may be NULL (implicit weight 1). */
+int gnnagg_gcn_create(const int *d_ptr, const int *d_idx, const float *d_val, int num_v, int num_e,
+                      gnnagg_handle *out);
+/* Aggregator_GAT ctor, aggr_gat.h:302-313 */
+int gnnagg_gat_create(const int *d_ptr, const int *d_idx, int num_v, int num_e, gnnagg_handle *out);
+/* Frees what the handle allocated (schedules, scratch).  Never frees caller pointers. */
+int gnnagg_destroy(gnnagg_handle h);
+/* hipStream_t as void*; NULL = default stream.  Work of later calls is enqueued there. */
+int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
+int gnnagg_update_val(gnnagg_handle h, const float *d_val);
+
+/* Aggregator::schedule, aggregator.h:67-99 / Aggregator_GCN::schedule aggr_gcn.h:501-538.
+ * kind = GNNAGG_SCHED_*; param[0] = NG or par_num, param[1] = NG for the combined schedule.
+ * total_num_v: the reference reads the global `n` (aggregator.h:79); pass num_v for a full graph. */
+int gnnagg_schedule(gnnagg_handle h, int kind, const int *param, int total_num_v);
+/* Library-chosen chunking of long rows into work items of <= chunk edges (0 = choose from the
+ * degree distribution).  Used by GNNAGG_MODE_BALANCED. */
+int gnnagg_schedule_balanced(gnnagg_handle h, int chunk);
+/* Aggregator::num_target (aggregator.h:126), and the scheduled arrays copied to host buffers
+ * (any may be NULL): ptr_s[num_target+1], idx_s[ptr_s[num_target]], target[num_target], val_s. */
+int gnnagg_num_target(gnnagg_handle h, int mode, int *out);
+int gnnagg_get_schedule(gnnagg_handle h, int mode, int *h_ptr_s, int *h_idx_s, int *h_target, float *h_val_s);
+
+/* Aggregator_GCN::run / run_with_feat, aggr_gcn.h:379-444.  x,y are [V,feat] row-major fp32 on
+ * device.  mode = GNNAGG_MODE_*, reduce = GNNAGG_REDUCE_*.  y is fully overwritten. */
+int gnnagg_gcn_run(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce);
+/* Aggregator_GCN::runEdgeWise, aggr_gcn.h:446-460 (edge-parallel atomics; any feat). */
+int gnnagg_gcn_run_edgewise(gnnagg_handle h, const float *d_x, float *d_y, int feat);
+/* Aggregator::csr2edgelist, aggregator.h:115-122: d_edgelist[2E] = (src, dst) pairs */
+int gnnagg_csr2edgelist(gnnagg_handle h, int *d_edgelist);
+
+/* Aggregator_GAT::run / run_with_feat, aggr_gat.h:317-394.  att is [V,heads,2] (heads = 1 is the
+ * reference layout), x,y are [V,feat], feat % heads == 0.  d_newval (may be NULL) receives the
+ * un-normalised edge weights [E,heads] the reference's scheduled kernel materialises (:187). */
+int gnnagg_gat_run(gnnagg_handle h, const float *d_x, const float *d_att, float *d_y, int feat, int heads,
+                   float slope, int mode, float *d_newval);
+/* Aggregator_GAT::run_att, aggr_gat.h:395-401 (attGat :5-31): out_val[E,heads] = softmax weights */
+int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, int heads, float slope);
+/* aggr_gat.h:402-425, single head as in the reference */
+int gnnagg_gat_run_u_add_v(gnnagg_handle h, const float *d_att, float *d_out_val);
+int gnnagg_gat_run_add_to_center(gnnagg_handle h, const float *d_in_val, float *d_out_att);
+int gnnagg_gat_run_div_each(gnnagg_handle h, const float *d_in_att, float *d_inout_val);
+
+/* spmm<L>, spmm.h:223-265 (naive thread-per-row baseline; empty rows are left untouched) */
+int gnnagg_spmm_naive(const int *d_ptr, const int *d_idx, const float *d_val, const float *d_x, float *d_y,
+                      int num_v, int feat, void *hip_stream);
+/* valid(), spmm.h:35-69 (validate2 :11-21): number of elements with |(ref-ans)/ref| > 1e-2 */
+int gnnagg_validate(const float *d_ref, const float *d_ans, int num, int *h_diff, void *hip_stream);
+/* validReordered(), spmm.h:71-91 (validateReordered :23-33) */
+int gnnagg_validate_reordered(const float *d_ref, const float *d_ans, const int *d_map, int num_v, int feat,
+                              int *h_diff, void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * C. Host graph preparation (pure host code; usable without a GPU)
+ * ------------------------------------------------------------------------------------------- */
+/* load_graph, src/data.cu:31-139.  Reads <datadir><dset>.config/.graph (or the .ptrdump/.edgedump
+ * caches, which it also writes), applies <datadir><dset>.reorder<reorder_suffix> when shuffle != 0
+ * and the file exists.  Unlike the reference (data.cu:34 hard-codes "../data/") datadir is honoured.
+ * Outputs are malloc'ed; release with gnnagg_free_host.  rows / reverse_rows are NULL outputs when
+ * no reorder was applied. */
+int gnnagg_load_graph(const char *datadir, const char *dset, const char *reorder_suffix, int shuffle,
+                      int *num_v, int *num_e, int **h_ptr, int **h_idx, int **h_rows, int **h_reverse_rows);
+void gnnagg_free_host(void *p);
+/* reorderCSR, src/data.cu:4-29 */
+int gnnagg_reorder_csr(const int *h_ptr, const int *h_idx, const int *h_map, const int *h_reverse_map,
+                       int num_v, int num_e, int *h_newptr, int *h_newidx);
+/* neighbor_grouping_schedule, graph_schedule.h:91-126.  Outputs may be NULL to size first. */
+int gnnagg_neighbor_grouping_schedule(const int *h_ptr, int neighbor_num, int num_v, int *h_ptr_out,
+                                      int *h_target_out, int *num_groups);
+/* locality_schedule :17-63 (neighbor_num <= 0) / localityNeighborGrouping :156-211 */
+int gnnagg_locality_schedule(const int *h_ptr, const int *h_idx, const float *h_val, int par_num,
+                             int neighbor_num, int num_v, int total_num_v, int *h_ptr_out, int *h_idx_out,
+                             float *h_val_out, int *h_target_out, int *num_groups);
+
+/* ---------------------------------------------------------------------------------------------
+ * D. 1-D row partition + halo exchange support
+ * ------------------------------------------------------------------------------------------- */
+/* nnz-balanced contiguous row blocks: bounds[nparts+1], bounds[0]=0, bounds[nparts]=num_v. */
+int gnnagg_partition_rows(const int *h_ptr, int num_v, int nparts, int *h_bounds);
+/* For rank `rank` owning rows [bounds[rank], bounds[rank+1]): builds the local CSR whose column ids
+ * are local-X slots: owned columns -> col - bounds[rank]; remote columns -> n_local + halo slot,
+ * halo slots grouped by owner rank in ascending global id.  h_local_ptr[n_local+1] and
+ * h_local_idx[nnz_local] are caller-allocated; h_halo_ids (malloc'ed, gnnagg_free_host) lists the
+ * global ids of the halo slots; h_halo_counts[nparts] = halo ids owned by each rank. */
+int gnnagg_halo_plan(const int *h_ptr, const int *h_idx, int num_v, const int *h_bounds, int nparts, int rank,
+                     int *h_local_ptr, int *h_local_idx, int **h_halo_ids, int *h_halo_counts, int *num_halo);
+/* out[i,:] = x[ids[i],:] for i < n  (send-buffer pack before the all-to-all) */
+int gnnagg_pack_rows(const float *d_x, const int *d_ids, int n, int feat, float *d_out, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNAGG_H */

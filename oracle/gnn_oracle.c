@@ -1,0 +1,413 @@
+/*
+ * gnn_oracle.c -- CPU restatement of the reference's neighbor-aggregation hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The shipped path is the HIP library
+ * (gnn_computing_amd/libgnnagg.so); nothing in it calls into this file.
+ *
+ * Every function below restates one reference routine (xxcclong/GNN-Computing) and cites
+ * the file:line it follows.  Arithmetic is written the way the reference's device code
+ * evaluates it: fp32, one fused multiply-add per edge, accumulation in CSR order
+ * (nvcc --use_fast_math contracts `rs += a * b` into an FMA, CMakeLists.txt:40).
+ *
+ * PARITY PINNING: the reference ships no tests, golden vectors or CPU compute path
+ * (SURVEY.md section 4), and its host sources cannot be compiled in this image without
+ * stand-in CUDA headers (util.h:4-8 pulls cusparse/cublas/curand), which the build rules
+ * forbid.  The integer stages are pinned against the vectors SURVEY.md section 8c records
+ * from the reference's own host code (tests/golden/survey_8c.json) plus hand-derived
+ * known-answer graphs; the fp32 stages are pinned by hand-computed known answers only
+ * => fp32 parity is "unpinned against a reference run".
+ *
+ * Build: make -C oracle   (gcc -O3 -fopenmp -shared)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------
+ * Integer stages (bit-exact contract)
+ * ---------------------------------------------------------------------------------- */
+
+/* src/data.cu:4-29 reorderCSR: row i of the new graph is old row map[i]; neighbor ids are
+ * relabelled through reverse_map; order inside a row is preserved (no re-sort). */
+ORC_API void orc_reorder_csr(const int *ptr, const int *idx, const int *map, const int *reverse_map,
+                             int num_v, int num_e, int *newptr, int *newidx)
+{
+    (void)num_e;
+    newptr[0] = 0;
+    int begin = 0;
+    for (int i = 0; i < num_v; ++i) {
+        int range = ptr[map[i] + 1] - ptr[map[i]];
+        int base = ptr[map[i]];
+        for (int j = 0; j < range; ++j)
+            newidx[begin + j] = reverse_map[idx[base + j]];
+        begin += range;
+        newptr[i + 1] = begin;
+    }
+}
+
+/* src/data.cu:105-113: rows[i] = old id placed at new position i; reverse_rows[rows[i]] = i. */
+ORC_API void orc_reverse_map(const int *rows, int num_v, int *reverse_rows)
+{
+    for (int i = 0; i < num_v; ++i)
+        reverse_rows[rows[i]] = i;
+}
+
+/* include/graph_schedule.h:91-126 neighbor_grouping_schedule.  Returns the number of groups G;
+ * ptr_out has G+1 entries, target_out G.  Pass NULL outputs to only count.  idx_vec is a plain
+ * copy of idx in the reference (:121-122) so it is not materialised here. */
+ORC_API int orc_neighbor_grouping(const int *ptr, int neighbor_num, int num_v, int *ptr_out, int *target_out)
+{
+    int g = 0;
+    if (ptr_out) ptr_out[0] = 0;
+    for (int i = 0; i < num_v; ++i) {
+        int left = ptr[i];
+        while (ptr[i + 1] - left > neighbor_num) {
+            left += neighbor_num;
+            if (ptr_out) ptr_out[g + 1] = left;
+            if (target_out) target_out[g] = i;
+            ++g;
+        }
+        if (ptr[i + 1] != left) {
+            if (ptr_out) ptr_out[g + 1] = ptr[i + 1];
+            if (target_out) target_out[g] = i;
+            ++g;
+        }
+    }
+    return g;
+}
+
+/* include/graph_schedule.h:17-63 locality_schedule (neighbor_num <= 0) and
+ * include/graph_schedule.h:156-211 localityNeighborGrouping (neighbor_num > 0).
+ * Column range of partition p: [p*(total/par), p*(total/par)+total/par), last one extended to
+ * total.  Outputs sized by the caller: ptr_out <= E+1 (+1), idx_out/val_out E, target_out <= E.
+ * Returns G. */
+ORC_API int orc_locality_schedule(const int *ptr, const int *idx, const float *val, int par_num,
+                                  int neighbor_num, int num_v, int total_num_v, int *ptr_out,
+                                  int *idx_out, float *val_out, int *target_out)
+{
+    int g = 0, pos = 0;
+    ptr_out[0] = 0;
+    for (int par = 0; par < par_num; ++par) {
+        int llim = par * (total_num_v / par_num);
+        int ulim = llim + total_num_v / par_num;
+        if (par == par_num - 1) ulim = total_num_v;
+        for (int i = 0; i < num_v; ++i) {
+            int cnt = 0;
+            for (int j = ptr[i]; j < ptr[i + 1]; ++j) {
+                if (idx[j] >= llim && idx[j] < ulim) {
+                    cnt++;
+                    idx_out[pos] = idx[j];
+                    if (val && val_out) val_out[pos] = val[j];
+                    pos++;
+                    if (neighbor_num > 0 && cnt == neighbor_num) {
+                        ptr_out[g + 1] = ptr_out[g] + cnt;
+                        target_out[g] = i;
+                        ++g;
+                        cnt = 0;
+                    }
+                }
+            }
+            if (cnt != 0) {
+                ptr_out[g + 1] = ptr_out[g] + cnt;
+                target_out[g] = i;
+                ++g;
+            }
+        }
+    }
+    return g;
+}
+
+/* include/aggregator.h:11-23 convertCSRToEdgelist: edgelist[2e] = idx[e] (source),
+ * edgelist[2e+1] = row (destination). */
+ORC_API void orc_csr2edgelist(const int *ptr, const int *idx, int num_v, int *edgelist)
+{
+    for (int row = 0; row < num_v; ++row)
+        for (int i = ptr[row]; i < ptr[row + 1]; ++i) {
+            edgelist[i * 2] = idx[i];
+            edgelist[i * 2 + 1] = row;
+        }
+}
+
+/* Row degrees (ptr differences) -- what "mean" divides by; trivially bit-exact. */
+ORC_API void orc_degrees(const int *ptr, int num_v, int *deg)
+{
+    for (int i = 0; i < num_v; ++i) deg[i] = ptr[i + 1] - ptr[i];
+}
+
+/* ------------------------------------------------------------------------------------
+ * GCN / GraphSAGE aggregation  Y = A * X
+ * ---------------------------------------------------------------------------------- */
+
+/* include/aggr_gcn.h:13-35 aggr_gcn: per (row, col) one FMA per edge, CSR order, rs starts at
+ * 0.0f; Y[row,:] = 0 for an empty row.  val == NULL means an implicit weight of 1.0f ("sum",
+ * our.py:78 passes ones). */
+ORC_API void orc_gcn_seq(const int *ptr, const int *idx, const float *val, const float *X, float *Y,
+                         int num_v, int F)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int r = 0; r < num_v; ++r) {
+        float *y = Y + (size_t)r * F;
+        for (int c = 0; c < F; ++c) y[c] = 0.0f;
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e) {
+            const float *x = X + (size_t)idx[e] * F;
+            const float v = val ? val[e] : 1.0f;
+            for (int c = 0; c < F; ++c) y[c] = fmaf(x[c], v, y[c]);
+        }
+    }
+}
+
+/* include/aggr_gcn.h:86-112 aggr_gcn_target after cudaMemset(vout,0) (:393): each group's
+ * partial sum starts at 0.0f and runs over its <= NG edges in order; partials are then added
+ * into the zeroed output row.  The reference adds them with atomicAdd in arbitrary order; this
+ * restatement fixes the order to ascending group index (one of the reference's legal outcomes
+ * and the order the HIP path's deterministic combine uses). */
+ORC_API void orc_gcn_grouped(const int *ptr_s, const int *target, int num_groups, const int *idx,
+                             const float *val, const float *X, float *Y, int num_v, int F)
+{
+    memset(Y, 0, (size_t)num_v * F * sizeof(float));
+    float *rs = (float *)malloc((size_t)F * sizeof(float));
+    for (int g = 0; g < num_groups; ++g) {
+        for (int c = 0; c < F; ++c) rs[c] = 0.0f;
+        for (int e = ptr_s[g]; e < ptr_s[g + 1]; ++e) {
+            const float *x = X + (size_t)idx[e] * F;
+            const float v = val ? val[e] : 1.0f;
+            for (int c = 0; c < F; ++c) rs[c] = fmaf(x[c], v, rs[c]);
+        }
+        float *y = Y + (size_t)target[g] * F;
+        for (int c = 0; c < F; ++c) y[c] += rs[c];
+    }
+    free(rs);
+}
+
+/* "mean" and "max" reductions.  The reference has no kernels for them (mean is the
+ * caller passing val = 1/deg to aggr_gcn, max is absent), so these are specifications:
+ *   mean: chain of fmaf(x, v, rs) as orc_gcn_seq, then one IEEE division by (float)deg; 0 if empty.
+ *   max : max over edges of v*x (plain product, no fma), 0 for an empty row. */
+ORC_API void orc_gcn_mean(const int *ptr, const int *idx, const float *val, const float *X, float *Y,
+                          int num_v, int F)
+{
+    orc_gcn_seq(ptr, idx, val, X, Y, num_v, F);
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < num_v; ++r) {
+        int deg = ptr[r + 1] - ptr[r];
+        if (deg > 0) {
+            float d = (float)deg;
+            for (int c = 0; c < F; ++c) Y[(size_t)r * F + c] /= d;
+        }
+    }
+}
+
+ORC_API void orc_gcn_max(const int *ptr, const int *idx, const float *val, const float *X, float *Y,
+                         int num_v, int F)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int r = 0; r < num_v; ++r) {
+        float *y = Y + (size_t)r * F;
+        if (ptr[r] == ptr[r + 1]) {
+            for (int c = 0; c < F; ++c) y[c] = 0.0f;
+            continue;
+        }
+        for (int c = 0; c < F; ++c) y[c] = -INFINITY;
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e) {
+            const float *x = X + (size_t)idx[e] * F;
+            const float v = val ? val[e] : 1.0f;
+            for (int c = 0; c < F; ++c) {
+                float p = x[c] * v;
+                y[c] = p > y[c] ? p : y[c];
+            }
+        }
+    }
+}
+
+/* include/spmm.h:223-265 spmm<L>: thread-per-row; first edge is a plain product, the rest FMAs;
+ * an empty row RETURNS WITHOUT WRITING (:236-237) -- Y keeps its previous contents there. */
+ORC_API void orc_spmm_naive(const int *ptr, const int *idx, const float *val, const float *X, float *Y,
+                            int num_v, int F)
+{
+    for (int r = 0; r < num_v; ++r) {
+        int begin = ptr[r], end = ptr[r + 1];
+        if (begin == end) continue;
+        float *y = Y + (size_t)r * F;
+        const float *x0 = X + (size_t)idx[begin] * F;
+        for (int c = 0; c < F; ++c) y[c] = val[begin] * x0[c];
+        for (int e = begin + 1; e < end; ++e) {
+            const float *x = X + (size_t)idx[e] * F;
+            for (int c = 0; c < F; ++c) y[c] = fmaf(val[e], x[c], y[c]);
+        }
+    }
+}
+
+/* include/spmm.h:11-21 validate2: count of elements with |(ref-ans)/ref| > 1e-2. */
+ORC_API int orc_validate2(const float *ref, const float *ans, int num)
+{
+    int diff = 0;
+    for (int i = 0; i < num; ++i)
+        if (fabsf((ref[i] - ans[i]) / ref[i]) > 1e-2f) ++diff;
+    return diff;
+}
+
+/* include/spmm.h:23-33 validateReordered: ref row r is compared with ans row map[r], abs 1e-2. */
+ORC_API int orc_validate_reordered(const float *ref, const float *ans, const int *map, int num_v, int F)
+{
+    int diff = 0;
+    for (int t = 0; t < num_v * F; ++t)
+        if (fabsf(ref[t] - ans[(size_t)map[t / F] * F + t % F]) > 1e-2f) ++diff;
+    return diff;
+}
+
+/* ------------------------------------------------------------------------------------
+ * GAT: edge softmax (rank-1 SDDMM) + weighted SpMM
+ *   att is [V, H, 2] row-major: [.,h,0] = destination/centre term, [.,h,1] = source term
+ *   (H = 1 is the reference layout [V,2], aggr_gat.h:125,138).  X, Y are [V, H*D].
+ * ---------------------------------------------------------------------------------- */
+
+static inline float orc_edge_score(float a_dst, float a_src, float slope)
+{
+    /* include/aggr_gat.h:138-143: s = a_dst + a_src; w = exp(max(s, s*slope)) */
+    float s = a_dst + a_src;
+    float l = s * slope;
+    return expf(s > l ? s : l);
+}
+
+/* include/aggr_gat.h:116-164 aggr_gat (fused, unscheduled): numerator chain of FMAs and
+ * denominator chain of adds in CSR order, one division at the end.  The reference divides 0/0
+ * for an empty row (NaN, :163); the build defines empty rows as 0 (SURVEY.md 8a semantics). */
+ORC_API void orc_gat_fused(const int *ptr, const int *idx, const float *att, const float *X, float *Y,
+                           int num_v, int H, int D, float slope)
+{
+    const int F = H * D;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int r = 0; r < num_v; ++r) {
+        float *y = Y + (size_t)r * F;
+        for (int c = 0; c < F; ++c) y[c] = 0.0f;
+        if (ptr[r] == ptr[r + 1]) continue;
+        for (int h = 0; h < H; ++h) {
+            const float a_dst = att[((size_t)r * H + h) * 2];
+            float den = 0.0f;
+            for (int e = ptr[r]; e < ptr[r + 1]; ++e) {
+                const int s = idx[e];
+                const float w = orc_edge_score(a_dst, att[((size_t)s * H + h) * 2 + 1], slope);
+                const float *x = X + (size_t)s * F + (size_t)h * D;
+                for (int c = 0; c < D; ++c) y[h * D + c] = fmaf(x[c], w, y[h * D + c]);
+                den += w;
+            }
+            for (int c = 0; c < D; ++c) y[h * D + c] /= den;
+        }
+    }
+}
+
+/* include/aggr_gat.h:5-31 attGat ("adapter"): newval[e] = w_e / sum_row(w).  The reference sums
+ * lane-strided partials through a shuffle tree; the row sum here is the plain CSR-order chain
+ * (all terms positive, so any order agrees to ~deg*2^-24 relative).  newval is [E, H]. */
+ORC_API void orc_gat_att(const int *ptr, const int *idx, const float *att, float *newval, int num_v,
+                         int H, float slope)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int r = 0; r < num_v; ++r)
+        for (int h = 0; h < H; ++h) {
+            const float a_dst = att[((size_t)r * H + h) * 2];
+            float sum = 0.0f;
+            for (int e = ptr[r]; e < ptr[r + 1]; ++e) {
+                float w = orc_edge_score(a_dst, att[((size_t)idx[e] * H + h) * 2 + 1], slope);
+                newval[(size_t)e * H + h] = w;
+                sum += w;
+            }
+            for (int e = ptr[r]; e < ptr[r + 1]; ++e) newval[(size_t)e * H + h] /= sum;
+        }
+}
+
+/* include/aggr_gat.h:33-48 u_add_v: newval[e] = att[row,0] + att[idx[e],1]  (single head). */
+ORC_API void orc_gat_u_add_v(const int *ptr, const int *idx, const float *att, float *newval, int num_v)
+{
+    for (int r = 0; r < num_v; ++r)
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e)
+            newval[e] = att[(size_t)r * 2] + att[(size_t)idx[e] * 2 + 1];
+}
+
+/* include/aggr_gat.h:50-74 add_to_center: out[row] = sum_row newval (stride-1 output, :71). */
+ORC_API void orc_gat_add_to_center(const int *ptr, const float *newval, float *out, int num_v)
+{
+    for (int r = 0; r < num_v; ++r) {
+        float s = 0.0f;
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e) s += newval[e];
+        out[r] = s;
+    }
+}
+
+/* include/aggr_gat.h:76-92 each_div: newval[e] /= in[row]. */
+ORC_API void orc_gat_div_each(const int *ptr, const float *in, float *newval, int num_v)
+{
+    for (int r = 0; r < num_v; ++r)
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e) newval[e] /= in[r];
+}
+
+/* include/aggr_gat.h:167-213 aggr_gat_fine + scaleArray (neighbor-grouped): per group the
+ * numerator partial (FMA chain from 0) and denominator partial (add chain from 0) are added into
+ * zeroed Y / scalar; newval[e] = w_e (un-normalised, :186-187); then Y[r,:] /= scalar[r] where
+ * scalar != 0.  The reference never re-zeroes Y/scalar between calls (:305,:333) -- the build zeroes
+ * them on every call, and so does this restatement.  Partials are combined in ascending group order. */
+ORC_API void orc_gat_grouped(const int *ptr_s, const int *target, int num_groups, const int *idx,
+                             const float *att, const float *X, float *Y, float *newval, float *scalar,
+                             int num_v, int H, int D, float slope)
+{
+    const int F = H * D;
+    memset(Y, 0, (size_t)num_v * F * sizeof(float));
+    memset(scalar, 0, (size_t)num_v * H * sizeof(float));
+    float *rs = (float *)malloc((size_t)F * sizeof(float));
+    for (int g = 0; g < num_groups; ++g) {
+        const int r = target[g];
+        for (int h = 0; h < H; ++h) {
+            const float a_dst = att[((size_t)r * H + h) * 2];
+            float den = 0.0f;
+            for (int c = 0; c < D; ++c) rs[c] = 0.0f;
+            for (int e = ptr_s[g]; e < ptr_s[g + 1]; ++e) {
+                const int s = idx[e];
+                const float w = orc_edge_score(a_dst, att[((size_t)s * H + h) * 2 + 1], slope);
+                if (newval) newval[(size_t)e * H + h] = w;
+                const float *x = X + (size_t)s * F + (size_t)h * D;
+                for (int c = 0; c < D; ++c) rs[c] = fmaf(x[c], w, rs[c]);
+                den += w;
+            }
+            for (int c = 0; c < D; ++c) Y[(size_t)r * F + h * D + c] += rs[c];
+            scalar[(size_t)r * H + h] += den;
+        }
+    }
+    for (int r = 0; r < num_v; ++r)
+        for (int h = 0; h < H; ++h) {
+            float d = scalar[(size_t)r * H + h];
+            if (d != 0.0f)
+                for (int c = 0; c < D; ++c) Y[(size_t)r * F + h * D + c] /= d;
+        }
+    free(rs);
+}
+
+/* Per-element magnitude sum  S[r,c] = sum_e |val_e * x_e,c|  -- the condition-aware error scale
+ * of SURVEY.md 8c ("|y - y^| <= 1e-5 * sum_e |val_e x_e|"); double accumulation. */
+ORC_API void orc_gcn_abs_scale(const int *ptr, const int *idx, const float *val, const float *X, float *S,
+                               int num_v, int F)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int r = 0; r < num_v; ++r)
+        for (int c = 0; c < F; ++c) {
+            double s = 0.0;
+            for (int e = ptr[r]; e < ptr[r + 1]; ++e)
+                s += fabs((double)(val ? val[e] : 1.0f) * (double)X[(size_t)idx[e] * F + c]);
+            S[(size_t)r * F + c] = (float)s;
+        }
+}

@@ -1,0 +1,395 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libgnnagg.so) against the CPU oracle.
+
+Bar (north_star): bit-exact for index/degree work; fp32 aggregation within 1e-5 relative, stated as
+the condition-aware bound |y - y_ref| <= 1e-5 * sum_e |val_e * x_e| -- and in fact
+bit-exact wherever the kernel keeps the oracle's summation order, which these tests assert.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import gnn_computing_amd as gnc
+from gnn_computing_amd import _lib
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+RTOL = 1e-5
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def make_graph(V, E, seed, sorted_rows=False):
+    ptr, idx = gnc.graph.uniform_random_csr(V, E, seed)
+    if sorted_rows:
+        for r in range(V):
+            idx[ptr[r]:ptr[r + 1]].sort()
+    return ptr, idx
+
+
+def rand(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+def assert_within(y, ref, scale, what):
+    """|y - ref| <= RTOL * scale elementwise, scale = sum_e |val_e x_e| (plus a floor of one ulp of it)."""
+    err = np.abs(y.astype(np.float64) - ref.astype(np.float64))
+    bound = RTOL * scale.astype(np.float64) + 1e-30
+    bad = err > bound
+    assert not bad.any(), "%s: %d elements outside 1e-5*sum|v x| (worst ratio %.3g)" % (
+        what, int(bad.sum()), float((err / bound).max()))
+
+
+CASES = [  # (V, E, F)
+    (1, 0, 4), (1, 3, 128), (7, 0, 32), (50, 400, 1), (50, 400, 3), (64, 900, 32), (200, 3000, 64),
+    (300, 5000, 100), (257, 4000, 128), (129, 3000, 256), (90, 2500, 602), (40, 800, 1024),
+]
+
+
+@pytest.mark.parametrize("V,E,F", CASES)
+@pytest.mark.parametrize("with_val", [True, False])
+def test_gcn_rows_bit_exact(V, E, F, with_val):
+    ptr, idx = make_graph(V, E, seed=V * 7 + F)
+    x, val = rand((V, F), 1), (rand(E, 2) if with_val else None)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if val is None else dev(val), F, F)
+    y = torch.full((V, F), 7.0, device=DEV)  # poison: every element must be overwritten
+    agg.run(dev(x), y, 512, 0)
+    ref = orc.gcn_seq(ptr, idx, val, x)
+    assert np.array_equal(y.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("V,E,F", [(64, 900, 32), (257, 6000, 128), (300, 5000, 100), (90, 2500, 602)])
+@pytest.mark.parametrize("ng", [1, 2, 16, 32])
+def test_gcn_neighbor_grouping_bit_exact(V, E, F, ng):
+    ptr, idx = make_graph(V, E, seed=V + ng)
+    x, val = rand((V, F), 3), rand(E, 4)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.schedule(gnc.Schedule.neighbor_grouping, [ng])
+    ps_ref, tg_ref = orc.neighbor_grouping(ptr, ng)
+    ps, ix, tg = agg.get_schedule("scheduled")
+    assert agg.num_target == len(tg_ref)
+    assert np.array_equal(ps, ps_ref) and np.array_equal(tg, tg_ref) and np.array_equal(ix, idx)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), y, 512, 1)
+    ref = orc.gcn_grouped(ps_ref, tg_ref, idx, val, x, V)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    # and against the canonical CSR-order chain within the fp32 bound
+    assert_within(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x), "NG vs CSR order")
+
+
+@pytest.mark.parametrize("kind,param", [("locality", [3]), ("locality_neighbor_grouping", [3, 4]),
+                                        ("locality", [1]), ("locality_neighbor_grouping", [7, 1])])
+def test_gcn_locality_schedules(kind, param):
+    V, E, F = 150, 2500, 64
+    ptr, idx = make_graph(V, E, seed=11)
+    x, val = rand((V, F), 5), rand(E, 6)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.schedule(gnc.Schedule[kind], param)
+    ng = param[1] if len(param) > 1 else 0
+    ps_ref, ix_ref, tg_ref, vs_ref = orc.locality_schedule(ptr, idx, param[0], V, ng, val)
+    ps, ix, tg, vs = agg.get_schedule("scheduled", with_val=True)
+    assert np.array_equal(ps, ps_ref) and np.array_equal(ix, ix_ref) and np.array_equal(tg, tg_ref)
+    assert np.array_equal(vs, vs_ref)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), y, 512, 1)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps_ref, tg_ref, ix_ref, vs_ref, x, V))
+
+
+@pytest.mark.parametrize("F", [32, 128, 100])
+def test_gcn_balanced_mode(F):
+    V, E = 400, 30000  # average degree 75 -> several chunks per row
+    ptr, idx = make_graph(V, E, seed=21)
+    x, val = rand((V, F), 7), rand(E, 8)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), y, 512, "balanced")
+    ps, ix, tg = agg.get_schedule("balanced")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+    assert_within(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x), "balanced")
+    agg.schedule_balanced(8)
+    agg.run(dev(x), y, 512, "balanced")
+    ps, ix, tg = agg.get_schedule("balanced")
+    assert np.array_equal(ps, orc.neighbor_grouping(ptr, 8)[0])
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+
+
+@pytest.mark.parametrize("mode", ["rows", "scheduled"])
+@pytest.mark.parametrize("F", [32, 128, 602])
+def test_gcn_mean_max(mode, F):
+    V, E = 120, 3000
+    ptr, idx = make_graph(V, E, seed=31)
+    x, val = rand((V, F), 9), rand(E, 10)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.schedule(gnc.Schedule.neighbor_grouping, [4])
+    y = torch.full((V, F), 7.0, device=DEV)
+    sched = mode == "scheduled"
+    agg.run(dev(x), y, 512, sched, reduce="max")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))  # max is order-independent
+    agg.run(dev(x), y, 512, sched, reduce="mean")
+    ref = orc.gcn_mean(ptr, idx, val, x)
+    if not sched:
+        assert np.array_equal(y.cpu().numpy(), ref)
+    else:
+        deg = np.maximum(orc.degrees(ptr), 1)[:, None].astype(np.float32)
+        assert_within(y.cpu().numpy(), ref, orc.gcn_abs_scale(ptr, idx, val, x) / deg, "mean scheduled")
+    # implicit weights (GraphSAGE mean: val = None)
+    agg2 = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, F, F)
+    agg2.run(dev(x), y, 512, 0, reduce="mean")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_mean(ptr, idx, None, x))
+
+
+def test_gcn_update_val_aliases():
+    V, E, F = 100, 1500, 64
+    ptr, idx = make_graph(V, E, seed=41)
+    x, v1, v2 = rand((V, F), 1), rand(E, 2), rand(E, 3)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(v1), F, F)
+    agg.schedule(gnc.Schedule.neighbor_grouping, [16])
+    agg.updateval(dev(v2))  # aggr_gcn.h:540-544: both the CSR and the scheduled val follow
+    y = torch.empty((V, F), device=DEV)
+    agg.run(dev(x), y, 128, 0)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, v2, x))
+    agg.run(dev(x), y, 128, 1)
+    ps, tg = orc.neighbor_grouping(ptr, 16)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, v2, x, V))
+
+
+def test_csr2edgelist_and_edgewise():
+    V, E, F = 130, 2000, 48
+    ptr, idx = make_graph(V, E, seed=51)
+    x, val = rand((V, F), 1), rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    assert np.array_equal(agg.csr2edgelist().cpu().numpy(), orc.csr2edgelist(ptr, idx))
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.runEdgeWise(dev(x), y)
+    # one product per edge added atomically in arbitrary order: fp32 bound only
+    assert_within(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x), "edgewise")
+
+
+def test_spmm_naive_and_validators():
+    V, E, F = 140, 2200, 40
+    ptr, idx = make_graph(V, E, seed=61)
+    x, val = rand((V, F), 1), rand(E, 2)
+    y0 = rand((V, F), 3)
+    y = dev(y0)
+    L = gnc.lib()
+    dptr, didx, dval, dx = dev(ptr), dev(idx), dev(val), dev(x)
+    _lib.check(L.gnnagg_spmm_naive(dptr.data_ptr(), didx.data_ptr(), dval.data_ptr(), dx.data_ptr(), y.data_ptr(), V, F,
+                                   None))
+    torch.cuda.synchronize()
+    ref = orc.spmm_naive(ptr, idx, val, x, y0)  # empty rows keep y0 (spmm.h:236-237)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    # validators: perturb some elements
+    ans = ref.copy()
+    ans[::7, ::5] *= 1.05
+    n = ctypes.c_int(-1)
+    _lib.check(L.gnnagg_validate(dev(ref).data_ptr(), dev(ans).data_ptr(), ref.size, ctypes.byref(n), None))
+    assert n.value == orc.validate2(ref, ans)
+    rows = np.random.default_rng(5).permutation(V).astype(np.int32)
+    ans_perm = np.empty_like(ref)
+    ans_perm[rows] = ref  # ans[map[r]] = ref[r]
+    ans_perm[3] += 1.0
+    _lib.check(L.gnnagg_validate_reordered(dev(ref).data_ptr(), dev(ans_perm).data_ptr(), dev(rows).data_ptr(), V, F,
+                                           ctypes.byref(n), None))
+    assert n.value == orc.validate_reordered(ref, ans_perm, rows) == F
+
+
+# ------------------------------------------------------------------------------------- GAT
+def gat_scale(ptr, idx, att, x, heads, slope=0.2):
+    """sum_e w_e |x_e| / sum_e w_e : the error scale of the normalised output."""
+    w = orc.gat_att(ptr, idx, att, heads, slope)  # normalised weights [E,H]
+    D = x.shape[1] // heads
+    s = np.zeros((len(ptr) - 1, x.shape[1]))
+    for r in range(len(ptr) - 1):
+        for e in range(ptr[r], ptr[r + 1]):
+            s[r] += np.repeat(w[e], D) * np.abs(x[idx[e]])
+    return s.astype(np.float32)
+
+
+@pytest.mark.parametrize("V,E,F,H", [(60, 700, 32, 1), (150, 2500, 128, 1), (80, 1500, 256, 8), (70, 900, 96, 4),
+                                     (50, 600, 30, 3), (9, 0, 32, 1)])
+def test_gat_fused_rows(V, E, F, H):
+    ptr, idx = make_graph(V, E, seed=71 + F)
+    x, att = rand((V, F), 1), rand((V, H, 2), 2)
+    agg = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), dev(att), y, 128, 0, heads=H)
+    ref = orc.gat_fused(ptr, idx, att, x, H)
+    # expf on device vs libm: a few ulp on each w_e -> relative 1e-5 of the weighted magnitude
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "gat fused")
+    assert np.all(y.cpu().numpy()[orc.degrees(ptr) == 0] == 0)  # empty rows -> 0, not NaN
+
+
+@pytest.mark.parametrize("F,H,ng", [(32, 1, 32), (128, 1, 16), (256, 8, 32), (64, 2, 3)])
+def test_gat_scheduled(F, H, ng):
+    V, E = 120, 4000
+    ptr, idx = make_graph(V, E, seed=81)
+    x, att = rand((V, F), 1), rand((V, H, 2), 2)
+    agg = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    agg.schedule(gnc.Schedule.neighbor_grouping, [ng])
+    y = torch.full((V, F), 7.0, device=DEV)
+    newval = torch.full((E, H), 7.0, device=DEV)
+    agg.run(dev(x), dev(att), y, 128, 1, heads=H, newval=newval)
+    ps, tg = orc.neighbor_grouping(ptr, ng)
+    ref, ref_newval, _ = orc.gat_grouped(ps, tg, idx, att, x, V, H)
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "gat scheduled")
+    np.testing.assert_allclose(newval.cpu().numpy(), ref_newval, rtol=1e-6)
+    # the fused result agrees with the unscheduled one (same math, different association)
+    y2 = torch.empty_like(y)
+    agg.run(dev(x), dev(att), y2, 128, 0, heads=H)
+    assert_within(y.cpu().numpy(), y2.cpu().numpy(), gat_scale(ptr, idx, att, x, H) + np.abs(ref), "gat sched vs rows")
+
+
+@pytest.mark.parametrize("H", [1, 8])
+def test_gat_adapter_and_three_step(H):
+    V, E, F = 140, 2600, 32 * H
+    ptr, idx = make_graph(V, E, seed=91)
+    x, att = rand((V, F), 1), rand((V, H, 2), 2)
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    out_val = torch.full((E, H), 7.0, device=DEV)
+    gat.run_att(dev(att), out_val, 128, heads=H)
+    np.testing.assert_allclose(out_val.cpu().numpy(), orc.gat_att(ptr, idx, att, H), rtol=RTOL)
+    if H == 1:
+        # adapter path of Figure10/main_a.cu:98-100: run_att -> updateval -> gcn.run == fused gat.run
+        gcn = gnc.Aggregator_GCN(dev(ptr), dev(idx), out_val.view(-1), F, F)
+        y = torch.empty((V, F), device=DEV)
+        gcn.run(dev(x), y, 128, 0)
+        ref = orc.gat_fused(ptr, idx, att, x, 1)
+        assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "adapter")
+        # 3-step baseline (aggr_gat.h:33-92): u_add_v, caller-side exp(leaky_relu), add_to_center, div_each
+        v = torch.empty(E, device=DEV)
+        gat.run_u_add_v(dev(att), v)
+        assert np.array_equal(v.cpu().numpy(), orc.gat_u_add_v(ptr, idx, att))
+        v = torch.exp(torch.nn.functional.leaky_relu(v, 0.2))
+        center = torch.full((V,), 7.0, device=DEV)
+        gat.run_add_to_center(v, center)
+        np.testing.assert_allclose(center.cpu().numpy(), orc.gat_add_to_center(ptr, v.cpu().numpy()), rtol=RTOL)
+        vh = v.cpu().numpy()
+        gat.run_div_each(center, v)
+        assert np.array_equal(v.cpu().numpy(), orc.gat_div_each(ptr, center.cpu().numpy(), vh))
+
+
+# ------------------------------------------------------------------------- boundary behaviour
+def test_error_behaviour():
+    V, E, F = 20, 100, 32
+    ptr, idx = make_graph(V, E, seed=5)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, F, F)
+    x, y = dev(rand((V, F), 1)), torch.empty((V, F), device=DEV)
+    with pytest.raises(gnc.GnnAggError) as ei:
+        agg.run(x, y, 512, 1)  # scheduled run without schedule(): reference asserts (aggr_gcn.h:392)
+    assert ei.value.code == _lib.ERR_STATE
+    with pytest.raises(gnc.GnnAggError):
+        agg.schedule(gnc.Schedule.neighbor_grouping, [0])
+    with pytest.raises(ValueError):
+        agg.run(x.cpu(), y, 512, 0)
+    h = agg._h.value
+    agg.close()
+    assert gnc.lib().gnnagg_destroy(ctypes.c_int64(h)) == _lib.ERR_ARG  # double destroy is caught
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    with pytest.raises(gnc.GnnAggError):
+        gat.run(x, dev(rand((V, 2), 2)), y, 128, 0, heads=3)  # 32 % 3 != 0
+
+
+def test_flat_reference_api():
+    """The Section-A entry points (reference Figure7/kernel.cpp:15-35), called the way the reference's
+    kernel.cpp wrappers call them: raw device pointers + sizes."""
+    V, E, F = 90, 1400, 128
+    ptr, idx = make_graph(V, E, seed=15)
+    x, val, att = rand((V, F), 1), np.ones(E, np.float32), rand((V, 2), 3)
+    dptr, didx, dval, dx, datt = dev(ptr), dev(idx), dev(val), dev(x), dev(att)
+    y = torch.full((V, F), 7.0, device=DEV)
+    L = gnc.lib()
+    at = L.GCN_init_impl(dptr.data_ptr(), didx.data_ptr(), dval.data_ptr(), V, E)
+    assert at != 0
+    arr = (ctypes.c_int * 1)(32)
+    L.GCN_schedule_impl(at, arr)
+    L.GCN_run_impl(at, dx.data_ptr(), y.data_ptr(), 128, 1, F)
+    torch.cuda.synchronize()
+    ps, tg = orc.neighbor_grouping(ptr, 32)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+    L.GCN_run_impl(at, dx.data_ptr(), y.data_ptr(), 128, 0, F)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x))
+    v2 = dev(rand(E, 9))
+    L.GCN_update_val_impl(at, v2.data_ptr())
+    L.GCN_run_impl(at, dx.data_ptr(), y.data_ptr(), 128, 0, F)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, v2.cpu().numpy(), x))
+    g = L.GAT_init_impl(dptr.data_ptr(), didx.data_ptr(), V, E)
+    L.GAT_schedule_impl(g, arr)
+    for sched in (0, 1):
+        L.GAT_run_impl(g, dx.data_ptr(), datt.data_ptr(), y.data_ptr(), 128, sched, F)
+        torch.cuda.synchronize()
+        ref = orc.gat_fused(ptr, idx, att, x, 1)
+        assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "flat gat")
+    ev = torch.empty(E, device=DEV)
+    L.GAT_run_u_add_v_impl(g, datt.data_ptr(), ev.data_ptr(), 128)
+    torch.cuda.synchronize()
+    assert np.array_equal(ev.cpu().numpy(), orc.gat_u_add_v(ptr, idx, att))
+    assert L.gnnagg_destroy(at) == 0 and L.gnnagg_destroy(g) == 0
+
+
+def test_stream_is_honoured():
+    V, E, F = 300, 6000, 128
+    ptr, idx = make_graph(V, E, seed=25)
+    x = rand((V, F), 1)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, F, F)
+    dx, y = dev(x), torch.empty((V, F), device=DEV)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        agg.run(dx, y, 512, 0)
+    s.synchronize()
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, None, x))
+
+
+def test_pack_rows():
+    n, V, F = 77, 200, 100
+    x = rand((V, F), 1)
+    ids = np.random.default_rng(3).integers(0, V, n).astype(np.int32)
+    out = torch.empty((n, F), device=DEV)
+    _lib.check(gnc.lib().gnnagg_pack_rows(dev(x).data_ptr(), dev(ids).data_ptr(), n, F, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), x[ids])
+
+
+# --------------------------------------------------------------------------- full-size checks
+def test_arxiv_full_size_parity_and_properties():
+    """BASELINE configs[1]: arxiv-shaped CSR (169 343 x 1 166 243), GCN sum, F=128.  The oracle finishes
+    this size in well under a second, so parity is checked directly, plus size-independent properties."""
+    ptr_t, idx_t = gnc.graph.dataset("arxiv")
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    V, E, F = len(ptr) - 1, len(idx), 128
+    assert (V, E) == gnc.graph.SHAPES["arxiv"]
+    x, val = rand((V, F), 123), np.ones(E, np.float32)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    dx, y = dev(x), torch.empty((V, F), device=DEV)
+    agg.run(dx, y, 512, 0)
+    ref = orc.gcn_seq(ptr, idx, val, x)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    agg.run(dx, y, 512, "balanced")
+    ps, ix, tg = agg.get_schedule("balanced")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+    assert_within(y.cpu().numpy(), ref, orc.gcn_abs_scale(ptr, idx, val, x), "arxiv balanced")
+    # degree property: X = ones -> every column equals the in-degree (exact in fp32 below 2^24)
+    ones = torch.ones((V, F), device=DEV)
+    agg.run(ones, y, 512, "balanced")
+    assert np.array_equal(y.cpu().numpy()[:, 0], orc.degrees(ptr).astype(np.float32))
+    assert float(y.sum().item()) == float(E) * F
+    # reorder invariance: permuting the graph permutes the output rows (validReordered's contract)
+    rows = np.random.default_rng(7).permutation(V).astype(np.int32)
+    nptr, nidx, rev = gnc.reorder_csr(ptr, idx, rows)
+    agg2 = gnc.Aggregator_GCN(dev(nptr), dev(nidx), dev(val), F, F)
+    y2 = torch.empty((V, F), device=DEV)
+    agg2.run(dev(x[rows]), y2, 512, 0)
+    n = ctypes.c_int(-1)
+    agg.run(dx, y, 512, 0)
+    # y (old order) row r must equal y2 row reverse_rows[r]
+    _lib.check(gnc.lib().gnnagg_validate_reordered(y.data_ptr(), y2.data_ptr(), dev(rev).data_ptr(), V, F,
+                                                   ctypes.byref(n), None))
+    assert n.value == 0
+    assert np.array_equal(y2.cpu().numpy()[rev], y.cpu().numpy())
