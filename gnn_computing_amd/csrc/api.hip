@@ -74,6 +74,7 @@ struct Schedule {
     DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s;
     DevBuf<float> val_s;
     int n_empty = 0, n_mrows = 0, n_slots = 0;
+    std::vector<long> cost_prefix;  // per work item (groups then empty-row items), for the XCD ranges
 
     void reset()
     {
@@ -94,6 +95,8 @@ struct Schedule {
     }
 };
 
+static constexpr int kItemCost = 2;  // fixed per-item overhead in edge-equivalents (XCD range balancing)
+
 struct Ctx {
     enum Kind { GCN, GAT } kind;
     int V = 0, E = 0;
@@ -106,8 +109,10 @@ struct Ctx {
     DevBuf<float> partial, partial_den;
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
     DevBuf<int> diffbuf;
-    int xcd_remap = 1;
+    int xcd_remap = 2;
     int variant = 0;
+    int idxmode = 0;
+    std::vector<long> row_cost_prefix;  // MODE_ROWS work items
     int avg_deg() const { return V > 0 ? (int)((long)E / V) : 0; }
 };
 
@@ -160,6 +165,9 @@ static int finalize_schedule(Ctx *c, Schedule &s)
     s.n_empty = (int)empty.size();
     s.n_mrows = (int)mrow_id.size();
     s.n_slots = nslots;
+    s.cost_prefix.assign((size_t)G + empty.size() + 1, 0);
+    for (int g = 0; g < G; ++g) s.cost_prefix[g + 1] = s.cost_prefix[g] + (s.h_ptr_s[g + 1] - s.h_ptr_s[g]) + kItemCost;
+    for (size_t k = 0; k < empty.size(); ++k) s.cost_prefix[G + k + 1] = s.cost_prefix[G + k] + 1;
     int rc;
     if ((rc = s.ptr_s.upload(s.h_ptr_s))) return rc;
     if ((rc = s.target.upload(s.h_target))) return rc;
@@ -259,13 +267,22 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     if (rc) return rc;
     GcnLaunch L;
     L.row_ptr = c->d_ptr; L.x = x; L.y = y; L.feat = feat; L.reduce = reduce;
-    L.xcd_remap = c->xcd_remap; L.variant = c->variant;
+    L.xcd_remap = c->xcd_remap; L.variant = c->variant; L.idxmode = c->idxmode;
     if (!s) {
         L.wl.ptr = c->d_ptr;
         L.wl.n_items = c->V;
         L.idx = c->d_idx;
         L.val = c->d_val;
+        if (c->xcd_remap == 2) {
+            if (c->row_cost_prefix.empty()) {
+                if ((rc = fetch_host_ptr(c))) return rc;
+                c->row_cost_prefix.resize((size_t)c->V + 1);
+                for (int r = 0; r <= c->V; ++r) c->row_cost_prefix[r] = (long)c->h_ptr[r] + (long)kItemCost * r;
+            }
+            L.xcd_item_cost_prefix = c->row_cost_prefix.data();
+        }
     } else {
+        L.xcd_item_cost_prefix = s->cost_prefix.data();
         L.wl = s->worklist();
         L.idx = s->permuted ? s->idx_s.p : c->d_idx;
         L.val = s->permuted ? s->val_s.p : c->d_val;
@@ -366,6 +383,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     c->kind = kind; c->V = V; c->E = E; c->d_ptr = d_ptr; c->d_idx = d_idx; c->d_val = d_val;
     if (const char *e = getenv("GNNAGG_XCD_REMAP")) c->xcd_remap = atoi(e);
     if (const char *e = getenv("GNNAGG_VARIANT")) c->variant = atoi(e);
+    if (const char *e = getenv("GNNAGG_IDXMODE")) c->idxmode = atoi(e);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);

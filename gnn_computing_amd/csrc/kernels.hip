@@ -20,6 +20,7 @@
 //    block are adjacent in the remapped block order so they hit the same DRAM pages / L2 lines.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 
 #include "common.h"
@@ -79,6 +80,26 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// Work-balanced XCD ranges: XCD x owns item blocks [first[x], first[x] + count[x]); ranges are cut so
+// that every XCD gets about the same number of edges (not the same number of blocks): a locality
+// reorder clusters the hub rows, and equal-count ranges would pile them onto one XCD.
+struct XcdRanges {
+    int first[8];
+    int count[8];
+};
+
+// remap == 0: identity.  remap == 1: equal-count contiguous ranges.  remap == 2: XcdRanges.
+// Returns the logical (item block * ntiles + tile) index, or -1 when this workgroup has no work.
+__device__ __forceinline__ int logical_block(int b, int nblocks, int ntiles, int remap, const XcdRanges &xr)
+{
+    if (remap == 0) return b;
+    if (remap == 1) return xcd_remap(b, nblocks);
+    const int xcd = b & 7, k = b >> 3;
+    const int ib = k / ntiles;
+    if (ib >= xr.count[xcd]) return -1;
+    return (xr.first[xcd] + ib) * ntiles + (k - ib * ntiles);
+}
+
 struct GcnArgs {
     const int *ptr, *target, *slot, *empty_rows;
     const int *row_ptr;
@@ -88,26 +109,31 @@ struct GcnArgs {
     float *y;
     float *partial;
     int n_items, n_total, feat, ntiles, nblocks, mean, remap;
+    XcdRanges xr;
 };
 
 // ------------------------------------------------------------------------- GCN / SAGE items
 // LIST = false: item g is CSR row g (reference aggr_gcn, aggr_gcn.h:5-36).
 // LIST = true : item g is a group of the schedule (reference aggr_gcn_target, aggr_gcn.h:78-114).
-template <int VEC, int GROUP, bool IS_MAX, bool LIST>
+template <int VEC, int GROUP, bool IS_MAX, bool LIST, int IDXMODE>
 __global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
 {
     constexpr int ITEMS = kBlock / GROUP;
-    const int b = a.remap ? xcd_remap(blockIdx.x, a.nblocks) : (int)blockIdx.x;
+    const int b = logical_block(blockIdx.x, a.nblocks, a.ntiles, a.remap, a.xr);
+    if (b < 0) return;
     const int tile = b % a.ntiles;
     const int item = (b / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
     const int lane = threadIdx.x & (GROUP - 1);
     const int col = (tile * GROUP + lane) * VEC;
-    if (item >= a.n_total || col >= a.feat) return;
+    if (item >= a.n_total) return;
+    // IDXMODE 1 keeps out-of-range column lanes alive: they still carry (idx,val) for the broadcast
+    const bool col_ok = col < a.feat;
+    if (IDXMODE == 0 && !col_ok) return;
     const int F = a.feat;
 
     if (LIST && item >= a.n_items) {  // rows without any group: the reference memsets vout (:393)
         const float z[VEC] = {};
-        store_pack<VEC>(a.y + (size_t)a.empty_rows[item - a.n_items] * F + col, z);
+        if (col_ok) store_pack<VEC>(a.y + (size_t)a.empty_rows[item - a.n_items] * F + col, z);
         return;
     }
 
@@ -120,6 +146,55 @@ __global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
 
+    if constexpr (IDXMODE == 1) {
+        // Metadata path B: lane j of the group fetches (idx,val) of edge cb+j with ONE coalesced
+        // load per GROUP edges; each edge's pair is then broadcast inside the group with
+        // ds_bpermute (LDS crossbar, no memory traffic, leaves the texture-address path to the
+        // feature gathers).
+        int my_s = 0;
+        float my_w = 1.0f;
+        if (beg + lane < end) {
+            my_s = idx[beg + lane];
+            if (val) my_w = val[beg + lane];
+        }
+        for (int cb = beg; cb < end; cb += GROUP) {
+            int nx_s = 0;
+            float nx_w = 1.0f;
+            if (cb + GROUP + lane < end) {  // next GROUP edges travel during this chunk's gathers
+                nx_s = idx[cb + GROUP + lane];
+                if (val) nx_w = val[cb + GROUP + lane];
+            }
+            const int n = end - cb < GROUP ? end - cb : GROUP;
+            for (int j = 0; j < n; j += kUnroll) {
+                int s[kUnroll];
+                float w[kUnroll];
+                Pack<VEC> xv[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    s[u] = __shfl(my_s, j + u, GROUP);
+                    w[u] = __shfl(my_w, j + u, GROUP);
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u)
+                    if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u)
+                    if (j + u < n && col_ok) {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            if (IS_MAX) {
+                                const float p = xv[u].v[k] * w[u];
+                                acc[k] = p > acc[k] ? p : acc[k];
+                            } else {
+                                acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
+                            }
+                        }
+                    }
+            }
+            my_s = nx_s;
+            my_w = nx_w;
+        }
+    } else {
     int s[kUnroll];
     float w[kUnroll];
 #pragma unroll
@@ -163,7 +238,9 @@ __global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
             w[u] = wn[u];
         }
     }
+    }
 
+    if (!col_ok) return;
     const int sl = (LIST && a.slot) ? a.slot[item] : -1;
     if (sl >= 0) {
         store_pack<VEC>(a.partial + (size_t)sl * F + col, acc);
@@ -208,16 +285,31 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
     for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
     float den = 0.0f;
     const int h = IS_GAT ? col / a.dhead : 0;
-    for (int s = s0; s < s1; ++s) {
-        const Pack<VEC> p = load_pack<VEC>(a.partial + (size_t)s * F + col);
+    // the adds stay in ascending slot order; only the loads are batched (a hub row of a power-law
+    // graph has hundreds of partials -- one dependent load per iteration made this kernel slower
+    // than the aggregation itself)
+    constexpr int CU = 16;
+    for (int sb = s0; sb < s1; sb += CU) {
+        Pack<VEC> p[CU];
+        float pd[CU];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            if (IS_MAX)
-                acc[k] = p.v[k] > acc[k] ? p.v[k] : acc[k];
-            else
-                acc[k] += p.v[k];
-        }
-        if (IS_GAT) den += a.partial_den[(size_t)s * a.heads + h];
+        for (int u = 0; u < CU; ++u)
+            if (sb + u < s1) {
+                p[u] = load_pack<VEC>(a.partial + (size_t)(sb + u) * F + col);
+                if (IS_GAT) pd[u] = a.partial_den[(size_t)(sb + u) * a.heads + h];
+            }
+#pragma unroll
+        for (int u = 0; u < CU; ++u)
+            if (sb + u < s1) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (IS_MAX)
+                        acc[k] = p[u].v[k] > acc[k] ? p[u].v[k] : acc[k];
+                    else
+                        acc[k] += p[u].v[k];
+                }
+                if (IS_GAT) den += pd[u];
+            }
     }
     if (IS_GAT) {
         if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
@@ -362,6 +454,35 @@ static Geometry pick_geometry(int F, const void *p0, const void *p1, const void 
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// cost_prefix[i] = total cost of items [0,i) (host array, n_items+1 entries).  Cuts the item blocks
+// into 8 contiguous ranges of about equal cost; returns the longest range (in blocks).
+static int fill_xcd_ranges(const long *cost_prefix, int n_items, int items_per_block, int item_blocks, XcdRanges &xr)
+{
+    const long total = cost_prefix[n_items];
+    int start = 0, longest = 0;
+    for (int x = 0; x < 8; ++x) {
+        int stop;
+        if (x == 7) {
+            stop = item_blocks;
+        } else {
+            const long want = total * (x + 1) / 8;
+            // first block boundary whose prefix cost reaches `want`
+            int lo = start, hi = item_blocks;
+            while (lo < hi) {
+                const int mid = (lo + hi) / 2;
+                const long c = cost_prefix[std::min((long)mid * items_per_block, (long)n_items)];
+                if (c < want) lo = mid + 1; else hi = mid;
+            }
+            stop = lo;
+        }
+        xr.first[x] = start;
+        xr.count[x] = stop - start;
+        longest = std::max(longest, stop - start);
+        start = stop;
+    }
+    return longest;
+}
+
 int launch_gcn(const GcnLaunch &L, void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
@@ -376,18 +497,30 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
     a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap;
     if (a.n_total > 0) {
         const int items_per_block = kBlock / g.group;
-        a.nblocks = ceil_div(a.n_total, items_per_block) * g.ntiles;
+        const int item_blocks = ceil_div(a.n_total, items_per_block);
+        a.nblocks = item_blocks * g.ntiles;
         if (a.remap && a.nblocks < 64) a.remap = 0;
-#define CALL_GCN                                                                                            \
-        if (list) {                                                                                         \
-            if (is_max) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, true, true>), dim3(a.nblocks), dim3(kBlock), 0, stream, a);  \
-            else        hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, false, true>), dim3(a.nblocks), dim3(kBlock), 0, stream, a); \
-        } else {                                                                                            \
-            if (is_max) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, true, false>), dim3(a.nblocks), dim3(kBlock), 0, stream, a); \
-            else        hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, false, false>), dim3(a.nblocks), dim3(kBlock), 0, stream, a);\
+        int grid = a.nblocks;
+        if (a.remap == 2) {
+            if (!L.xcd_item_cost_prefix) {
+                a.remap = 1;
+            } else {
+                grid = 8 * fill_xcd_ranges(L.xcd_item_cost_prefix, a.n_total, items_per_block, item_blocks, a.xr) * g.ntiles;
+            }
+        }
+        const int idxmode = L.idxmode;
+#define LAUNCH_GCN(MAXF, LISTF, IM) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, MAXF, LISTF, IM>), dim3(grid), dim3(kBlock), 0, stream, a)
+#define CALL_GCN                                                                     \
+        if (idxmode == 1) {                                                          \
+            if (list) { if (is_max) LAUNCH_GCN(true, true, 1); else LAUNCH_GCN(false, true, 1); }    \
+            else      { if (is_max) LAUNCH_GCN(true, false, 1); else LAUNCH_GCN(false, false, 1); }  \
+        } else {                                                                     \
+            if (list) { if (is_max) LAUNCH_GCN(true, true, 0); else LAUNCH_GCN(false, true, 0); }    \
+            else      { if (is_max) LAUNCH_GCN(true, false, 0); else LAUNCH_GCN(false, false, 0); }  \
         }
         DISPATCH_GEOM(g, CALL_GCN)
 #undef CALL_GCN
+#undef LAUNCH_GCN
         HIP_TRY(hipGetLastError());
     }
     if (L.wl.n_mrows > 0) {

@@ -187,13 +187,15 @@ def test_spmm_naive_and_validators():
     ans = ref.copy()
     ans[::7, ::5] *= 1.05
     n = ctypes.c_int(-1)
-    _lib.check(L.gnnagg_validate(dev(ref).data_ptr(), dev(ans).data_ptr(), ref.size, ctypes.byref(n), None))
+    d_ref, d_ans = dev(ref), dev(ans)  # keep the tensors alive across the call
+    _lib.check(L.gnnagg_validate(d_ref.data_ptr(), d_ans.data_ptr(), ref.size, ctypes.byref(n), None))
     assert n.value == orc.validate2(ref, ans)
     rows = np.random.default_rng(5).permutation(V).astype(np.int32)
     ans_perm = np.empty_like(ref)
     ans_perm[rows] = ref  # ans[map[r]] = ref[r]
     ans_perm[3] += 1.0
-    _lib.check(L.gnnagg_validate_reordered(dev(ref).data_ptr(), dev(ans_perm).data_ptr(), dev(rows).data_ptr(), V, F,
+    d_perm, d_rows = dev(ans_perm), dev(rows)
+    _lib.check(L.gnnagg_validate_reordered(d_ref.data_ptr(), d_perm.data_ptr(), d_rows.data_ptr(), V, F,
                                            ctypes.byref(n), None))
     assert n.value == orc.validate_reordered(ref, ans_perm, rows) == F
 
@@ -291,7 +293,7 @@ def test_error_behaviour():
     assert gnc.lib().gnnagg_destroy(ctypes.c_int64(h)) == _lib.ERR_ARG  # double destroy is caught
     gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
     with pytest.raises(gnc.GnnAggError):
-        gat.run(x, dev(rand((V, 2), 2)), y, 128, 0, heads=3)  # 32 % 3 != 0
+        gat.run(x, dev(rand((V, 3, 2), 2)), y, 128, 0, heads=3)  # 32 % 3 != 0
 
 
 def test_flat_reference_api():
@@ -352,7 +354,8 @@ def test_pack_rows():
     x = rand((V, F), 1)
     ids = np.random.default_rng(3).integers(0, V, n).astype(np.int32)
     out = torch.empty((n, F), device=DEV)
-    _lib.check(gnc.lib().gnnagg_pack_rows(dev(x).data_ptr(), dev(ids).data_ptr(), n, F, out.data_ptr(), None))
+    d_x, d_ids = dev(x), dev(ids)
+    _lib.check(gnc.lib().gnnagg_pack_rows(d_x.data_ptr(), d_ids.data_ptr(), n, F, out.data_ptr(), None))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), x[ids])
 
@@ -389,7 +392,8 @@ def test_arxiv_full_size_parity_and_properties():
     n = ctypes.c_int(-1)
     agg.run(dx, y, 512, 0)
     # y (old order) row r must equal y2 row reverse_rows[r]
-    _lib.check(gnc.lib().gnnagg_validate_reordered(y.data_ptr(), y2.data_ptr(), dev(rev).data_ptr(), V, F,
+    d_rev = dev(rev)
+    _lib.check(gnc.lib().gnnagg_validate_reordered(y.data_ptr(), y2.data_ptr(), d_rev.data_ptr(), V, F,
                                                    ctypes.byref(n), None))
     assert n.value == 0
     assert np.array_equal(y2.cpu().numpy()[rev], y.cpu().numpy())

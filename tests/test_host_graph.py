@@ -1,0 +1,125 @@
+"""CPU: the product's host graph preparation (libgnnagg.so Section C/D, pure host code) against the
+oracle and the golden vectors -- bit-exact (integer work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gnn_computing_amd as gnc
+from gnn_computing_amd import _lib, graph
+from oracle import oracle as orc
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+S = json.load(open(os.path.join(G, "survey_8c.json")))
+PTR, IDX = np.array(S["graph"]["ptr"], np.int32), np.array(S["graph"]["idx"], np.int32)
+
+
+def test_golden_vectors_through_cabi():
+    ps, tg = gnc.neighbor_grouping_schedule(PTR, 2)
+    assert ps.tolist() == S["neighbor_grouping_ng2"]["ptr_s"] and tg.tolist() == S["neighbor_grouping_ng2"]["target"]
+    ps, ix, tg, _ = gnc.locality_schedule(PTR, IDX, 2, 4)
+    g = S["locality_par2_total4"]
+    assert (ps.tolist(), ix.tolist(), tg.tolist()) == (g["ptr_s"], g["idx_s"], g["target"])
+    ps, ix, tg, _ = gnc.locality_schedule(PTR, IDX, 2, 4, ng=2)
+    g = S["locality_ng_par2_ng2"]
+    assert (ps.tolist(), ix.tolist(), tg.tolist()) == (g["ptr_s"], g["idx_s"], g["target"])
+    g = S["reorder_2031"]
+    nptr, nidx, rev = gnc.reorder_csr(PTR, IDX, g["rows"])
+    assert (nptr.tolist(), nidx.tolist(), rev.tolist()) == (g["ptr"], g["idx"], g["reverse_rows"])
+
+
+@pytest.mark.parametrize("V,E", [(1, 0), (1, 5), (17, 0), (50, 700), (1000, 20000), (3000, 9000)])
+def test_schedules_match_oracle(V, E):
+    ptr, idx = graph.uniform_random_csr(V, E, seed=V + E)
+    val = np.random.default_rng(1).standard_normal(E, dtype=np.float32)
+    for ng in (1, 2, 7, 16, 32, 10 ** 6):
+        a, b = gnc.neighbor_grouping_schedule(ptr, ng), orc.neighbor_grouping(ptr, ng)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for par, ng, total in ((1, 0, V), (2, 0, V), (3, 4, V), (7, 1, V), (5, 0, V + 13), (4, 2, max(V - 3, 1)), (V + 5, 0, V)):
+        a = gnc.locality_schedule(ptr, idx, par, total, ng, val)
+        b = orc.locality_schedule(ptr, idx, par, total, ng, val)
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+    rows = np.random.default_rng(2).permutation(V).astype(np.int32)
+    a, b = gnc.reorder_csr(ptr, idx, rows), orc.reorder_csr(ptr, idx, rows)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[3])
+
+
+def test_powerlaw_arxiv_shape_schedule_matches_oracle():
+    ptr, idx = graph.dataset("arxiv")
+    ptr, idx = ptr.numpy(), idx.numpy()
+    for ng in (16, 32):
+        a, b = gnc.neighbor_grouping_schedule(ptr, ng), orc.neighbor_grouping(ptr, ng)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    rows = graph.locality_order(ptr, idx)
+    assert sorted(rows.tolist()) == list(range(len(ptr) - 1))
+    a, b = gnc.reorder_csr(ptr, idx, rows), orc.reorder_csr(ptr, idx, rows)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("fmt", ["text", "dumps", "both"])
+def test_load_graph(tmp_path, fmt):
+    d = str(tmp_path) + "/"
+    ptr, idx = graph.uniform_random_csr(300, 4000, seed=3)
+    graph.write_graph_files(d, "g", ptr, idx, text=fmt in ("text", "both"), dumps=fmt in ("dumps", "both"))
+    rows = np.random.default_rng(4).permutation(300).astype(np.int32)
+    graph.write_reorder_file(d, "g", rows)
+    out = gnc.load_graph_host("g", "", d)
+    assert out["num_v"] == 300 and out["num_e"] == 4000
+    assert np.array_equal(out["ptr"], ptr) and np.array_equal(out["idx"], idx) and out["rows"] is None
+    # caches exist afterwards with the raw int32 sizes (data.cu:64-67,:88-91)
+    assert os.path.getsize(d + "g.graph.ptrdump") == 301 * 4 and os.path.getsize(d + "g.graph.edgedump") == 4000 * 4
+    out = gnc.load_graph_host("g", "_thres_0.2", d)
+    ref = orc.load_graph(d, "g", "_thres_0.2")
+    for k in ("ptr", "idx", "rows", "reverse_rows"):
+        assert np.array_equal(out[k], ref[k])
+    # shuffle=False ignores the reorder file (data.cu:98)
+    out = gnc.load_graph_host("g", "_thres_0.2", d, shuffle=False)
+    assert np.array_equal(out["idx"], idx)
+    # a suffix whose file does not exist loads un-reordered (data.cu:134-138)
+    out = gnc.load_graph_host("g", "_nope", d)
+    assert np.array_equal(out["idx"], idx) and out["rows"] is None
+
+
+def test_load_graph_errors(tmp_path):
+    d = str(tmp_path) + "/"
+    with pytest.raises(gnc.GnnAggError) as ei:
+        gnc.load_graph_host("missing", "", d)
+    assert ei.value.code == _lib.ERR_IO
+    ptr, idx = graph.uniform_random_csr(10, 30, seed=1)
+    graph.write_graph_files(d, "bad", ptr, idx)
+    open(d + "bad.config", "w").write("10 31")  # indptr[num_v] != num_e (data.cu:69-74)
+    with pytest.raises(gnc.GnnAggError):
+        gnc.load_graph_host("bad", "", d)
+    graph.write_graph_files(d, "perm", ptr, idx)
+    open(d + "perm.reorder_x", "w").write(" ".join(["0"] * 10))  # not a permutation
+    with pytest.raises(gnc.GnnAggError):
+        gnc.load_graph_host("perm", "_x", d)
+    with pytest.raises(gnc.GnnAggError):
+        gnc.neighbor_grouping_schedule(ptr, 0)
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 3, 8])
+def test_partition_and_halo_plan(nparts):
+    V, E = 500, 9000
+    ptr, idx = graph.uniform_random_csr(V, E, seed=9)
+    b = gnc.partition_rows(ptr, nparts)
+    assert b[0] == 0 and b[-1] == V and np.all(np.diff(b) >= 0)
+    nnz = np.diff(ptr[b])
+    assert nnz.max() <= E / nparts + orc.degrees(ptr).max() + 1  # balanced up to one row
+    seen_rows = 0
+    for r in range(nparts):
+        p = gnc.halo_plan(ptr, idx, b, r)
+        n_loc = p["n_local"]
+        seen_rows += n_loc
+        assert np.array_equal(p["local_ptr"], ptr[b[r]:b[r + 1] + 1] - ptr[b[r]])
+        glob = idx[ptr[b[r]]:ptr[b[r + 1]]]
+        # translate local slots back to global ids
+        slot2glob = np.concatenate([np.arange(b[r], b[r + 1]), p["halo_ids"]]).astype(np.int32)
+        assert np.array_equal(slot2glob[p["local_idx"]], glob)
+        assert np.all(np.diff(p["halo_ids"]) > 0)  # ascending, deduplicated
+        assert not np.any((p["halo_ids"] >= b[r]) & (p["halo_ids"] < b[r + 1]))
+        owners = np.searchsorted(b, p["halo_ids"], side="right") - 1
+        assert np.array_equal(np.bincount(owners, minlength=nparts), p["halo_counts"])
+    assert seen_rows == V
