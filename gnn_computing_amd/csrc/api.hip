@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <set>
 #include <vector>
@@ -71,17 +72,22 @@ struct Schedule {
     bool permuted = false;  // locality schedules permute idx/val; neighbor grouping aliases them
     std::vector<int> h_ptr_s, h_target, h_idx_s;
     std::vector<float> h_val_s;
-    DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s;
+    DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s, big_rows;
+    int n_big = 0;
     DevBuf<float> val_s;
     int n_empty = 0, n_mrows = 0, n_slots = 0;
     std::vector<long> cost_prefix;  // per work item (groups then empty-row items), for the XCD ranges
+    DevBuf<int> desc;                           // int2 {end edge, dest} per item (source of the edge tags)
+    DevBuf<int> tag;                            // streaming kernel: per-edge destination tag
+    std::map<int, DevBuf<int>> stream_ranges;   // lane-group count -> first edge of every group's range
 
     void reset()
     {
         valid = false;
         ptr_s.release(); target.release(); slot.release(); empty_rows.release();
-        mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release();
+        mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release(); big_rows.release(); n_big = 0;
         h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear();
+        desc.release(); tag.release(); stream_ranges.clear(); cost_prefix.clear();
         num_target = n_empty = n_mrows = n_slots = 0;
         permuted = false;
     }
@@ -91,6 +97,7 @@ struct Schedule {
         w.ptr = ptr_s.p; w.target = target.p; w.slot = slot.p; w.empty_rows = empty_rows.p;
         w.n_items = num_target; w.n_empty = n_empty;
         w.mrow_id = mrow_id.p; w.mrow_ptr = mrow_ptr.p; w.n_mrows = n_mrows; w.n_slots = n_slots;
+        w.big_rows = big_rows.p; w.n_big = n_big;
         return w;
     }
 };
@@ -112,6 +119,10 @@ struct Ctx {
     int xcd_remap = 2;
     int variant = 0;
     int idxmode = 1;
+    int use_stream = 0;        // 1: LIST modes run the persistent streaming kernel (A/B knob; the item kernel measured faster)
+    int stream_bpc = 8;        // workgroups per CU for the streaming grid
+    int stream_min_edges = 32; // lower bound on edges per lane group
+    int num_cus = 256;
     std::vector<long> row_cost_prefix;  // MODE_ROWS work items
     int avg_deg() const { return V > 0 ? (int)((long)E / V) : 0; }
 };
@@ -169,12 +180,33 @@ static int finalize_schedule(Ctx *c, Schedule &s)
     for (int g = 0; g < G; ++g) s.cost_prefix[g + 1] = s.cost_prefix[g] + (s.h_ptr_s[g + 1] - s.h_ptr_s[g]) + kItemCost;
     for (size_t k = 0; k < empty.size(); ++k) s.cost_prefix[G + k + 1] = s.cost_prefix[G + k] + 1;
     int rc;
+    {
+        std::vector<int> desc((size_t)2 * G);
+        for (int g = 0; g < G; ++g) {
+            if (s.h_ptr_s[g + 1] <= s.h_ptr_s[g]) return fail(GNNAGG_ERR_STATE, "internal: empty work item in a schedule");
+            desc[2 * g] = s.h_ptr_s[g + 1];
+            desc[2 * g + 1] = slot[g] >= 0 ? ~slot[g] : s.h_target[g];
+        }
+        if ((rc = s.desc.upload(desc))) return rc;
+        const long ne = G > 0 ? s.h_ptr_s[G] : 0;
+        if (ne > 0) {
+            if ((rc = s.tag.reserve((size_t)ne))) return rc;
+            if ((rc = launch_build_tags(s.desc.p, G, ne, s.tag.p, c->stream))) return rc;
+        }
+    }
     if ((rc = s.ptr_s.upload(s.h_ptr_s))) return rc;
     if ((rc = s.target.upload(s.h_target))) return rc;
     if ((rc = s.slot.upload(slot))) return rc;
     if ((rc = s.empty_rows.upload(empty))) return rc;
     if ((rc = s.mrow_id.upload(mrow_id))) return rc;
     if ((rc = s.mrow_ptr.upload(mrow_ptr))) return rc;
+    {
+        std::vector<int> big;
+        for (int m = 0; m < (int)mrow_id.size(); ++m)
+            if (mrow_ptr[m + 1] - mrow_ptr[m] > 16) big.push_back(m);  // kCombineBatch in kernels.hip
+        s.n_big = (int)big.size();
+        if ((rc = s.big_rows.upload(big))) return rc;
+    }
     if (s.permuted) {
         if ((rc = s.idx_s.upload(s.h_idx_s))) return rc;
         if (!s.h_val_s.empty() && (rc = s.val_s.upload(s.h_val_s))) return rc;
@@ -226,6 +258,34 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
     s.h_ptr_s.swap(ptr_s);
     s.h_target.swap(tgt);
     return finalize_schedule(c, s);
+}
+
+// Cuts the items of a schedule into `ngroups` contiguous ranges of about equal cost.
+static int stream_range_table(Schedule &s, int ngroups, const int **out)
+{
+    auto it = s.stream_ranges.find(ngroups);
+    if (it == s.stream_ranges.end()) {
+        const int G = s.num_target;
+        const long total = s.cost_prefix[G];
+        std::vector<int> tab((size_t)ngroups + 1);
+        int item = 0;
+        for (int q = 0; q <= ngroups; ++q) {
+            if (q == ngroups) {
+                item = G;
+            } else {
+                const long want = total * q / ngroups;
+                item = (int)(std::lower_bound(s.cost_prefix.begin() + item, s.cost_prefix.begin() + G + 1, want) -
+                             s.cost_prefix.begin());
+                if (item > G) item = G;
+            }
+            tab[q] = s.h_ptr_s[item];
+        }
+        int rc = s.stream_ranges[ngroups].upload(tab);
+        if (rc) return rc;
+        it = s.stream_ranges.find(ngroups);
+    }
+    *out = it->second.p;
+    return GNNAGG_OK;
 }
 
 static int pick_chunk(const Ctx *c)
@@ -284,6 +344,19 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     } else {
         L.xcd_item_cost_prefix = s->cost_prefix.data();
         L.wl = s->worklist();
+        if (c->use_stream && s->num_target > 0) {
+            const int gpb = lane_groups_per_block(feat, x, y, nullptr, feat, c->variant);
+            int ngroups = c->num_cus * c->stream_bpc * gpb;
+            // keep a few batches of work per group; tiny graphs use fewer groups
+            const long edges = s->h_ptr_s[s->num_target];
+            const long max_groups = std::max<long>(gpb, edges / c->stream_min_edges);
+            if (ngroups > max_groups) ngroups = (int)(max_groups / gpb) * gpb;
+            const int *tab = nullptr;
+            if ((rc = stream_range_table(*s, ngroups, &tab))) return rc;
+            L.stream_tag = s->tag.p;
+            L.stream_range = tab;
+            L.stream_groups = ngroups;
+        }
         L.idx = s->permuted ? s->idx_s.p : c->d_idx;
         L.val = s->permuted ? s->val_s.p : c->d_val;
         if (s->n_slots > 0) {
@@ -384,6 +457,15 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_XCD_REMAP")) c->xcd_remap = atoi(e);
     if (const char *e = getenv("GNNAGG_VARIANT")) c->variant = atoi(e);
     if (const char *e = getenv("GNNAGG_IDXMODE")) c->idxmode = atoi(e);
+    if (const char *e = getenv("GNNAGG_STREAM")) c->use_stream = atoi(e);
+    if (const char *e = getenv("GNNAGG_STREAM_BPC")) c->stream_bpc = std::max(1, atoi(e));
+    if (const char *e = getenv("GNNAGG_STREAM_MIN_EDGES")) c->stream_min_edges = std::max(1, atoi(e));
+    {
+        hipDeviceProp_t prop;
+        int devid = 0;
+        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+            c->num_cus = std::max(1, prop.multiProcessorCount);
+    }
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);

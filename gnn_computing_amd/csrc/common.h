@@ -41,6 +41,9 @@ struct WorkList {
     const int *mrow_ptr = nullptr;
     int n_mrows = 0;
     int n_slots = 0;
+    // multi-item rows with more partials than one lane group keeps in flight (hub rows): indices into mrow_*
+    const int *big_rows = nullptr;
+    int n_big = 0;
 };
 
 struct GcnLaunch {
@@ -58,6 +61,12 @@ struct GcnLaunch {
     int idxmode = 0;  // 0: per-lane (idx,val) loads; 1: group-coalesced load + ds_bpermute broadcast
     // host array [n_items + n_empty + 1]: prefix sums of the per-item cost, for xcd_remap == 2
     const long *xcd_item_cost_prefix = nullptr;
+    // streaming kernel (LIST modes): device arrays int tag[n_edges] (destination on the last edge of
+    // every item) and int range[stream_groups + 1] (first edge of each lane group's range);
+    // null => item-per-group kernel
+    const void *stream_tag = nullptr;
+    const void *stream_range = nullptr;
+    int stream_groups = 0;
 };
 
 struct GatLaunch {
@@ -75,6 +84,8 @@ struct GatLaunch {
     int xcd_remap = 1;
 };
 
+int lane_groups_per_block(int feat, const void *x, const void *y, const void *partial, int dhead, int variant);
+int launch_build_tags(const void *desc, int n_items, long n_edges, int *tag, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);
 int launch_gat(const GatLaunch &a, void *stream);
 int launch_gat_att(const int *ptr, const int *idx, const float *att, float *out, int V, int heads, float slope,

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -258,8 +259,157 @@ __global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
     store_pack<VEC>(a.y + (size_t)row * F + col, acc);
 }
 
+// ------------------------------------------------------------------ GCN / SAGE, streaming
+// Persistent streaming variant for work lists (all LIST modes; every item is non-empty).
+// Lane group q owns the contiguous edge range [range[q], range[q+1]) -- whole items, cut on the host so
+// that every group gets about the same cost -- and walks its EDGES in batches of kUnroll, independent
+// of item boundaries: 8 feature-row gathers are in flight for every batch even when the items are
+// 1-2 edges long (arxiv: avg degree 6.9).  An item boundary is carried by the edge itself:
+// tag[e] = destination of the item whose LAST edge is e (>= 0: output row, < 0: scratch row ~tag),
+// kTagNone otherwise (built once per schedule by k_build_tags).  Lane j keeps (idx,val,tag) of edge
+// win+j -- one coalesced load per GROUP edges, the next window prefetched during the gathers -- and
+// the triples are broadcast inside the group with ds_bpermute; a finished item is a fire-and-forget
+// store + accumulator reset, so nothing but the gathers sits on the critical path.
+// The FMA chain of an item is unchanged (CSR order): results are bit-identical to k_gcn_items.
+static constexpr int kTagNone = (int)0x80000000;
+
+struct StreamArgs {
+    const int *range;  // per lane group (+1): first edge
+    const int *tag;    // per edge
+    const int *empty_rows;
+    const int *idx;
+    const float *val;
+    const float *x;
+    float *y;
+    float *partial;
+    int n_groups, n_empty, feat, ntiles, nblocks_main, mean, remap;
+};
+
+__global__ void k_build_tags(const int2 *__restrict__ desc, int n_items, int *__restrict__ tag)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_items) tag[desc[g].x - 1] = desc[g].y;
+}
+
+__global__ void k_fill_int(int *__restrict__ p, long n, int v)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+template <int VEC, int GROUP, bool IS_MAX>
+__global__ __launch_bounds__(kBlock) void k_gcn_stream(const StreamArgs a)
+{
+    constexpr int GROUPS = kBlock / GROUP;
+    const int F = a.feat;
+    if ((int)blockIdx.x >= a.nblocks_main) {  // rows without any item: zero fill (reference memset, aggr_gcn.h:393)
+        const int r = ((int)blockIdx.x - a.nblocks_main) * GROUPS + (int)threadIdx.x / GROUP;
+        if (r >= a.n_empty) return;
+        const int row = a.empty_rows[r];
+        const float z[VEC] = {};
+        for (int c = (threadIdx.x & (GROUP - 1)) * VEC; c < F; c += GROUP * VEC) store_pack<VEC>(a.y + (size_t)row * F + c, z);
+        return;
+    }
+    const int b = a.remap ? xcd_remap(blockIdx.x, a.nblocks_main) : (int)blockIdx.x;
+    const int tile = b % a.ntiles;
+    const int q = (b / a.ntiles) * GROUPS + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int col = (tile * GROUP + lane) * VEC;
+    if (q >= a.n_groups) return;
+    const bool col_ok = col < F;
+
+    const int e_beg = a.range[q], e_end = a.range[q + 1];
+    if (e_beg >= e_end) return;
+    const int *__restrict__ idx = a.idx;
+    const int *__restrict__ tag = a.tag;
+    const float *__restrict__ val = a.val;
+    const float *__restrict__ xcol = a.x + col;
+
+    int my_s = 0, nx_s = 0, my_t = kTagNone, nx_t = kTagNone;
+    float my_w = 1.0f, nx_w = 1.0f;
+    if (e_beg + lane < e_end) {
+        my_s = idx[e_beg + lane];
+        my_t = tag[e_beg + lane];
+        if (val) my_w = val[e_beg + lane];
+    }
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+    int cnt = 0;
+
+    for (int win = e_beg; win < e_end; win += GROUP) {
+        if (win + GROUP + lane < e_end) {  // next window travels during this window's gathers
+            nx_s = idx[win + GROUP + lane];
+            nx_t = tag[win + GROUP + lane];
+            if (val) nx_w = val[win + GROUP + lane];
+        }
+        const int n = e_end - win < GROUP ? e_end - win : GROUP;
+        for (int j = 0; j < n; j += kUnroll) {
+            int s[kUnroll], t[kUnroll];
+            float w[kUnroll];
+            Pack<VEC> xv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                s[u] = __shfl(my_s, j + u, GROUP);
+                w[u] = __shfl(my_w, j + u, GROUP);
+                t[u] = __shfl(my_t, j + u, GROUP);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        if (IS_MAX) {
+                            const float p = xv[u].v[k] * w[u];
+                            acc[k] = p > acc[k] ? p : acc[k];
+                        } else {
+                            acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
+                        }
+                    }
+                    ++cnt;
+                    if (t[u] != kTagNone) {  // last edge of its item: store and reset
+                        if (t[u] >= 0) {
+                            if (a.mean) {
+                                const float d = (float)cnt;
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
+                            }
+                            store_pack<VEC>(a.y + (size_t)t[u] * F + col, acc);
+                        } else {
+                            store_pack<VEC>(a.partial + (size_t)(~t[u]) * F + col, acc);
+                        }
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+                        cnt = 0;
+                    }
+                }
+        }
+        my_s = nx_s;
+        my_w = nx_w;
+        my_t = nx_t;
+    }
+}
+
+int launch_build_tags(const void *desc, int n_items, long n_edges, int *tag, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (n_edges <= 0) return GNNAGG_OK;
+    hipLaunchKernelGGL(k_fill_int, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, stream, tag, n_edges, kTagNone);
+    if (n_items > 0)
+        hipLaunchKernelGGL(k_build_tags, dim3((n_items + 255) / 256), dim3(256), 0, stream,
+                           reinterpret_cast<const int2 *>(desc), n_items, tag);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    return GNNAGG_OK;
+}
+
 struct CombineArgs {
     const int *mrow_id, *mrow_ptr, *row_ptr;
+    const int *big_rows;  // indices into mrow_* of the rows with more than kCombineBatch partials
+    int n_big, nblocks_small;
     const float *partial;
     const float *partial_den;  // GAT only
     float *y;
@@ -268,17 +418,84 @@ struct CombineArgs {
 
 // Adds the partial rows of every split row in ascending slot order (deterministic counterpart of
 // the reference's atomicAdd, aggr_gcn.h:112) and applies mean / softmax normalisation.
+static constexpr int kCombineBatch = 16;   // partial rows a lane group keeps in flight
+static constexpr int kCombineStage = 128;  // partial rows a workgroup stages in LDS per round (big rows)
+
 template <int VEC, int GROUP, bool IS_MAX, bool IS_GAT>
 __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
 {
     constexpr int ITEMS = kBlock / GROUP;
+    const int F = a.feat;
+    if ((int)blockIdx.x >= a.nblocks_small) {
+        // ---- big rows (hubs: hundreds of partials): one workgroup per (row, column tile).  All lane
+        // groups fetch partial rows in parallel into LDS (kCombineStage rows per round, kCombineBatch
+        // loads in flight per group), then each column is summed from LDS in ascending slot order.
+        __shared__ float stage[kCombineStage * GROUP * VEC];
+        __shared__ float stage_den[IS_GAT ? kCombineStage * 64 : 1];
+        const int bb = (int)blockIdx.x - a.nblocks_small;
+        const int tile = bb % a.ntiles;
+        const int m = a.big_rows[bb / a.ntiles];
+        const int s0 = a.mrow_ptr[m], s1 = a.mrow_ptr[m + 1];
+        const int row = a.mrow_id[m];
+        const int grp = (int)threadIdx.x / GROUP, lane = threadIdx.x & (GROUP - 1);
+        const int col0 = tile * GROUP * VEC;
+        const int col = col0 + lane * VEC;
+        constexpr int W = GROUP * VEC;                // columns of this tile
+        const int c = (int)threadIdx.x;               // summing thread <-> column c of the tile
+        const bool sum_ok = c < W && col0 + c < F;
+        const int hc = IS_GAT ? (col0 + c) / a.dhead : 0;
+        float acc = IS_MAX ? -INFINITY : 0.0f, den = 0.0f;
+        for (int sb = s0; sb < s1; sb += kCombineStage) {
+            const int nst = s1 - sb < kCombineStage ? s1 - sb : kCombineStage;
+            for (int p0 = grp * kCombineBatch; p0 < nst; p0 += ITEMS * kCombineBatch) {
+                Pack<VEC> p[kCombineBatch];
+#pragma unroll
+                for (int u = 0; u < kCombineBatch; ++u)
+                    if (p0 + u < nst && col < F) p[u] = load_pack<VEC>(a.partial + (size_t)(sb + p0 + u) * F + col);
+#pragma unroll
+                for (int u = 0; u < kCombineBatch; ++u)
+                    if (p0 + u < nst && col < F) store_pack<VEC>(&stage[(p0 + u) * W + lane * VEC], p[u].v);
+            }
+            if (IS_GAT)
+                for (int i = threadIdx.x; i < nst * a.heads; i += kBlock)
+                    stage_den[i] = a.partial_den[(size_t)sb * a.heads + i];
+            __syncthreads();
+            if (sum_ok) {
+                // LDS reads issued 16 at a time; the adds stay in ascending order
+                for (int p0 = 0; p0 < nst; p0 += 16) {
+                    float v[16], dv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (p0 + u < nst) {
+                            v[u] = stage[(p0 + u) * W + c];
+                            if (IS_GAT) dv[u] = stage_den[(p0 + u) * a.heads + hc];
+                        }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (p0 + u < nst) {
+                            if (IS_MAX) acc = v[u] > acc ? v[u] : acc; else acc += v[u];
+                            if (IS_GAT) den += dv[u];
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        if (!sum_ok) return;
+        if (IS_GAT) {
+            if (den != 0.0f) acc = acc / den;
+        } else if (a.mean) {
+            acc = acc / (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
+        }
+        a.y[(size_t)row * F + col0 + c] = acc;
+        return;
+    }
     const int tile = blockIdx.x % a.ntiles;
     const int m = (blockIdx.x / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
     const int lane = threadIdx.x & (GROUP - 1);
     const int col = (tile * GROUP + lane) * VEC;
     if (m >= a.n_mrows || col >= a.feat) return;
-    const int F = a.feat;
     const int s0 = a.mrow_ptr[m], s1 = a.mrow_ptr[m + 1];
+    if (a.n_big > 0 && s1 - s0 > kCombineBatch) return;  // handled by the workgroup-per-row path
     const int row = a.mrow_id[m];
     float acc[VEC];
 #pragma unroll
@@ -288,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
     // the adds stay in ascending slot order; only the loads are batched (a hub row of a power-law
     // graph has hundreds of partials -- one dependent load per iteration made this kernel slower
     // than the aggregation itself)
-    constexpr int CU = 16;
+    constexpr int CU = kCombineBatch;
     for (int sb = s0; sb < s1; sb += CU) {
         Pack<VEC> p[CU];
         float pd[CU];
@@ -483,6 +700,33 @@ static int fill_xcd_ranges(const long *cost_prefix, int n_items, int items_per_b
     return longest;
 }
 
+int lane_groups_per_block(int feat, const void *x, const void *y, const void *partial, int dhead, int variant)
+{
+    return kBlock / pick_geometry(feat, x, y, partial, dhead, variant).group;
+}
+
+static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max, hipStream_t stream)
+{
+    static const int dbg_skip = getenv("GNNAGG_DEBUG_SKIP_COMBINE") ? atoi(getenv("GNNAGG_DEBUG_SKIP_COMBINE")) : 0;
+    if (dbg_skip == 1) return GNNAGG_OK;  // timing experiments only: output of split rows is left incomplete
+    if (L.wl.n_mrows > 0) {
+        CombineArgs c;
+        c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = L.row_ptr; c.partial = L.partial;
+        c.partial_den = nullptr; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
+        c.heads = 1; c.dhead = L.feat; c.mean = L.reduce == GNNAGG_REDUCE_MEAN;
+        c.big_rows = L.wl.big_rows; c.n_big = L.wl.n_big;
+        c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
+        const int nb = c.nblocks_small + c.n_big * g.ntiles;
+#define CALL_COMB                                                                                           \
+        if (is_max) hipLaunchKernelGGL((k_combine<VEC, GROUP, true, false>), dim3(nb), dim3(kBlock), 0, stream, c);  \
+        else        hipLaunchKernelGGL((k_combine<VEC, GROUP, false, false>), dim3(nb), dim3(kBlock), 0, stream, c);
+        DISPATCH_GEOM(g, CALL_COMB)
+#undef CALL_COMB
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
 int launch_gcn(const GcnLaunch &L, void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
@@ -490,6 +734,25 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
     const bool list = L.wl.target != nullptr || L.wl.slot != nullptr || L.wl.n_empty > 0;
     const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, L.feat, L.variant);
     const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
+    if (L.stream_tag && L.stream_range && L.stream_groups > 0) {
+        StreamArgs sa;
+        sa.range = reinterpret_cast<const int *>(L.stream_range);
+        sa.tag = reinterpret_cast<const int *>(L.stream_tag);
+        sa.empty_rows = L.wl.empty_rows; sa.idx = L.idx; sa.val = L.val; sa.x = L.x; sa.y = L.y; sa.partial = L.partial;
+        sa.n_groups = L.stream_groups; sa.n_empty = L.wl.n_empty; sa.feat = L.feat;
+        sa.ntiles = g.ntiles; sa.mean = L.reduce == GNNAGG_REDUCE_MEAN; sa.remap = L.xcd_remap ? 1 : 0;
+        const int gpb = kBlock / g.group;
+        sa.nblocks_main = ceil_div(sa.n_groups, gpb) * g.ntiles;
+        if (sa.nblocks_main < 64) sa.remap = 0;
+        const int grid = sa.nblocks_main + ceil_div(sa.n_empty, gpb);
+#define CALL_STREAM                                                                                         \
+        if (is_max) hipLaunchKernelGGL((k_gcn_stream<VEC, GROUP, true>), dim3(grid), dim3(kBlock), 0, stream, sa);  \
+        else        hipLaunchKernelGGL((k_gcn_stream<VEC, GROUP, false>), dim3(grid), dim3(kBlock), 0, stream, sa);
+        if (grid > 0) { DISPATCH_GEOM(g, CALL_STREAM) }
+#undef CALL_STREAM
+        HIP_TRY(hipGetLastError());
+        return launch_combine_gcn(L, g, is_max, stream);
+    }
     GcnArgs a;
     a.ptr = L.wl.ptr; a.target = L.wl.target; a.slot = L.wl.slot; a.empty_rows = L.wl.empty_rows;
     a.row_ptr = L.row_ptr; a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
@@ -523,19 +786,7 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
 #undef LAUNCH_GCN
         HIP_TRY(hipGetLastError());
     }
-    if (L.wl.n_mrows > 0) {
-        CombineArgs c;
-        c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = L.row_ptr; c.partial = L.partial;
-        c.partial_den = nullptr; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
-        c.heads = 1; c.dhead = L.feat; c.mean = a.mean;
-        const int nb = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
-#define CALL_COMB                                                                                           \
-        if (is_max) hipLaunchKernelGGL((k_combine<VEC, GROUP, true, false>), dim3(nb), dim3(kBlock), 0, stream, c);  \
-        else        hipLaunchKernelGGL((k_combine<VEC, GROUP, false, false>), dim3(nb), dim3(kBlock), 0, stream, c);
-        DISPATCH_GEOM(g, CALL_COMB)
-#undef CALL_COMB
-        HIP_TRY(hipGetLastError());
-    }
+    { int rc = launch_combine_gcn(L, g, is_max, stream); if (rc) return rc; }
     return GNNAGG_OK;
 }
 
@@ -567,7 +818,9 @@ int launch_gat(const GatLaunch &L, void *stream_v)
         c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = nullptr; c.partial = L.partial;
         c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
         c.heads = L.heads; c.dhead = dhead; c.mean = 0;
-        const int nb = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
+        c.big_rows = L.wl.big_rows; c.n_big = L.heads <= 64 ? L.wl.n_big : 0;
+        c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
+        const int nb = c.nblocks_small + c.n_big * g.ntiles;
 #define CALL_COMB hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true>), dim3(nb), dim3(kBlock), 0, stream, c);
         DISPATCH_GEOM(g, CALL_COMB)
 #undef CALL_COMB

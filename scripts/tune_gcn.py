@@ -40,8 +40,17 @@ def main():
     y = torch.empty((V, F), device=dev)
     configs = []
     modes = os.environ.get("TUNE_MODES", "rows,balanced").split(",")
-    for mode, remap, idxm, var in itertools.product(modes, (0, 1, 2), (0, 1), (0, 1)):
-        configs.append(dict(mode=mode, remap=remap, idxmode=idxm, variant=var))
+    streams = [int(v) for v in os.environ.get("TUNE_STREAM", "0,1").split(",")]
+    bpcs = [int(v) for v in os.environ.get("TUNE_BPC", "8").split(",")]
+    remaps = [int(v) for v in os.environ.get("TUNE_REMAP", "0,1,2").split(",")]
+    idxms = [int(v) for v in os.environ.get("TUNE_IDXMODE", "0,1").split(",")]
+    variants = [int(v) for v in os.environ.get("TUNE_VARIANT", "0").split(",")]
+    for mode, remap, idxm, var, st, bpc in itertools.product(modes, remaps, idxms, variants, streams, bpcs):
+        if st == 0 and bpc != bpcs[0]:
+            continue
+        if st == 1 and (idxm != idxms[0] or remap == 2):
+            continue
+        configs.append(dict(mode=mode, remap=remap, idxmode=idxm, variant=var, stream=st, bpc=bpc))
     extra_chunks = [int(c) for c in os.environ.get("TUNE_CHUNKS", "").split(",") if c]
     aggs = {}
     for gname, (ptr, idx) in gs.items():
@@ -51,6 +60,8 @@ def main():
             os.environ["GNNAGG_XCD_REMAP"] = str(c["remap"])
             os.environ["GNNAGG_IDXMODE"] = str(c["idxmode"])
             os.environ["GNNAGG_VARIANT"] = str(c["variant"])
+            os.environ["GNNAGG_STREAM"] = str(c["stream"])
+            os.environ["GNNAGG_STREAM_BPC"] = str(c["bpc"])
             a = gnc.Aggregator_GCN(dptr, didx, dval, F, F)
             a._keep = [dptr, didx, dval]
             if c["mode"] == "balanced":
@@ -77,11 +88,11 @@ def main():
             torch.cuda.synchronize()
             if r > 0:
                 times[k].append(e0.elapsed_time(e1) * 1e3 / inner)
-    print("%-10s %-9s %5s %5s %4s %6s | %9s %9s" % ("graph", "mode", "remap", "idxm", "var", "chunk", "med_us", "min_us"))
+    print("%-10s %-9s %5s %5s %4s %6s %4s %4s | %9s %9s" % ("graph", "mode", "remap", "idxm", "var", "chunk", "strm", "bpc", "med_us", "min_us"))
     for k in sorted(times, key=lambda k: (k[0], np.median(times[k]))):
         c = configs[k[1]]
-        print("%-10s %-9s %5d %5d %4d %6d | %9.1f %9.1f" % (k[0], c["mode"], c["remap"], c["idxmode"], c["variant"], k[2],
-                                                          np.median(times[k]), np.min(times[k])))
+        print("%-10s %-9s %5d %5d %4d %6d %4d %4d | %9.1f %9.1f" % (k[0], c["mode"], c["remap"], c["idxmode"], c["variant"], k[2],
+                                                                  c["stream"], c["bpc"], np.median(times[k]), np.min(times[k])))
 
 
 if __name__ == "__main__":

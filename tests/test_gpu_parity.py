@@ -397,3 +397,36 @@ def test_arxiv_full_size_parity_and_properties():
                                                    ctypes.byref(n), None))
     assert n.value == 0
     assert np.array_equal(y2.cpu().numpy()[rev], y.cpu().numpy())
+
+
+@pytest.mark.parametrize("F,ng", [(128, 2), (100, 7), (602, 16), (32, 1)])
+def test_hub_rows_block_cooperative_combine(F, ng):
+    """Hub rows (thousands of partial rows) go through the workgroup-per-row combine path."""
+    V = 300
+    rng = np.random.default_rng(5)
+    deg = rng.integers(0, 6, V)
+    deg[7], deg[150], deg[299] = 5000, 1337, 18  # two hubs, one row just above the batch size
+    ptr = np.zeros(V + 1, np.int32)
+    ptr[1:] = np.cumsum(deg)
+    E = int(ptr[-1])
+    idx = rng.integers(0, V, E).astype(np.int32)
+    x, val = rand((V, F), 1), rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.schedule(gnc.Schedule.neighbor_grouping, [ng])
+    ps, tg = orc.neighbor_grouping(ptr, ng)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), y, 512, 1)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+    agg.run(dev(x), y, 512, 1, reduce="max")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))
+    agg.run(dev(x), y, 512, 1, reduce="mean")
+    d = np.maximum(deg, 1)[:, None].astype(np.float32)
+    assert_within(y.cpu().numpy(), orc.gcn_mean(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x) / d, "hub mean")
+    if F % 2 == 0 and F <= 128:
+        H = 2
+        att = rand((V, H, 2), 3) * 0.3
+        gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+        gat.schedule(gnc.Schedule.neighbor_grouping, [ng])
+        gat.run(dev(x), dev(att), y, 128, 1, heads=H)
+        ref, _, _ = orc.gat_grouped(ps, tg, idx, att, x, V, H)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
