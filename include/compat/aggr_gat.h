@@ -1,0 +1,67 @@
+// aggr_gat.h -- class Aggregator_GAT with the reference's public surface (reference include/aggr_gat.h:299-441).
+#ifndef GNNAGG_COMPAT_AGGR_GAT_H
+#define GNNAGG_COMPAT_AGGR_GAT_H
+#include "aggregator.h"
+
+class Aggregator_GAT : public Aggregator
+{
+public:
+    // reference aggr_gat.h:302
+    Aggregator_GAT(int *host_out_ptr, int *host_out_idx, int *dev_out_ptr, int *dev_out_idx, int out_num_v, int out_num_e,
+                   int out_feat_in, int out_feat_out)
+        : Aggregator(host_out_ptr, host_out_idx, dev_out_ptr, dev_out_idx, out_num_v, out_num_e, out_feat_in, out_feat_out)
+    {
+        checkGnnagg(gnnagg_gat_create(d_ptr, d_idx, num_v, num_e, &handle));
+    }
+    // reference aggr_gat.h:308
+    Aggregator_GAT(CSRSubGraph g, int out_feat_in, int out_feat_out) : Aggregator(g, out_feat_in, out_feat_out)
+    {
+        checkGnnagg(gnnagg_gat_create(d_ptr, d_idx, num_v, num_e, &handle));
+    }
+    // two aggregators may share one CSR (Figure10/main_a.cu:66-70): only one of them may own it
+    void releaseGraphOwnership() { d_ptr = nullptr; d_idx = nullptr; d_vset = nullptr; }
+
+    // reference aggr_gat.h:317-354; leaky slope 0.2 (:347); att is [V,2]
+    double run(float *vin, float *vatt, float *vout, int BLOCK_SIZE, bool scheduled) override
+    {
+        return run_with_feat(vin, vatt, vout, BLOCK_SIZE, scheduled, feat_in);
+    }
+    // reference aggr_gat.h:355-394
+    double run_with_feat(float *vin, float *vatt, float *vout, int BLOCK_SIZE, bool scheduled, int feat)
+    {
+        (void)BLOCK_SIZE;
+        feat_in = feat;
+        checkGnnagg(gnnagg_gat_run(handle, vin, vatt, vout, feat, 1, 0.2f,
+                                   scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS, nullptr));
+        return 0.0;
+    }
+    // multi-head extension: att [V,heads,2], feat % heads == 0
+    double run_heads(float *vin, float *vatt, float *vout, int feat, int heads, int mode = GNNAGG_MODE_BALANCED,
+                     float slope = 0.2f)
+    {
+        checkGnnagg(gnnagg_gat_run(handle, vin, vatt, vout, feat, heads, slope, mode, nullptr));
+        return 0.0;
+    }
+    // reference aggr_gat.h:395-425
+    void run_att(float *in_att, float *out_val, int BLOCK_SIZE)
+    {
+        (void)BLOCK_SIZE;
+        checkGnnagg(gnnagg_gat_run_att(handle, in_att, out_val, 1, 0.2f));
+    }
+    void run_u_add_v(float *in_att, float *out_val, int BLOCK_SIZE)
+    {
+        (void)BLOCK_SIZE;
+        checkGnnagg(gnnagg_gat_run_u_add_v(handle, in_att, out_val));
+    }
+    void run_add_to_center(float *in_val, float *out_att, int BLOCK_SIZE)
+    {
+        (void)BLOCK_SIZE;
+        checkGnnagg(gnnagg_gat_run_add_to_center(handle, in_val, out_att));
+    }
+    void run_div_each(float *in_att, float *in_out_val, int BLOCK_SIZE)
+    {
+        (void)BLOCK_SIZE;
+        checkGnnagg(gnnagg_gat_run_div_each(handle, in_att, in_out_val));
+    }
+};
+#endif

@@ -1,0 +1,67 @@
+// aggr_gcn.h -- class Aggregator_GCN with the reference's public surface (reference include/aggr_gcn.h:362-550).
+#ifndef GNNAGG_COMPAT_AGGR_GCN_H
+#define GNNAGG_COMPAT_AGGR_GCN_H
+#include "aggregator.h"
+
+class Aggregator_GCN : public Aggregator
+{
+public:
+    // reference aggr_gcn.h:365
+    Aggregator_GCN(int *host_out_ptr, int *host_out_idx, int *dev_out_ptr, int *dev_out_idx, int out_num_v, int out_num_e,
+                   int out_feat_in, int out_feat_out, float *out_val)
+        : Aggregator(host_out_ptr, host_out_idx, dev_out_ptr, dev_out_idx, out_num_v, out_num_e, out_feat_in, out_feat_out),
+          d_val(out_val)
+    {
+        checkGnnagg(gnnagg_gcn_create(d_ptr, d_idx, d_val, num_v, num_e, &handle));
+    }
+    // reference aggr_gcn.h:370
+    Aggregator_GCN(CSRSubGraph g, int out_feat_in, int out_feat_out, float *out_val)
+        : Aggregator(g, out_feat_in, out_feat_out), d_val(out_val)
+    {
+        checkGnnagg(gnnagg_gcn_create(d_ptr, d_idx, d_val, num_v, num_e, &handle));
+    }
+    ~Aggregator_GCN() { safeFree(d_val); }
+
+    // reference aggr_gcn.h:379-410.  BLOCK_SIZE encodes CUDA block geometry there; ignored here.
+    double run(float *vin, float *vout, int BLOCK_SIZE, bool scheduled) override
+    {
+        return run_with_feat(vin, vout, BLOCK_SIZE, scheduled, feat_in);
+    }
+    // reference aggr_gcn.h:411-444
+    double run_with_feat(float *vin, float *vout, int BLOCK_SIZE, bool scheduled, int feat)
+    {
+        (void)BLOCK_SIZE;
+        feat_in = feat;
+        checkGnnagg(gnnagg_gcn_run(handle, vin, vout, feat, scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS,
+                                   GNNAGG_REDUCE_SUM));
+        return 0.0;
+    }
+    // library-chosen chunking of long rows (no reference counterpart); reduce = GNNAGG_REDUCE_*
+    double run_balanced(float *vin, float *vout, int feat, int reduce = GNNAGG_REDUCE_SUM)
+    {
+        checkGnnagg(gnnagg_gcn_run(handle, vin, vout, feat, GNNAGG_MODE_BALANCED, reduce));
+        return 0.0;
+    }
+    // reference aggr_gcn.h:446-460 (synchronous and timed, like the reference)
+    double runEdgeWise(float *vin, float *vout, int BLOCK_SIZE, bool scheduled) override
+    {
+        (void)BLOCK_SIZE;
+        (void)scheduled;
+        checkHipErrors(hipDeviceSynchronize());
+        timestamp(t0);
+        checkGnnagg(gnnagg_gcn_run_edgewise(handle, vin, vout, feat_in));
+        checkHipErrors(hipDeviceSynchronize());
+        timestamp(t1);
+        return getDuration(t0, t1);
+    }
+    // reference aggr_gcn.h:540-544
+    void updateval(float *out_d_val)
+    {
+        d_val = out_d_val;
+        checkGnnagg(gnnagg_update_val(handle, out_d_val));
+    }
+
+private:
+    float *d_val = nullptr;
+};
+#endif
