@@ -88,6 +88,12 @@ class Aggregator:
     def schedule_balanced(self, chunk=0):
         check(lib().gnnagg_schedule_balanced(self._h, int(chunk)))
 
+    def balanced_params(self):
+        """(chunk, seg_chunks) of the balanced mode's summation order (see gnnagg_balanced_params)."""
+        ch, sg = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib().gnnagg_balanced_params(self._h, ctypes.byref(ch), ctypes.byref(sg)))
+        return ch.value, sg.value
+
     @property
     def num_target(self):
         """aggregator.h:126"""

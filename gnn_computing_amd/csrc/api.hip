@@ -102,6 +102,23 @@ struct Schedule {
     }
 };
 
+// GNNAGG_MODE_BALANCED plan of a GCN aggregator (k_gcn_plan): short rows, long-row segments, hub slots.
+struct BalancedPlan {
+    bool valid = false;
+    int chunk = 64;
+    int n0 = 0, n1 = 0, n_mrows = 0, n_slots = 0, n_big = 0;
+    DevBuf<int> t0, t1, mrow_id, mrow_ptr, big_rows;
+    std::vector<long> t0_cost_prefix;
+    void reset()
+    {
+        valid = false;
+        t0.release(); t1.release(); mrow_id.release(); mrow_ptr.release(); big_rows.release();
+        t0_cost_prefix.clear();
+        n0 = n1 = n_mrows = n_slots = n_big = 0;
+    }
+};
+static constexpr int kSegChunksHost = 16;  // kSegChunks in kernels.hip
+
 static constexpr int kItemCost = 2;  // fixed per-item overhead in edge-equivalents (XCD range balancing)
 
 struct Ctx {
@@ -112,13 +129,16 @@ struct Ctx {
     const float *d_val = nullptr;
     hipStream_t stream = nullptr;
     std::vector<int> h_ptr;  // host mirror, fetched on first schedule (reference ctor: aggregator.h:50)
-    Schedule sched[2];       // [0] user schedule (MODE_SCHEDULED), [1] balanced (MODE_BALANCED)
+    Schedule sched[2];       // [0] user schedule (MODE_SCHEDULED), [1] balanced (MODE_BALANCED; GAT, and the
+                             //     host arrays that describe the GCN plan's summation order)
+    BalancedPlan plan;       // GCN balanced mode
     DevBuf<float> partial, partial_den;
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
     DevBuf<int> diffbuf;
     int xcd_remap = 2;
     int variant = 0;
     int idxmode = 1;
+    int use_plan = 1;          // GCN balanced mode runs k_gcn_plan (0: items + combine, the round-1 first design)
     int use_stream = 0;        // 1: LIST modes run the persistent streaming kernel (A/B knob; the item kernel measured faster)
     int stream_bpc = 8;        // workgroups per CU for the streaming grid
     int stream_min_edges = 32; // lower bound on edges per lane group
@@ -189,7 +209,7 @@ static int finalize_schedule(Ctx *c, Schedule &s)
         }
         if ((rc = s.desc.upload(desc))) return rc;
         const long ne = G > 0 ? s.h_ptr_s[G] : 0;
-        if (ne > 0) {
+        if (ne > 0 && c->use_stream) {
             if ((rc = s.tag.reserve((size_t)ne))) return rc;
             if ((rc = launch_build_tags(s.desc.p, G, ne, s.tag.p, c->stream))) return rc;
         }
@@ -288,6 +308,65 @@ static int stream_range_table(Schedule &s, int ngroups, const int **out)
     return GNNAGG_OK;
 }
 
+static int build_balanced_plan(Ctx *c, int chunk)
+{
+    int rc = fetch_host_ptr(c);
+    if (rc) return rc;
+    BalancedPlan &p = c->plan;
+    p.reset();
+    p.chunk = chunk;
+    const int V = c->V;
+    const long seg_edges = (long)chunk * kSegChunksHost;
+    std::vector<int> t0, t1, mrow_id, mrow_ptr(1, 0), big;
+    struct Seg { int beg, end, dest; };
+    std::vector<Seg> segs;
+    p.t0_cost_prefix.assign(1, 0);
+    int nslots = 0;
+    for (int r = 0; r < V; ++r) {
+        const int beg = c->h_ptr[r], end = c->h_ptr[r + 1], deg = end - beg;
+        if (deg <= chunk) {
+            t0.insert(t0.end(), {beg, end, r, 0});
+            p.t0_cost_prefix.push_back(p.t0_cost_prefix.back() + deg + kItemCost);
+        } else if (deg <= seg_edges) {
+            segs.push_back({beg, end, r});
+        } else {
+            const int nseg = (int)((deg + seg_edges - 1) / seg_edges);
+            for (int j = 0; j < nseg; ++j) {
+                const long sb = beg + (long)j * seg_edges;
+                segs.push_back({(int)sb, (int)std::min<long>(sb + seg_edges, end), ~(nslots + j)});
+            }
+            if (nseg > 16) big.push_back((int)mrow_id.size());  // kCombineBatch in kernels.hip
+            nslots += nseg;
+            mrow_id.push_back(r);
+            mrow_ptr.push_back(nslots);
+        }
+    }
+    // heaviest segments first: they start at t = 0 and never form the tail of the launch
+    std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.end - a.beg > b.end - b.beg; });
+    for (const Seg &sg : segs) t1.insert(t1.end(), {sg.beg, sg.end, sg.dest, 0});
+    p.n0 = (int)(t0.size() / 4);
+    p.n1 = (int)(t1.size() / 4);
+    p.n_mrows = (int)mrow_id.size();
+    p.n_slots = nslots;
+    p.n_big = (int)big.size();
+    if ((rc = p.t0.upload(t0))) return rc;
+    if ((rc = p.t1.upload(t1))) return rc;
+    if ((rc = p.mrow_id.upload(mrow_id))) return rc;
+    if ((rc = p.mrow_ptr.upload(mrow_ptr))) return rc;
+    if ((rc = p.big_rows.upload(big))) return rc;
+    // host description of the summation order (chunks of `chunk` edges per row) for get_schedule()
+    Schedule &s = c->sched[1];
+    s.reset();
+    s.kind = GNNAGG_SCHED_NEIGHBOR_GROUPING;
+    const int G = neighbor_grouping(c->h_ptr.data(), chunk, V, nullptr, nullptr);
+    s.h_ptr_s.resize((size_t)G + 1);
+    s.h_target.resize((size_t)G);
+    neighbor_grouping(c->h_ptr.data(), chunk, V, s.h_ptr_s.data(), s.h_target.data());
+    s.num_target = G;
+    p.valid = true;
+    return GNNAGG_OK;
+}
+
 static int pick_chunk(const Ctx *c)
 {
     // long rows become work items of <= chunk edges: small enough that the hub rows of a
@@ -305,7 +384,12 @@ static int get_sched(Ctx *c, int mode, Schedule **out)
             return fail(GNNAGG_ERR_STATE, "scheduled run without schedule() (reference: assert aggr_gcn.h:392)");
         *out = &c->sched[0];
     } else if (mode == GNNAGG_MODE_BALANCED) {
-        if (!c->sched[1].valid) {
+        if (c->kind == Ctx::GCN && c->use_plan) {
+            if (!c->plan.valid) {
+                int rc = build_balanced_plan(c, pick_chunk(c));
+                if (rc) return rc;
+            }
+        } else if (!c->sched[1].valid) {
             int rc = build_grouping(c, c->sched[1], pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
             if (rc) return rc;
         }
@@ -325,6 +409,21 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
+    if (mode == GNNAGG_MODE_BALANCED && c->use_plan) {
+        BalancedPlan &p = c->plan;
+        GcnPlanLaunch P;
+        P.t0 = p.t0.p; P.t1 = p.t1.p; P.n0 = p.n0; P.n1 = p.n1; P.chunk = p.chunk;
+        P.t0_cost_prefix = p.t0_cost_prefix.data();
+        P.hubs.mrow_id = p.mrow_id.p; P.hubs.mrow_ptr = p.mrow_ptr.p; P.hubs.n_mrows = p.n_mrows;
+        P.hubs.n_slots = p.n_slots; P.hubs.big_rows = p.big_rows.p; P.hubs.n_big = p.n_big;
+        P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
+        P.xcd_remap = c->xcd_remap; P.variant = c->variant;
+        if (p.n_slots > 0) {
+            if ((rc = c->partial.reserve((size_t)p.n_slots * feat))) return rc;
+            P.partial = c->partial.p;
+        }
+        return launch_gcn_plan(P, c->stream);
+    }
     GcnLaunch L;
     L.row_ptr = c->d_ptr; L.x = x; L.y = y; L.feat = feat; L.reduce = reduce;
     L.xcd_remap = c->xcd_remap; L.variant = c->variant; L.idxmode = c->idxmode;
@@ -458,6 +557,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_VARIANT")) c->variant = atoi(e);
     if (const char *e = getenv("GNNAGG_IDXMODE")) c->idxmode = atoi(e);
     if (const char *e = getenv("GNNAGG_STREAM")) c->use_stream = atoi(e);
+    if (const char *e = getenv("GNNAGG_PLAN")) c->use_plan = atoi(e);
     if (const char *e = getenv("GNNAGG_STREAM_BPC")) c->stream_bpc = std::max(1, atoi(e));
     if (const char *e = getenv("GNNAGG_STREAM_MIN_EDGES")) c->stream_min_edges = std::max(1, atoi(e));
     {
@@ -524,7 +624,25 @@ int gnnagg_schedule_balanced(gnnagg_handle h, int chunk)
 {
     GET_CTX(h);
     if (chunk < 0) return fail(GNNAGG_ERR_ARG, "chunk must be >= 0");
+    if (c->kind == Ctx::GCN && c->use_plan) return build_balanced_plan(c, chunk > 0 ? chunk : pick_chunk(c));
     return build_grouping(c, c->sched[1], chunk > 0 ? chunk : pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
+}
+
+int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks)
+{
+    GET_CTX(h);
+    Schedule *s = nullptr;
+    int rc = get_sched(c, GNNAGG_MODE_BALANCED, &s);
+    if (rc) return rc;
+    const bool plan = c->kind == Ctx::GCN && c->use_plan;
+    if (chunk) {
+        int mx = 0;
+        if (plan) mx = c->plan.chunk;
+        else for (int g = 0; g < s->num_target; ++g) mx = std::max(mx, s->h_ptr_s[g + 1] - s->h_ptr_s[g]);
+        *chunk = mx;
+    }
+    if (seg_chunks) *seg_chunks = plan ? kSegChunksHost : 0;
+    return GNNAGG_OK;
 }
 
 int gnnagg_num_target(gnnagg_handle h, int mode, int *out)
@@ -549,10 +667,9 @@ int gnnagg_get_schedule(gnnagg_handle h, int mode, int *h_ptr_s, int *h_idx_s, i
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
     if (!s) return fail(GNNAGG_ERR_ARG, "MODE_ROWS has no schedule");
-    // read back from the device: this is what the kernels consume
     const int G = s->num_target;
-    if (h_ptr_s) HIP_TRY(hipMemcpy(h_ptr_s, s->ptr_s.p, ((size_t)G + 1) * sizeof(int), hipMemcpyDeviceToHost));
-    if (h_target && G > 0) HIP_TRY(hipMemcpy(h_target, s->target.p, (size_t)G * sizeof(int), hipMemcpyDeviceToHost));
+    if (h_ptr_s) memcpy(h_ptr_s, s->h_ptr_s.data(), ((size_t)G + 1) * sizeof(int));
+    if (h_target && G > 0) memcpy(h_target, s->h_target.data(), (size_t)G * sizeof(int));
     const size_t ne = s->permuted ? s->h_idx_s.size() : (size_t)c->E;
     if (h_idx_s && ne > 0)
         HIP_TRY(hipMemcpy(h_idx_s, s->permuted ? s->idx_s.p : c->d_idx, ne * sizeof(int), hipMemcpyDeviceToHost));

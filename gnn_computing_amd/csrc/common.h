@@ -69,6 +69,25 @@ struct GcnLaunch {
     int stream_groups = 0;
 };
 
+// Balanced plan (GNNAGG_MODE_BALANCED, GCN): see k_gcn_plan in kernels.hip.
+struct GcnPlanLaunch {
+    const void *t0 = nullptr;  // int4 {beg,end,row,-} per short row
+    const void *t1 = nullptr;  // int4 {beg,end,dest,-} per long-row segment
+    int n0 = 0, n1 = 0, chunk = 64;
+    const long *t0_cost_prefix = nullptr;  // host, n0+1 entries
+    WorkList hubs;                          // only mrow_* / big_rows / n_slots are used (combine of multi-segment rows)
+    const int *row_ptr = nullptr;
+    const int *idx = nullptr;
+    const float *val = nullptr;
+    const float *x = nullptr;
+    float *y = nullptr;
+    float *partial = nullptr;
+    int feat = 0;
+    int reduce = GNNAGG_REDUCE_SUM;
+    int xcd_remap = 2;
+    int variant = 0;
+};
+
 struct GatLaunch {
     WorkList wl;
     const int *idx = nullptr;
@@ -87,6 +106,7 @@ struct GatLaunch {
 int lane_groups_per_block(int feat, const void *x, const void *y, const void *partial, int dhead, int variant);
 int launch_build_tags(const void *desc, int n_items, long n_edges, int *tag, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);
+int launch_gcn_plan(const GcnPlanLaunch &a, void *stream);
 int launch_gat(const GatLaunch &a, void *stream);
 int launch_gat_att(const int *ptr, const int *idx, const float *att, float *out, int V, int heads, float slope,
                    int avg_deg, void *stream);

@@ -259,6 +259,158 @@ __global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
     store_pack<VEC>(a.y + (size_t)row * F + col, acc);
 }
 
+// The FMA (or max) chain of one work item over edges [beg,end) in CSR order.  Lane j of the group fetches
+// (idx,val) of edge cb+j with ONE coalesced load per GROUP edges (next window prefetched); each edge's
+// pair is broadcast inside the group with ds_bpermute (LDS crossbar, no memory traffic), kUnroll feature
+// gathers are issued before the first FMA.  Lanes with col_ok == false still carry metadata.
+template <int VEC, int GROUP, bool IS_MAX>
+__device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end, int lane, bool col_ok,
+                                            const int *__restrict__ idx, const float *__restrict__ val,
+                                            const float *__restrict__ xcol, int F)
+{
+    int my_s = 0;
+    float my_w = 1.0f;
+    if (beg + lane < end) {
+        my_s = idx[beg + lane];
+        if (val) my_w = val[beg + lane];
+    }
+    for (int cb = beg; cb < end; cb += GROUP) {
+        int nx_s = 0;
+        float nx_w = 1.0f;
+        if (cb + GROUP + lane < end) {
+            nx_s = idx[cb + GROUP + lane];
+            if (val) nx_w = val[cb + GROUP + lane];
+        }
+        const int n = end - cb < GROUP ? end - cb : GROUP;
+        for (int j = 0; j < n; j += kUnroll) {
+            int s[kUnroll];
+            float w[kUnroll];
+            Pack<VEC> xv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                s[u] = __shfl(my_s, j + u, GROUP);
+                w[u] = __shfl(my_w, j + u, GROUP);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        if (IS_MAX) {
+                            const float p = xv[u].v[k] * w[u];
+                            acc[k] = p > acc[k] ? p : acc[k];
+                        } else {
+                            acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
+                        }
+                    }
+                }
+        }
+        my_s = nx_s;
+        my_w = nx_w;
+    }
+}
+
+// ------------------------------------------------------------------ GCN / SAGE, balanced plan
+// One launch, two kinds of workgroups (heavy ones first in the grid so they never form the tail):
+//  * blocks [0, n1*ntiles): one SEGMENT (<= kSegChunks chunks of `chunk` edges) of a long row per
+//    workgroup.  Lane group g computes the partial chains of chunks g, g+GPB, ...; the partials meet in
+//    LDS and group 0 folds them in ascending chunk order (deterministic; the reference's
+//    aggr_gcn_target adds them with fp32 atomics in arbitrary order, aggr_gcn.h:112).  A row that fits one
+//    segment is written straight to Y; only rows with several segments (hubs) go through scratch + k_combine.
+//  * the remaining blocks: GPB short rows each (deg <= chunk, empty rows included), one lane group per
+//    row, descriptor {beg,end,row} fetched with ONE 16-byte load; XCD-aware work-balanced block ranges.
+static constexpr int kSegChunks = 16;
+
+struct PlanArgs {
+    const int4 *t0;  // {beg, end, row, -}
+    const int4 *t1;  // {beg, end, dest (>=0 row, <0 ~scratch slot), -}
+    const int *idx;
+    const float *val;
+    const float *x;
+    float *y;
+    float *partial;
+    int n0, n1, feat, ntiles, chunk, mean, remap, nblocks0;
+    XcdRanges xr;
+};
+
+template <int VEC, int GROUP, bool IS_MAX>
+__global__ __launch_bounds__(kBlock) void k_gcn_plan(const PlanArgs a)
+{
+    constexpr int GPB = kBlock / GROUP;
+    const int F = a.feat;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int grp = (int)threadIdx.x / GROUP;
+    const int nb1 = a.n1 * a.ntiles;
+    if ((int)blockIdx.x < nb1) {
+        __shared__ float stage[kSegChunks * GROUP * VEC];
+        const int tile = (int)blockIdx.x % a.ntiles;
+        const int4 d = a.t1[(int)blockIdx.x / a.ntiles];
+        const int col = (tile * GROUP + lane) * VEC;
+        const bool col_ok = col < F;
+        const int nch = (d.y - d.x + a.chunk - 1) / a.chunk;
+        for (int c = grp; c < nch; c += GPB) {
+            float acc[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+            const int cb = d.x + c * a.chunk;
+            const int ce = cb + a.chunk < d.y ? cb + a.chunk : d.y;
+            chain_edges<VEC, GROUP, IS_MAX>(acc, cb, ce, lane, col_ok, a.idx, a.val, a.x + col, F);
+            store_pack<VEC>(&stage[(c * GROUP + lane) * VEC], acc);
+        }
+        __syncthreads();
+        if (grp != 0 || !col_ok) return;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+#pragma unroll
+        for (int c = 0; c < kSegChunks; ++c)
+            if (c < nch) {
+                const Pack<VEC> p = load_pack<VEC>(&stage[(c * GROUP + lane) * VEC]);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (IS_MAX) acc[k] = p.v[k] > acc[k] ? p.v[k] : acc[k];
+                    else acc[k] += p.v[k];
+                }
+            }
+        if (d.z >= 0) {
+            if (a.mean) {
+                const float dg = (float)(d.y - d.x);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
+            }
+            store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
+        } else {
+            store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
+        }
+        return;
+    }
+    const int b = logical_block((int)blockIdx.x - nb1, a.nblocks0, a.ntiles, a.remap, a.xr);
+    if (b < 0) return;
+    const int tile = b % a.ntiles;
+    const int item = (b / a.ntiles) * GPB + grp;
+    if (item >= a.n0) return;
+    const int col = (tile * GROUP + lane) * VEC;
+    const bool col_ok = col < F;
+    const int4 d = a.t0[item];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+    chain_edges<VEC, GROUP, IS_MAX>(acc, d.x, d.y, lane, col_ok, a.idx, a.val, a.x + col, F);
+    if (!col_ok) return;
+    if (d.x == d.y) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    } else if (a.mean) {
+        const float dg = (float)(d.y - d.x);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
+    }
+    store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
+}
+
 // ------------------------------------------------------------------ GCN / SAGE, streaming
 // Persistent streaming variant for work lists (all LIST modes; every item is non-empty).
 // Lane group q owns the contiguous edge range [range[q], range[q+1]) -- whole items, cut on the host so
@@ -725,6 +877,40 @@ static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max
         HIP_TRY(hipGetLastError());
     }
     return GNNAGG_OK;
+}
+
+int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (L.feat <= 0) return fail(GNNAGG_ERR_ARG, "feature length must be >= 1");
+    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, L.feat, L.variant);
+    const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
+    PlanArgs a;
+    a.t0 = reinterpret_cast<const int4 *>(L.t0); a.t1 = reinterpret_cast<const int4 *>(L.t1);
+    a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
+    a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
+    a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap;
+    const int gpb = kBlock / g.group;
+    const int item_blocks = ceil_div(a.n0, gpb);
+    a.nblocks0 = item_blocks * g.ntiles;
+    if (a.remap && a.nblocks0 < 64) a.remap = 0;
+    int grid0 = a.nblocks0;
+    if (a.remap == 2) {
+        if (!L.t0_cost_prefix) a.remap = 1;
+        else grid0 = 8 * fill_xcd_ranges(L.t0_cost_prefix, a.n0, gpb, item_blocks, a.xr) * g.ntiles;
+    }
+    const int grid = a.n1 * g.ntiles + grid0;
+    if (grid > 0) {
+#define CALL_PLAN                                                                                            \
+        if (is_max) hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, true>), dim3(grid), dim3(kBlock), 0, stream, a);      \
+        else        hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+        DISPATCH_GEOM(g, CALL_PLAN)
+#undef CALL_PLAN
+        HIP_TRY(hipGetLastError());
+    }
+    GcnLaunch C;
+    C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
+    return launch_combine_gcn(C, g, is_max, stream);
 }
 
 int launch_gcn(const GcnLaunch &L, void *stream_v)

@@ -104,6 +104,11 @@ int gnnagg_schedule(gnnagg_handle h, int kind, const int *param, int total_num_v
 /* Library-chosen chunking of long rows into work items of <= chunk edges (0 = choose from the
  * degree distribution).  Used by GNNAGG_MODE_BALANCED. */
 int gnnagg_schedule_balanced(gnnagg_handle h, int chunk);
+/* Summation order of GNNAGG_MODE_BALANCED: rows are cut into chunks of *chunk edges (partial FMA chains
+ * from 0, like the reference's neighbor groups); seg_chunks > 0 means the chunk partials of a row are folded
+ * in ascending order inside segments of seg_chunks chunks and the segment sums are then added in ascending
+ * order; 0 means one flat ascending fold.  (Rows of at most seg_chunks chunks are identical either way.) */
+int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks);
 /* Aggregator::num_target (aggregator.h:126), and the scheduled arrays copied to host buffers
  * (any may be NULL): ptr_s[num_target+1], idx_s[ptr_s[num_target]], target[num_target], val_s. */
 int gnnagg_num_target(gnnagg_handle h, int mode, int *out);

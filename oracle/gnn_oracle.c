@@ -177,11 +177,17 @@ ORC_API void orc_gcn_seq(const int *ptr, const int *idx, const float *val, const
  * into the zeroed output row.  The reference adds them with atomicAdd in arbitrary order; this
  * restatement fixes the order to ascending group index (one of the reference's legal outcomes
  * and the order the HIP path's deterministic combine uses). */
-ORC_API void orc_gcn_grouped(const int *ptr_s, const int *target, int num_groups, const int *idx,
-                             const float *val, const float *X, float *Y, int num_v, int F)
+ORC_API void orc_gcn_grouped_seg(const int *ptr_s, const int *target, int num_groups, const int *idx,
+                                 const float *val, const float *X, float *Y, int num_v, int F, int seg)
 {
+    /* seg <= 0: every group partial is added straight into the zeroed output row (flat ascending fold).
+     * seg  > 0: the partials of `seg` consecutive groups of one row are first folded into a segment
+     * accumulator (from 0), and the segment sums are added into the row in ascending order -- the
+     * order of the HIP path's in-workgroup reduction (k_gcn_plan) followed by k_combine. */
     memset(Y, 0, (size_t)num_v * F * sizeof(float));
     float *rs = (float *)malloc((size_t)F * sizeof(float));
+    float *sg = (float *)malloc((size_t)F * sizeof(float));
+    int in_seg = 0, seg_row = -1;
     for (int g = 0; g < num_groups; ++g) {
         for (int c = 0; c < F; ++c) rs[c] = 0.0f;
         for (int e = ptr_s[g]; e < ptr_s[g + 1]; ++e) {
@@ -190,9 +196,37 @@ ORC_API void orc_gcn_grouped(const int *ptr_s, const int *target, int num_groups
             for (int c = 0; c < F; ++c) rs[c] = fmaf(x[c], v, rs[c]);
         }
         float *y = Y + (size_t)target[g] * F;
-        for (int c = 0; c < F; ++c) y[c] += rs[c];
+        if (seg <= 0) {
+            for (int c = 0; c < F; ++c) y[c] += rs[c];
+            continue;
+        }
+        if (in_seg == 0 || seg_row != target[g]) {  /* flush a pending segment, start a new one */
+            if (in_seg > 0) {
+                float *yp = Y + (size_t)seg_row * F;
+                for (int c = 0; c < F; ++c) yp[c] += sg[c];
+            }
+            for (int c = 0; c < F; ++c) sg[c] = 0.0f;
+            in_seg = 0;
+            seg_row = target[g];
+        }
+        for (int c = 0; c < F; ++c) sg[c] += rs[c];
+        if (++in_seg == seg) {
+            for (int c = 0; c < F; ++c) y[c] += sg[c];
+            in_seg = 0;
+        }
+    }
+    if (seg > 0 && in_seg > 0) {
+        float *yp = Y + (size_t)seg_row * F;
+        for (int c = 0; c < F; ++c) yp[c] += sg[c];
     }
     free(rs);
+    free(sg);
+}
+
+ORC_API void orc_gcn_grouped(const int *ptr_s, const int *target, int num_groups, const int *idx,
+                             const float *val, const float *X, float *Y, int num_v, int F)
+{
+    orc_gcn_grouped_seg(ptr_s, target, num_groups, idx, val, X, Y, num_v, F, 0);
 }
 
 /* "mean" and "max" reductions.  The reference has no kernels for them (mean is the

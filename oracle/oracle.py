@@ -145,11 +145,14 @@ def gcn_abs_scale(ptr, idx, val, X):
     return _gcn(lib().orc_gcn_abs_scale, ptr, idx, val, X)
 
 
-def gcn_grouped(ptr_s, target, idx, val, X, num_v):
+def gcn_grouped(ptr_s, target, idx, val, X, num_v, seg=0):
+    """seg > 0: partials folded inside segments of `seg` groups per row, then the segment sums (the balanced
+    mode's order, see orc_gcn_grouped_seg); seg = 0: flat ascending fold (reference NG semantics)."""
     ptr_s, target, idx, val, X = _ci(ptr_s), _ci(target), _ci(idx), _cf(val), _cf(X)
     F = X.shape[1]
     Y = np.empty((num_v, F), np.float32)
-    lib().orc_gcn_grouped(_i(ptr_s), _i(target), len(target), _i(idx), _f(val), _f(X), _f(Y), int(num_v), F)
+    lib().orc_gcn_grouped_seg(_i(ptr_s), _i(target), len(target), _i(idx), _f(val), _f(X), _f(Y), int(num_v), F,
+                              int(seg))
     return Y
 
 

@@ -52,9 +52,9 @@ def test_reddit_sage_mean_f602(reddit):
     rows = pick_rows(ptr, 40, 1)
     sp, si, _ = sample_rows(ptr, idx, rows)
     xh = x.cpu().numpy()
-    chunk = int(np.diff(agg.get_schedule("balanced")[0]).max())
+    chunk, seg = agg.balanced_params()
     ps, tg = orc.neighbor_grouping(sp, chunk)
-    ref_sum = orc.gcn_grouped(ps, tg, si, None, xh, len(rows))
+    ref_sum = orc.gcn_grouped(ps, tg, si, None, xh, len(rows), seg=seg)
     deg = np.maximum(np.diff(sp), 1)[:, None].astype(np.float32)
     got = y[torch.from_numpy(rows).to(DEV)].cpu().numpy()
     assert np.array_equal(got, ref_sum / deg)  # same partial order, same final IEEE division
@@ -127,10 +127,10 @@ def test_products_gcn_f100():
     sp, si, eids = sample_rows(ptr, idx, rows)
     xh = x.cpu().numpy()
     vh = val[torch.from_numpy(eids).to(DEV)].cpu().numpy()
-    chunk = int(np.diff(agg.get_schedule("balanced")[0]).max())
+    chunk, seg = agg.balanced_params()
     ps, tg = orc.neighbor_grouping(sp, chunk)
     got = y[torch.from_numpy(rows).to(DEV)].cpu().numpy()
-    assert np.array_equal(got, orc.gcn_grouped(ps, tg, si, vh, xh, len(rows)))
+    assert np.array_equal(got, orc.gcn_grouped(ps, tg, si, vh, xh, len(rows), seg=seg))
     # linearity (checksum of checksums): A(2x) == 2 A(x) exactly (power-of-two scaling commutes with rounding)
     y2 = torch.empty_like(y)
     agg.run(x * 2.0, y2, 512, "balanced")

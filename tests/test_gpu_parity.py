@@ -109,13 +109,22 @@ def test_gcn_balanced_mode(F):
     y = torch.full((V, F), 7.0, device=DEV)
     agg.run(dev(x), y, 512, "balanced")
     ps, ix, tg = agg.get_schedule("balanced")
-    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+    chunk, seg = agg.balanced_params()
+    assert np.array_equal(ps, orc.neighbor_grouping(ptr, chunk)[0])
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=seg))
     assert_within(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x), "balanced")
-    agg.schedule_balanced(8)
+    agg.schedule_balanced(8)  # rows of 8..128 edges: one segment; longer rows: several segments + combine
     agg.run(dev(x), y, 512, "balanced")
     ps, ix, tg = agg.get_schedule("balanced")
-    assert np.array_equal(ps, orc.neighbor_grouping(ptr, 8)[0])
-    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+    chunk, seg = agg.balanced_params()
+    assert chunk == 8 and np.array_equal(ps, orc.neighbor_grouping(ptr, 8)[0])
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=seg))
+    for red, ref in (("max", orc.gcn_max(ptr, idx, val, x)),):
+        agg.run(dev(x), y, 512, "balanced", reduce=red)
+        assert np.array_equal(y.cpu().numpy(), ref)
+    agg.run(dev(x), y, 512, "balanced", reduce="mean")
+    d = np.maximum(orc.degrees(ptr), 1)[:, None].astype(np.float32)
+    assert_within(y.cpu().numpy(), orc.gcn_mean(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x) / d, "balanced mean")
 
 
 @pytest.mark.parametrize("mode", ["rows", "scheduled"])
@@ -376,7 +385,7 @@ def test_arxiv_full_size_parity_and_properties():
     assert np.array_equal(y.cpu().numpy(), ref)
     agg.run(dx, y, 512, "balanced")
     ps, ix, tg = agg.get_schedule("balanced")
-    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=agg.balanced_params()[1]))
     assert_within(y.cpu().numpy(), ref, orc.gcn_abs_scale(ptr, idx, val, x), "arxiv balanced")
     # degree property: X = ones -> every column equals the in-degree (exact in fp32 below 2^24)
     ones = torch.ones((V, F), device=DEV)
@@ -418,6 +427,12 @@ def test_hub_rows_block_cooperative_combine(F, ng):
     agg.run(dev(x), y, 512, 1)
     assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
     agg.run(dev(x), y, 512, 1, reduce="max")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))
+    # the balanced plan with the same chunk: hubs span several 16-chunk segments (+ combine)
+    agg.schedule_balanced(ng)
+    agg.run(dev(x), y, 512, "balanced")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=agg.balanced_params()[1]))
+    agg.run(dev(x), y, 512, "balanced", reduce="max")
     assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))
     agg.run(dev(x), y, 512, 1, reduce="mean")
     d = np.maximum(deg, 1)[:, None].astype(np.float32)
