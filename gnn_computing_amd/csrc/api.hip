@@ -132,12 +132,15 @@ struct Ctx {
     Schedule sched[2];       // [0] user schedule (MODE_SCHEDULED), [1] balanced (MODE_BALANCED; GAT, and the
                              //     host arrays that describe the GCN plan's summation order)
     BalancedPlan plan;       // GCN balanced mode
+    Schedule sched_edges;    // chunked work items of the edge kernels (run_att, u_add_v, add_to_center, div_each)
+    DevBuf<float> den;       // [V,heads] row sums of run_att
     DevBuf<float> partial, partial_den;
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
     DevBuf<int> diffbuf;
     int xcd_remap = 2;
     int variant = 0;
     int idxmode = 1;
+    int edge_items_mode = 1;   // edge kernels on chunked work items (0: one lane group per row)
     int use_plan = 1;          // GCN balanced mode runs k_gcn_plan (0: items + combine, the round-1 first design)
     int use_stream = 0;        // 1: LIST modes run the persistent streaming kernel (A/B knob; the item kernel measured faster)
     int stream_bpc = 8;        // workgroups per CU for the streaming grid
@@ -497,6 +500,34 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     return launch_gat(L, c->stream);
 }
 
+// Work items for the edge kernels: the balanced neighbor grouping (device arrays) of this handle.
+static int edge_items(Ctx *c, Schedule **out)
+{
+    Schedule &s = c->sched_edges;
+    if (!s.valid) {
+        int rc = build_grouping(c, s, pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
+        if (rc) return rc;
+    }
+    *out = &s;
+    return GNNAGG_OK;
+}
+
+static int edge_launch(Ctx *c, EdgeItemLaunch &L, int heads)
+{
+    Schedule *s = nullptr;
+    int rc = edge_items(c, &s);
+    if (rc) return rc;
+    L.wl = s->worklist();
+    L.idx = c->d_idx;
+    L.heads = heads;
+    L.avg_item_edges = s->num_target > 0 ? std::max(1, c->E / s->num_target) : 1;
+    if (s->n_slots > 0) {
+        if ((rc = c->partial_den.reserve((size_t)s->n_slots * heads))) return rc;
+        L.partial_den = c->partial_den.p;
+    }
+    return GNNAGG_OK;
+}
+
 static int do_schedule(Ctx *c, int kind, const int *param, int total_v)
 {
     if (!param) return fail(GNNAGG_ERR_ARG, "null schedule parameter array");
@@ -558,6 +589,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_IDXMODE")) c->idxmode = atoi(e);
     if (const char *e = getenv("GNNAGG_STREAM")) c->use_stream = atoi(e);
     if (const char *e = getenv("GNNAGG_PLAN")) c->use_plan = atoi(e);
+    if (const char *e = getenv("GNNAGG_EDGE_ITEMS")) c->edge_items_mode = atoi(e);
     if (const char *e = getenv("GNNAGG_STREAM_BPC")) c->stream_bpc = std::max(1, atoi(e));
     if (const char *e = getenv("GNNAGG_STREAM_MIN_EDGES")) c->stream_min_edges = std::max(1, atoi(e));
     {
@@ -718,28 +750,55 @@ int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, in
 {
     GET_CTX(h);
     if (!d_att || (!d_out_val && c->E > 0) || heads <= 0) return fail(GNNAGG_ERR_ARG, "bad run_att arguments");
-    return launch_gat_att(c->d_ptr, c->d_idx, d_att, d_out_val, c->V, heads, slope, c->avg_deg(), c->stream);
+    if (!c->edge_items_mode)
+        return launch_gat_att(c->d_ptr, c->d_idx, d_att, d_out_val, c->V, heads, slope, c->avg_deg(), c->stream);
+    EdgeItemLaunch L;
+    int rc = edge_launch(c, L, heads);
+    if (rc) return rc;
+    if ((rc = c->den.reserve((size_t)std::max(c->V, 1) * heads))) return rc;
+    L.att = d_att; L.out = d_out_val; L.den = c->den.p; L.slope = slope;
+    if ((rc = launch_edge_items_sum(L, 0, c->stream))) return rc;  // w_e and row sums   (attGat :13-25)
+    L.in = c->den.p;
+    return launch_edge_items_map(L, 0, c->stream);                 // w_e / sum          (attGat :26-29)
 }
 
 int gnnagg_gat_run_u_add_v(gnnagg_handle h, const float *d_att, float *d_out_val)
 {
     GET_CTX(h);
     if (!d_att || (!d_out_val && c->E > 0)) return fail(GNNAGG_ERR_ARG, "bad u_add_v arguments");
-    return launch_u_add_v(c->d_ptr, c->d_idx, d_att, d_out_val, c->V, c->avg_deg(), c->stream);
+    if (!c->edge_items_mode)
+        return launch_u_add_v(c->d_ptr, c->d_idx, d_att, d_out_val, c->V, c->avg_deg(), c->stream);
+    EdgeItemLaunch L;
+    int rc = edge_launch(c, L, 1);
+    if (rc) return rc;
+    L.att = d_att; L.out = d_out_val;
+    return launch_edge_items_map(L, 1, c->stream);
 }
 
 int gnnagg_gat_run_add_to_center(gnnagg_handle h, const float *d_in_val, float *d_out_att)
 {
     GET_CTX(h);
     if ((!d_in_val && c->E > 0) || !d_out_att) return fail(GNNAGG_ERR_ARG, "bad add_to_center arguments");
-    return launch_add_to_center(c->d_ptr, d_in_val, d_out_att, c->V, c->avg_deg(), c->stream);
+    if (!c->edge_items_mode)
+        return launch_add_to_center(c->d_ptr, d_in_val, d_out_att, c->V, c->avg_deg(), c->stream);
+    EdgeItemLaunch L;
+    int rc = edge_launch(c, L, 1);
+    if (rc) return rc;
+    L.in = d_in_val; L.den = d_out_att;
+    return launch_edge_items_sum(L, 1, c->stream);
 }
 
 int gnnagg_gat_run_div_each(gnnagg_handle h, const float *d_in_att, float *d_inout_val)
 {
     GET_CTX(h);
     if (!d_in_att || (!d_inout_val && c->E > 0)) return fail(GNNAGG_ERR_ARG, "bad div_each arguments");
-    return launch_div_each(c->d_ptr, d_in_att, d_inout_val, c->V, c->avg_deg(), c->stream);
+    if (!c->edge_items_mode)
+        return launch_div_each(c->d_ptr, d_in_att, d_inout_val, c->V, c->avg_deg(), c->stream);
+    EdgeItemLaunch L;
+    int rc = edge_launch(c, L, 1);
+    if (rc) return rc;
+    L.in = d_in_att; L.out = d_inout_val;
+    return launch_edge_items_map(L, 0, c->stream);
 }
 
 int gnnagg_spmm_naive(const int *d_ptr, const int *d_idx, const float *d_val, const float *d_x, float *d_y,

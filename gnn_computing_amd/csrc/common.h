@@ -105,6 +105,21 @@ struct GatLaunch {
 
 int lane_groups_per_block(int feat, const void *x, const void *y, const void *partial, int dhead, int variant);
 int launch_build_tags(const void *desc, int n_items, long n_edges, int *tag, void *stream);
+// Edge kernels on chunked work items (attGat / u_add_v / add_to_center / each_div without the hub-row tail)
+struct EdgeItemLaunch {
+    WorkList wl;
+    const int *idx = nullptr;
+    const float *att = nullptr;
+    const float *in = nullptr;
+    float *out = nullptr;
+    float *den = nullptr;
+    float *partial_den = nullptr;
+    int heads = 1;
+    float slope = 0.2f;
+    int avg_item_edges = 8;
+};
+int launch_edge_items_sum(const EdgeItemLaunch &L, int op, void *stream);
+int launch_edge_items_map(const EdgeItemLaunch &L, int op, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);
 int launch_gcn_plan(const GcnPlanLaunch &a, void *stream);
 int launch_gat(const GatLaunch &a, void *stream);

@@ -1173,6 +1173,169 @@ int launch_csr2edgelist(const int *ptr, const int *idx, int *edgelist, int V, in
     return GNNAGG_OK;
 }
 
+// ------------------------------------------------- edge kernels on chunked work items (hub-safe)
+// The per-row kernels above give one lane group a whole row; a 15 k-edge hub row then serialises
+// (860 us for attGat on the arxiv-shaped graph).  These variants run on the work items of the balanced
+// neighbor grouping (<= chunk edges each): pass 1 writes the edge values and per-item sums (straight to
+// den[row] when the row has one item, to partial_den[slot] otherwise), an ordered combine finishes the
+// split rows, pass 2 normalises.  Lanes walk the flattened (edge, head) pairs of an item, so out[e,h]
+// stores are fully coalesced and a lane keeps one head when GROUP % H == 0.
+struct EdgeItemArgs {
+    const int *ptr_s, *target, *slot, *empty_rows, *idx;
+    const float *att;   // [V,H,2]
+    const float *in;    // per-edge input (add_to_center) / per-row divisor (div)
+    float *out;         // per-edge output [E,H]
+    float *den;         // per-row sums [V,H]
+    float *partial_den; // [n_slots,H]
+    int n_items, n_empty, H;
+    float slope;
+};
+
+// OP 0: attGat pass 1 (w = exp(leaky(a_dst + a_src)) -> out, item sums)   aggr_gat.h:13-19
+// OP 1: add_to_center (item sums of in[e])                                 aggr_gat.h:62-73
+template <int GROUP, int OP>
+__global__ __launch_bounds__(kBlock) void k_edge_items_sum(const EdgeItemArgs a)
+{
+    const int item = blockIdx.x * (kBlock / GROUP) + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int H = a.H;
+    if (item >= a.n_items + a.n_empty) return;
+    if (item >= a.n_items) {  // rows without edges: sum = 0
+        const int row = a.empty_rows[item - a.n_items];
+        for (int h = lane; h < H; h += GROUP) a.den[(size_t)row * H + h] = 0.0f;
+        return;
+    }
+    const int beg = a.ptr_s[item], end = a.ptr_s[item + 1];
+    const int row = a.target[item];
+    const int sl = a.slot[item];
+    float *dst = sl >= 0 ? a.partial_den + (size_t)sl * H : a.den + (size_t)row * H;
+    const int n = (end - beg) * H;
+    if (H <= GROUP && (GROUP % H) == 0) {
+        const int h = lane % H;  // fixed head per lane: the stride GROUP is a multiple of H
+        const float a_dst = OP == 0 ? a.att[((size_t)row * H + h) * 2] : 0.0f;
+        float part = 0.0f;
+        for (int j = lane; j < n; j += GROUP) {
+            const int e = beg + j / H;
+            float w;
+            if (OP == 0) {
+                w = edge_weight(a_dst, a.att[((size_t)a.idx[e] * H + h) * 2 + 1], a.slope);
+                a.out[(size_t)beg * H + j] = w;
+            } else {
+                w = a.in[(size_t)beg * H + j];
+            }
+            part += w;
+        }
+        for (int msk = GROUP / 2; msk >= H; msk >>= 1) part += __shfl_xor(part, msk, GROUP);
+        if (lane < H) dst[lane] = part;
+    } else {
+        for (int h = 0; h < H; ++h) {  // odd head counts: one head at a time
+            const float a_dst = OP == 0 ? a.att[((size_t)row * H + h) * 2] : 0.0f;
+            float part = 0.0f;
+            for (int e = beg + lane; e < end; e += GROUP) {
+                float w;
+                if (OP == 0) {
+                    w = edge_weight(a_dst, a.att[((size_t)a.idx[e] * H + h) * 2 + 1], a.slope);
+                    a.out[(size_t)e * H + h] = w;
+                } else {
+                    w = a.in[(size_t)e * H + h];
+                }
+                part += w;
+            }
+            part = group_sum<GROUP>(part);
+            if (lane == 0) dst[h] = part;
+        }
+    }
+}
+
+// ordered sum of the item sums of split rows
+__global__ void k_den_combine(const int *__restrict__ mrow_id, const int *__restrict__ mrow_ptr,
+                              const float *__restrict__ partial_den, float *__restrict__ den, int n_mrows, int H)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_mrows * H) return;
+    const int m = t / H, h = t % H;
+    float s = 0.0f;
+    for (int p = mrow_ptr[m]; p < mrow_ptr[m + 1]; ++p) s += partial_den[(size_t)p * H + h];
+    den[(size_t)mrow_id[m] * H + h] = s;
+}
+
+// OP 0: out[e,h] /= den[row,h]   (attGat pass 2 aggr_gat.h:26-29, each_div aggr_gat.h:84-90)
+// OP 1: out[e] = att[row,0] + att[idx[e],1]   (u_add_v aggr_gat.h:44-46)
+template <int GROUP, int OP>
+__global__ __launch_bounds__(kBlock) void k_edge_items_map(const EdgeItemArgs a)
+{
+    const int item = blockIdx.x * (kBlock / GROUP) + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (item >= a.n_items) return;
+    const int beg = a.ptr_s[item], end = a.ptr_s[item + 1];
+    const int row = a.target[item];
+    const int H = a.H;
+    if (OP == 0) {
+        const int n = (end - beg) * H;
+        for (int j = lane; j < n; j += GROUP) a.out[(size_t)beg * H + j] /= a.in[(size_t)row * H + j % H];
+    } else {
+        const float a_dst = a.att[(size_t)row * 2];
+        for (int e = beg + lane; e < end; e += GROUP) a.out[e] = a_dst + a.att[(size_t)a.idx[e] * 2 + 1];
+    }
+}
+
+static int edge_item_group(long avg_pairs)
+{
+    return avg_pairs <= 8 ? 8 : (avg_pairs <= 32 ? 32 : 64);
+}
+
+#define DISPATCH_EIG(G, CALL)                               \
+    switch (G) {                                            \
+        case 8:  { constexpr int GROUP = 8;  CALL; } break; \
+        case 32: { constexpr int GROUP = 32; CALL; } break; \
+        default: { constexpr int GROUP = 64; CALL; } break; \
+    }
+
+static void fill_edge_args(EdgeItemArgs &a, const EdgeItemLaunch &L)
+{
+    a.ptr_s = L.wl.ptr; a.target = L.wl.target; a.slot = L.wl.slot; a.empty_rows = L.wl.empty_rows; a.idx = L.idx;
+    a.att = L.att; a.in = L.in; a.out = L.out; a.den = L.den; a.partial_den = L.partial_den;
+    a.n_items = L.wl.n_items; a.n_empty = L.wl.n_empty; a.H = L.heads; a.slope = L.slope;
+}
+
+// sums: op 0 = attGat weights + row sums, op 1 = add_to_center
+int launch_edge_items_sum(const EdgeItemLaunch &L, int op, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    EdgeItemArgs a;
+    fill_edge_args(a, L);
+    const int total = a.n_items + a.n_empty;
+    if (total > 0) {
+        const int G = edge_item_group((long)L.avg_item_edges * L.heads);
+        const int nb = ceil_div(total, kBlock / G);
+        if (op == 0) { DISPATCH_EIG(G, hipLaunchKernelGGL((k_edge_items_sum<GROUP, 0>), dim3(nb), dim3(kBlock), 0, stream, a)) }
+        else         { DISPATCH_EIG(G, hipLaunchKernelGGL((k_edge_items_sum<GROUP, 1>), dim3(nb), dim3(kBlock), 0, stream, a)) }
+        HIP_TRY(hipGetLastError());
+    }
+    if (L.wl.n_mrows > 0) {
+        const int n = L.wl.n_mrows * L.heads;
+        hipLaunchKernelGGL(k_den_combine, dim3(ceil_div(n, 256)), dim3(256), 0, stream, L.wl.mrow_id, L.wl.mrow_ptr,
+                           L.partial_den, L.den, L.wl.n_mrows, L.heads);
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
+// maps: op 0 = divide by the row value, op 1 = u_add_v
+int launch_edge_items_map(const EdgeItemLaunch &L, int op, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    EdgeItemArgs a;
+    fill_edge_args(a, L);
+    if (a.n_items <= 0) return GNNAGG_OK;
+    const int G = edge_item_group((long)L.avg_item_edges * L.heads);
+    const int nb = ceil_div(a.n_items, kBlock / G);
+    if (op == 0) { DISPATCH_EIG(G, hipLaunchKernelGGL((k_edge_items_map<GROUP, 0>), dim3(nb), dim3(kBlock), 0, stream, a)) }
+    else         { DISPATCH_EIG(G, hipLaunchKernelGGL((k_edge_items_map<GROUP, 1>), dim3(nb), dim3(kBlock), 0, stream, a)) }
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
 // ------------------------------------------------------------------------ edge-wise variant
 // reference aggr_gcn_edgewise, aggr_gcn.h:291-302 (which covers only 32 columns and reads one edge
 // past the end, :296); here one 64-lane wavefront per edge strides over all F columns.

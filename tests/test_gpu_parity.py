@@ -468,3 +468,37 @@ def test_cpp_drivers_run(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")]
         assert len(lines) >= 3 and all(l["seconds"] > 0 for l in lines)
+
+
+@pytest.mark.parametrize("H", [1, 3, 4])
+def test_edge_softmax_kernels_with_hub_rows(H):
+    """run_att / u_add_v / add_to_center / div_each on chunked work items: hub rows span many items."""
+    V = 400
+    rng = np.random.default_rng(9)
+    deg = rng.integers(0, 5, V)
+    deg[3], deg[200] = 3000, 700
+    ptr = np.zeros(V + 1, np.int32)
+    ptr[1:] = np.cumsum(deg)
+    E = int(ptr[-1])
+    idx = rng.integers(0, V, E).astype(np.int32)
+    att = rand((V, H, 2), 4) * 0.5
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), 32, 32)
+    out = torch.full((E, H), 7.0, device=DEV)
+    gat.run_att(dev(att), out, 128, heads=H)
+    ref = orc.gat_att(ptr, idx, att, H)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL)
+    sums = np.add.reduceat(out.cpu().numpy().astype(np.float64), ptr[:-1][deg > 0], axis=0)
+    np.testing.assert_allclose(sums, 1.0, rtol=1e-5)  # softmax rows sum to one
+    if H == 1:
+        a2 = att.reshape(V, 2)
+        v = torch.empty(E, device=DEV)
+        gat.run_u_add_v(dev(a2), v)
+        assert np.array_equal(v.cpu().numpy(), orc.gat_u_add_v(ptr, idx, a2))
+        w = torch.exp(torch.nn.functional.leaky_relu(v, 0.2))
+        center = torch.full((V,), 7.0, device=DEV)
+        gat.run_add_to_center(w, center)
+        np.testing.assert_allclose(center.cpu().numpy(), orc.gat_add_to_center(ptr, w.cpu().numpy()), rtol=RTOL)
+        assert np.all(center.cpu().numpy()[deg == 0] == 0)
+        wh = w.cpu().numpy()
+        gat.run_div_each(center, w)
+        assert np.array_equal(w.cpu().numpy(), orc.gat_div_each(ptr, center.cpu().numpy(), wh))
