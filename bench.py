@@ -104,7 +104,10 @@ def run_single(args, dev):
     results["no_reorder"] = time_steps(lambda: agg0.run(dx, y, 512, mode), args.steps, args.warmup, lambda: None)
     # with the locality reorder applied on load (reference: load_graph(..., "_thres_0.2"), our.py:79)
     t0 = time.perf_counter()
-    rows = gnc.graph.locality_order(ptr, idx)
+    # the reorder GENERATOR is the reference's offline clustering (script/cluster2.py) restated in C++:
+    # MinHash-64 + LSH(0.2) + greedy capped-64 merge (gnnagg_cluster_reorder); its output is what a
+    # <dset>.reorder_thres_0.2 file holds
+    rows, n_clusters = gnc.cluster_reorder(ptr, idx)
     nptr, nidx, rev = gnc.reorder_csr(ptr, idx, rows)
     t_reorder = time.perf_counter() - t0
     agg1 = build(nptr, nidx)
@@ -134,7 +137,7 @@ def run_single(args, dev):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "arxiv-shaped power-law CSR 169343x1166243 (seed 123), GCN sum, feat=128, "
                                "explicit unit weights, %s, mode=%s" % (
-                                   "locality reorder applied on load" if which == "reorder" else "no reorder", mode),
+                                   "reorder_thres_0.2 (MinHash-LSH clustering) applied on load" if which == "reorder" else "no reorder", mode),
                    "num_v": V, "num_e": E, "feat": FEAT},
         "achieved_gbps": achieved,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

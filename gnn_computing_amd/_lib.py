@@ -64,6 +64,7 @@ SIGNATURES = {
     "gnnagg_neighbor_grouping_schedule": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, P_INT]),
     "gnnagg_locality_schedule": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, P_INT]),
+    "gnnagg_cluster_reorder": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_int, ctypes.c_ulonglong, c_void_p, P_INT]),
     # D
     "gnnagg_partition_rows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "gnnagg_halo_plan": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, PP_INT,

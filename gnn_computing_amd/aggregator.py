@@ -331,6 +331,18 @@ def locality_schedule(ptr, idx, par_num, total_v, ng=0, val=None):
     return ptr_s[:G + 1].copy(), idx_s[:ne].copy(), tgt[:G].copy(), (None if val is None else val_s[:ne].copy())
 
 
+def cluster_reorder(ptr, idx, threshold=0.2, num_perm=64, cluster_cap=64, seed=123):
+    """gnnagg_cluster_reorder (reference script/cluster2.py).  Returns (rows, num_clusters); rows[i] = old node id
+    placed at new position i, ready for graph.write_reorder_file / reorder_csr."""
+    ptr, idx = _np_i(ptr), _np_i(idx)
+    V = len(ptr) - 1
+    rows = np.empty(V, np.int32)
+    nc = ctypes.c_int(0)
+    check(lib().gnnagg_cluster_reorder(ptr.ctypes.data, idx.ctypes.data, V, ctypes.c_float(threshold), int(num_perm),
+                                       int(cluster_cap), ctypes.c_ulonglong(seed), rows.ctypes.data, ctypes.byref(nc)))
+    return rows, nc.value
+
+
 def partition_rows(ptr, nparts):
     ptr = _np_i(ptr)
     b = np.empty(nparts + 1, np.int32)

@@ -940,6 +940,15 @@ int gnnagg_locality_schedule(const int *h_ptr, const int *h_idx, const float *h_
     return GNNAGG_OK;
 }
 
+int gnnagg_cluster_reorder(const int *h_ptr, const int *h_idx, int num_v, float threshold, int num_perm, int cluster_cap,
+                           unsigned long long seed, int *h_rows_out, int *num_clusters)
+{
+    if (!h_ptr || !h_rows_out || num_v < 0 || (h_ptr[num_v] > 0 && !h_idx))
+        return fail(GNNAGG_ERR_ARG, "bad cluster_reorder arguments");
+    return cluster_reorder(h_ptr, h_idx, num_v, threshold > 0 ? threshold : 0.2, num_perm > 0 ? num_perm : 64,
+                           cluster_cap > 0 ? cluster_cap : 64, seed, 256, h_rows_out, num_clusters);
+}
+
 // ------------------------------------------------------------------------------- Section D
 int gnnagg_partition_rows(const int *h_ptr, int num_v, int nparts, int *h_bounds)
 {

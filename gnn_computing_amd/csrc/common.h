@@ -22,6 +22,10 @@ void partition_rows(const int *ptr, int V, int nparts, int *bounds);
 int halo_plan(const int *ptr, const int *idx, int V, const int *bounds, int nparts, int rank, int *lptr, int *lidx,
               int **halo_ids_o, int *halo_counts, int *num_halo);
 
+// ---- reorder.cpp
+int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int num_perm, int cap, uint64_t seed,
+                    int max_bucket, int *rows_out, int *num_clusters_out);
+
 // ---- kernels.hip : launch descriptors (all pointers are device pointers)
 
 // A work list: item g covers edges [ptr[g], ptr[g+1]) of output row (target ? target[g] : g).

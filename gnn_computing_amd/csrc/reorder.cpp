@@ -1,0 +1,176 @@
+// reorder.cpp -- locality reorder generator: the clustering of the reference's offline script
+// (script/cluster2.py:29-171), restated as host C++ behind the C-ABI (gnnagg_cluster_reorder).
+//
+//   1. MinHash signature (num_perm hash functions) of every row's neighbor set          (cluster2.py:29-38)
+//   2. LSH banding tuned for a Jaccard threshold (b bands x r rows minimising FP+FN area,
+//      the rule datasketch's MinHashLSH uses); rows sharing a band bucket are candidates  (:79-94)
+//   3. max-heap of candidate pairs keyed by the EXACT Jaccard similarity of the two rows'
+//      neighbor lists (:45-50, :91)
+//   4. greedy merge with path-halving union-find: a popped pair whose ends are both cluster roots is
+//      merged (smaller into larger, ties into the first); a cluster reaching `cap` nodes is frozen;
+//      a pair with a non-root end is re-queued as (root, root) with the roots' own similarity (:121-151)
+//   5. nodes are written cluster by cluster in order of each cluster's first node id, ascending
+//      inside a cluster (:156-171): rows[i] = old id placed at new position i.
+//
+// Parity note: the reference hashes with datasketch (sha1 + its own permutations, README.md:16), whose
+// source is not part of the reference tree, so the candidate sets -- and therefore the exact permutation --
+// are not reproducible here ("parity unpinned" for reorder GENERATION).  Tests pin the
+// algorithmic contract instead: valid permutation, planted clusters recovered, cluster cap respected.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <queue>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "common.h"
+
+namespace gnnagg {
+
+static inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+// (b, r) with b*r <= num_perm minimising false-positive + false-negative probability mass around `t`
+static void lsh_params(double t, int num_perm, int *b_out, int *r_out)
+{
+    double best = 1e300;
+    for (int b = 1; b <= num_perm; ++b)
+        for (int r = 1; r <= num_perm / b; ++r) {
+            double fp = 0, fn = 0;
+            const double ds = 0.001;
+            for (double s = ds / 2; s < 1.0; s += ds) {
+                const double p = 1.0 - std::pow(1.0 - std::pow(s, r), b);
+                if (s < t) fp += p * ds; else fn += (1.0 - p) * ds;
+            }
+            if (0.5 * fp + 0.5 * fn < best) { best = 0.5 * fp + 0.5 * fn; *b_out = b; *r_out = r; }
+        }
+}
+
+static double jaccard_sorted(const int *a, int na, const int *b, int nb)
+{
+    if (na == 0 || nb == 0) return 0.0;
+    int i = 0, j = 0, inter = 0, uni = 0;
+    while (i < na && j < nb) {
+        if (a[i] == b[j]) { ++inter; ++uni; const int v = a[i]; while (i < na && a[i] == v) ++i; while (j < nb && b[j] == v) ++j; }
+        else if (a[i] < b[j]) { ++uni; const int v = a[i]; while (i < na && a[i] == v) ++i; }
+        else { ++uni; const int v = b[j]; while (j < nb && b[j] == v) ++j; }
+    }
+    while (i < na) { ++uni; const int v = a[i]; while (i < na && a[i] == v) ++i; }
+    while (j < nb) { ++uni; const int v = b[j]; while (j < nb && b[j] == v) ++j; }
+    return (double)inter / (double)uni;
+}
+
+int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int num_perm, int cap, uint64_t seed,
+                    int max_bucket, int *rows_out, int *num_clusters_out)
+{
+    if (V < 0 || num_perm < 1 || num_perm > 256 || cap < 1) return fail(GNNAGG_ERR_ARG, "bad cluster_reorder arguments");
+    // sorted neighbor sets (the similarity is on sets; the CSR itself is not modified)
+    std::vector<int> sidx(idx, idx + ptr[V]);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int i = 0; i < V; ++i) std::sort(sidx.begin() + ptr[i], sidx.begin() + ptr[i + 1]);
+
+    int B = 1, R = 1;
+    lsh_params(threshold, num_perm, &B, &R);
+    std::vector<uint64_t> ha(num_perm), hb(num_perm);
+    for (int k = 0; k < num_perm; ++k) { ha[k] = mix64(seed + 2 * k + 1) | 1ULL; hb[k] = mix64(seed + 2 * k + 2); }
+
+    // band keys per row
+    std::vector<uint64_t> bandkey((size_t)V * B);
+#pragma omp parallel
+    {
+        std::vector<uint64_t> sig(num_perm);
+#pragma omp for schedule(dynamic, 1024)
+        for (int i = 0; i < V; ++i) {
+            std::fill(sig.begin(), sig.end(), ~0ULL);
+            for (int e = ptr[i]; e < ptr[i + 1]; ++e) {
+                const uint64_t x = mix64((uint64_t)(uint32_t)sidx[e] + 0x9e3779b97f4a7c15ULL);
+                for (int k = 0; k < num_perm; ++k) {
+                    const uint64_t h = mix64(x * ha[k] + hb[k]);
+                    if (h < sig[k]) sig[k] = h;
+                }
+            }
+            for (int b = 0; b < B; ++b) {
+                uint64_t key = 0x1234567ULL + b;
+                for (int r = 0; r < R; ++r) key = mix64(key ^ sig[b * R + r]);
+                bandkey[(size_t)i * B + b] = key;
+            }
+        }
+    }
+
+    struct Pair { double simi; int p1, p2; };
+    auto cmp = [](const Pair &a, const Pair &b) { return a.simi < b.simi; };
+    std::priority_queue<Pair, std::vector<Pair>, decltype(cmp)> que(cmp);
+    std::unordered_set<uint64_t> queued;
+    auto makenum = [&](int a, int b) { if (a > b) std::swap(a, b); return (uint64_t)a * (uint64_t)V + (uint64_t)b; };
+    auto simi = [&](int a, int b) {
+        return jaccard_sorted(sidx.data() + ptr[a], ptr[a + 1] - ptr[a], sidx.data() + ptr[b], ptr[b + 1] - ptr[b]);
+    };
+    // candidates: rows sharing a band bucket (empty rows are never queried, cluster2.py:83-84)
+    {
+        std::vector<std::pair<uint64_t, int>> keys;
+        keys.reserve(V);
+        for (int b = 0; b < B; ++b) {
+            keys.clear();
+            for (int i = 0; i < V; ++i)
+                if (ptr[i] != ptr[i + 1]) keys.emplace_back(bandkey[(size_t)i * B + b], i);
+            std::sort(keys.begin(), keys.end());
+            for (size_t s = 0; s < keys.size();) {
+                size_t t = s;
+                while (t < keys.size() && keys[t].first == keys[s].first) ++t;
+                // a bucket shared by a huge number of rows (hub co-neighbors) is quadratic; cap it like a
+                // bounded LSH query (rows beyond the cap in one bucket still meet through other bands)
+                const size_t lim = std::min(t, s + (size_t)max_bucket);
+                for (size_t u = s; u < lim; ++u)
+                    for (size_t v = u + 1; v < lim; ++v) {
+                        const uint64_t id = makenum(keys[u].second, keys[v].second);
+                        if (queued.insert(id).second) que.push({simi(keys[u].second, keys[v].second), keys[u].second, keys[v].second});
+                    }
+                s = t;
+            }
+        }
+    }
+
+    std::vector<int> cluster_id(V), cluster_sz(V, 1);
+    std::vector<char> deleted(V, 0);
+    for (int i = 0; i < V; ++i) cluster_id[i] = i;
+    auto root = [&](int i) {
+        while (i != cluster_id[i]) { cluster_id[i] = cluster_id[cluster_id[i]]; i = cluster_id[i]; }
+        return i;
+    };
+    while (!que.empty()) {
+        const Pair it = que.top();
+        que.pop();
+        int p1 = it.p1, p2 = it.p2;
+        queued.erase(makenum(p1, p2));
+        if (p1 == cluster_id[p1] && p2 == cluster_id[p2]) {
+            if (deleted[p1] || deleted[p2]) continue;
+            if (cluster_sz[p1] < cluster_sz[p2]) std::swap(p1, p2);  // merge the smaller (p2) into p1; ties keep p1
+            cluster_id[p2] = p1;
+            cluster_sz[p1] += cluster_sz[p2];
+            if (cluster_sz[p1] >= cap) deleted[p1] = 1;
+        } else {
+            p1 = root(p1);
+            p2 = root(p2);
+            if (deleted[p1] || deleted[p2] || p1 == p2) continue;
+            if (queued.insert(makenum(p1, p2)).second) que.push({simi(p1, p2), p1, p2});
+        }
+    }
+    // clusters in order of first appearance, members ascending
+    std::vector<int> first_pos(V, -1), order;
+    std::vector<std::vector<int>> members;
+    for (int i = 0; i < V; ++i) {
+        const int ro = root(i);
+        if (first_pos[ro] < 0) { first_pos[ro] = (int)members.size(); members.emplace_back(); }
+        members[first_pos[ro]].push_back(i);
+    }
+    int pos = 0;
+    for (auto &mset : members) for (int v : mset) rows_out[pos++] = v;
+    if (num_clusters_out) *num_clusters_out = (int)members.size();
+    return GNNAGG_OK;
+}
+
+}  // namespace gnnagg

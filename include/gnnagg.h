@@ -165,6 +165,13 @@ int gnnagg_locality_schedule(const int *h_ptr, const int *h_idx, const float *h_
                              int neighbor_num, int num_v, int total_num_v, int *h_ptr_out, int *h_idx_out,
                              float *h_val_out, int *h_target_out, int *num_groups);
 
+/* Locality reorder GENERATOR: the clustering of script/cluster2.py:29-171 (MinHash with num_perm
+ * permutations, LSH at Jaccard `threshold`, greedy union-find merge of the most similar candidate rows
+ * until clusters reach cluster_cap nodes).  0 / 0.0 select the reference's constants (64, 0.2, 64).
+ * h_rows_out[i] = old node id placed at new position i: the content of a <dset>.reorder<suffix> file. */
+int gnnagg_cluster_reorder(const int *h_ptr, const int *h_idx, int num_v, float threshold, int num_perm, int cluster_cap,
+                           unsigned long long seed, int *h_rows_out, int *num_clusters);
+
 /* ---------------------------------------------------------------------------------------------
  * D. 1-D row partition + halo exchange support
  * ------------------------------------------------------------------------------------------- */

@@ -27,6 +27,9 @@ def graphs():
     rows = gnc.graph.locality_order(ptr, idx)
     nptr, nidx, _ = gnc.reorder_csr(ptr, idx, rows)
     out["rcm"] = (nptr, nidx)
+    rows, _ = gnc.cluster_reorder(ptr, idx)
+    lptr, lidx, _ = gnc.reorder_csr(ptr, idx, rows)
+    out["lsh"] = (lptr, lidx)
     V, E = gnc.graph.SHAPES["arxiv"]
     cp, ci = gnc.graph.powerlaw_csr(V, E, seed=123, community_order=True)
     out["community"] = (cp.numpy(), ci.numpy())
