@@ -8,6 +8,6 @@ from .aggregator import (  # noqa: F401
     Aggregator, Aggregator_GAT, Aggregator_GCN, Schedule,
     gat_init, gat_run, gat_run_add_to_center, gat_run_div_each, gat_run_u_add_v, gat_schedule,
     gcn_init, gcn_run, gcn_schedule, gcn_update_val, new_load, load_graph_host,
-    reorder_csr, neighbor_grouping_schedule, locality_schedule, partition_rows, halo_plan, cluster_reorder,
+    reorder_csr, neighbor_grouping_schedule, locality_schedule, partition_rows, halo_plan, cluster_reorder, matmul_NN,
 )
 from . import graph  # noqa: F401

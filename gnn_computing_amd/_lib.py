@@ -49,6 +49,8 @@ SIGNATURES = {
     "gnnagg_gcn_run": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int]),
     "gnnagg_gcn_run_edgewise": (c_int, [c_int64, c_void_p, c_void_p, c_int]),
     "gnnagg_csr2edgelist": (c_int, [c_int64, c_void_p]),
+    "gnnagg_matmul_nn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gnnagg_gcn_run_with_nn": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "gnnagg_gat_run": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "gnnagg_gat_run_att": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_float]),
     "gnnagg_gat_run_u_add_v": (c_int, [c_int64, c_void_p, c_void_p]),

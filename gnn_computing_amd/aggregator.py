@@ -155,6 +155,14 @@ class Aggregator_GCN(Aggregator):
                                             _dev_ptr(vout, torch.float32, "vout"), int(vin.shape[1])))
         return 0.0
 
+    def run_with_nn(self, vin, vout, weight, transformed, BLOCK_SIZE=128, scheduled=1):
+        """aggr_gcn.h:491-499: vout = A.vin, transformed = vout @ weight (weight [feat_in, feat_out])."""
+        self._use_current_stream()
+        check(lib().gnnagg_gcn_run_with_nn(self._h, _dev_ptr(vin, torch.float32, "vin"), _dev_ptr(vout, torch.float32, "vout"),
+                                           _dev_ptr(weight, torch.float32, "weight"),
+                                           _dev_ptr(transformed, torch.float32, "transformed"), int(vin.shape[1]),
+                                           int(weight.shape[1]), _mode(scheduled)))
+
     def updateval(self, val):
         """aggr_gcn.h:540-544"""
         self.val = val
@@ -212,6 +220,17 @@ class Aggregator_GAT(Aggregator):
 # Flat functions with the reference pybind names (Figure7/kernel.cpp:166-179).  Handles are
 # Python objects here (the reference returns the raw pointer as int64 and leaks it).
 # ------------------------------------------------------------------------------------------
+def matmul_NN(A, B, C=None):
+    """include/dense.h:4-23: row-major C = A @ B on the MFMA kernel of libgnnagg (device fp32 tensors)."""
+    M, K = A.shape
+    N = B.shape[1]
+    if C is None:
+        C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    check(lib().gnnagg_matmul_nn(_dev_ptr(A, torch.float32, "A"), _dev_ptr(B, torch.float32, "B"), _dev_ptr(C, torch.float32, "C"),
+                                 int(M), int(N), int(K), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return C
+
+
 def load_graph_host(dset, reorder="", datadir="../data/", shuffle=True):
     """gnnagg_load_graph -> dict of numpy arrays (ptr, idx, rows, reverse_rows)."""
     L = lib()

@@ -719,6 +719,23 @@ int gnnagg_gcn_run(gnnagg_handle h, const float *d_x, float *d_y, int feat, int 
     return gcn_run(c, d_x, d_y, feat, mode, reduce);
 }
 
+int gnnagg_matmul_nn(const float *d_a, const float *d_b, float *d_c, int m, int n, int k, void *hip_stream)
+{
+    if (m < 0 || n < 0 || k < 0 || ((long)m * n > 0 && !d_c) || ((long)m * k > 0 && !d_a) || ((long)k * n > 0 && !d_b))
+        return fail(GNNAGG_ERR_ARG, "bad matmul_nn arguments");
+    return launch_dense_nn(d_a, d_b, d_c, m, n, k, hip_stream);
+}
+
+int gnnagg_gcn_run_with_nn(gnnagg_handle h, const float *d_x, float *d_y, const float *d_weight, float *d_transformed,
+                           int feat_in, int feat_out, int mode)
+{
+    GET_CTX(h);
+    if (!d_weight || !d_transformed || feat_out <= 0) return fail(GNNAGG_ERR_ARG, "bad run_with_nn arguments");
+    int rc = gcn_run(c, d_x, d_y, feat_in, mode, GNNAGG_REDUCE_SUM);
+    if (rc) return rc;
+    return launch_dense_nn(d_y, d_weight, d_transformed, c->V, feat_out, feat_in, c->stream);
+}
+
 int gnnagg_csr2edgelist(gnnagg_handle h, int *d_edgelist)
 {
     GET_CTX(h);

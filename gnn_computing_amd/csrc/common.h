@@ -140,6 +140,7 @@ int launch_spmm_naive(const int *ptr, const int *idx, const float *val, const fl
 int launch_validate(const float *ref, const float *ans, int num, int *d_diff, void *stream);
 int launch_validate_reordered(const float *ref, const float *ans, const int *map, int V, int feat, int *d_diff,
                               void *stream);
+int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream);
 int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out, void *stream);
 
 }  // namespace gnnagg

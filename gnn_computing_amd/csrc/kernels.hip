@@ -1437,6 +1437,88 @@ int launch_validate_reordered(const float *ref, const float *ans, const int *map
     return GNNAGG_OK;
 }
 
+// ------------------------------------------------------------------- dense combine GEMM (MFMA)
+// C[M,N] = A[M,K] . B[K,N], all row-major fp32 -- the reference's matmul_NN (include/dense.h:4-23: cuBLAS
+// Sgemm(T,T) + Sgeam transpose) and the dense half of aggr_gcn_nn (aggr_gcn.h:304-359).  Tall-skinny in this
+// path (M = |V|, K = feat_in, N = feat_out <= a few hundred): HBM-bound on reading A once.
+// One wavefront owns a 32x32 output tile and accumulates it with v_mfma_f32_32x32x2_f32 (f32 in / f32
+// accumulate; bit-for-bit an ascending-k fmaf chain, so the result equals the oracle's chain exactly).
+// A workgroup = 4 wavefronts = 128 rows x 32 columns; K is walked in chunks of 32 staged through LDS:
+// A chunk with coalesced 128-byte row segments into a pitch-33 image (conflict-free operand reads:
+// lane l reads row l&31, k = l>>5), B chunk as is (lane reads consecutive columns).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+static constexpr int kGemmRows = 128, kGemmCols = 32, kGemmKC = 32, kGemmPitch = 33;
+
+__global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, const float *__restrict__ B,
+                                                  float *__restrict__ C, int M, int N, int K)
+{
+    __shared__ float As[kGemmRows * kGemmPitch];
+    __shared__ float Bs[kGemmKC * kGemmCols];
+    const int row0 = blockIdx.x * kGemmRows, col0 = blockIdx.y * kGemmCols;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += kGemmKC) {
+        // stage A[row0 .. +128, k0 .. +32): thread t loads rows t/8 + 32*j, floats (t%8)*4 .. +4
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (threadIdx.x >> 3) + 32 * j, kq = (threadIdx.x & 7) * 4;
+            const int gr = row0 + r, gk = k0 + kq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gr < M) {
+                const float *src = A + (size_t)gr * K + gk;
+                if (gk + 3 < K && ((uintptr_t)src & 15) == 0) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (gk + q < K) v[q] = src[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) As[r * kGemmPitch + kq + q] = v[q];
+        }
+        // stage B[k0 .. +32, col0 .. +32): 1024 floats, 4 per thread
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = threadIdx.x + 256 * j, kk = e >> 5, cc = e & 31;
+            Bs[e] = (k0 + kk < K && col0 + cc < N) ? B[(size_t)(k0 + kk) * N + col0 + cc] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kGemmKC; kk += 2) {
+            const float a = As[(wave * 32 + (lane & 31)) * kGemmPitch + kk + (lane >> 5)];
+            const float b = Bs[(kk + (lane >> 5)) * kGemmCols + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col = col0 + (lane & 31);
+    if (col < N) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (row < M) C[(size_t)row * N + col] = acc[reg];
+        }
+    }
+}
+
+int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (M <= 0 || N <= 0) return GNNAGG_OK;
+    if (K <= 0) {
+        HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream));
+        return GNNAGG_OK;
+    }
+    const dim3 grid(ceil_div(M, kGemmRows), ceil_div(N, kGemmCols));
+    hipLaunchKernelGGL(k_dense_nn, grid, dim3(256), 0, stream, A, B, C, M, N, K);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
 // ----------------------------------------------------------------------------- halo packing
 // out[i,:] = x[ids[i],:]  -- send buffer of the halo all-to-all (gnnagg.h Section D)
 template <int VEC, int GROUP>

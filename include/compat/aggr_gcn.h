@@ -54,6 +54,12 @@ public:
         timestamp(t1);
         return getDuration(t0, t1);
     }
+    // reference aggr_gcn.h:491-499: vout = A.vin (groups of the last schedule()), transformed = vout . weight
+    void run_with_nn(float *vin, float *vout, float *weight, float *transformed, int BLOCK_SIZE)
+    {
+        (void)BLOCK_SIZE;
+        checkGnnagg(gnnagg_gcn_run_with_nn(handle, vin, vout, weight, transformed, feat_in, feat_out, GNNAGG_MODE_SCHEDULED));
+    }
     // reference aggr_gcn.h:540-544
     void updateval(float *out_d_val)
     {

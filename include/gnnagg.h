@@ -119,6 +119,14 @@ int gnnagg_get_schedule(gnnagg_handle h, int mode, int *h_ptr_s, int *h_idx_s, i
 int gnnagg_gcn_run(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce);
 /* Aggregator_GCN::runEdgeWise, aggr_gcn.h:446-460 (edge-parallel atomics; any feat). */
 int gnnagg_gcn_run_edgewise(gnnagg_handle h, const float *d_x, float *d_y, int feat);
+/* matmul_NN, include/dense.h:4-23: c[m,n] = a[m,k] . b[k,n], row-major fp32 (the dense combine after an
+ * aggregation).  f32 MFMA, accumulation in ascending k. */
+int gnnagg_matmul_nn(const float *d_a, const float *d_b, float *d_c, int m, int n, int k, void *hip_stream);
+/* Aggregator_GCN::run_with_nn, aggr_gcn.h:491-499 (kernel aggr_gcn_nn :304-359): y = A.x, then
+ * transformed[V,feat_out] = y . weight[feat_in,feat_out].  Both outputs are fully overwritten (the
+ * reference accumulates into whatever they held). */
+int gnnagg_gcn_run_with_nn(gnnagg_handle h, const float *d_x, float *d_y, const float *d_weight, float *d_transformed,
+                           int feat_in, int feat_out, int mode);
 /* Aggregator::csr2edgelist, aggregator.h:115-122: d_edgelist[2E] = (src, dst) pairs */
 int gnnagg_csr2edgelist(gnnagg_handle h, int *d_edgelist);
 

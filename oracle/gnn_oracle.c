@@ -269,6 +269,20 @@ ORC_API void orc_gcn_max(const int *ptr, const int *idx, const float *val, const
     }
 }
 
+/* include/dense.h:4-23 matmul_NN: row-major C[M,N] = A[M,K] . B[K,N].  The reference calls cuBLAS (summation
+ * order unspecified); this restatement accumulates in ascending k with one FMA per term from 0.0f, the order
+ * of the dense loop of aggr_gcn_nn (aggr_gcn.h:349-352) and of the HIP path's f32 MFMA. */
+ORC_API void orc_matmul_nn(const float *A, const float *B, float *C, int M, int N, int K)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < N; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) acc = fmaf(A[(size_t)i * K + k], B[(size_t)k * N + j], acc);
+            C[(size_t)i * N + j] = acc;
+        }
+}
+
 /* include/spmm.h:223-265 spmm<L>: thread-per-row; first edge is a plain product, the rest FMAs;
  * an empty row RETURNS WITHOUT WRITING (:236-237) -- Y keeps its previous contents there. */
 ORC_API void orc_spmm_naive(const int *ptr, const int *idx, const float *val, const float *X, float *Y,

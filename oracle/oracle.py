@@ -156,6 +156,13 @@ def gcn_grouped(ptr_s, target, idx, val, X, num_v, seg=0):
     return Y
 
 
+def matmul_nn(A, B):
+    A, B = _cf(A), _cf(B)
+    C = np.empty((A.shape[0], B.shape[1]), np.float32)
+    lib().orc_matmul_nn(_f(A), _f(B), _f(C), A.shape[0], B.shape[1], A.shape[1])
+    return C
+
+
 def spmm_naive(ptr, idx, val, X, Y_init):
     ptr, idx, val, X = _ci(ptr), _ci(idx), _cf(val), _cf(X)
     Y = np.array(Y_init, dtype=np.float32, order="C", copy=True)

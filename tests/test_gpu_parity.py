@@ -502,3 +502,29 @@ def test_edge_softmax_kernels_with_hub_rows(H):
         wh = w.cpu().numpy()
         gat.run_div_each(center, w)
         assert np.array_equal(w.cpu().numpy(), orc.gat_div_each(ptr, center.cpu().numpy(), wh))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 5, 3), (300, 32, 128), (1000, 64, 64), (513, 100, 602), (129, 33, 7)])
+def test_matmul_nn_bit_exact(M, N, K):
+    """Dense combine GEMM (reference include/dense.h:4-23) on f32 MFMA: ascending-k fmaf chain == oracle."""
+    A, B = rand((M, K), 1), rand((K, N), 2)
+    C = gnc.matmul_NN(dev(A), dev(B))
+    torch.cuda.synchronize()
+    assert np.array_equal(C.cpu().numpy(), orc.matmul_nn(A, B))
+    # asymmetric operands: a transposed C-write would not survive this
+    np.testing.assert_allclose(C.cpu().numpy(), A.astype(np.float64) @ B.astype(np.float64), rtol=1e-4, atol=1e-4)
+
+
+def test_run_with_nn():
+    V, E, F, OUT = 500, 9000, 128, 32
+    ptr, idx = make_graph(V, E, seed=77)
+    x, val, w = rand((V, F), 1), rand(E, 2), rand((F, OUT), 3)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, OUT)
+    agg.schedule(gnc.Schedule.neighbor_grouping, [16])
+    y = torch.full((V, F), 7.0, device=DEV)
+    t = torch.full((V, OUT), 7.0, device=DEV)
+    agg.run_with_nn(dev(x), y, dev(w), t, 128, 1)
+    ps, tg = orc.neighbor_grouping(ptr, 16)
+    y_ref = orc.gcn_grouped(ps, tg, idx, val, x, V)
+    assert np.array_equal(y.cpu().numpy(), y_ref)
+    assert np.array_equal(t.cpu().numpy(), orc.matmul_nn(y_ref, w))
