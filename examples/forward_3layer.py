@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""3-layer GCN / GAT forward (512 -> 128 -> 64 -> 32) on top of the aggregation library -- the harness of the
+reference's Figure7/our.py (layers :171-188, timing loop :247-263: 100 warm-up + 100 timed iterations), written
+against the same extension function names (gcn_init / gcn_schedule / gcn_run / gat_init / gat_run ...).
+
+    python examples/forward_3layer.py --model our_GCN --dataset arxiv [--datadir DIR --reorder _thres_0.2]
+
+Without --datadir a synthetic arxiv/reddit/products-shaped CSR is generated (the reference's data sets are an
+external download).  The dense layers are torch.mm (rocBLAS/hipBLASLt), exactly as in the reference script."""
+import argparse
+import json
+import sys
+import os
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gnn_computing_amd as gnc  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="our_GCN", choices=["our_GCN", "our_GAT"])
+    ap.add_argument("--dataset", default="arxiv")
+    ap.add_argument("--datadir", default=None)
+    ap.add_argument("--reorder", default="")
+    ap.add_argument("--gpu", type=int, default=0)
+    ap.add_argument("--neighbor-num", type=int, default=32)   # our.py:84
+    ap.add_argument("--iters", type=int, default=100)
+    args = ap.parse_args()
+    dev = torch.device("cuda", args.gpu)
+    torch.manual_seed(123)                                   # our.py:76
+
+    if args.datadir:
+        ptrs, idxs = gnc.new_load(args.dataset, args.reorder, args.gpu, datadir=args.datadir)
+    else:
+        p, i = gnc.graph.dataset(args.dataset, device=dev)
+        ptrs, idxs = p, i
+    num_v, num_e = ptrs.numel() - 1, idxs.numel()
+    vals = torch.ones(num_e, device=dev)                     # our.py:78
+    at = gnc.gcn_init(ptrs, idxs, vals)
+    gnc.gcn_schedule(at, args.neighbor_num)
+    at_gat = gnc.gat_init(ptrs, idxs)
+    gnc.gat_schedule(at_gat, args.neighbor_num)
+
+    dims = [512, 128, 64, 32]                                # our.py:92-95
+    # 1/sqrt(fan_in) scaling keeps activations O(1): the reference's GAT kernel exponentiates raw scores without a
+    # max-subtraction (aggr_gat.h:138-143), so un-scaled randn weights overflow exp() in the deeper layers
+    weights = [torch.randn(dims[k], dims[k + 1], device=dev) / dims[k] ** 0.5 for k in range(3)]
+    weights_lr = [torch.randn(dims[k + 1], 2, device=dev) / dims[k + 1] ** 0.5 for k in range(3)]
+    h = torch.randn(num_v, 512, device=dev)
+    outs = [torch.empty(num_v, dims[k + 1], device=dev) for k in range(3)]
+
+    def gcn_layer(feat, out, w):                             # our.py:171-176
+        feat2 = torch.mm(feat, w)
+        gnc.gcn_run(at, feat2, out, 128, 1)
+        return F.relu(out)
+
+    def gat_layer(feat, out, w, w_lr):                       # our.py:179-188
+        feat2 = torch.mm(feat, w)
+        att_lr = torch.mm(feat2, w_lr)
+        gnc.gat_run(at_gat, feat2, att_lr, out, 128, 1)
+        return out
+
+    def forward():
+        x = h
+        for k in range(3):
+            x = gcn_layer(x, outs[k], weights[k]) if args.model == "our_GCN" else gat_layer(x, outs[k], weights[k], weights_lr[k])
+        return x
+
+    for _ in range(args.iters):
+        forward()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        forward()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.iters
+    y = forward()
+    print(json.dumps({"model": args.model, "dataset": args.dataset, "num_v": num_v, "num_e": num_e,
+                      "seconds_per_forward": dt, "finite": bool(torch.isfinite(y).all().item())}))
+
+
+if __name__ == "__main__":
+    main()
