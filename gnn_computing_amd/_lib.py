@@ -13,6 +13,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_IO = 0, 1, 2, 3, 4
 SCHED_LOCALITY, SCHED_NEIGHBOR_GROUPING, SCHED_LOCALITY_NEIGHBOR_GROUPING, SCHED_NOP = 0, 1, 2, 3
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
 MODE_ROWS, MODE_SCHEDULED, MODE_BALANCED = 0, 1, 2
+FLAG_ACCUMULATE = 1
 
 c_int, c_float, c_void_p, c_char_p, c_int64 = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p,
                                                 ctypes.c_int64)
@@ -47,6 +48,7 @@ SIGNATURES = {
     "gnnagg_num_target": (c_int, [c_int64, c_int, P_INT]),
     "gnnagg_get_schedule": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gnnagg_gcn_run": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "gnnagg_gcn_run_ex": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "gnnagg_gcn_run_edgewise": (c_int, [c_int64, c_void_p, c_void_p, c_int]),
     "gnnagg_csr2edgelist": (c_int, [c_int64, c_void_p]),
     "gnnagg_matmul_nn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

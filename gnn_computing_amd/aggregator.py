@@ -134,18 +134,20 @@ class Aggregator_GCN(Aggregator):
                                       _dev_ptr(val, torch.float32, "val"), self.num_v, self.num_e,
                                       ctypes.byref(self._h)))
 
-    def run(self, vin, vout, BLOCK_SIZE=512, scheduled=0, reduce="sum"):
-        """aggr_gcn.h:379-410.  BLOCK_SIZE is accepted for signature parity and ignored."""
-        return self.run_with_feat(vin, vout, BLOCK_SIZE, scheduled, int(vin.shape[1]), reduce)
+    def run(self, vin, vout, BLOCK_SIZE=512, scheduled=0, reduce="sum", accumulate=False):
+        """aggr_gcn.h:379-410.  BLOCK_SIZE is accepted for signature parity and ignored.
+        accumulate=True (balanced mode, sum): vout += A.vin."""
+        return self.run_with_feat(vin, vout, BLOCK_SIZE, scheduled, int(vin.shape[1]), reduce, accumulate)
 
-    def run_with_feat(self, vin, vout, BLOCK_SIZE, scheduled, feat, reduce="sum"):
+    def run_with_feat(self, vin, vout, BLOCK_SIZE, scheduled, feat, reduce="sum", accumulate=False):
         """aggr_gcn.h:411-444"""
         if vout.numel() < self.num_v * feat:
             raise ValueError("vout must hold num_v * feat floats")
         self.feat_in = feat
         self._use_current_stream()
-        check(lib().gnnagg_gcn_run(self._h, _dev_ptr(vin, torch.float32, "vin"), _dev_ptr(vout, torch.float32, "vout"),
-                                   int(feat), _mode(scheduled), REDUCE[reduce]))
+        check(lib().gnnagg_gcn_run_ex(self._h, _dev_ptr(vin, torch.float32, "vin"), _dev_ptr(vout, torch.float32, "vout"),
+                                      int(feat), _mode(scheduled), REDUCE[reduce],
+                                      _lib.FLAG_ACCUMULATE if accumulate else 0))
         return 0.0
 
     def runEdgeWise(self, vin, vout, BLOCK_SIZE=512, scheduled=0):

@@ -403,8 +403,10 @@ static int get_sched(Ctx *c, int mode, Schedule **out)
     return GNNAGG_OK;
 }
 
-static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce)
+static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0)
 {
+    if ((flags & GNNAGG_FLAG_ACCUMULATE) && (mode != GNNAGG_MODE_BALANCED || reduce != GNNAGG_REDUCE_SUM || !c->use_plan))
+        return fail(GNNAGG_ERR_ARG, "GNNAGG_FLAG_ACCUMULATE needs GNNAGG_MODE_BALANCED and GNNAGG_REDUCE_SUM");
     if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
     if (!x || !y) return fail(GNNAGG_ERR_ARG, "null feature pointer");
     if (reduce < GNNAGG_REDUCE_SUM || reduce > GNNAGG_REDUCE_MAX) return fail(GNNAGG_ERR_ARG, "bad reduce");
@@ -420,7 +422,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         P.hubs.mrow_id = p.mrow_id.p; P.hubs.mrow_ptr = p.mrow_ptr.p; P.hubs.n_mrows = p.n_mrows;
         P.hubs.n_slots = p.n_slots; P.hubs.big_rows = p.big_rows.p; P.hubs.n_big = p.n_big;
         P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
-        P.xcd_remap = c->xcd_remap; P.variant = c->variant;
+        P.xcd_remap = c->xcd_remap; P.variant = c->variant; P.accumulate = (flags & GNNAGG_FLAG_ACCUMULATE) ? 1 : 0;
         if (p.n_slots > 0) {
             if ((rc = c->partial.reserve((size_t)p.n_slots * feat))) return rc;
             P.partial = c->partial.p;
@@ -734,6 +736,12 @@ int gnnagg_gcn_run_with_nn(gnnagg_handle h, const float *d_x, float *d_y, const 
     int rc = gcn_run(c, d_x, d_y, feat_in, mode, GNNAGG_REDUCE_SUM);
     if (rc) return rc;
     return launch_dense_nn(d_y, d_weight, d_transformed, c->V, feat_out, feat_in, c->stream);
+}
+
+int gnnagg_gcn_run_ex(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce, int flags)
+{
+    GET_CTX(h);
+    return gcn_run(c, d_x, d_y, feat, mode, reduce, flags);
 }
 
 int gnnagg_csr2edgelist(gnnagg_handle h, int *d_edgelist)

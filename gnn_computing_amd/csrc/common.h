@@ -62,6 +62,7 @@ struct GcnLaunch {
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 1;
     int variant = 0;  // tuning knob: 0 = default lane geometry
+    int accumulate = 0;  // combine only: y += sum of partials
     int idxmode = 0;  // 0: per-lane (idx,val) loads; 1: group-coalesced load + ds_bpermute broadcast
     // host array [n_items + n_empty + 1]: prefix sums of the per-item cost, for xcd_remap == 2
     const long *xcd_item_cost_prefix = nullptr;
@@ -90,6 +91,7 @@ struct GcnPlanLaunch {
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 2;
     int variant = 0;
+    int accumulate = 0;  // y += A.x (sum only); rows without edges keep their value
 };
 
 struct GatLaunch {

@@ -333,6 +333,7 @@ struct PlanArgs {
     float *y;
     float *partial;
     int n0, n1, feat, ntiles, chunk, mean, remap, nblocks0;
+    int accumulate;  // 1: y += result (rows without edges are left untouched); sum only
     XcdRanges xr;
 };
 
@@ -381,6 +382,11 @@ __global__ __launch_bounds__(kBlock) void k_gcn_plan(const PlanArgs a)
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
             }
+            if (a.accumulate) {
+                const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)d.z * F + col);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
+            }
             store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
         } else {
             store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
@@ -395,12 +401,17 @@ __global__ __launch_bounds__(kBlock) void k_gcn_plan(const PlanArgs a)
     const int col = (tile * GROUP + lane) * VEC;
     const bool col_ok = col < F;
     const int4 d = a.t0[item];
+    if (a.accumulate && d.x == d.y) return;  // y += 0
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
     chain_edges<VEC, GROUP, IS_MAX>(acc, d.x, d.y, lane, col_ok, a.idx, a.val, a.x + col, F);
     if (!col_ok) return;
-    if (d.x == d.y) {
+    if (a.accumulate) {
+        const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)d.z * F + col);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
+    } else if (d.x == d.y) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
     } else if (a.mean) {
@@ -562,6 +573,7 @@ struct CombineArgs {
     const int *mrow_id, *mrow_ptr, *row_ptr;
     const int *big_rows;  // indices into mrow_* of the rows with more than kCombineBatch partials
     int n_big, nblocks_small;
+    int accumulate;  // 1: y += (sum of partials)
     const float *partial;
     const float *partial_den;  // GAT only
     float *y;
@@ -638,6 +650,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
         } else if (a.mean) {
             acc = acc / (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
         }
+        if (a.accumulate) acc = a.y[(size_t)row * F + col0 + c] + acc;
         a.y[(size_t)row * F + col0 + c] = acc;
         return;
     }
@@ -689,6 +702,11 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
         const float d = (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
+    }
+    if (a.accumulate) {
+        const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)row * F + col);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
     }
     store_pack<VEC>(a.y + (size_t)row * F + col, acc);
 }
@@ -866,6 +884,7 @@ static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max
         c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = L.row_ptr; c.partial = L.partial;
         c.partial_den = nullptr; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
         c.heads = 1; c.dhead = L.feat; c.mean = L.reduce == GNNAGG_REDUCE_MEAN;
+        c.accumulate = L.accumulate;
         c.big_rows = L.wl.big_rows; c.n_big = L.wl.n_big;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
         const int nb = c.nblocks_small + c.n_big * g.ntiles;
@@ -889,7 +908,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     a.t0 = reinterpret_cast<const int4 *>(L.t0); a.t1 = reinterpret_cast<const int4 *>(L.t1);
     a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
     a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
-    a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap;
+    a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap; a.accumulate = L.accumulate;
     const int gpb = kBlock / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
     a.nblocks0 = item_blocks * g.ntiles;
@@ -910,6 +929,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     }
     GcnLaunch C;
     C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
+    C.accumulate = L.accumulate;
     return launch_combine_gcn(C, g, is_max, stream);
 }
 
@@ -1003,7 +1023,7 @@ int launch_gat(const GatLaunch &L, void *stream_v)
         CombineArgs c;
         c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = nullptr; c.partial = L.partial;
         c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
-        c.heads = L.heads; c.dhead = dhead; c.mean = 0;
+        c.heads = L.heads; c.dhead = dhead; c.mean = 0; c.accumulate = 0;
         c.big_rows = L.wl.big_rows; c.n_big = L.heads <= 64 ? L.wl.n_big : 0;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
         const int nb = c.nblocks_small + c.n_big * g.ntiles;

@@ -117,6 +117,11 @@ int gnnagg_get_schedule(gnnagg_handle h, int mode, int *h_ptr_s, int *h_idx_s, i
 /* Aggregator_GCN::run / run_with_feat, aggr_gcn.h:379-444.  x,y are [V,feat] row-major fp32 on
  * device.  mode = GNNAGG_MODE_*, reduce = GNNAGG_REDUCE_*.  y is fully overwritten. */
 int gnnagg_gcn_run(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce);
+/* Same with flags.  GNNAGG_FLAG_ACCUMULATE (balanced mode, sum): y += A.x -- the row's result is computed as
+ * usual and added to the value already in y with one fp32 add; rows without edges are left untouched.  Used by the
+ * row-partitioned path to add the halo-column part after the local-column part. */
+#define GNNAGG_FLAG_ACCUMULATE 1
+int gnnagg_gcn_run_ex(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce, int flags);
 /* Aggregator_GCN::runEdgeWise, aggr_gcn.h:446-460 (edge-parallel atomics; any feat). */
 int gnnagg_gcn_run_edgewise(gnnagg_handle h, const float *d_x, float *d_y, int feat);
 /* matmul_NN, include/dense.h:4-23: c[m,n] = a[m,k] . b[k,n], row-major fp32 (the dense combine after an

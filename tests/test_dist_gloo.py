@@ -47,12 +47,22 @@ def _worker(rank, world, port, F, q):
         x_ext = hx.alloc_x_ext(F)
         x_ext[:hx.n_local] = torch.from_numpy(x[r0:r1])
         x_ext[hx.n_local:] = float("nan")
-        for _ in range(2):  # the plan is reusable step after step
-            hx.exchange(x_ext)
+        for k in range(2):  # the plan is reusable step after step; second round asynchronous
+            w = hx.exchange(x_ext[:hx.n_local], x_ext[hx.n_local:], async_op=(k == 1))
+            if w is not None:
+                w.wait()
         ok_halo = np.array_equal(x_ext[hx.n_local:].numpy(), x[hx.halo_ids])
         y_local = orc.gcn_seq(hx.local_ptr, hx.local_idx, val[hx.e0:hx.e1], x_ext.numpy())
         y_global = orc.gcn_seq(ptr, idx, val, x)
         ok_y = np.array_equal(y_local, y_global[r0:r1])
+        # overlap plan: local-source edges and halo-source edges as two CSRs whose results add up to the row
+        pl, il, pr, ir, is_loc = hx.split_local_remote()
+        vl = val[hx.e0:hx.e1]
+        y_split = (orc.gcn_seq(pl, il, vl[is_loc], x_ext[:hx.n_local].numpy()) +
+                   orc.gcn_seq(pr, ir, vl[~is_loc], x_ext[hx.n_local:].numpy()))
+        scale = orc.gcn_abs_scale(ptr, idx, val, x)[r0:r1]
+        ok_y = ok_y and bool(np.all(np.abs(y_split - y_global[r0:r1]) <= 1e-5 * scale + 1e-30))
+        ok_y = ok_y and len(il) + len(ir) == hx.e1 - hx.e0 and (ir.max(initial=-1) < hx.n_halo)
         tot = torch.tensor([hx.e1 - hx.e0, hx.n_local], dtype=torch.int64)
         dist.all_reduce(tot)
         q.put((rank, ok_halo, ok_y, int(tot[0]) == E, int(tot[1]) == V, hx.n_halo, int(hx.send_counts.sum())))

@@ -528,3 +528,43 @@ def test_run_with_nn():
     y_ref = orc.gcn_grouped(ps, tg, idx, val, x, V)
     assert np.array_equal(y.cpu().numpy(), y_ref)
     assert np.array_equal(t.cpu().numpy(), orc.matmul_nn(y_ref, w))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_partitioned_gcn_single_gpu_emulation(world, overlap):
+    """The row-partitioned plan of every rank, run one rank at a time on this GPU with the halo filled by hand
+    (offline plan: the collective itself is covered by tests/test_dist_gloo.py)."""
+    from gnn_computing_amd.dist import PartitionedGCN
+    V, E, F = 4000, 90000, 128
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=11)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    x, val = rand((V, F), 1), rand(E, 2)
+    y_ref = orc.gcn_seq(ptr, idx, val, x)
+    scale = orc.gcn_abs_scale(ptr, idx, val, x)
+    seen = 0
+    for r in range(world):
+        pg = PartitionedGCN(ptr, idx, val, F, device=DEV, rank=r, world=world, overlap=overlap, offline=True)
+        hx = pg.hx
+        r0, r1 = int(hx.bounds[r]), int(hx.bounds[r + 1])
+        pg.set_local_x(dev(x[r0:r1]))
+        pg.x_halo.copy_(dev(x[hx.halo_ids]))
+        y = pg.step().cpu().numpy()
+        seen += r1 - r0
+        assert_within(y, y_ref[r0:r1], scale[r0:r1], "rank %d/%d" % (r, world))
+        if overlap:
+            # exact statement of the overlap plan: (balanced fold of local-source edges) + (balanced fold of halo-source edges)
+            pl, il, pr, ir, is_loc = hx.split_local_remote()
+            vl = val[hx.e0:hx.e1]
+            cl, sl = pg.agg_loc.balanced_params()
+            cr, sr = pg.agg_rem.balanced_params()
+            a = orc.gcn_grouped(*orc.neighbor_grouping(pl, cl), il, vl[is_loc], x[r0:r1], r1 - r0, seg=sl)
+            b = orc.gcn_grouped(*orc.neighbor_grouping(pr, cr), ir, vl[~is_loc], x[hx.halo_ids], r1 - r0, seg=sr)
+            has_rem = (np.diff(pr) > 0)[:, None]
+            assert np.array_equal(y, np.where(has_rem, a + b, a))
+        else:
+            ch, sg = pg.agg.balanced_params()
+            ps, tg = orc.neighbor_grouping(hx.local_ptr, ch)
+            x_ext = np.concatenate([x[r0:r1], x[hx.halo_ids]])
+            assert np.array_equal(y, orc.gcn_grouped(ps, tg, hx.local_idx, val[hx.e0:hx.e1], x_ext, r1 - r0, seg=sg))
+    assert seen == V
