@@ -8,7 +8,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
 #include <mutex>
 #include <set>
 #include <vector>
@@ -77,9 +76,6 @@ struct Schedule {
     DevBuf<float> val_s;
     int n_empty = 0, n_mrows = 0, n_slots = 0;
     std::vector<long> cost_prefix;  // per work item (groups then empty-row items), for the XCD ranges
-    DevBuf<int> desc;                           // int2 {end edge, dest} per item (source of the edge tags)
-    DevBuf<int> tag;                            // streaming kernel: per-edge destination tag
-    std::map<int, DevBuf<int>> stream_ranges;   // lane-group count -> first edge of every group's range
 
     void reset()
     {
@@ -87,7 +83,7 @@ struct Schedule {
         ptr_s.release(); target.release(); slot.release(); empty_rows.release();
         mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release(); big_rows.release(); n_big = 0;
         h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear();
-        desc.release(); tag.release(); stream_ranges.clear(); cost_prefix.clear();
+        cost_prefix.clear();
         num_target = n_empty = n_mrows = n_slots = 0;
         permuted = false;
     }
@@ -137,15 +133,8 @@ struct Ctx {
     DevBuf<float> partial, partial_den;
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
     DevBuf<int> diffbuf;
-    int xcd_remap = 2;
-    int variant = 0;
-    int idxmode = 1;
-    int edge_items_mode = 1;   // edge kernels on chunked work items (0: one lane group per row)
+    int xcd_remap = 2;         // 0 identity, 1 equal-count XCD ranges, 2 work-balanced XCD ranges
     int use_plan = 1;          // GCN balanced mode runs k_gcn_plan (0: items + combine, the round-1 first design)
-    int use_stream = 0;        // 1: LIST modes run the persistent streaming kernel (A/B knob; the item kernel measured faster)
-    int stream_bpc = 8;        // workgroups per CU for the streaming grid
-    int stream_min_edges = 32; // lower bound on edges per lane group
-    int num_cus = 256;
     std::vector<long> row_cost_prefix;  // MODE_ROWS work items
     int avg_deg() const { return V > 0 ? (int)((long)E / V) : 0; }
 };
@@ -203,20 +192,8 @@ static int finalize_schedule(Ctx *c, Schedule &s)
     for (int g = 0; g < G; ++g) s.cost_prefix[g + 1] = s.cost_prefix[g] + (s.h_ptr_s[g + 1] - s.h_ptr_s[g]) + kItemCost;
     for (size_t k = 0; k < empty.size(); ++k) s.cost_prefix[G + k + 1] = s.cost_prefix[G + k] + 1;
     int rc;
-    {
-        std::vector<int> desc((size_t)2 * G);
-        for (int g = 0; g < G; ++g) {
-            if (s.h_ptr_s[g + 1] <= s.h_ptr_s[g]) return fail(GNNAGG_ERR_STATE, "internal: empty work item in a schedule");
-            desc[2 * g] = s.h_ptr_s[g + 1];
-            desc[2 * g + 1] = slot[g] >= 0 ? ~slot[g] : s.h_target[g];
-        }
-        if ((rc = s.desc.upload(desc))) return rc;
-        const long ne = G > 0 ? s.h_ptr_s[G] : 0;
-        if (ne > 0 && c->use_stream) {
-            if ((rc = s.tag.reserve((size_t)ne))) return rc;
-            if ((rc = launch_build_tags(s.desc.p, G, ne, s.tag.p, c->stream))) return rc;
-        }
-    }
+    for (int g = 0; g < G; ++g)
+        if (s.h_ptr_s[g + 1] <= s.h_ptr_s[g]) return fail(GNNAGG_ERR_STATE, "internal: empty work item in a schedule");
     if ((rc = s.ptr_s.upload(s.h_ptr_s))) return rc;
     if ((rc = s.target.upload(s.h_target))) return rc;
     if ((rc = s.slot.upload(slot))) return rc;
@@ -281,34 +258,6 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
     s.h_ptr_s.swap(ptr_s);
     s.h_target.swap(tgt);
     return finalize_schedule(c, s);
-}
-
-// Cuts the items of a schedule into `ngroups` contiguous ranges of about equal cost.
-static int stream_range_table(Schedule &s, int ngroups, const int **out)
-{
-    auto it = s.stream_ranges.find(ngroups);
-    if (it == s.stream_ranges.end()) {
-        const int G = s.num_target;
-        const long total = s.cost_prefix[G];
-        std::vector<int> tab((size_t)ngroups + 1);
-        int item = 0;
-        for (int q = 0; q <= ngroups; ++q) {
-            if (q == ngroups) {
-                item = G;
-            } else {
-                const long want = total * q / ngroups;
-                item = (int)(std::lower_bound(s.cost_prefix.begin() + item, s.cost_prefix.begin() + G + 1, want) -
-                             s.cost_prefix.begin());
-                if (item > G) item = G;
-            }
-            tab[q] = s.h_ptr_s[item];
-        }
-        int rc = s.stream_ranges[ngroups].upload(tab);
-        if (rc) return rc;
-        it = s.stream_ranges.find(ngroups);
-    }
-    *out = it->second.p;
-    return GNNAGG_OK;
 }
 
 static int build_balanced_plan(Ctx *c, int chunk)
@@ -422,7 +371,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         P.hubs.mrow_id = p.mrow_id.p; P.hubs.mrow_ptr = p.mrow_ptr.p; P.hubs.n_mrows = p.n_mrows;
         P.hubs.n_slots = p.n_slots; P.hubs.big_rows = p.big_rows.p; P.hubs.n_big = p.n_big;
         P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
-        P.xcd_remap = c->xcd_remap; P.variant = c->variant; P.accumulate = (flags & GNNAGG_FLAG_ACCUMULATE) ? 1 : 0;
+        P.xcd_remap = c->xcd_remap; P.accumulate = (flags & GNNAGG_FLAG_ACCUMULATE) ? 1 : 0;
         if (p.n_slots > 0) {
             if ((rc = c->partial.reserve((size_t)p.n_slots * feat))) return rc;
             P.partial = c->partial.p;
@@ -431,7 +380,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     }
     GcnLaunch L;
     L.row_ptr = c->d_ptr; L.x = x; L.y = y; L.feat = feat; L.reduce = reduce;
-    L.xcd_remap = c->xcd_remap; L.variant = c->variant; L.idxmode = c->idxmode;
+    L.xcd_remap = c->xcd_remap;
     if (!s) {
         L.wl.ptr = c->d_ptr;
         L.wl.n_items = c->V;
@@ -448,19 +397,6 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     } else {
         L.xcd_item_cost_prefix = s->cost_prefix.data();
         L.wl = s->worklist();
-        if (c->use_stream && s->num_target > 0) {
-            const int gpb = lane_groups_per_block(feat, x, y, nullptr, feat, c->variant);
-            int ngroups = c->num_cus * c->stream_bpc * gpb;
-            // keep a few batches of work per group; tiny graphs use fewer groups
-            const long edges = s->h_ptr_s[s->num_target];
-            const long max_groups = std::max<long>(gpb, edges / c->stream_min_edges);
-            if (ngroups > max_groups) ngroups = (int)(max_groups / gpb) * gpb;
-            const int *tab = nullptr;
-            if ((rc = stream_range_table(*s, ngroups, &tab))) return rc;
-            L.stream_tag = s->tag.p;
-            L.stream_range = tab;
-            L.stream_groups = ngroups;
-        }
         L.idx = s->permuted ? s->idx_s.p : c->d_idx;
         L.val = s->permuted ? s->val_s.p : c->d_val;
         if (s->n_slots > 0) {
@@ -587,19 +523,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     Ctx *c = new Ctx;
     c->kind = kind; c->V = V; c->E = E; c->d_ptr = d_ptr; c->d_idx = d_idx; c->d_val = d_val;
     if (const char *e = getenv("GNNAGG_XCD_REMAP")) c->xcd_remap = atoi(e);
-    if (const char *e = getenv("GNNAGG_VARIANT")) c->variant = atoi(e);
-    if (const char *e = getenv("GNNAGG_IDXMODE")) c->idxmode = atoi(e);
-    if (const char *e = getenv("GNNAGG_STREAM")) c->use_stream = atoi(e);
     if (const char *e = getenv("GNNAGG_PLAN")) c->use_plan = atoi(e);
-    if (const char *e = getenv("GNNAGG_EDGE_ITEMS")) c->edge_items_mode = atoi(e);
-    if (const char *e = getenv("GNNAGG_STREAM_BPC")) c->stream_bpc = std::max(1, atoi(e));
-    if (const char *e = getenv("GNNAGG_STREAM_MIN_EDGES")) c->stream_min_edges = std::max(1, atoi(e));
-    {
-        hipDeviceProp_t prop;
-        int devid = 0;
-        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
-            c->num_cus = std::max(1, prop.multiProcessorCount);
-    }
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);
@@ -775,8 +699,6 @@ int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, in
 {
     GET_CTX(h);
     if (!d_att || (!d_out_val && c->E > 0) || heads <= 0) return fail(GNNAGG_ERR_ARG, "bad run_att arguments");
-    if (!c->edge_items_mode)
-        return launch_gat_att(c->d_ptr, c->d_idx, d_att, d_out_val, c->V, heads, slope, c->avg_deg(), c->stream);
     EdgeItemLaunch L;
     int rc = edge_launch(c, L, heads);
     if (rc) return rc;
@@ -791,8 +713,6 @@ int gnnagg_gat_run_u_add_v(gnnagg_handle h, const float *d_att, float *d_out_val
 {
     GET_CTX(h);
     if (!d_att || (!d_out_val && c->E > 0)) return fail(GNNAGG_ERR_ARG, "bad u_add_v arguments");
-    if (!c->edge_items_mode)
-        return launch_u_add_v(c->d_ptr, c->d_idx, d_att, d_out_val, c->V, c->avg_deg(), c->stream);
     EdgeItemLaunch L;
     int rc = edge_launch(c, L, 1);
     if (rc) return rc;
@@ -804,8 +724,6 @@ int gnnagg_gat_run_add_to_center(gnnagg_handle h, const float *d_in_val, float *
 {
     GET_CTX(h);
     if ((!d_in_val && c->E > 0) || !d_out_att) return fail(GNNAGG_ERR_ARG, "bad add_to_center arguments");
-    if (!c->edge_items_mode)
-        return launch_add_to_center(c->d_ptr, d_in_val, d_out_att, c->V, c->avg_deg(), c->stream);
     EdgeItemLaunch L;
     int rc = edge_launch(c, L, 1);
     if (rc) return rc;
@@ -817,8 +735,6 @@ int gnnagg_gat_run_div_each(gnnagg_handle h, const float *d_in_att, float *d_ino
 {
     GET_CTX(h);
     if (!d_in_att || (!d_inout_val && c->E > 0)) return fail(GNNAGG_ERR_ARG, "bad div_each arguments");
-    if (!c->edge_items_mode)
-        return launch_div_each(c->d_ptr, d_in_att, d_inout_val, c->V, c->avg_deg(), c->stream);
     EdgeItemLaunch L;
     int rc = edge_launch(c, L, 1);
     if (rc) return rc;

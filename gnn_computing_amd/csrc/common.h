@@ -61,17 +61,9 @@ struct GcnLaunch {
     int feat = 0;
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 1;
-    int variant = 0;  // tuning knob: 0 = default lane geometry
     int accumulate = 0;  // combine only: y += sum of partials
-    int idxmode = 0;  // 0: per-lane (idx,val) loads; 1: group-coalesced load + ds_bpermute broadcast
     // host array [n_items + n_empty + 1]: prefix sums of the per-item cost, for xcd_remap == 2
     const long *xcd_item_cost_prefix = nullptr;
-    // streaming kernel (LIST modes): device arrays int tag[n_edges] (destination on the last edge of
-    // every item) and int range[stream_groups + 1] (first edge of each lane group's range);
-    // null => item-per-group kernel
-    const void *stream_tag = nullptr;
-    const void *stream_range = nullptr;
-    int stream_groups = 0;
 };
 
 // Balanced plan (GNNAGG_MODE_BALANCED, GCN): see k_gcn_plan in kernels.hip.
@@ -90,7 +82,6 @@ struct GcnPlanLaunch {
     int feat = 0;
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 2;
-    int variant = 0;
     int accumulate = 0;  // y += A.x (sum only); rows without edges keep their value
 };
 
@@ -109,8 +100,6 @@ struct GatLaunch {
     int xcd_remap = 1;
 };
 
-int lane_groups_per_block(int feat, const void *x, const void *y, const void *partial, int dhead, int variant);
-int launch_build_tags(const void *desc, int n_items, long n_edges, int *tag, void *stream);
 // Edge kernels on chunked work items (attGat / u_add_v / add_to_center / each_div without the hub-row tail)
 struct EdgeItemLaunch {
     WorkList wl;
@@ -129,11 +118,6 @@ int launch_edge_items_map(const EdgeItemLaunch &L, int op, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);
 int launch_gcn_plan(const GcnPlanLaunch &a, void *stream);
 int launch_gat(const GatLaunch &a, void *stream);
-int launch_gat_att(const int *ptr, const int *idx, const float *att, float *out, int V, int heads, float slope,
-                   int avg_deg, void *stream);
-int launch_u_add_v(const int *ptr, const int *idx, const float *att, float *out, int V, int avg_deg, void *stream);
-int launch_add_to_center(const int *ptr, const float *in, float *out, int V, int avg_deg, void *stream);
-int launch_div_each(const int *ptr, const float *in, float *inout, int V, int avg_deg, void *stream);
 int launch_csr2edgelist(const int *ptr, const int *idx, int *edgelist, int V, int avg_deg, void *stream);
 int launch_edgewise(const int *edgelist, const float *val, const float *x, float *y, int E, int V, int feat,
                     void *stream);

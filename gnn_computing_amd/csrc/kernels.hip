@@ -8,8 +8,8 @@
 //    GROUP < 64 packs several short rows into one wavefront (avg degree of arxiv is 6.9), which
 //    is what keeps lanes busy where the reference's warp-per-row scheme idles.
 //  * The FMA chain of an item runs in CSR order (bit-exact against the oracle); memory-level
-//    parallelism comes from issuing the U=8 neighbor gathers of a chunk before the first FMA and
-//    from prefetching the next chunk's (idx,val) while the current gathers are in flight.
+//    parallelism comes from issuing the U=8 neighbor gathers of a batch before the first FMA;
+//    (idx,val) of GROUP edges arrive with ONE coalesced load and are broadcast with ds_bpermute.
 //  * Long rows are split into several items by the schedule; their partial sums go to a scratch
 //    slab and a second kernel adds them in ascending order (deterministic; the reference uses
 //    fp32 atomics in arbitrary order, aggr_gcn.h:112).
@@ -113,152 +113,6 @@ struct GcnArgs {
     XcdRanges xr;
 };
 
-// ------------------------------------------------------------------------- GCN / SAGE items
-// LIST = false: item g is CSR row g (reference aggr_gcn, aggr_gcn.h:5-36).
-// LIST = true : item g is a group of the schedule (reference aggr_gcn_target, aggr_gcn.h:78-114).
-template <int VEC, int GROUP, bool IS_MAX, bool LIST, int IDXMODE>
-__global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
-{
-    constexpr int ITEMS = kBlock / GROUP;
-    const int b = logical_block(blockIdx.x, a.nblocks, a.ntiles, a.remap, a.xr);
-    if (b < 0) return;
-    const int tile = b % a.ntiles;
-    const int item = (b / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
-    const int lane = threadIdx.x & (GROUP - 1);
-    const int col = (tile * GROUP + lane) * VEC;
-    if (item >= a.n_total) return;
-    // IDXMODE 1 keeps out-of-range column lanes alive: they still carry (idx,val) for the broadcast
-    const bool col_ok = col < a.feat;
-    if (IDXMODE == 0 && !col_ok) return;
-    const int F = a.feat;
-
-    if (LIST && item >= a.n_items) {  // rows without any group: the reference memsets vout (:393)
-        const float z[VEC] = {};
-        if (col_ok) store_pack<VEC>(a.y + (size_t)a.empty_rows[item - a.n_items] * F + col, z);
-        return;
-    }
-
-    const int beg = a.ptr[item], end = a.ptr[item + 1];
-    const int *__restrict__ idx = a.idx;
-    const float *__restrict__ val = a.val;
-    const float *__restrict__ xcol = a.x + col;
-
-    float acc[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
-
-    if constexpr (IDXMODE == 1) {
-        // Metadata path B: lane j of the group fetches (idx,val) of edge cb+j with ONE coalesced
-        // load per GROUP edges; each edge's pair is then broadcast inside the group with
-        // ds_bpermute (LDS crossbar, no memory traffic, leaves the texture-address path to the
-        // feature gathers).
-        int my_s = 0;
-        float my_w = 1.0f;
-        if (beg + lane < end) {
-            my_s = idx[beg + lane];
-            if (val) my_w = val[beg + lane];
-        }
-        for (int cb = beg; cb < end; cb += GROUP) {
-            int nx_s = 0;
-            float nx_w = 1.0f;
-            if (cb + GROUP + lane < end) {  // next GROUP edges travel during this chunk's gathers
-                nx_s = idx[cb + GROUP + lane];
-                if (val) nx_w = val[cb + GROUP + lane];
-            }
-            const int n = end - cb < GROUP ? end - cb : GROUP;
-            for (int j = 0; j < n; j += kUnroll) {
-                int s[kUnroll];
-                float w[kUnroll];
-                Pack<VEC> xv[kUnroll];
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-                    s[u] = __shfl(my_s, j + u, GROUP);
-                    w[u] = __shfl(my_w, j + u, GROUP);
-                }
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u)
-                    if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u)
-                    if (j + u < n && col_ok) {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) {
-                            if (IS_MAX) {
-                                const float p = xv[u].v[k] * w[u];
-                                acc[k] = p > acc[k] ? p : acc[k];
-                            } else {
-                                acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
-                            }
-                        }
-                    }
-            }
-            my_s = nx_s;
-            my_w = nx_w;
-        }
-    } else {
-    int s[kUnroll];
-    float w[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u)
-        if (beg + u < end) {
-            s[u] = idx[beg + u];
-            w[u] = val ? val[beg + u] : 1.0f;
-        }
-
-    for (int e = beg; e < end; e += kUnroll) {
-        Pack<VEC> xv[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
-            if (e + u < end) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
-        // next chunk's neighbor ids / weights travel while the gathers above are in flight
-        int sn[kUnroll];
-        float wn[kUnroll];
-        const int en = e + kUnroll;
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
-            if (en + u < end) {
-                sn[u] = idx[en + u];
-                wn[u] = val ? val[en + u] : 1.0f;
-            }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
-            if (e + u < end) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if (IS_MAX) {
-                        const float p = xv[u].v[k] * w[u];
-                        acc[k] = p > acc[k] ? p : acc[k];
-                    } else {
-                        acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
-                    }
-                }
-            }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            s[u] = sn[u];
-            w[u] = wn[u];
-        }
-    }
-    }
-
-    if (!col_ok) return;
-    const int sl = (LIST && a.slot) ? a.slot[item] : -1;
-    if (sl >= 0) {
-        store_pack<VEC>(a.partial + (size_t)sl * F + col, acc);
-        return;
-    }
-    const int row = (LIST && a.target) ? a.target[item] : item;
-    if (beg == end) {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-    } else if (a.mean) {
-        const float d = (float)(end - beg);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
-    }
-    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
-}
-
 // The FMA (or max) chain of one work item over edges [beg,end) in CSR order.  Lane j of the group fetches
 // (idx,val) of edge cb+j with ONE coalesced load per GROUP edges (next window prefetched); each edge's
 // pair is broadcast inside the group with ds_bpermute (LDS crossbar, no memory traffic), kUnroll feature
@@ -311,6 +165,51 @@ __device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end,
         my_s = nx_s;
         my_w = nx_w;
     }
+}
+
+// ------------------------------------------------------------------------- GCN / SAGE items
+// LIST = false: item g is CSR row g (reference aggr_gcn, aggr_gcn.h:5-36): the `scheduled = 0` path.
+// LIST = true : item g is a group of the schedule (reference aggr_gcn_target, aggr_gcn.h:78-114).
+template <int VEC, int GROUP, bool IS_MAX, bool LIST>
+__global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
+{
+    constexpr int ITEMS = kBlock / GROUP;
+    const int b = logical_block(blockIdx.x, a.nblocks, a.ntiles, a.remap, a.xr);
+    if (b < 0) return;
+    const int tile = b % a.ntiles;
+    const int item = (b / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int col = (tile * GROUP + lane) * VEC;
+    if (item >= a.n_total) return;
+    const bool col_ok = col < a.feat;  // out-of-range column lanes stay alive: they carry (idx,val) for the broadcast
+    const int F = a.feat;
+
+    if (LIST && item >= a.n_items) {  // rows without any group: the reference memsets vout (:393)
+        const float z[VEC] = {};
+        if (col_ok) store_pack<VEC>(a.y + (size_t)a.empty_rows[item - a.n_items] * F + col, z);
+        return;
+    }
+    const int beg = a.ptr[item], end = a.ptr[item + 1];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+    chain_edges<VEC, GROUP, IS_MAX>(acc, beg, end, lane, col_ok, a.idx, a.val, a.x + col, F);
+    if (!col_ok) return;
+    const int sl = (LIST && a.slot) ? a.slot[item] : -1;
+    if (sl >= 0) {
+        store_pack<VEC>(a.partial + (size_t)sl * F + col, acc);
+        return;
+    }
+    const int row = (LIST && a.target) ? a.target[item] : item;
+    if (beg == end) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    } else if (a.mean) {
+        const float d = (float)(end - beg);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
+    }
+    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
 }
 
 // ------------------------------------------------------------------ GCN / SAGE, balanced plan
@@ -420,153 +319,6 @@ __global__ __launch_bounds__(kBlock) void k_gcn_plan(const PlanArgs a)
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
     }
     store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
-}
-
-// ------------------------------------------------------------------ GCN / SAGE, streaming
-// Persistent streaming variant for work lists (all LIST modes; every item is non-empty).
-// Lane group q owns the contiguous edge range [range[q], range[q+1]) -- whole items, cut on the host so
-// that every group gets about the same cost -- and walks its EDGES in batches of kUnroll, independent
-// of item boundaries: 8 feature-row gathers are in flight for every batch even when the items are
-// 1-2 edges long (arxiv: avg degree 6.9).  An item boundary is carried by the edge itself:
-// tag[e] = destination of the item whose LAST edge is e (>= 0: output row, < 0: scratch row ~tag),
-// kTagNone otherwise (built once per schedule by k_build_tags).  Lane j keeps (idx,val,tag) of edge
-// win+j -- one coalesced load per GROUP edges, the next window prefetched during the gathers -- and
-// the triples are broadcast inside the group with ds_bpermute; a finished item is a fire-and-forget
-// store + accumulator reset, so nothing but the gathers sits on the critical path.
-// The FMA chain of an item is unchanged (CSR order): results are bit-identical to k_gcn_items.
-static constexpr int kTagNone = (int)0x80000000;
-
-struct StreamArgs {
-    const int *range;  // per lane group (+1): first edge
-    const int *tag;    // per edge
-    const int *empty_rows;
-    const int *idx;
-    const float *val;
-    const float *x;
-    float *y;
-    float *partial;
-    int n_groups, n_empty, feat, ntiles, nblocks_main, mean, remap;
-};
-
-__global__ void k_build_tags(const int2 *__restrict__ desc, int n_items, int *__restrict__ tag)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n_items) tag[desc[g].x - 1] = desc[g].y;
-}
-
-__global__ void k_fill_int(int *__restrict__ p, long n, int v)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
-template <int VEC, int GROUP, bool IS_MAX>
-__global__ __launch_bounds__(kBlock) void k_gcn_stream(const StreamArgs a)
-{
-    constexpr int GROUPS = kBlock / GROUP;
-    const int F = a.feat;
-    if ((int)blockIdx.x >= a.nblocks_main) {  // rows without any item: zero fill (reference memset, aggr_gcn.h:393)
-        const int r = ((int)blockIdx.x - a.nblocks_main) * GROUPS + (int)threadIdx.x / GROUP;
-        if (r >= a.n_empty) return;
-        const int row = a.empty_rows[r];
-        const float z[VEC] = {};
-        for (int c = (threadIdx.x & (GROUP - 1)) * VEC; c < F; c += GROUP * VEC) store_pack<VEC>(a.y + (size_t)row * F + c, z);
-        return;
-    }
-    const int b = a.remap ? xcd_remap(blockIdx.x, a.nblocks_main) : (int)blockIdx.x;
-    const int tile = b % a.ntiles;
-    const int q = (b / a.ntiles) * GROUPS + (int)threadIdx.x / GROUP;
-    const int lane = threadIdx.x & (GROUP - 1);
-    const int col = (tile * GROUP + lane) * VEC;
-    if (q >= a.n_groups) return;
-    const bool col_ok = col < F;
-
-    const int e_beg = a.range[q], e_end = a.range[q + 1];
-    if (e_beg >= e_end) return;
-    const int *__restrict__ idx = a.idx;
-    const int *__restrict__ tag = a.tag;
-    const float *__restrict__ val = a.val;
-    const float *__restrict__ xcol = a.x + col;
-
-    int my_s = 0, nx_s = 0, my_t = kTagNone, nx_t = kTagNone;
-    float my_w = 1.0f, nx_w = 1.0f;
-    if (e_beg + lane < e_end) {
-        my_s = idx[e_beg + lane];
-        my_t = tag[e_beg + lane];
-        if (val) my_w = val[e_beg + lane];
-    }
-    float acc[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
-    int cnt = 0;
-
-    for (int win = e_beg; win < e_end; win += GROUP) {
-        if (win + GROUP + lane < e_end) {  // next window travels during this window's gathers
-            nx_s = idx[win + GROUP + lane];
-            nx_t = tag[win + GROUP + lane];
-            if (val) nx_w = val[win + GROUP + lane];
-        }
-        const int n = e_end - win < GROUP ? e_end - win : GROUP;
-        for (int j = 0; j < n; j += kUnroll) {
-            int s[kUnroll], t[kUnroll];
-            float w[kUnroll];
-            Pack<VEC> xv[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                s[u] = __shfl(my_s, j + u, GROUP);
-                w[u] = __shfl(my_w, j + u, GROUP);
-                t[u] = __shfl(my_t, j + u, GROUP);
-            }
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-                if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
-                if (j + u < n && col_ok) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        if (IS_MAX) {
-                            const float p = xv[u].v[k] * w[u];
-                            acc[k] = p > acc[k] ? p : acc[k];
-                        } else {
-                            acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
-                        }
-                    }
-                    ++cnt;
-                    if (t[u] != kTagNone) {  // last edge of its item: store and reset
-                        if (t[u] >= 0) {
-                            if (a.mean) {
-                                const float d = (float)cnt;
-#pragma unroll
-                                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
-                            }
-                            store_pack<VEC>(a.y + (size_t)t[u] * F + col, acc);
-                        } else {
-                            store_pack<VEC>(a.partial + (size_t)(~t[u]) * F + col, acc);
-                        }
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
-                        cnt = 0;
-                    }
-                }
-        }
-        my_s = nx_s;
-        my_w = nx_w;
-        my_t = nx_t;
-    }
-}
-
-int launch_build_tags(const void *desc, int n_items, long n_edges, int *tag, void *stream_v)
-{
-    hipStream_t stream = (hipStream_t)stream_v;
-    if (n_edges <= 0) return GNNAGG_OK;
-    hipLaunchKernelGGL(k_fill_int, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, stream, tag, n_edges, kTagNone);
-    if (n_items > 0)
-        hipLaunchKernelGGL(k_build_tags, dim3((n_items + 255) / 256), dim3(256), 0, stream,
-                           reinterpret_cast<const int2 *>(desc), n_items, tag);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(stream));
-    return GNNAGG_OK;
 }
 
 struct CombineArgs {
@@ -804,7 +556,7 @@ struct Geometry {
     int vec, group, ntiles;
 };
 
-static Geometry pick_geometry(int F, const void *p0, const void *p1, const void *p2, int dhead, int variant)
+static Geometry pick_geometry(int F, const void *p0, const void *p1, const void *p2, int dhead)
 {
     auto aligned = [](const void *p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; };
     int vec = 1;
@@ -812,12 +564,9 @@ static Geometry pick_geometry(int F, const void *p0, const void *p1, const void 
         vec = 4;
     else if (F % 2 == 0 && dhead % 2 == 0 && aligned(p0, 8) && aligned(p1, 8) && aligned(p2, 8))
         vec = 2;
-    if (variant == 1 && vec == 4) vec = 2;  // wave-per-row flavour for F=128 (A/B knob)
-    if (variant == 2 && vec == 4) vec = 2;
     const int lanes = (F + vec - 1) / vec;
     int group = 8;
     while (group < 64 && group < lanes) group <<= 1;
-    if (variant == 2 && group > 8) group >>= 1;  // half-width groups, two column tiles
     const int ntiles = (lanes + group - 1) / group;
     return {vec, group, ntiles};
 }
@@ -870,11 +619,6 @@ static int fill_xcd_ranges(const long *cost_prefix, int n_items, int items_per_b
     return longest;
 }
 
-int lane_groups_per_block(int feat, const void *x, const void *y, const void *partial, int dhead, int variant)
-{
-    return kBlock / pick_geometry(feat, x, y, partial, dhead, variant).group;
-}
-
 static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max, hipStream_t stream)
 {
     static const int dbg_skip = getenv("GNNAGG_DEBUG_SKIP_COMBINE") ? atoi(getenv("GNNAGG_DEBUG_SKIP_COMBINE")) : 0;
@@ -902,7 +646,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
     if (L.feat <= 0) return fail(GNNAGG_ERR_ARG, "feature length must be >= 1");
-    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, L.feat, L.variant);
+    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, L.feat);
     const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
     PlanArgs a;
     a.t0 = reinterpret_cast<const int4 *>(L.t0); a.t1 = reinterpret_cast<const int4 *>(L.t1);
@@ -938,27 +682,8 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
     hipStream_t stream = (hipStream_t)stream_v;
     if (L.feat <= 0) return fail(GNNAGG_ERR_ARG, "feature length must be >= 1");
     const bool list = L.wl.target != nullptr || L.wl.slot != nullptr || L.wl.n_empty > 0;
-    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, L.feat, L.variant);
+    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, L.feat);
     const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
-    if (L.stream_tag && L.stream_range && L.stream_groups > 0) {
-        StreamArgs sa;
-        sa.range = reinterpret_cast<const int *>(L.stream_range);
-        sa.tag = reinterpret_cast<const int *>(L.stream_tag);
-        sa.empty_rows = L.wl.empty_rows; sa.idx = L.idx; sa.val = L.val; sa.x = L.x; sa.y = L.y; sa.partial = L.partial;
-        sa.n_groups = L.stream_groups; sa.n_empty = L.wl.n_empty; sa.feat = L.feat;
-        sa.ntiles = g.ntiles; sa.mean = L.reduce == GNNAGG_REDUCE_MEAN; sa.remap = L.xcd_remap ? 1 : 0;
-        const int gpb = kBlock / g.group;
-        sa.nblocks_main = ceil_div(sa.n_groups, gpb) * g.ntiles;
-        if (sa.nblocks_main < 64) sa.remap = 0;
-        const int grid = sa.nblocks_main + ceil_div(sa.n_empty, gpb);
-#define CALL_STREAM                                                                                         \
-        if (is_max) hipLaunchKernelGGL((k_gcn_stream<VEC, GROUP, true>), dim3(grid), dim3(kBlock), 0, stream, sa);  \
-        else        hipLaunchKernelGGL((k_gcn_stream<VEC, GROUP, false>), dim3(grid), dim3(kBlock), 0, stream, sa);
-        if (grid > 0) { DISPATCH_GEOM(g, CALL_STREAM) }
-#undef CALL_STREAM
-        HIP_TRY(hipGetLastError());
-        return launch_combine_gcn(L, g, is_max, stream);
-    }
     GcnArgs a;
     a.ptr = L.wl.ptr; a.target = L.wl.target; a.slot = L.wl.slot; a.empty_rows = L.wl.empty_rows;
     a.row_ptr = L.row_ptr; a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
@@ -977,16 +702,10 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
                 grid = 8 * fill_xcd_ranges(L.xcd_item_cost_prefix, a.n_total, items_per_block, item_blocks, a.xr) * g.ntiles;
             }
         }
-        const int idxmode = L.idxmode;
-#define LAUNCH_GCN(MAXF, LISTF, IM) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, MAXF, LISTF, IM>), dim3(grid), dim3(kBlock), 0, stream, a)
-#define CALL_GCN                                                                     \
-        if (idxmode == 1) {                                                          \
-            if (list) { if (is_max) LAUNCH_GCN(true, true, 1); else LAUNCH_GCN(false, true, 1); }    \
-            else      { if (is_max) LAUNCH_GCN(true, false, 1); else LAUNCH_GCN(false, false, 1); }  \
-        } else {                                                                     \
-            if (list) { if (is_max) LAUNCH_GCN(true, true, 0); else LAUNCH_GCN(false, true, 0); }    \
-            else      { if (is_max) LAUNCH_GCN(true, false, 0); else LAUNCH_GCN(false, false, 0); }  \
-        }
+#define LAUNCH_GCN(MAXF, LISTF) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, MAXF, LISTF>), dim3(grid), dim3(kBlock), 0, stream, a)
+#define CALL_GCN                                                                                  \
+        if (list) { if (is_max) LAUNCH_GCN(true, true); else LAUNCH_GCN(false, true); }           \
+        else      { if (is_max) LAUNCH_GCN(true, false); else LAUNCH_GCN(false, false); }
         DISPATCH_GEOM(g, CALL_GCN)
 #undef CALL_GCN
 #undef LAUNCH_GCN
@@ -1003,7 +722,7 @@ int launch_gat(const GatLaunch &L, void *stream_v)
         return fail(GNNAGG_ERR_ARG, "GAT needs feat >= 1 and feat % heads == 0");
     const bool list = L.wl.target != nullptr || L.wl.slot != nullptr || L.wl.n_empty > 0;
     const int dhead = L.feat / L.heads;
-    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, dhead, 0);
+    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, dhead);
     GatArgs a;
     a.ptr = L.wl.ptr; a.target = L.wl.target; a.slot = L.wl.slot; a.empty_rows = L.wl.empty_rows;
     a.idx = L.idx; a.att = L.att; a.x = L.x; a.y = L.y; a.partial = L.partial; a.partial_den = L.partial_den;
@@ -1035,7 +754,7 @@ int launch_gat(const GatLaunch &L, void *stream_v)
     return GNNAGG_OK;
 }
 
-// ----------------------------------------------------------- per-row edge kernels (GAT adapter)
+// ------------------------------------------------------------------------- CSR -> edge list
 // A lane group strides over the edges of one row; group size follows the average degree so short
 // rows do not idle a whole wavefront.
 static int edge_group(int avg_deg)
@@ -1051,66 +770,6 @@ __device__ __forceinline__ float group_sum(float v)
 #pragma unroll
     for (int m = GROUP / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, GROUP);
     return v;
-}
-
-// reference attGat, aggr_gat.h:5-31; item = (row, head)
-template <int GROUP>
-__global__ __launch_bounds__(kBlock) void k_gat_att(const int *__restrict__ ptr, const int *__restrict__ idx,
-                                                   const float *__restrict__ att, float *__restrict__ out, int V,
-                                                   int H, float slope)
-{
-    const long item = (long)blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
-    const int lane = threadIdx.x & (GROUP - 1);
-    if (item >= (long)V * H) return;
-    const int row = (int)(item / H), h = (int)(item % H);
-    const int beg = ptr[row], end = ptr[row + 1];
-    const float a_dst = att[((size_t)row * H + h) * 2];
-    float part = 0.0f;
-    for (int e = beg + lane; e < end; e += GROUP) {
-        const float w = edge_weight(a_dst, att[((size_t)idx[e] * H + h) * 2 + 1], slope);
-        out[(size_t)e * H + h] = w;
-        part += w;
-    }
-    const float sum = group_sum<GROUP>(part);
-    for (int e = beg + lane; e < end; e += GROUP) out[(size_t)e * H + h] /= sum;
-}
-
-// reference u_add_v, aggr_gat.h:33-48
-template <int GROUP>
-__global__ __launch_bounds__(kBlock) void k_u_add_v(const int *__restrict__ ptr, const int *__restrict__ idx,
-                                                   const float *__restrict__ att, float *__restrict__ out, int V)
-{
-    const int row = blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
-    const int lane = threadIdx.x & (GROUP - 1);
-    if (row >= V) return;
-    const float a_dst = att[(size_t)row * 2];
-    for (int e = ptr[row] + lane; e < ptr[row + 1]; e += GROUP) out[e] = a_dst + att[(size_t)idx[e] * 2 + 1];
-}
-
-// reference add_to_center, aggr_gat.h:50-74 (stride-1 output, :71)
-template <int GROUP>
-__global__ __launch_bounds__(kBlock) void k_add_to_center(const int *__restrict__ ptr, const float *__restrict__ in,
-                                                         float *__restrict__ out, int V)
-{
-    const int row = blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
-    const int lane = threadIdx.x & (GROUP - 1);
-    if (row >= V) return;
-    float part = 0.0f;
-    for (int e = ptr[row] + lane; e < ptr[row + 1]; e += GROUP) part += in[e];
-    const float sum = group_sum<GROUP>(part);
-    if (lane == 0) out[row] = sum;
-}
-
-// reference each_div, aggr_gat.h:76-92
-template <int GROUP>
-__global__ __launch_bounds__(kBlock) void k_div_each(const int *__restrict__ ptr, const float *__restrict__ in,
-                                                    float *__restrict__ inout, int V)
-{
-    const int row = blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
-    const int lane = threadIdx.x & (GROUP - 1);
-    if (row >= V) return;
-    const float d = in[row];
-    for (int e = ptr[row] + lane; e < ptr[row + 1]; e += GROUP) inout[e] /= d;
 }
 
 // reference convertCSRToEdgelist, aggregator.h:11-23 ((src,dst) written as one 8-byte store)
@@ -1132,55 +791,6 @@ __global__ __launch_bounds__(kBlock) void k_csr2edgelist(const int *__restrict__
         default: { constexpr int GROUP = 64; CALL; } break;  \
     }
 
-int launch_gat_att(const int *ptr, const int *idx, const float *att, float *out, int V, int heads, float slope,
-                   int avg_deg, void *stream_v)
-{
-    hipStream_t stream = (hipStream_t)stream_v;
-    if (V <= 0) return GNNAGG_OK;
-    const int G = edge_group(avg_deg);
-    const int nb = ceil_div((long)V * heads, kBlock / G);
-    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_gat_att<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, idx, att,
-                                              out, V, heads, slope))
-    HIP_TRY(hipGetLastError());
-    return GNNAGG_OK;
-}
-
-int launch_u_add_v(const int *ptr, const int *idx, const float *att, float *out, int V, int avg_deg, void *stream_v)
-{
-    hipStream_t stream = (hipStream_t)stream_v;
-    if (V <= 0) return GNNAGG_OK;
-    const int G = edge_group(avg_deg);
-    const int nb = ceil_div(V, kBlock / G);
-    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_u_add_v<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, idx, att,
-                                              out, V))
-    HIP_TRY(hipGetLastError());
-    return GNNAGG_OK;
-}
-
-int launch_add_to_center(const int *ptr, const float *in, float *out, int V, int avg_deg, void *stream_v)
-{
-    hipStream_t stream = (hipStream_t)stream_v;
-    if (V <= 0) return GNNAGG_OK;
-    const int G = edge_group(avg_deg);
-    const int nb = ceil_div(V, kBlock / G);
-    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_add_to_center<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, in,
-                                              out, V))
-    HIP_TRY(hipGetLastError());
-    return GNNAGG_OK;
-}
-
-int launch_div_each(const int *ptr, const float *in, float *inout, int V, int avg_deg, void *stream_v)
-{
-    hipStream_t stream = (hipStream_t)stream_v;
-    if (V <= 0) return GNNAGG_OK;
-    const int G = edge_group(avg_deg);
-    const int nb = ceil_div(V, kBlock / G);
-    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_div_each<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, in,
-                                              inout, V))
-    HIP_TRY(hipGetLastError());
-    return GNNAGG_OK;
-}
-
 int launch_csr2edgelist(const int *ptr, const int *idx, int *edgelist, int V, int avg_deg, void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
@@ -1194,8 +804,9 @@ int launch_csr2edgelist(const int *ptr, const int *idx, int *edgelist, int V, in
 }
 
 // ------------------------------------------------- edge kernels on chunked work items (hub-safe)
-// The per-row kernels above give one lane group a whole row; a 15 k-edge hub row then serialises
-// (860 us for attGat on the arxiv-shaped graph).  These variants run on the work items of the balanced
+// Giving one lane group a whole row (the reference's warp-per-row attGat / u_add_v / add_to_center / each_div,
+// aggr_gat.h:5-92) serialises on a 15 k-edge hub row: 860 us for attGat on the arxiv-shaped graph in the first
+// version of this file.  These kernels run on the work items of the balanced
 // neighbor grouping (<= chunk edges each): pass 1 writes the edge values and per-item sums (straight to
 // den[row] when the row has one item, to partial_den[slot] otherwise), an ordered combine finishes the
 // split rows, pass 2 normalises.  Lanes walk the flattened (edge, head) pairs of an item, so out[e,h]
@@ -1557,7 +1168,7 @@ int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out
 {
     hipStream_t stream = (hipStream_t)stream_v;
     if (n <= 0) return GNNAGG_OK;
-    const Geometry g = pick_geometry(feat, x, out, nullptr, feat, 0);
+    const Geometry g = pick_geometry(feat, x, out, nullptr, feat);
     const int nb = ceil_div(n, kBlock / g.group) * g.ntiles;
 #define CALL_PACK hipLaunchKernelGGL((k_pack_rows<VEC, GROUP>), dim3(nb), dim3(kBlock), 0, stream, x, ids, n, feat, g.ntiles, out);
     DISPATCH_GEOM(g, CALL_PACK)

@@ -3,8 +3,9 @@
 the arxiv-shaped input (un-reordered / RCM-reordered / community order), median microseconds.
 Variants are selected through environment knobs read at aggregator creation:
   GNNAGG_XCD_REMAP (0 identity, 1 equal-count XCD ranges, 2 work-balanced XCD ranges)
-  GNNAGG_IDXMODE   (0 per-lane (idx,val) loads, 1 group-coalesced + ds_bpermute)
-  GNNAGG_VARIANT   (lane geometry: 0 default, 1 VEC2, 2 VEC2 + half-width groups)
+  GNNAGG_PLAN      (1 balanced plan kernel, 0 items + combine)
+(the per-lane metadata loads, the VEC2 geometries and the persistent streaming kernel this harness also compared
+ in round 1 lost and were removed)
 """
 import itertools
 import os
@@ -43,17 +44,12 @@ def main():
     y = torch.empty((V, F), device=dev)
     configs = []
     modes = os.environ.get("TUNE_MODES", "rows,balanced").split(",")
-    streams = [int(v) for v in os.environ.get("TUNE_STREAM", "0,1").split(",")]
-    bpcs = [int(v) for v in os.environ.get("TUNE_BPC", "8").split(",")]
     remaps = [int(v) for v in os.environ.get("TUNE_REMAP", "0,1,2").split(",")]
-    idxms = [int(v) for v in os.environ.get("TUNE_IDXMODE", "0,1").split(",")]
-    variants = [int(v) for v in os.environ.get("TUNE_VARIANT", "0").split(",")]
-    for mode, remap, idxm, var, st, bpc in itertools.product(modes, remaps, idxms, variants, streams, bpcs):
-        if st == 0 and bpc != bpcs[0]:
+    plans = [int(v) for v in os.environ.get("TUNE_PLAN", "0,1").split(",")]
+    for mode, remap, plan in itertools.product(modes, remaps, plans):
+        if mode != "balanced" and plan != plans[0]:
             continue
-        if st == 1 and (idxm != idxms[0] or remap == 2):
-            continue
-        configs.append(dict(mode=mode, remap=remap, idxmode=idxm, variant=var, stream=st, bpc=bpc))
+        configs.append(dict(mode=mode, remap=remap, plan=plan))
     extra_chunks = [int(c) for c in os.environ.get("TUNE_CHUNKS", "").split(",") if c]
     aggs = {}
     for gname, (ptr, idx) in gs.items():
@@ -61,14 +57,13 @@ def main():
         dval = torch.ones(len(idx), device=dev)
         for ci, c in enumerate(configs):
             os.environ["GNNAGG_XCD_REMAP"] = str(c["remap"])
-            os.environ["GNNAGG_IDXMODE"] = str(c["idxmode"])
-            os.environ["GNNAGG_VARIANT"] = str(c["variant"])
-            os.environ["GNNAGG_STREAM"] = str(c["stream"])
-            os.environ["GNNAGG_STREAM_BPC"] = str(c["bpc"])
+            os.environ["GNNAGG_PLAN"] = str(c["plan"])
             a = gnc.Aggregator_GCN(dptr, didx, dval, F, F)
             a._keep = [dptr, didx, dval]
             if c["mode"] == "balanced":
                 a.schedule_balanced(0)
+            elif c["mode"] == "scheduled":
+                a.schedule(gnc.Schedule.neighbor_grouping, [int(os.environ.get("TUNE_NG", "32"))])
             aggs[(gname, ci, 0)] = a
             if c["mode"] == "balanced":
                 for ch in extra_chunks:
@@ -91,11 +86,11 @@ def main():
             torch.cuda.synchronize()
             if r > 0:
                 times[k].append(e0.elapsed_time(e1) * 1e3 / inner)
-    print("%-10s %-9s %5s %5s %4s %6s %4s %4s | %9s %9s" % ("graph", "mode", "remap", "idxm", "var", "chunk", "strm", "bpc", "med_us", "min_us"))
+    print("%-10s %-9s %5s %5s %6s | %9s %9s" % ("graph", "mode", "remap", "plan", "chunk", "med_us", "min_us"))
     for k in sorted(times, key=lambda k: (k[0], np.median(times[k]))):
         c = configs[k[1]]
-        print("%-10s %-9s %5d %5d %4d %6d %4d %4d | %9.1f %9.1f" % (k[0], c["mode"], c["remap"], c["idxmode"], c["variant"], k[2],
-                                                                  c["stream"], c["bpc"], np.median(times[k]), np.min(times[k])))
+        print("%-10s %-9s %5d %5d %6d | %9.1f %9.1f" % (k[0], c["mode"], c["remap"], c["plan"], k[2],
+                                                        np.median(times[k]), np.min(times[k])))
 
 
 if __name__ == "__main__":
