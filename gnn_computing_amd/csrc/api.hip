@@ -115,6 +115,14 @@ struct BalancedPlan {
 };
 static constexpr int kSegChunksHost = 16;  // kSegChunks in kernels.hip
 
+// GNNAGG_MODE_ROWS plan of a GCN aggregator (k_gcn_rows_plan): short rows per lane group, long rows per workgroup.
+struct RowsPlan {
+    bool valid = false;
+    int n0 = 0, n1 = 0, long_deg = 256;
+    DevBuf<int> r0, r1;
+    std::vector<long> r0_cost_prefix;
+};
+
 static constexpr int kItemCost = 2;  // fixed per-item overhead in edge-equivalents (XCD range balancing)
 
 struct Ctx {
@@ -128,6 +136,9 @@ struct Ctx {
     Schedule sched[2];       // [0] user schedule (MODE_SCHEDULED), [1] balanced (MODE_BALANCED; GAT, and the
                              //     host arrays that describe the GCN plan's summation order)
     BalancedPlan plan;       // GCN balanced mode
+    RowsPlan rows_plan;      // GCN rows mode
+    hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     Schedule sched_edges;    // chunked work items of the edge kernels (run_att, u_add_v, add_to_center, div_each)
     DevBuf<float> den;       // [V,heads] row sums of run_att
     DevBuf<float> partial, partial_den;
@@ -319,6 +330,46 @@ static int build_balanced_plan(Ctx *c, int chunk)
     return GNNAGG_OK;
 }
 
+static int build_rows_plan(Ctx *c)
+{
+    int rc = fetch_host_ptr(c);
+    if (rc) return rc;
+    RowsPlan &p = c->rows_plan;
+    // The workgroup-per-row kernel wins on latency for isolated hubs but has less memory parallelism per CU than
+    // many lane groups walking their own rows, so it is used only for rows far above the average degree and only
+    // when those rows hold a small share of the edges (reddit-shaped graphs, where hub rows dominate, measured
+    // slower with it).
+    p.long_deg = std::max(1024, 4 * c->avg_deg());
+    {
+        long long_edges = 0;
+        for (int r = 0; r < c->V; ++r)
+            if (c->h_ptr[r + 1] - c->h_ptr[r] > p.long_deg) long_edges += c->h_ptr[r + 1] - c->h_ptr[r];
+        if (long_edges * 4 > (long)c->E) p.long_deg = 0x7fffffff;
+    }
+    std::vector<int> r0;
+    struct Long { int beg, end, row; };
+    std::vector<Long> longs;
+    p.r0_cost_prefix.assign(1, 0);
+    for (int r = 0; r < c->V; ++r) {
+        const int beg = c->h_ptr[r], end = c->h_ptr[r + 1];
+        if (end - beg <= p.long_deg) {
+            r0.insert(r0.end(), {beg, end, r, 0});
+            p.r0_cost_prefix.push_back(p.r0_cost_prefix.back() + (end - beg) + kItemCost);
+        } else {
+            longs.push_back({beg, end, r});
+        }
+    }
+    std::stable_sort(longs.begin(), longs.end(), [](const Long &a, const Long &b) { return a.end - a.beg > b.end - b.beg; });
+    std::vector<int> r1;
+    for (const Long &l : longs) r1.insert(r1.end(), {l.beg, l.end, l.row, 0});
+    p.n0 = (int)(r0.size() / 4);
+    p.n1 = (int)(r1.size() / 4);
+    if ((rc = p.r0.upload(r0))) return rc;
+    if ((rc = p.r1.upload(r1))) return rc;
+    p.valid = true;
+    return GNNAGG_OK;
+}
+
 static int pick_chunk(const Ctx *c)
 {
     // long rows become work items of <= chunk edges: small enough that the hub rows of a
@@ -377,6 +428,30 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             P.partial = c->partial.p;
         }
         return launch_gcn_plan(P, c->stream);
+    }
+    if (mode == GNNAGG_MODE_ROWS && c->use_plan) {
+        if (!c->rows_plan.valid && (rc = build_rows_plan(c))) return rc;
+        RowsPlan &p = c->rows_plan;
+        if (p.n1 > 0) {  // fork: long rows on the auxiliary stream (disjoint output rows)
+            if (!c->aux_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            GcnRowsLongLaunch R;
+            R.r1 = p.r1.p; R.n1 = p.n1; R.idx = c->d_idx; R.val = c->d_val; R.x = x; R.y = y; R.feat = feat; R.reduce = reduce;
+            if ((rc = launch_gcn_rows_long(R, c->aux_stream))) return rc;
+            HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
+        }
+        GcnPlanLaunch P;  // short rows: the descriptor path of the plan kernel (no segments, no hubs)
+        P.t0 = p.r0.p; P.n0 = p.n0; P.t0_cost_prefix = p.r0_cost_prefix.data();
+        P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
+        P.xcd_remap = c->xcd_remap;
+        rc = launch_gcn_plan(P, c->stream);
+        if (p.n1 > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // join
+        return rc;
     }
     GcnLaunch L;
     L.row_ptr = c->d_ptr; L.x = x; L.y = y; L.feat = feat; L.reduce = reduce;
@@ -553,6 +628,12 @@ int gnnagg_destroy(gnnagg_handle h)
         g_live.erase(c);
     }
     (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) {
+        (void)hipStreamSynchronize(c->aux_stream);
+        (void)hipStreamDestroy(c->aux_stream);
+        (void)hipEventDestroy(c->ev_fork);
+        (void)hipEventDestroy(c->ev_join);
+    }
     delete c;
     return GNNAGG_OK;
 }

@@ -85,6 +85,18 @@ struct GcnPlanLaunch {
     int accumulate = 0;  // y += A.x (sum only); rows without edges keep their value
 };
 
+// Long rows of the rows mode (`scheduled = 0`, canonical CSR-order chains): k_gcn_rows_long.
+struct GcnRowsLongLaunch {
+    const void *r1 = nullptr;  // int4 {beg,end,row,-} per long row, heaviest first
+    int n1 = 0;
+    const int *idx = nullptr;
+    const float *val = nullptr;
+    const float *x = nullptr;
+    float *y = nullptr;
+    int feat = 0;
+    int reduce = GNNAGG_REDUCE_SUM;
+};
+
 struct GatLaunch {
     WorkList wl;
     const int *idx = nullptr;
@@ -117,6 +129,7 @@ int launch_edge_items_sum(const EdgeItemLaunch &L, int op, void *stream);
 int launch_edge_items_map(const EdgeItemLaunch &L, int op, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);
 int launch_gcn_plan(const GcnPlanLaunch &a, void *stream);
+int launch_gcn_rows_long(const GcnRowsLongLaunch &a, void *stream);
 int launch_gat(const GatLaunch &a, void *stream);
 int launch_csr2edgelist(const int *ptr, const int *idx, int *edgelist, int V, int avg_deg, void *stream);
 int launch_edgewise(const int *edgelist, const float *val, const float *x, float *y, int E, int V, int feat,

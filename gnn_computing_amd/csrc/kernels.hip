@@ -321,6 +321,104 @@ __global__ __launch_bounds__(kBlock) void k_gcn_plan(const PlanArgs a)
     store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
 }
 
+// ---------------------------------------------------------- GCN / SAGE, rows mode (canonical order)
+// `scheduled = 0` keeps the reference's summation order exactly -- one sequential FMA chain per (row, column)
+// in CSR order (aggr_gcn.h:13-35) -- but does not serialise a hub row on one lane group the way a
+// warp-per-row kernel does (1.49 ms on the arxiv-shaped input, whose largest row has 15 k edges).
+//  * rows of at most `long_deg` edges: one lane group per row -- the short-row path of k_gcn_plan;
+//  * longer rows: this kernel, launched on an auxiliary stream so it overlaps the short rows: one 512-thread
+//    workgroup per (row, 32-column tile).  The chain itself cannot be split, but the GATHERS can: every lane
+//    group fetches the 128-byte tile segments of different neighbors in parallel (8 per group per round,
+//    512 edges per round), the segments meet in LDS in edge order, and 32 threads -- one per column -- run the
+//    chain from LDS.  The loads of round r+1 are issued before round r is consumed.  Heaviest rows first.
+//    (A 15 k-edge row takes ~0.3 ms this way instead of 1.49 ms; the consumer's ~20 cycles per edge bound it.
+//    A column-major stage read with b128 was tried and lost to its scattered LDS writes.)
+static constexpr int kLongBlock = 512;
+
+struct RowsLongArgs {
+    const int4 *r1;  // {beg, end, row, -}
+    const int *idx;
+    const float *val;
+    const float *x;
+    float *y;
+    int n1, feat, ntiles32, mean;
+};
+
+template <int VEC, bool IS_MAX>
+__global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs a)
+{
+    constexpr int GL = 32 / VEC;           // lanes of one gather group: GL * VEC = 32 columns = 128 bytes
+    constexpr int NG = kLongBlock / GL;    // gather groups per workgroup
+    constexpr int U = 8;                   // neighbors per group per round
+    constexpr int RE = NG * U;             // edges per round
+    extern __shared__ float lds[];         // stage[RE * 32] (edge-major) then wstage[RE]
+    float *stage = lds, *wstage = lds + RE * 32;
+    const int F = a.feat;
+    const int tile = (int)blockIdx.x % a.ntiles32;
+    const int4 d = a.r1[(int)blockIdx.x / a.ntiles32];
+    const int g = (int)threadIdx.x / GL, lane = threadIdx.x & (GL - 1);
+    const int col = tile * 32 + lane * VEC;
+    const bool col_ok = col < F;
+    const int c = (int)threadIdx.x;  // consumer thread <-> column tile*32 + c (c < 32)
+    const bool consumer = c < 32 && tile * 32 + c < F;
+    float acc = IS_MAX ? -INFINITY : 0.0f;
+    const float *__restrict__ xcol = a.x + col;
+    Pack<VEC> xv[U];
+    float wv[U];
+    auto issue = [&](int base) {  // gathers of the round starting at edge `base`; this group's edges: base + g*U + u
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + g * U + u;
+            if (e < d.y) {
+                const int s = a.idx[e];
+                wv[u] = a.val ? a.val[e] : 1.0f;
+                if (col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s * F);
+            }
+        }
+    };
+    auto step = [&](float xs, float ws) {
+        if (IS_MAX) {
+            const float p = xs * ws;
+            acc = p > acc ? p : acc;
+        } else {
+            acc = __builtin_fmaf(xs, ws, acc);
+        }
+    };
+    issue(d.x);
+    for (int base = d.x; base < d.y; base += RE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {  // registers -> LDS in edge order
+            const int k = g * U + u;
+            if (base + k < d.y) {
+                if (col_ok) store_pack<VEC>(&stage[k * 32 + lane * VEC], xv[u].v);
+                if (lane == 0) wstage[k] = wv[u];
+            }
+        }
+        __syncthreads();
+        if (base + RE < d.y) issue(base + RE);  // next round travels while this one is consumed
+        if (consumer) {
+            const int n = d.y - base < RE ? d.y - base : RE;
+            int k0 = 0;
+            for (; k0 + 16 <= n; k0 += 16) {  // 16 independent LDS reads (no per-element branches), then 16 chain steps
+                float xs[16], ws[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    xs[u] = stage[(k0 + u) * 32 + c];
+                    ws[u] = wstage[k0 + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) step(xs[u], ws[u]);
+            }
+            for (; k0 < n; ++k0) step(stage[k0 * 32 + c], wstage[k0]);
+        }
+        __syncthreads();
+    }
+    if (consumer) {
+        if (a.mean) acc = acc / (float)(d.y - d.x);
+        a.y[(size_t)d.z * F + tile * 32 + c] = acc;
+    }
+}
+
 struct CombineArgs {
     const int *mrow_id, *mrow_ptr, *row_ptr;
     const int *big_rows;  // indices into mrow_* of the rows with more than kCombineBatch partials
@@ -675,6 +773,32 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
     C.accumulate = L.accumulate;
     return launch_combine_gcn(C, g, is_max, stream);
+}
+
+int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (L.n1 <= 0) return GNNAGG_OK;
+    auto aligned = [](const void *p, size_t al) { return ((uintptr_t)p % al) == 0; };
+    int vec = 1;
+    if (L.feat % 4 == 0 && aligned(L.x, 16)) vec = 4;
+    else if (L.feat % 2 == 0 && aligned(L.x, 8)) vec = 2;
+    RowsLongArgs a;
+    a.r1 = reinterpret_cast<const int4 *>(L.r1); a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y;
+    a.n1 = L.n1; a.feat = L.feat; a.ntiles32 = ceil_div(L.feat, 32); a.mean = L.reduce == GNNAGG_REDUCE_MEAN;
+    const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
+    const int grid = a.n1 * a.ntiles32;
+#define LAUNCH_LONG(V)                                                                                               \
+    {                                                                                                                \
+        const size_t re = (size_t)(kLongBlock / (32 / V)) * 8;                                                       \
+        const size_t lds = (32 * re + re) * sizeof(float);                                 \
+        if (is_max) hipLaunchKernelGGL((k_gcn_rows_long<V, true>), dim3(grid), dim3(kLongBlock), lds, stream, a);    \
+        else        hipLaunchKernelGGL((k_gcn_rows_long<V, false>), dim3(grid), dim3(kLongBlock), lds, stream, a);   \
+    }
+    if (vec == 4) LAUNCH_LONG(4) else if (vec == 2) LAUNCH_LONG(2) else LAUNCH_LONG(1)
+#undef LAUNCH_LONG
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
 }
 
 int launch_gcn(const GcnLaunch &L, void *stream_v)

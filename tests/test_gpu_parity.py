@@ -428,6 +428,13 @@ def test_hub_rows_block_cooperative_combine(F, ng):
     assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
     agg.run(dev(x), y, 512, 1, reduce="max")
     assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))
+    # rows mode keeps the canonical CSR-order chain even for the hubs (workgroup-per-row path), all reductions
+    agg.run(dev(x), y, 512, 0)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x))
+    agg.run(dev(x), y, 512, 0, reduce="mean")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_mean(ptr, idx, val, x))
+    agg.run(dev(x), y, 512, 0, reduce="max")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))
     # the balanced plan with the same chunk: hubs span several 16-chunk segments (+ combine)
     agg.schedule_balanced(ng)
     agg.run(dev(x), y, 512, "balanced")
