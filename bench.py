@@ -62,19 +62,35 @@ def time_steps(step_fn, steps, warmup, barrier):
 
 
 def cpu_baseline(ptr, idx, val, x, budget_s=10.0):
-    """The oracle (port of aggr_gcn.h:13-35) timed on the host cores: whole arxiv passes until ~budget_s."""
+    """The oracle (port of aggr_gcn.h:13-35; OpenMP over rows, AVX2 FMA over columns) timed on the host cores:
+    whole passes over the same arxiv-shaped workload.  A quick sweep picks the thread count first (all hardware
+    threads is rarely the fastest for a 90 MB gather working set), then the rest of the budget is measured."""
     from oracle import oracle as orc
+    hw = orc.num_threads()
     orc.gcn_seq(ptr, idx, val, x)  # warm-up (page-in, thread pool)
+    best_n, best_t = hw, float("inf")
+    for n in sorted({hw, max(hw // 2, 1), max(hw // 4, 1), min(hw, 32), min(hw, 16), min(hw, 8)}, reverse=True):
+        orc.set_num_threads(n)
+        orc.gcn_seq(ptr, idx, val, x)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            orc.gcn_seq(ptr, idx, val, x)
+            ts.append(time.perf_counter() - t0)
+        if min(ts) < best_t:
+            best_n, best_t = n, min(ts)
+    orc.set_num_threads(best_n)
     times = []
     t_end = time.perf_counter() + budget_s
-    while time.perf_counter() < t_end and len(times) < 200:
+    while time.perf_counter() < t_end and len(times) < 300:
         t0 = time.perf_counter()
         orc.gcn_seq(ptr, idx, val, x)
         times.append(time.perf_counter() - t0)
+    orc.set_num_threads(hw)
     med = float(np.median(times))
-    return {"value": len(idx) / med, "unit": "edges/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": "%d full passes of the same arxiv-shaped workload (median %.2f ms), OpenMP over rows"
-                      % (len(times), med * 1e3)}
+    return {"value": len(idx) / med, "unit": "edges/s", "cores": best_n, "kind": "port",
+            "sample": "%d full passes of the same arxiv-shaped workload (median %.2f ms) on %d of %d hardware threads "
+                      "(best of a thread-count sweep), OpenMP over rows" % (len(times), med * 1e3, best_n, hw)}
 
 
 def run_single(args, dev):

@@ -281,7 +281,7 @@ static int build_balanced_plan(Ctx *c, int chunk)
     const int V = c->V;
     const long seg_edges = (long)chunk * kSegChunksHost;
     std::vector<int> t0, t1, mrow_id, mrow_ptr(1, 0), big;
-    struct Seg { int beg, end, dest; };
+    struct Seg { int beg, end, dest, row; };
     std::vector<Seg> segs;
     p.t0_cost_prefix.assign(1, 0);
     int nslots = 0;
@@ -291,12 +291,12 @@ static int build_balanced_plan(Ctx *c, int chunk)
             t0.insert(t0.end(), {beg, end, r, 0});
             p.t0_cost_prefix.push_back(p.t0_cost_prefix.back() + deg + kItemCost);
         } else if (deg <= seg_edges) {
-            segs.push_back({beg, end, r});
+            segs.push_back({beg, end, r, r});
         } else {
             const int nseg = (int)((deg + seg_edges - 1) / seg_edges);
             for (int j = 0; j < nseg; ++j) {
                 const long sb = beg + (long)j * seg_edges;
-                segs.push_back({(int)sb, (int)std::min<long>(sb + seg_edges, end), ~(nslots + j)});
+                segs.push_back({(int)sb, (int)std::min<long>(sb + seg_edges, end), ~(nslots + j), r});
             }
             if (nseg > 16) big.push_back((int)mrow_id.size());  // kCombineBatch in kernels.hip
             nslots += nseg;
@@ -306,7 +306,7 @@ static int build_balanced_plan(Ctx *c, int chunk)
     }
     // heaviest segments first: they start at t = 0 and never form the tail of the launch
     std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.end - a.beg > b.end - b.beg; });
-    for (const Seg &sg : segs) t1.insert(t1.end(), {sg.beg, sg.end, sg.dest, 0});
+    for (const Seg &sg : segs) t1.insert(t1.end(), {sg.beg, sg.end, sg.dest, sg.row});
     p.n0 = (int)(t0.size() / 4);
     p.n1 = (int)(t1.size() / 4);
     p.n_mrows = (int)mrow_id.size();
@@ -387,7 +387,7 @@ static int get_sched(Ctx *c, int mode, Schedule **out)
             return fail(GNNAGG_ERR_STATE, "scheduled run without schedule() (reference: assert aggr_gcn.h:392)");
         *out = &c->sched[0];
     } else if (mode == GNNAGG_MODE_BALANCED) {
-        if (c->kind == Ctx::GCN && c->use_plan) {
+        if (c->use_plan) {
             if (!c->plan.valid) {
                 int rc = build_balanced_plan(c, pick_chunk(c));
                 if (rc) return rc;
@@ -491,6 +491,22 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
+    if (mode == GNNAGG_MODE_BALANCED && c->use_plan) {
+        BalancedPlan &p = c->plan;
+        GatPlanLaunch P;
+        P.t0 = p.t0.p; P.t1 = p.t1.p; P.n0 = p.n0; P.n1 = p.n1; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
+        P.hubs.mrow_id = p.mrow_id.p; P.hubs.mrow_ptr = p.mrow_ptr.p; P.hubs.n_mrows = p.n_mrows;
+        P.hubs.n_slots = p.n_slots; P.hubs.big_rows = p.big_rows.p; P.hubs.n_big = p.n_big;
+        P.idx = c->d_idx; P.att = att; P.x = x; P.y = y; P.newval = newval; P.feat = feat; P.heads = heads; P.slope = slope;
+        P.xcd_remap = c->xcd_remap;
+        if (p.n_slots > 0) {
+            if ((rc = c->partial.reserve((size_t)p.n_slots * feat))) return rc;
+            if ((rc = c->partial_den.reserve((size_t)p.n_slots * heads))) return rc;
+            P.partial = c->partial.p;
+            P.partial_den = c->partial_den.p;
+        }
+        return launch_gat_plan(P, c->stream);
+    }
     GatLaunch L;
     L.att = att; L.x = x; L.y = y; L.feat = feat; L.heads = heads; L.slope = slope; L.newval = newval;
     L.xcd_remap = c->xcd_remap;
@@ -663,7 +679,7 @@ int gnnagg_schedule_balanced(gnnagg_handle h, int chunk)
 {
     GET_CTX(h);
     if (chunk < 0) return fail(GNNAGG_ERR_ARG, "chunk must be >= 0");
-    if (c->kind == Ctx::GCN && c->use_plan) return build_balanced_plan(c, chunk > 0 ? chunk : pick_chunk(c));
+    if (c->use_plan) return build_balanced_plan(c, chunk > 0 ? chunk : pick_chunk(c));
     return build_grouping(c, c->sched[1], chunk > 0 ? chunk : pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
 }
 
@@ -673,7 +689,7 @@ int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks)
     Schedule *s = nullptr;
     int rc = get_sched(c, GNNAGG_MODE_BALANCED, &s);
     if (rc) return rc;
-    const bool plan = c->kind == Ctx::GCN && c->use_plan;
+    const bool plan = c->use_plan != 0;
     if (chunk) {
         int mx = 0;
         if (plan) mx = c->plan.chunk;

@@ -127,6 +127,22 @@ struct EdgeItemLaunch {
 };
 int launch_edge_items_sum(const EdgeItemLaunch &L, int op, void *stream);
 int launch_edge_items_map(const EdgeItemLaunch &L, int op, void *stream);
+// Balanced plan, GAT (k_gat_plan).  t1 descriptors carry the destination row in .w (the segment's attention centre).
+struct GatPlanLaunch {
+    const void *t0 = nullptr, *t1 = nullptr;
+    int n0 = 0, n1 = 0, chunk = 64;
+    const long *t0_cost_prefix = nullptr;
+    WorkList hubs;
+    const int *idx = nullptr;
+    const float *att = nullptr;
+    const float *x = nullptr;
+    float *y = nullptr;
+    float *partial = nullptr, *partial_den = nullptr, *newval = nullptr;
+    int feat = 0, heads = 1;
+    float slope = 0.2f;
+    int xcd_remap = 2;
+};
+int launch_gat_plan(const GatPlanLaunch &a, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);
 int launch_gcn_plan(const GcnPlanLaunch &a, void *stream);
 int launch_gcn_rows_long(const GcnRowsLongLaunch &a, void *stream);

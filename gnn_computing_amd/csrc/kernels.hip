@@ -649,6 +649,145 @@ __global__ __launch_bounds__(kBlock) void k_gat_items(const GatArgs a)
     store_pack<VEC>(a.y + (size_t)row * F + col, acc);
 }
 
+// --------------------------------------------------------------------------- GAT, balanced plan
+// The fused edge-softmax + weighted SpMM (reference aggr_gat / aggr_gat_fine, aggr_gat.h:116-205) on the same
+// plan as k_gcn_plan: short rows one lane group each, long rows one workgroup per <= 16-chunk segment with the
+// numerator AND denominator partials folded in ascending chunk order in LDS, hubs through scratch + k_combine.
+template <int VEC, int GROUP>
+__device__ __forceinline__ void chain_edges_gat(float (&acc)[VEC], float &den, int beg, int end, int lane, bool col_ok,
+                                                const int *__restrict__ idx, const float *__restrict__ att_src, int H,
+                                                float a_dst, float slope, const float *__restrict__ xcol, int F,
+                                                float *newval, int h, bool head_leader)
+{
+    int my_s = 0;
+    if (beg + lane < end) my_s = idx[beg + lane];
+    for (int cb = beg; cb < end; cb += GROUP) {
+        int nx_s = 0;
+        if (cb + GROUP + lane < end) nx_s = idx[cb + GROUP + lane];
+        const int n = end - cb < GROUP ? end - cb : GROUP;
+        for (int j = 0; j < n; j += kUnroll) {
+            int s[kUnroll];
+            float as[kUnroll];
+            Pack<VEC> xv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) s[u] = __shfl(my_s, j + u, GROUP);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+                    as[u] = att_src[(size_t)s[u] * H * 2];
+                    xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+                }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+                    const float w = edge_weight(a_dst, as[u], slope);
+                    if (newval && head_leader) newval[(size_t)(cb + j + u) * H + h] = w;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
+                    den += w;
+                }
+        }
+        my_s = nx_s;
+    }
+}
+
+struct GatPlanArgs {
+    const int4 *t0, *t1;
+    const int *idx;
+    const float *att;
+    const float *x;
+    float *y;
+    float *partial, *partial_den, *newval;
+    int n0, n1, feat, ntiles, chunk, heads, dhead, remap, nblocks0;
+    float slope;
+    XcdRanges xr;
+};
+
+template <int VEC, int GROUP>
+__global__ __launch_bounds__(kBlock) void k_gat_plan(const GatPlanArgs a)
+{
+    constexpr int GPB = kBlock / GROUP;
+    const int F = a.feat, H = a.heads;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int grp = (int)threadIdx.x / GROUP;
+    const int nb1 = a.n1 * a.ntiles;
+    const bool seg_block = (int)blockIdx.x < nb1;
+    int tile, row_or_dest;
+    int4 d;
+    if (seg_block) {
+        tile = (int)blockIdx.x % a.ntiles;
+        d = a.t1[(int)blockIdx.x / a.ntiles];
+    } else {
+        const int b = logical_block((int)blockIdx.x - nb1, a.nblocks0, a.ntiles, a.remap, a.xr);
+        if (b < 0) return;
+        tile = b % a.ntiles;
+        const int item = (b / a.ntiles) * GPB + grp;
+        if (item >= a.n0) return;
+        d = a.t0[item];
+    }
+    row_or_dest = d.z;
+    const int col = (tile * GROUP + lane) * VEC;
+    const bool col_ok = col < F;
+    const int h = col_ok ? col / a.dhead : 0;
+    const bool head_leader = col_ok && (col % a.dhead) == 0;
+    const float *__restrict__ att_src = a.att + (size_t)h * 2 + 1;
+    const float *__restrict__ xcol = a.x + col;
+    if (seg_block) {
+        __shared__ float stage[kSegChunks * GROUP * VEC];
+        __shared__ float stage_den[kSegChunks * GROUP];
+        const int row = d.w;  // destination row of this segment (its attention centre term)
+        const float a_dst = a.att[((size_t)row * H + h) * 2];
+        const int nch = (d.y - d.x + a.chunk - 1) / a.chunk;
+        for (int c = grp; c < nch; c += GPB) {
+            float acc[VEC] = {};
+            float den = 0.0f;
+            const int cb = d.x + c * a.chunk;
+            const int ce = cb + a.chunk < d.y ? cb + a.chunk : d.y;
+            chain_edges_gat<VEC, GROUP>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval, h,
+                                        head_leader);
+            store_pack<VEC>(&stage[(c * GROUP + lane) * VEC], acc);
+            stage_den[c * GROUP + lane] = den;
+        }
+        __syncthreads();
+        if (grp != 0 || !col_ok) return;
+        float acc[VEC] = {};
+        float den = 0.0f;
+#pragma unroll
+        for (int c = 0; c < kSegChunks; ++c)
+            if (c < nch) {
+                const Pack<VEC> p = load_pack<VEC>(&stage[(c * GROUP + lane) * VEC]);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += p.v[k];
+                den += stage_den[c * GROUP + lane];
+            }
+        if (row_or_dest >= 0) {
+            if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+            }
+            store_pack<VEC>(a.y + (size_t)row_or_dest * F + col, acc);
+        } else {
+            store_pack<VEC>(a.partial + (size_t)(~row_or_dest) * F + col, acc);
+            if (head_leader) a.partial_den[(size_t)(~row_or_dest) * H + h] = den;
+        }
+        return;
+    }
+    const int row = d.z;
+    float acc[VEC] = {};
+    float den = 0.0f;
+    if (d.x < d.y) {
+        const float a_dst = a.att[((size_t)row * H + h) * 2];
+        chain_edges_gat<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval, h,
+                                    head_leader);
+    }
+    if (!col_ok) return;
+    if (d.x < d.y && den != 0.0f) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+    }
+    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+}
+
 // --------------------------------------------------------------------- geometry + dispatch
 struct Geometry {
     int vec, group, ntiles;
@@ -868,6 +1007,50 @@ int launch_gat(const GatLaunch &L, void *stream_v)
         c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
         c.heads = L.heads; c.dhead = dhead; c.mean = 0; c.accumulate = 0;
         c.big_rows = L.wl.big_rows; c.n_big = L.heads <= 64 ? L.wl.n_big : 0;
+        c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
+        const int nb = c.nblocks_small + c.n_big * g.ntiles;
+#define CALL_COMB hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true>), dim3(nb), dim3(kBlock), 0, stream, c);
+        DISPATCH_GEOM(g, CALL_COMB)
+#undef CALL_COMB
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
+int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (L.feat <= 0 || L.heads <= 0 || L.feat % L.heads != 0)
+        return fail(GNNAGG_ERR_ARG, "GAT needs feat >= 1 and feat % heads == 0");
+    const int dhead = L.feat / L.heads;
+    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, dhead);
+    GatPlanArgs a;
+    a.t0 = reinterpret_cast<const int4 *>(L.t0); a.t1 = reinterpret_cast<const int4 *>(L.t1);
+    a.idx = L.idx; a.att = L.att; a.x = L.x; a.y = L.y; a.partial = L.partial; a.partial_den = L.partial_den;
+    a.newval = L.newval; a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
+    a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope;
+    const int gpb = kBlock / g.group;
+    const int item_blocks = ceil_div(a.n0, gpb);
+    a.nblocks0 = item_blocks * g.ntiles;
+    if (a.remap && a.nblocks0 < 64) a.remap = 0;
+    int grid0 = a.nblocks0;
+    if (a.remap == 2) {
+        if (!L.t0_cost_prefix) a.remap = 1;
+        else grid0 = 8 * fill_xcd_ranges(L.t0_cost_prefix, a.n0, gpb, item_blocks, a.xr) * g.ntiles;
+    }
+    const int grid = a.n1 * g.ntiles + grid0;
+    if (grid > 0) {
+#define CALL_GP hipLaunchKernelGGL((k_gat_plan<VEC, GROUP>), dim3(grid), dim3(kBlock), 0, stream, a);
+        DISPATCH_GEOM(g, CALL_GP)
+#undef CALL_GP
+        HIP_TRY(hipGetLastError());
+    }
+    if (L.hubs.n_mrows > 0) {
+        CombineArgs c;
+        c.mrow_id = L.hubs.mrow_id; c.mrow_ptr = L.hubs.mrow_ptr; c.row_ptr = nullptr; c.partial = L.partial;
+        c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.hubs.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
+        c.heads = L.heads; c.dhead = dhead; c.mean = 0; c.accumulate = 0;
+        c.big_rows = L.hubs.big_rows; c.n_big = L.heads <= 64 ? L.hubs.n_big : 0;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
         const int nb = c.nblocks_small + c.n_big * g.ntiles;
 #define CALL_COMB hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true>), dim3(nb), dim3(kBlock), 0, stream, c);

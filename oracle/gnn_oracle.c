@@ -30,6 +30,15 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+ORC_API void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP
@@ -410,31 +419,63 @@ ORC_API void orc_gat_div_each(const int *ptr, const float *in, float *newval, in
  * zeroed Y / scalar; newval[e] = w_e (un-normalised, :186-187); then Y[r,:] /= scalar[r] where
  * scalar != 0.  The reference never re-zeroes Y/scalar between calls (:305,:333) -- the build zeroes
  * them on every call, and so does this restatement.  Partials are combined in ascending group order. */
-ORC_API void orc_gat_grouped(const int *ptr_s, const int *target, int num_groups, const int *idx,
-                             const float *att, const float *X, float *Y, float *newval, float *scalar,
-                             int num_v, int H, int D, float slope)
+ORC_API void orc_gat_grouped_seg(const int *ptr_s, const int *target, int num_groups, const int *idx,
+                                 const float *att, const float *X, float *Y, float *newval, float *scalar,
+                                 int num_v, int H, int D, float slope, int seg)
 {
+    /* seg <= 0: flat ascending fold of the group partials (reference NG semantics with a fixed order);
+     * seg  > 0: numerator and denominator partials of `seg` consecutive groups of a row are folded into segment
+     * accumulators first, the segment sums are then added in ascending order (k_gat_plan + k_combine). */
     const int F = H * D;
     memset(Y, 0, (size_t)num_v * F * sizeof(float));
     memset(scalar, 0, (size_t)num_v * H * sizeof(float));
     float *rs = (float *)malloc((size_t)F * sizeof(float));
+    float *sg = (float *)calloc((size_t)F, sizeof(float));
+    float *dn = (float *)malloc((size_t)H * sizeof(float));
+    float *sd = (float *)calloc((size_t)H, sizeof(float));
+    int in_seg = 0, seg_row = -1;
     for (int g = 0; g < num_groups; ++g) {
         const int r = target[g];
         for (int h = 0; h < H; ++h) {
             const float a_dst = att[((size_t)r * H + h) * 2];
             float den = 0.0f;
-            for (int c = 0; c < D; ++c) rs[c] = 0.0f;
+            for (int c = 0; c < D; ++c) rs[h * D + c] = 0.0f;
             for (int e = ptr_s[g]; e < ptr_s[g + 1]; ++e) {
                 const int s = idx[e];
                 const float w = orc_edge_score(a_dst, att[((size_t)s * H + h) * 2 + 1], slope);
                 if (newval) newval[(size_t)e * H + h] = w;
                 const float *x = X + (size_t)s * F + (size_t)h * D;
-                for (int c = 0; c < D; ++c) rs[c] = fmaf(x[c], w, rs[c]);
+                for (int c = 0; c < D; ++c) rs[h * D + c] = fmaf(x[c], w, rs[h * D + c]);
                 den += w;
             }
-            for (int c = 0; c < D; ++c) Y[(size_t)r * F + h * D + c] += rs[c];
-            scalar[(size_t)r * H + h] += den;
+            dn[h] = den;
         }
+        if (seg <= 0) {
+            for (int c = 0; c < F; ++c) Y[(size_t)r * F + c] += rs[c];
+            for (int h = 0; h < H; ++h) scalar[(size_t)r * H + h] += dn[h];
+            continue;
+        }
+        if (in_seg == 0 || seg_row != r) {
+            if (in_seg > 0) {
+                for (int c = 0; c < F; ++c) Y[(size_t)seg_row * F + c] += sg[c];
+                for (int h = 0; h < H; ++h) scalar[(size_t)seg_row * H + h] += sd[h];
+            }
+            for (int c = 0; c < F; ++c) sg[c] = 0.0f;
+            for (int h = 0; h < H; ++h) sd[h] = 0.0f;
+            in_seg = 0;
+            seg_row = r;
+        }
+        for (int c = 0; c < F; ++c) sg[c] += rs[c];
+        for (int h = 0; h < H; ++h) sd[h] += dn[h];
+        if (++in_seg == seg) {
+            for (int c = 0; c < F; ++c) Y[(size_t)r * F + c] += sg[c];
+            for (int h = 0; h < H; ++h) scalar[(size_t)r * H + h] += sd[h];
+            in_seg = 0;
+        }
+    }
+    if (seg > 0 && in_seg > 0) {
+        for (int c = 0; c < F; ++c) Y[(size_t)seg_row * F + c] += sg[c];
+        for (int h = 0; h < H; ++h) scalar[(size_t)seg_row * H + h] += sd[h];
     }
     for (int r = 0; r < num_v; ++r)
         for (int h = 0; h < H; ++h) {
@@ -442,7 +483,14 @@ ORC_API void orc_gat_grouped(const int *ptr_s, const int *target, int num_groups
             if (d != 0.0f)
                 for (int c = 0; c < D; ++c) Y[(size_t)r * F + h * D + c] /= d;
         }
-    free(rs);
+    free(rs); free(sg); free(dn); free(sd);
+}
+
+ORC_API void orc_gat_grouped(const int *ptr_s, const int *target, int num_groups, const int *idx,
+                             const float *att, const float *X, float *Y, float *newval, float *scalar,
+                             int num_v, int H, int D, float slope)
+{
+    orc_gat_grouped_seg(ptr_s, target, num_groups, idx, att, X, Y, newval, scalar, num_v, H, D, slope, 0);
 }
 
 /* Per-element magnitude sum  S[r,c] = sum_e |val_e * x_e,c|  -- the condition-aware error scale

@@ -61,6 +61,10 @@ def num_threads():
     return lib().orc_num_threads()
 
 
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
 # ---------------------------------------------------------------- integer stages
 def reverse_map(rows):
     rows = _ci(rows)
@@ -219,15 +223,15 @@ def gat_div_each(ptr, center, newval):
     return out
 
 
-def gat_grouped(ptr_s, target, idx, att, X, num_v, heads=1, slope=0.2):
-    """Returns (Y, newval[E,H] un-normalised, scalar[V,H])."""
+def gat_grouped(ptr_s, target, idx, att, X, num_v, heads=1, slope=0.2, seg=0):
+    """Returns (Y, newval[E,H] un-normalised, scalar[V,H]); seg as in gcn_grouped."""
     ptr_s, target, idx, att, X = _ci(ptr_s), _ci(target), _ci(idx), _cf(att), _cf(X)
     F = X.shape[1]
     Y = np.empty((num_v, F), np.float32)
     newval = np.zeros((len(idx), heads), np.float32)
     scalar = np.empty((num_v, heads), np.float32)
-    lib().orc_gat_grouped(_i(ptr_s), _i(target), len(target), _i(idx), _f(att), _f(X), _f(Y), _f(newval),
-                          _f(scalar), int(num_v), int(heads), F // heads, ctypes.c_float(slope))
+    lib().orc_gat_grouped_seg(_i(ptr_s), _i(target), len(target), _i(idx), _f(att), _f(X), _f(Y), _f(newval),
+                              _f(scalar), int(num_v), int(heads), F // heads, ctypes.c_float(slope), int(seg))
     return Y, newval, scalar
 
 

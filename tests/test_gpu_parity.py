@@ -575,3 +575,30 @@ def test_partitioned_gcn_single_gpu_emulation(world, overlap):
             x_ext = np.concatenate([x[r0:r1], x[hx.halo_ids]])
             assert np.array_equal(y, orc.gcn_grouped(ps, tg, hx.local_idx, val[hx.e0:hx.e1], x_ext, r1 - r0, seg=sg))
     assert seen == V
+
+
+@pytest.mark.parametrize("F,H,chunk", [(128, 1, 64), (256, 8, 8), (96, 4, 5), (30, 3, 16)])
+def test_gat_balanced_plan_with_hubs(F, H, chunk):
+    """GAT balanced mode on the plan kernel: short rows, in-workgroup segment fold, hubs through scratch."""
+    V = 350
+    rng = np.random.default_rng(13)
+    deg = rng.integers(0, 7, V)
+    deg[11], deg[180], deg[349] = 4000, 900, 70
+    ptr = np.zeros(V + 1, np.int32)
+    ptr[1:] = np.cumsum(deg)
+    E = int(ptr[-1])
+    idx = rng.integers(0, V, E).astype(np.int32)
+    x, att = rand((V, F), 1), rand((V, H, 2), 2) * 0.4
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.schedule_balanced(chunk)
+    y = torch.full((V, F), 7.0, device=DEV)
+    newval = torch.full((E, H), 7.0, device=DEV)
+    gat.run(dev(x), dev(att), y, 128, "balanced", heads=H, newval=newval)
+    ch, seg = gat.balanced_params()
+    assert ch == chunk and seg == 16
+    ps, tg = orc.neighbor_grouping(ptr, chunk)
+    ref, ref_newval, _ = orc.gat_grouped(ps, tg, idx, att, x, V, H, seg=seg)
+    # same association as the oracle; only expf (device vs libm) differs by ulps
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=3e-6, atol=1e-6)
+    np.testing.assert_allclose(newval.cpu().numpy(), ref_newval, rtol=1e-6)
+    assert np.all(y.cpu().numpy()[deg == 0] == 0)
