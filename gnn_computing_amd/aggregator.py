@@ -63,7 +63,6 @@ class Aggregator:
         self.num_e = int(idx.numel())
         self.feat_in, self.feat_out = feat_in, feat_out
         self._h = ctypes.c_int64(0)
-        self._keep = []
 
     # -- lifetime
     def close(self):

@@ -858,8 +858,6 @@ static int fill_xcd_ranges(const long *cost_prefix, int n_items, int items_per_b
 
 static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max, hipStream_t stream)
 {
-    static const int dbg_skip = getenv("GNNAGG_DEBUG_SKIP_COMBINE") ? atoi(getenv("GNNAGG_DEBUG_SKIP_COMBINE")) : 0;
-    if (dbg_skip == 1) return GNNAGG_OK;  // timing experiments only: output of split rows is left incomplete
     if (L.wl.n_mrows > 0) {
         CombineArgs c;
         c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = L.row_ptr; c.partial = L.partial;

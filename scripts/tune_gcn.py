@@ -59,7 +59,6 @@ def main():
             os.environ["GNNAGG_XCD_REMAP"] = str(c["remap"])
             os.environ["GNNAGG_PLAN"] = str(c["plan"])
             a = gnc.Aggregator_GCN(dptr, didx, dval, F, F)
-            a._keep = [dptr, didx, dval]
             if c["mode"] == "balanced":
                 a.schedule_balanced(0)
             elif c["mode"] == "scheduled":
@@ -68,7 +67,6 @@ def main():
             if c["mode"] == "balanced":
                 for ch in extra_chunks:
                     b = gnc.Aggregator_GCN(dptr, didx, dval, F, F)
-                    b._keep = [dptr, didx, dval]
                     b.schedule_balanced(ch)
                     aggs[(gname, ci, ch)] = b
     times = {k: [] for k in aggs}
