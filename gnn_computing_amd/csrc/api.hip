@@ -421,7 +421,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         P.hubs.mrow_id = p.mrow_id.p; P.hubs.mrow_ptr = p.mrow_ptr.p; P.hubs.n_mrows = p.n_mrows;
         P.hubs.n_slots = p.n_slots; P.hubs.big_rows = p.big_rows.p; P.hubs.n_big = p.n_big;
         P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
-        P.xcd_remap = c->xcd_remap; P.accumulate = (flags & GNNAGG_FLAG_ACCUMULATE) ? 1 : 0;
+        P.xcd_remap = c->xcd_remap; P.accumulate = (flags & GNNAGG_FLAG_ACCUMULATE) ? 1 : 0; P.num_rows = c->V;
         if (p.n_slots > 0) {
             if ((rc = c->partial.reserve((size_t)p.n_slots * feat))) return rc;
             P.partial = c->partial.p;
@@ -447,7 +447,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         GcnPlanLaunch P;  // short rows: the descriptor path of the plan kernel (no segments, no hubs)
         P.t0 = p.r0.p; P.n0 = p.n0; P.t0_cost_prefix = p.r0_cost_prefix.data();
         P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
-        P.xcd_remap = c->xcd_remap;
+        P.xcd_remap = c->xcd_remap; P.num_rows = c->V;
         rc = launch_gcn_plan(P, c->stream);
         if (p.n1 > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // join
         return rc;

@@ -83,6 +83,7 @@ struct GcnPlanLaunch {
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 2;
     int accumulate = 0;  // y += A.x (sum only); rows without edges keep their value
+    int num_rows = 0;    // rows of y
 };
 
 // Long rows of the rows mode (`scheduled = 0`, canonical CSR-order chains): k_gcn_rows_long.

@@ -72,6 +72,27 @@ __device__ __forceinline__ void store_pack(float *p, const float (&a)[VEC])
     }
 }
 
+// Output rows are written once and never re-read by this kernel: a write-through (sc1) store leaves the XCD's L2
+// to the gathered feature rows instead of parking 87 MB of results in it.  Buffer store so the cache bits can be
+// given (aux 16 = sc1); `yoff` is the element offset from `ybase` (callers guarantee the byte offset fits 31 bits).
+template <int VEC>
+__device__ __forceinline__ void store_pack_wt(float *ybase, unsigned nbytes, size_t yoff, const float (&a)[VEC])
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, (int)nbytes, 0x00020000);
+    const int voff = (int)(yoff * sizeof(float));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    if constexpr (VEC == 4) {
+        u4 v = {__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 16);
+    } else if constexpr (VEC == 2) {
+        u2 v = {__float_as_uint(a[0]), __float_as_uint(a[1])};
+        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, 0, 16);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[0]), rsrc, voff, 0, 16);
+    }
+}
+
 // Block b runs on XCD b % 8 (observed dispatch rule).  Give every XCD a contiguous range of
 // logical blocks; bijective for any nb (q = nb/8, r = nb%8: the first r XCDs get q+1 blocks).
 __device__ __forceinline__ int xcd_remap(int b, int nb)
@@ -115,7 +136,8 @@ struct GcnArgs {
 
 // The FMA (or max) chain of one work item over edges [beg,end) in CSR order.  Lane j of the group fetches
 // (idx,val) of edge cb+j with ONE coalesced load per GROUP edges (next window prefetched); each edge's
-// pair is broadcast inside the group with ds_bpermute (LDS crossbar, no memory traffic), kUnroll feature
+// pair is broadcast inside the group with ds_bpermute (LDS crossbar, no memory traffic; nontemporal loads of
+// this once-streamed metadata were measured 1-5 % SLOWER and are not used), kUnroll feature
 // gathers are issued before the first FMA.  Lanes with col_ok == false still carry metadata.
 template <int VEC, int GROUP, bool IS_MAX>
 __device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end, int lane, bool col_ok,
@@ -233,6 +255,8 @@ struct PlanArgs {
     float *partial;
     int n0, n1, feat, ntiles, chunk, mean, remap, nblocks0;
     int accumulate;  // 1: y += result (rows without edges are left untouched); sum only
+    int wt;          // 1: write-through (sc1) stores of the short-row results
+    unsigned ybytes;
     XcdRanges xr;
 };
 
@@ -318,7 +342,8 @@ __global__ __launch_bounds__(kBlock) void k_gcn_plan(const PlanArgs a)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
     }
-    store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
+    if (a.wt) store_pack_wt<VEC>(a.y, a.ybytes, (size_t)d.z * F + col, acc);
+    else store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
 }
 
 // ---------------------------------------------------------- GCN / SAGE, rows mode (canonical order)
@@ -888,6 +913,12 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
     a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
     a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap; a.accumulate = L.accumulate;
+    {
+        static const int wt_env = getenv("GNNAGG_WT_STORES") ? atoi(getenv("GNNAGG_WT_STORES")) : 1;
+        const size_t ybytes = (size_t)L.num_rows * L.feat * sizeof(float);
+        a.wt = (wt_env && !L.accumulate && ybytes < 0x7fffffffULL) ? 1 : 0;
+        a.ybytes = (unsigned)ybytes;
+    }
     const int gpb = kBlock / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
     a.nblocks0 = item_blocks * g.ntiles;
