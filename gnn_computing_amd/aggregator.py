@@ -149,6 +149,18 @@ class Aggregator_GCN(Aggregator):
                                       _lib.FLAG_ACCUMULATE if accumulate else 0))
         return 0.0
 
+    def run_clock(self, vin, vout, BLOCK_SIZE=64, scheduled=0):
+        """aggr_gcn.h:462-489.  Returns an int64 tensor [blocks, 3] = (start tick, end tick, CU id) per workgroup of
+        the one-item-per-lane-group kernel (ticks of gnnagg_wall_clock_hz())."""
+        nb = ctypes.c_int(0)
+        mode = _mode(scheduled)
+        check(lib().gnnagg_gcn_run_clock(self._h, None, None, int(vin.shape[1]), mode, None, ctypes.byref(nb), None))
+        timer = torch.zeros((max(nb.value, 1), 3), dtype=torch.int64, device=vin.device)
+        self._use_current_stream()
+        check(lib().gnnagg_gcn_run_clock(self._h, _dev_ptr(vin, torch.float32, "vin"), _dev_ptr(vout, torch.float32, "vout"),
+                                         int(vin.shape[1]), mode, ctypes.c_void_p(timer.data_ptr()), ctypes.byref(nb), None))
+        return timer[:nb.value]
+
     def runEdgeWise(self, vin, vout, BLOCK_SIZE=512, scheduled=0):
         """aggr_gcn.h:446-460"""
         self._use_current_stream()

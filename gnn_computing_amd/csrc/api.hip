@@ -758,6 +758,43 @@ int gnnagg_gcn_run_with_nn(gnnagg_handle h, const float *d_x, float *d_y, const 
     return launch_dense_nn(d_y, d_weight, d_transformed, c->V, feat_out, feat_in, c->stream);
 }
 
+int gnnagg_gcn_run_clock(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, unsigned long long *d_timer,
+                         int *num_blocks, int *waves_per_cu)
+{
+    GET_CTX(h);
+    if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
+    if (mode != GNNAGG_MODE_ROWS && mode != GNNAGG_MODE_SCHEDULED) return fail(GNNAGG_ERR_ARG, "run_clock: mode must be rows or scheduled");
+    if (!num_blocks) return fail(GNNAGG_ERR_ARG, "null num_blocks");
+    if (d_timer && (!d_x || !d_y)) return fail(GNNAGG_ERR_ARG, "null feature pointer");
+    Schedule *s = nullptr;
+    int rc = get_sched(c, mode, &s);
+    if (rc) return rc;
+    GcnLaunch L;
+    L.row_ptr = c->d_ptr; L.x = d_x; L.y = d_y; L.feat = feat; L.reduce = GNNAGG_REDUCE_SUM; L.xcd_remap = 0;
+    L.timer = d_timer; L.timer_blocks_out = num_blocks;
+    if (!s) {
+        L.wl.ptr = c->d_ptr; L.wl.n_items = c->V; L.idx = c->d_idx; L.val = c->d_val;
+    } else {
+        L.wl = s->worklist();
+        L.idx = s->permuted ? s->idx_s.p : c->d_idx;
+        L.val = s->permuted ? s->val_s.p : c->d_val;
+        if (s->n_slots > 0 && d_timer) {
+            if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
+            L.partial = c->partial.p;
+        }
+    }
+    if (waves_per_cu) *waves_per_cu = 32;  // hardware limit; the items kernel's register budget allows 24-28
+    return launch_gcn(L, c->stream);
+}
+
+long long gnnagg_wall_clock_hz(void)
+{
+    int khz = 0, devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, devid) != hipSuccess)
+        return 100000000LL;
+    return (long long)khz * 1000LL;
+}
+
 int gnnagg_gcn_run_ex(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce, int flags)
 {
     GET_CTX(h);

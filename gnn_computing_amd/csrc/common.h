@@ -62,6 +62,8 @@ struct GcnLaunch {
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 1;
     int accumulate = 0;  // combine only: y += sum of partials
+    void *timer = nullptr;          // run_clock: unsigned long long[3 * blocks]
+    int *timer_blocks_out = nullptr;  // run_clock: receives the number of workgroups of the items kernel
     // host array [n_items + n_empty + 1]: prefix sums of the per-item cost, for xcd_remap == 2
     const long *xcd_item_cost_prefix = nullptr;
 };

@@ -131,6 +131,7 @@ struct GcnArgs {
     float *y;
     float *partial;
     int n_items, n_total, feat, ntiles, nblocks, mean, remap;
+    unsigned long long *timer;  // run_clock: per workgroup {first wave start, last wave end, CU id}; null otherwise
     XcdRanges xr;
 };
 
@@ -193,7 +194,7 @@ __device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end,
 // LIST = false: item g is CSR row g (reference aggr_gcn, aggr_gcn.h:5-36): the `scheduled = 0` path.
 // LIST = true : item g is a group of the schedule (reference aggr_gcn_target, aggr_gcn.h:78-114).
 template <int VEC, int GROUP, bool IS_MAX, bool LIST>
-__global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
+__device__ __forceinline__ void gcn_items_body(const GcnArgs &a)
 {
     constexpr int ITEMS = kBlock / GROUP;
     const int b = logical_block(blockIdx.x, a.nblocks, a.ntiles, a.remap, a.xr);
@@ -232,6 +233,32 @@ __global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
     }
     store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+}
+
+// Kernel wrapper.  With a.timer set (reference run_clock, aggr_gcn.h:462-489: %globaltimer / %smid per block,
+// kernels aggr_gcn_clock :159-201 and aggr_gcn_target_clock :203-248) the first lane of every wavefront stamps the
+// constant-rate wall clock (s_memrealtime) before and after the work: timer[3b] = earliest start, timer[3b+1] =
+// latest end, timer[3b+2] = hardware CU id (__smid: XCC / SE / CU bits of HW_ID).
+template <int VEC, int GROUP, bool IS_MAX, bool LIST>
+__global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
+{
+    if (a.timer && (threadIdx.x & 63) == 0) {
+        atomicMin(&a.timer[3 * (size_t)blockIdx.x], (unsigned long long)wall_clock64());
+        if (threadIdx.x == 0) a.timer[3 * (size_t)blockIdx.x + 2] = __smid();
+    }
+    gcn_items_body<VEC, GROUP, IS_MAX, LIST>(a);
+    if (a.timer && (threadIdx.x & 63) == 0)
+        atomicMax(&a.timer[3 * (size_t)blockIdx.x + 1], (unsigned long long)wall_clock64());
+}
+
+__global__ void k_timer_init(unsigned long long *timer, int nblocks)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblocks) {
+        timer[3 * (size_t)b] = ~0ULL;
+        timer[3 * (size_t)b + 1] = 0ULL;
+        timer[3 * (size_t)b + 2] = 0ULL;
+    }
 }
 
 // ------------------------------------------------------------------ GCN / SAGE, balanced plan
@@ -981,6 +1008,12 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
     a.row_ptr = L.row_ptr; a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
     a.n_items = L.wl.n_items; a.n_total = L.wl.n_items + L.wl.n_empty; a.feat = L.feat; a.ntiles = g.ntiles;
     a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap;
+    a.timer = reinterpret_cast<unsigned long long *>(L.timer);
+    if (L.timer || L.timer_blocks_out) a.remap = 0;  // natural block order for the load-balance study
+    if (L.timer_blocks_out) {
+        *L.timer_blocks_out = a.n_total > 0 ? ceil_div(a.n_total, kBlock / g.group) * g.ntiles : 0;
+        if (!L.timer) return GNNAGG_OK;  // size query only
+    }
     if (a.n_total > 0) {
         const int items_per_block = kBlock / g.group;
         const int item_blocks = ceil_div(a.n_total, items_per_block);
@@ -994,6 +1027,7 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
                 grid = 8 * fill_xcd_ranges(L.xcd_item_cost_prefix, a.n_total, items_per_block, item_blocks, a.xr) * g.ntiles;
             }
         }
+        if (a.timer) hipLaunchKernelGGL(k_timer_init, dim3(ceil_div(grid, 256)), dim3(256), 0, stream, a.timer, grid);
 #define LAUNCH_GCN(MAXF, LISTF) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, MAXF, LISTF>), dim3(grid), dim3(kBlock), 0, stream, a)
 #define CALL_GCN                                                                                  \
         if (list) { if (is_max) LAUNCH_GCN(true, true); else LAUNCH_GCN(false, true); }           \

@@ -3,6 +3,8 @@
 #define GNNAGG_COMPAT_AGGR_GCN_H
 #include "aggregator.h"
 
+typedef unsigned long long clocktype;  // reference aggr_gcn.h:116
+
 class Aggregator_GCN : public Aggregator
 {
 public:
@@ -50,6 +52,27 @@ public:
         checkHipErrors(hipDeviceSynchronize());
         timestamp(t0);
         checkGnnagg(gnnagg_gcn_run_edgewise(handle, vin, vout, feat_in));
+        checkHipErrors(hipDeviceSynchronize());
+        timestamp(t1);
+        return getDuration(t0, t1);
+    }
+    // reference aggr_gcn.h:462-489: timer[3b] = start, [3b+1] = end, [3b+2] = CU id of workgroup b (wall-clock ticks,
+    // gnnagg_wall_clock_hz()); returns seconds like the reference.  clock_blocks() sizes the timer.
+    int clock_blocks(bool scheduled)
+    {
+        int nb = 0;
+        checkGnnagg(gnnagg_gcn_run_clock(handle, nullptr, nullptr, feat_in, scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS,
+                                         nullptr, &nb, nullptr));
+        return nb;
+    }
+    double run_clock(float *vin, float *vout, clocktype *timer, int BLOCK_SIZE, bool scheduled)
+    {
+        (void)BLOCK_SIZE;
+        int nb = 0;
+        checkHipErrors(hipDeviceSynchronize());
+        timestamp(t0);
+        checkGnnagg(gnnagg_gcn_run_clock(handle, vin, vout, feat_in, scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS, timer,
+                                         &nb, nullptr));
         checkHipErrors(hipDeviceSynchronize());
         timestamp(t1);
         return getDuration(t0, t1);

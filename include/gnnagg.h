@@ -122,6 +122,13 @@ int gnnagg_gcn_run(gnnagg_handle h, const float *d_x, float *d_y, int feat, int 
  * row-partitioned path to add the halo-column part after the local-column part. */
 #define GNNAGG_FLAG_ACCUMULATE 1
 int gnnagg_gcn_run_ex(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce, int flags);
+/* Aggregator_GCN::run_clock, aggr_gcn.h:462-489 (Figure 8 load-balance study).  Runs the one-item-per-lane-group
+ * kernel of mode rows (the reference's aggr_gcn_clock) or scheduled (aggr_gcn_target_clock) with per-workgroup
+ * stamps: d_timer[3b] = start, [3b+1] = end (ticks of the constant wall clock, gnnagg_wall_clock_hz), [3b+2] = CU id.
+ * Call with d_timer == NULL to get *num_blocks (the timer needs 3 * num_blocks entries). */
+int gnnagg_gcn_run_clock(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, unsigned long long *d_timer,
+                         int *num_blocks, int *waves_per_cu);
+long long gnnagg_wall_clock_hz(void);
 /* Aggregator_GCN::runEdgeWise, aggr_gcn.h:446-460 (edge-parallel atomics; any feat). */
 int gnnagg_gcn_run_edgewise(gnnagg_handle h, const float *d_x, float *d_y, int feat);
 /* matmul_NN, include/dense.h:4-23: c[m,n] = a[m,k] . b[k,n], row-major fp32 (the dense combine after an
