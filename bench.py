@@ -175,9 +175,15 @@ def run_multi(args, dev, rank, world):
     from gnn_computing_amd.dist import PartitionedGCN
     V1, E1 = gnc.graph.SHAPES["arxiv"]
     Vg, Eg = V1 * world, E1 * world
-    # every rank generates the same global graph on its GPU (seeded), in community order: this is the
-    # "locality reorder applied on load" input; rows are then split into nnz-balanced blocks
-    ptr_t, idx_t = gnc.graph.powerlaw_csr(Vg, Eg, seed=123, device=dev, community_order=True)
+    # rank 0 generates the global graph on its GPU (seeded, community order = "locality reorder applied on load") and
+    # broadcasts it: every rank must cut exactly the same partition, or the all-to-all split sizes would disagree
+    if rank == 0:
+        ptr_t, idx_t = gnc.graph.powerlaw_csr(Vg, Eg, seed=123, device=dev, community_order=True)
+    else:
+        ptr_t = torch.empty(Vg + 1, dtype=torch.int32, device=dev)
+        idx_t = torch.empty(Eg, dtype=torch.int32, device=dev)
+    dist.broadcast(ptr_t, src=0)
+    dist.broadcast(idx_t, src=0)
     ptr, idx = ptr_t.cpu().numpy(), idx_t.cpu().numpy()
     del ptr_t, idx_t
     val = np.ones(Eg, np.float32)
