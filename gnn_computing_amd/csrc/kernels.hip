@@ -1488,12 +1488,15 @@ __global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, c
             Bs[e] = (k0 + kk < K && col0 + cc < N) ? B[(size_t)(k0 + kk) * N + col0 + cc] : 0.0f;
         }
         __syncthreads();
+        // all 16 operand pairs of the chunk into registers first, then 16 back-to-back MFMAs
+        float av[kGemmKC / 2], bv[kGemmKC / 2];
 #pragma unroll
-        for (int kk = 0; kk < kGemmKC; kk += 2) {
-            const float a = As[(wave * 32 + (lane & 31)) * kGemmPitch + kk + (lane >> 5)];
-            const float b = Bs[(kk + (lane >> 5)) * kGemmCols + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int t = 0; t < kGemmKC / 2; ++t) {
+            av[t] = As[(wave * 32 + (lane & 31)) * kGemmPitch + 2 * t + (lane >> 5)];
+            bv[t] = Bs[(2 * t + (lane >> 5)) * kGemmCols + (lane & 31)];
         }
+#pragma unroll
+        for (int t = 0; t < kGemmKC / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
         __syncthreads();
     }
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)

@@ -627,3 +627,33 @@ def test_run_clock_instrumentation():
         span = (busy[:, 1].max() - busy[:, 0].min()) / hz
         assert 0 < span < 0.05                                         # the whole launch takes well under 50 ms
         assert len(np.unique(busy[:, 2])) > 8                          # workgroups ran on many CUs
+
+
+@pytest.mark.parametrize("mode", ["balanced", "rows", "scheduled"])
+def test_hipgraph_capture_and_replay(mode):
+    """The launch-bound inner loop can be captured into a hipGraph (no allocation or synchronisation inside run()
+    once the scratch is warm); the rows mode's auxiliary-stream fork/join is captured with it."""
+    V, E, F = 6000, 120000, 128
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=31)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    x1, x2, val = rand((V, F), 1), rand((V, F), 2), rand(E, 3)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.schedule(gnc.Schedule.neighbor_grouping, [16])
+    dx, y = dev(x1), torch.empty((V, F), device=DEV)
+    agg.run(dx, y, 512, mode)  # warm-up: plans, scratch
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        agg.run(dx, y, 512, mode)
+    dx.copy_(dev(x2))  # new input, same buffers
+    y.fill_(7.0)
+    g.replay()
+    torch.cuda.synchronize()
+    if mode == "rows":
+        ref = orc.gcn_seq(ptr, idx, val, x2)
+    elif mode == "scheduled":
+        ref = orc.gcn_grouped(*orc.neighbor_grouping(ptr, 16), idx, val, x2, V)
+    else:
+        ch, sg = agg.balanced_params()
+        ref = orc.gcn_grouped(*orc.neighbor_grouping(ptr, ch), idx, val, x2, V, seg=sg)
+    assert np.array_equal(y.cpu().numpy(), ref)
