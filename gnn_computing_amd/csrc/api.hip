@@ -1020,7 +1020,7 @@ int gnnagg_cluster_reorder(const int *h_ptr, const int *h_idx, int num_v, float 
     if (!h_ptr || !h_rows_out || num_v < 0 || (h_ptr[num_v] > 0 && !h_idx))
         return fail(GNNAGG_ERR_ARG, "bad cluster_reorder arguments");
     return cluster_reorder(h_ptr, h_idx, num_v, threshold > 0 ? threshold : 0.2, num_perm > 0 ? num_perm : 64,
-                           cluster_cap > 0 ? cluster_cap : 64, seed, 256, h_rows_out, num_clusters);
+                           cluster_cap > 0 ? cluster_cap : 64, seed, 8, h_rows_out, num_clusters);
 }
 
 // ------------------------------------------------------------------------------- Section D

@@ -121,14 +121,18 @@ int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int
             for (size_t s = 0; s < keys.size();) {
                 size_t t = s;
                 while (t < keys.size() && keys[t].first == keys[s].first) ++t;
-                // a bucket shared by a huge number of rows (hub co-neighbors) is quadratic; cap it like a
-                // bounded LSH query (rows beyond the cap in one bucket still meet through other bands)
-                const size_t lim = std::min(t, s + (size_t)max_bucket);
-                for (size_t u = s; u < lim; ++u)
+                // Small buckets contribute all their pairs (what an LSH query returns).  A bucket shared by very many
+                // rows (dense graphs: reddit-shaped rows all overlap a little) would be quadratic in time and memory,
+                // so there every row is only paired with the next `max_bucket` rows of the bucket; rows still meet
+                // through the other bands and through the root-to-root re-queueing of the merge phase.
+                const size_t nb = t - s;
+                for (size_t u = s; u < t; ++u) {
+                    const size_t lim = nb <= 16 ? t : std::min(t, u + 1 + (size_t)max_bucket);
                     for (size_t v = u + 1; v < lim; ++v) {
                         const uint64_t id = makenum(keys[u].second, keys[v].second);
                         if (queued.insert(id).second) que.push({simi(keys[u].second, keys[v].second), keys[u].second, keys[v].second});
                     }
+                }
                 s = t;
             }
         }
