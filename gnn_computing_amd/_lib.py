@@ -52,6 +52,7 @@ SIGNATURES = {
     "gnnagg_gcn_run_clock": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, P_INT, P_INT]),
     "gnnagg_wall_clock_hz": (ctypes.c_longlong, []),
     "gnnagg_gcn_run_edgewise": (c_int, [c_int64, c_void_p, c_void_p, c_int]),
+    "gnnagg_check_csr": (c_int, [c_int64, c_int, P_INT, P_INT]),
     "gnnagg_csr2edgelist": (c_int, [c_int64, c_void_p]),
     "gnnagg_matmul_nn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gnnagg_gcn_run_with_nn": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),

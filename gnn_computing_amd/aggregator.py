@@ -115,6 +115,13 @@ class Aggregator:
                                         val_s.ctypes.data if with_val else None))
         return (ptr_s, idx_s, tgt, val_s) if with_val else (ptr_s, idx_s, tgt)
 
+    def check_csr(self, num_cols=0):
+        """(rows with ptr[r] > ptr[r+1], neighbor ids outside [0, num_cols)) -- gnnagg_check_csr."""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        self._use_current_stream()
+        check(lib().gnnagg_check_csr(self._h, int(num_cols), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     # -- aggregator.h:115-122
     def csr2edgelist(self):
         out = torch.empty(2 * self.num_e, dtype=torch.int32, device=self.ptr.device)

@@ -506,6 +506,36 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
         }
         return launch_gat_plan(P, c->stream);
     }
+    if (mode == GNNAGG_MODE_ROWS && c->use_plan && !newval && heads > 0 && feat % heads == 0) {
+        // canonical order: short rows on the descriptor path of k_gat_plan, isolated hub rows on the long-row kernel
+        // (auxiliary stream) when a 32-column tile lies inside one head
+        if (!c->rows_plan.valid && (rc = build_rows_plan(c))) return rc;
+        RowsPlan &p = c->rows_plan;
+        const bool long_ok = p.n1 > 0 && ((feat / heads) % 32) == 0;
+        if (p.n1 == 0 || long_ok) {
+            if (long_ok) {
+                if (!c->aux_stream) {
+                    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+                GcnRowsLongLaunch R;
+                R.r1 = p.r1.p; R.n1 = p.n1; R.idx = c->d_idx; R.x = x; R.y = y; R.feat = feat;
+                R.att = att; R.heads = heads; R.slope = slope;
+                if ((rc = launch_gcn_rows_long(R, c->aux_stream))) return rc;
+                HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
+            }
+            GatPlanLaunch P;
+            P.t0 = p.r0.p; P.n0 = p.n0; P.t0_cost_prefix = p.r0_cost_prefix.data();
+            P.idx = c->d_idx; P.att = att; P.x = x; P.y = y; P.feat = feat; P.heads = heads; P.slope = slope;
+            P.xcd_remap = c->xcd_remap; P.rows_semantics = 1;
+            rc = launch_gat_plan(P, c->stream);
+            if (long_ok) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            return rc;
+        }
+    }
     GatLaunch L;
     L.att = att; L.x = x; L.y = y; L.feat = feat; L.heads = heads; L.slope = slope; L.newval = newval;
     L.xcd_remap = c->xcd_remap;
@@ -799,6 +829,23 @@ int gnnagg_gcn_run_ex(gnnagg_handle h, const float *d_x, float *d_y, int feat, i
 {
     GET_CTX(h);
     return gcn_run(c, d_x, d_y, feat, mode, reduce, flags);
+}
+
+int gnnagg_check_csr(gnnagg_handle h, int num_cols, int *bad_rows, int *bad_indices)
+{
+    GET_CTX(h);
+    int *d_counts = nullptr, counts[2] = {0, 0};
+    HIP_TRY(hipMalloc((void **)&d_counts, 2 * sizeof(int)));
+    int rc = launch_check_csr(c->d_ptr, c->d_idx, c->V, c->E, num_cols > 0 ? num_cols : c->V, d_counts, c->stream);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(GNNAGG_ERR_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_counts);
+    if (bad_rows) *bad_rows = counts[0];
+    if (bad_indices) *bad_indices = counts[1];
+    return rc;
 }
 
 int gnnagg_csr2edgelist(gnnagg_handle h, int *d_edgelist)

@@ -98,6 +98,9 @@ struct GcnRowsLongLaunch {
     float *y = nullptr;
     int feat = 0;
     int reduce = GNNAGG_REDUCE_SUM;
+    const float *att = nullptr;  // non-null: GAT flavour (fused edge softmax), needs (feat / heads) % 32 == 0
+    int heads = 1;
+    float slope = 0.2f;
 };
 
 struct GatLaunch {
@@ -144,6 +147,7 @@ struct GatPlanLaunch {
     int feat = 0, heads = 1;
     float slope = 0.2f;
     int xcd_remap = 2;
+    int rows_semantics = 0;  // 1: `scheduled = 0` semantics (aggr_gat: divide by the denominator unconditionally)
 };
 int launch_gat_plan(const GatPlanLaunch &a, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);
@@ -159,6 +163,7 @@ int launch_validate(const float *ref, const float *ans, int num, int *d_diff, vo
 int launch_validate_reordered(const float *ref, const float *ans, const int *map, int V, int feat, int *d_diff,
                               void *stream);
 int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream);
+int launch_check_csr(const int *ptr, const int *idx, int V, int E, int num_cols, int *d_counts, void *stream);
 int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out, void *stream);
 
 }  // namespace gnnagg

@@ -386,6 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_gcn_plan(const PlanArgs a)
 //    chain from LDS.  The loads of round r+1 are issued before round r is consumed.  Heaviest rows first.
 //    (A 15 k-edge row takes ~0.3 ms this way instead of 1.49 ms; the consumer's ~20 cycles per edge bound it.
 //    A column-major stage read with b128 was tried and lost to its scattered LDS writes.)
+__device__ __forceinline__ float edge_weight(float a_dst, float a_src, float slope);
 static constexpr int kLongBlock = 512;
 
 struct RowsLongArgs {
@@ -395,9 +396,15 @@ struct RowsLongArgs {
     const float *x;
     float *y;
     int n1, feat, ntiles32, mean;
+    // GAT flavour (reference aggr_gat, aggr_gat.h:116-164): the edge weight is exp(leaky(att[row,h,0] + att[src,h,1]))
+    // computed by the gathering lanes; the consumer also runs the denominator chain.  Needs dhead % 32 == 0 so
+    // that a 32-column tile lies inside one head.
+    const float *att;
+    int heads, dhead;
+    float slope;
 };
 
-template <int VEC, bool IS_MAX>
+template <int VEC, bool IS_MAX, bool IS_GAT>
 __global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs a)
 {
     constexpr int GL = 32 / VEC;           // lanes of one gather group: GL * VEC = 32 columns = 128 bytes
@@ -414,8 +421,10 @@ __global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs
     const bool col_ok = col < F;
     const int c = (int)threadIdx.x;  // consumer thread <-> column tile*32 + c (c < 32)
     const bool consumer = c < 32 && tile * 32 + c < F;
-    float acc = IS_MAX ? -INFINITY : 0.0f;
+    float acc = IS_MAX ? -INFINITY : 0.0f, den = 0.0f;
     const float *__restrict__ xcol = a.x + col;
+    const int head = IS_GAT ? (tile * 32) / a.dhead : 0;
+    const float a_dst = IS_GAT ? a.att[((size_t)d.z * a.heads + head) * 2] : 0.0f;
     Pack<VEC> xv[U];
     float wv[U];
     auto issue = [&](int base) {  // gathers of the round starting at edge `base`; this group's edges: base + g*U + u
@@ -424,7 +433,8 @@ __global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs
             const int e = base + g * U + u;
             if (e < d.y) {
                 const int s = a.idx[e];
-                wv[u] = a.val ? a.val[e] : 1.0f;
+                if (IS_GAT) wv[u] = a.att[((size_t)s * a.heads + head) * 2 + 1];  // source term; exp() after it landed
+                else wv[u] = a.val ? a.val[e] : 1.0f;
                 if (col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s * F);
             }
         }
@@ -435,6 +445,7 @@ __global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs
             acc = p > acc ? p : acc;
         } else {
             acc = __builtin_fmaf(xs, ws, acc);
+            if (IS_GAT) den += ws;
         }
     };
     issue(d.x);
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs
             const int k = g * U + u;
             if (base + k < d.y) {
                 if (col_ok) store_pack<VEC>(&stage[k * 32 + lane * VEC], xv[u].v);
-                if (lane == 0) wstage[k] = wv[u];
+                if (lane == 0) wstage[k] = IS_GAT ? edge_weight(a_dst, wv[u], a.slope) : wv[u];
             }
         }
         __syncthreads();
@@ -467,7 +478,8 @@ __global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs
         __syncthreads();
     }
     if (consumer) {
-        if (a.mean) acc = acc / (float)(d.y - d.x);
+        if (IS_GAT) acc = acc / den;  // aggr_gat.h:163 (rows here are never empty)
+        else if (a.mean) acc = acc / (float)(d.y - d.x);
         a.y[(size_t)d.z * F + tile * 32 + c] = acc;
     }
 }
@@ -751,7 +763,7 @@ struct GatPlanArgs {
     const float *x;
     float *y;
     float *partial, *partial_den, *newval;
-    int n0, n1, feat, ntiles, chunk, heads, dhead, remap, nblocks0;
+    int n0, n1, feat, ntiles, chunk, heads, dhead, remap, nblocks0, rows_semantics;
     float slope;
     XcdRanges xr;
 };
@@ -834,7 +846,7 @@ __global__ __launch_bounds__(kBlock) void k_gat_plan(const GatPlanArgs a)
                                     head_leader);
     }
     if (!col_ok) return;
-    if (d.x < d.y && den != 0.0f) {
+    if (d.x < d.y && (den != 0.0f || a.rows_semantics)) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
     }
@@ -982,14 +994,18 @@ int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)
     RowsLongArgs a;
     a.r1 = reinterpret_cast<const int4 *>(L.r1); a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y;
     a.n1 = L.n1; a.feat = L.feat; a.ntiles32 = ceil_div(L.feat, 32); a.mean = L.reduce == GNNAGG_REDUCE_MEAN;
+    a.att = L.att; a.heads = L.heads; a.dhead = L.heads > 0 ? L.feat / L.heads : L.feat; a.slope = L.slope;
     const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
+    const bool is_gat = L.att != nullptr;
+    if (is_gat && (a.dhead % 32) != 0) return fail(GNNAGG_ERR_ARG, "long-row GAT kernel needs head width % 32 == 0");
     const int grid = a.n1 * a.ntiles32;
 #define LAUNCH_LONG(V)                                                                                               \
     {                                                                                                                \
         const size_t re = (size_t)(kLongBlock / (32 / V)) * 8;                                                       \
         const size_t lds = (32 * re + re) * sizeof(float);                                 \
-        if (is_max) hipLaunchKernelGGL((k_gcn_rows_long<V, true>), dim3(grid), dim3(kLongBlock), lds, stream, a);    \
-        else        hipLaunchKernelGGL((k_gcn_rows_long<V, false>), dim3(grid), dim3(kLongBlock), lds, stream, a);   \
+        if (is_gat)      hipLaunchKernelGGL((k_gcn_rows_long<V, false, true>), dim3(grid), dim3(kLongBlock), lds, stream, a);  \
+        else if (is_max) hipLaunchKernelGGL((k_gcn_rows_long<V, true, false>), dim3(grid), dim3(kLongBlock), lds, stream, a);  \
+        else             hipLaunchKernelGGL((k_gcn_rows_long<V, false, false>), dim3(grid), dim3(kLongBlock), lds, stream, a); \
     }
     if (vec == 4) LAUNCH_LONG(4) else if (vec == 2) LAUNCH_LONG(2) else LAUNCH_LONG(1)
 #undef LAUNCH_LONG
@@ -1092,7 +1108,7 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     a.t0 = reinterpret_cast<const int4 *>(L.t0); a.t1 = reinterpret_cast<const int4 *>(L.t1);
     a.idx = L.idx; a.att = L.att; a.x = L.x; a.y = L.y; a.partial = L.partial; a.partial_den = L.partial_den;
     a.newval = L.newval; a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
-    a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope;
+    a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope; a.rows_semantics = L.rows_semantics;
     const int gpb = kBlock / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
     a.nblocks0 = item_blocks * g.ntiles;
@@ -1520,6 +1536,26 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
     }
     const dim3 grid(ceil_div(M, kGemmRows), ceil_div(N, kGemmCols));
     hipLaunchKernelGGL(k_dense_nn, grid, dim3(256), 0, stream, A, B, C, M, N, K);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// --------------------------------------------------------------------------------- CSR check
+// The reference trusts its inputs (an out-of-range neighbor id is a silent out-of-bounds gather).  counts[0] = rows with
+// ptr[r] > ptr[r+1], counts[1] = neighbor ids outside [0, num_cols).
+__global__ void k_check_csr(const int *__restrict__ ptr, const int *__restrict__ idx, int V, int E, int num_cols, int *counts)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < V && ptr[t] > ptr[t + 1]) atomicAdd(&counts[0], 1);
+    if (t < E && (idx[t] < 0 || idx[t] >= num_cols)) atomicAdd(&counts[1], 1);
+}
+
+int launch_check_csr(const int *ptr, const int *idx, int V, int E, int num_cols, int *d_counts, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), stream));
+    const long n = std::max<long>(V, E);
+    if (n > 0) hipLaunchKernelGGL(k_check_csr, dim3(ceil_div(n, 256)), dim3(256), 0, stream, ptr, idx, V, E, num_cols, d_counts);
     HIP_TRY(hipGetLastError());
     return GNNAGG_OK;
 }

@@ -139,6 +139,10 @@ int gnnagg_matmul_nn(const float *d_a, const float *d_b, float *d_c, int m, int 
  * reference accumulates into whatever they held). */
 int gnnagg_gcn_run_with_nn(gnnagg_handle h, const float *d_x, float *d_y, const float *d_weight, float *d_transformed,
                            int feat_in, int feat_out, int mode);
+/* Input check the reference does not have (an out-of-range neighbor id is a silent out-of-bounds gather there):
+ * *bad_rows = rows with ptr[r] > ptr[r+1], *bad_indices = neighbor ids outside [0, num_cols) (num_cols <= 0: num_v).
+ * Synchronises the handle's stream. */
+int gnnagg_check_csr(gnnagg_handle h, int num_cols, int *bad_rows, int *bad_indices);
 /* Aggregator::csr2edgelist, aggregator.h:115-122: d_edgelist[2E] = (src, dst) pairs */
 int gnnagg_csr2edgelist(gnnagg_handle h, int *d_edgelist);
 

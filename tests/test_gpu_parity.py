@@ -657,3 +657,38 @@ def test_hipgraph_capture_and_replay(mode):
         ch, sg = agg.balanced_params()
         ref = orc.gcn_grouped(*orc.neighbor_grouping(ptr, ch), idx, val, x2, V, seg=sg)
     assert np.array_equal(y.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("F,H", [(128, 1), (256, 8), (96, 4)])
+def test_rows_mode_isolated_hub_gcn_and_gat(F, H):
+    """`scheduled = 0` on a graph whose hub row holds a small share of the edges: the hub goes through the
+    workgroup-per-row kernel on the auxiliary stream (GAT: when the head width is a multiple of 32), everything
+    else through the descriptor path -- canonical CSR-order results either way."""
+    V = 4000
+    rng = np.random.default_rng(17)
+    deg = rng.integers(0, 12, V)
+    deg[123] = 3000  # ~12 % of the edges, far above 4x the average degree and above 1024
+    ptr = np.zeros(V + 1, np.int32)
+    ptr[1:] = np.cumsum(deg)
+    E = int(ptr[-1])
+    idx = rng.integers(0, V, E).astype(np.int32)
+    x, val, att = rand((V, F), 1), rand(E, 2), rand((V, H, 2), 3) * 0.4
+    gcn = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    assert gcn.check_csr() == (0, 0)
+    y = torch.full((V, F), 7.0, device=DEV)
+    gcn.run(dev(x), y, 512, 0)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x))
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    y.fill_(7.0)
+    gat.run(dev(x), dev(att), y, 128, 0, heads=H)
+    ref = orc.gat_fused(ptr, idx, att, x, H)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=3e-6, atol=1e-6)
+    assert np.all(y.cpu().numpy()[deg == 0] == 0)
+
+
+def test_check_csr_flags_bad_input():
+    ptr = np.array([0, 2, 1, 4], np.int32)           # row 1 has ptr[1] > ptr[2]
+    idx = np.array([0, 5, 2, -1], np.int32)          # 5 and -1 are outside [0, 3)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, 4, 4)
+    assert agg.check_csr() == (1, 2)
+    assert agg.check_csr(num_cols=6) == (1, 1)
