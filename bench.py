@@ -175,12 +175,57 @@ def run_single(args, dev):
     return out
 
 
+def run_other_config(args, dev):
+    """The other single-GPU configurations of BASELINE.json (parity-test cases; not the default bench line):
+    R = reddit-shaped SAGE mean F=602, G = reddit-shaped GAT 8x32, P1 = products-shaped GCN F=100."""
+    import gnn_computing_amd as gnc
+    name = {"R": "reddit", "G": "reddit", "P1": "products"}[args.config]
+    ptr, idx = gnc.graph.dataset(name, device=dev)
+    V, E = ptr.numel() - 1, idx.numel()
+    if args.config == "R":
+        F, what = 602, "reddit-shaped CSR %dx%d, GraphSAGE mean, feat=602, implicit weights, mode=balanced" % (V, E)
+        agg = gnc.Aggregator_GCN(ptr, idx, None, F, F)
+        x, y = torch.randn((V, F), device=dev), torch.empty((V, F), device=dev)
+        step = lambda: agg.run(x, y, 512, "balanced", reduce="mean")  # noqa: E731
+        B = E * (4 * F + 4) + V * 4 * F + 4 * (V + 1)
+        kernel = "k_gcn_plan"
+    elif args.config == "G":
+        H, F = 8, 256
+        what = "reddit-shaped CSR %dx%d, GAT 8 heads x 32 fused edge-softmax + SpMM, mode=balanced" % (V, E)
+        agg = gnc.Aggregator_GAT(ptr, idx, F, F)
+        x, y = torch.randn((V, F), device=dev), torch.empty((V, F), device=dev)
+        att = torch.randn((V, H, 2), device=dev)
+        step = lambda: agg.run(x, att, y, 128, "balanced", heads=H)  # noqa: E731
+        B = E * (4 * F + 4 + 4 * H) + V * (4 * F + 4 * H) + 4 * (V + 1)
+        kernel = "k_gat_plan"
+    else:
+        F, what = 100, "products-shaped CSR %dx%d, GCN sum, feat=100, explicit unit weights, mode=balanced, 1 GPU" % (V, E)
+        agg = gnc.Aggregator_GCN(ptr, idx, torch.ones(E, device=dev), F, F)
+        x, y = torch.randn((V, F), device=dev), torch.empty((V, F), device=dev)
+        step = lambda: agg.run(x, y, 512, "balanced")  # noqa: E731
+        B = algorithmic_bytes(V, E, F)
+        kernel = "k_gcn_plan"
+    steps, warm = min(args.steps, 20), min(args.warmup, 3)
+    wall, dev_s, med_s = time_steps(step, steps, warm, lambda: None)
+    achieved = B / dev_s / 1e9
+    return {"metric": "aggregated edges/sec, config %s" % args.config, "value": E / (wall / steps), "unit": "edges/s",
+            "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": wall / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what, "num_v": V, "num_e": E, "feat": F},
+            "achieved_gbps": achieved,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel, "algorithmic_bytes": B,
+                         "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6}}
+
+
 def run_multi(args, dev, rank, world):
     import torch.distributed as dist
     import gnn_computing_amd as gnc
     from gnn_computing_amd.dist import PartitionedGCN
-    V1, E1 = gnc.graph.SHAPES["arxiv"]
-    Vg, Eg = V1 * world, E1 * world
+    strong = args.config == "P"  # BASELINE configs[4]: ONE products-shaped graph row-partitioned over the N GPUs
+    feat = 100 if strong else FEAT
+    V1, E1 = gnc.graph.SHAPES["products" if strong else "arxiv"]
+    Vg, Eg = (V1, E1) if strong else (V1 * world, E1 * world)
     # rank 0 generates the global graph on its GPU (seeded, community order = "locality reorder applied on load") and
     # broadcasts it: every rank must cut exactly the same partition, or the all-to-all split sizes would disagree
     if rank == 0:
@@ -193,26 +238,28 @@ def run_multi(args, dev, rank, world):
     ptr, idx = ptr_t.cpu().numpy(), idx_t.cpu().numpy()
     del ptr_t, idx_t
     val = np.ones(Eg, np.float32)
-    pg = PartitionedGCN(ptr, idx, val, FEAT, device=dev, mode=os.environ.get("BENCH_MODE", "balanced"))
+    pg = PartitionedGCN(ptr, idx, val, feat, device=dev, mode=os.environ.get("BENCH_MODE", "balanced"))
     g = torch.Generator(device=dev)
     g.manual_seed(123 + rank)
-    pg.set_local_x(torch.randn((pg.hx.n_local, FEAT), generator=g, device=dev))
+    pg.set_local_x(torch.randn((pg.hx.n_local, feat), generator=g, device=dev))
     wall, dev_s, med_s = time_steps(pg.step, args.steps, args.warmup, dist.barrier)
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    halo = torch.tensor([pg.hx.halo_bytes(FEAT), pg.num_e_local], dtype=torch.float64, device=dev)
+    halo = torch.tensor([pg.hx.halo_bytes(feat), pg.num_e_local], dtype=torch.float64, device=dev)
     dist.all_reduce(halo, op=dist.ReduceOp.SUM)
     wall = float(t.item())
     if rank != 0:
         return None
-    B = algorithmic_bytes(Vg, Eg, FEAT)
+    B = algorithmic_bytes(Vg, Eg, feat)
     return {
-        "metric": "aggregated edges/sec, GCN SpMM feat=128", "value": Eg / (wall / args.steps), "unit": "edges/s",
+        "metric": "aggregated edges/sec, GCN SpMM feat=%d" % feat, "value": Eg / (wall / args.steps), "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%d x arxiv-shaped power-law CSR (%dx%d, seed 123, community order), GCN sum, "
-                               "feat=128, 1-D row partition + RCCL all-to-all halo pull per step" % (world, Vg, Eg),
-                   "num_v": Vg, "num_e": Eg, "feat": FEAT, "halo_bytes_per_step_all_ranks": float(halo[0].item())},
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s power-law CSR (%dx%d, seed 123, community order), GCN sum, feat=%d, 1-D row "
+                               "partition + RCCL all-to-all halo pull per step (overlapped with the local-source edges)" % (
+                                   "products-shaped" if strong else "%d x arxiv-shaped" % world, Vg, Eg, feat),
+                   "num_v": Vg, "num_e": Eg, "feat": feat, "halo_bytes_per_step_all_ranks": float(halo[0].item())},
         "achieved_gbps": B / (wall / args.steps) / 1e9,
         "roofline": {"bound": "hbm", "achieved": B / (wall / args.steps) / 1e9 / world, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": B / (wall / args.steps) / 1e9 / world / HBM_PEAK_GBPS, "traffic": None,
@@ -227,6 +274,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
+    ap.add_argument("--config", default="A", choices=["A", "R", "G", "P1", "P"],
+                    help="A (default): arxiv-shaped GCN sum feat=128, the headline line (weak scaling for N > 1); "
+                         "R/G/P1: the other 1-GPU configs; P (N > 1): products-shaped GCN feat=100, strong scaling")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line.  RCCL prints a version banner through C stdio that is flushed at
@@ -259,7 +309,9 @@ def main():
     else:
         if args.gpus != 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with that many processes" % args.gpus)
-        out = run_single(args, dev)
+        if args.config == "P":
+            args.config = "P1"
+        out = run_single(args, dev) if args.config == "A" else run_other_config(args, dev)
     if rank == 0 and out is not None:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
