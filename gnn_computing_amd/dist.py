@@ -120,7 +120,7 @@ class HaloExchange:
     def exchange(self, x_local, x_halo, send_buf=None, async_op=False):
         """Fills x_halo[n_halo, F] with the halo rows; x_local[n_local, F] holds this rank's rows.
         Returns the work handle when async_op (None for a single rank / offline plan)."""
-        if self.world == 1 or self.offline:
+        if self.offline or (self.world == 1 and not (dist.is_available() and dist.is_initialized())):
             return None
         feat = x_local.shape[1]
         if send_buf is None or send_buf.shape[0] < self.n_send:
