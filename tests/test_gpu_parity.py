@@ -692,3 +692,59 @@ def test_check_csr_flags_bad_input():
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, 4, 4)
     assert agg.check_csr() == (1, 2)
     assert agg.check_csr(num_cols=6) == (1, 1)
+
+
+def test_fuzz_gcn_modes_reductions_alignment():
+    """Randomised sweep: graph shape, feature width (incl. odd widths), mode, reduction, weights on/off and
+    deliberately mis-aligned feature buffers (forces the narrower vector paths) -- always against the oracle."""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        V = int(rng.integers(1, 400))
+        E = int(rng.integers(0, 30 * V))
+        F = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 31, 32, 33, 64, 100, 128, 130, 256]))
+        ptr, idx = gnc.graph.uniform_random_csr(V, E, seed=1000 + case)
+        if E and rng.random() < 0.3:  # a hub row
+            hub = int(rng.integers(0, V))
+            deg = np.diff(ptr).astype(np.int64)
+            deg[hub] += int(rng.integers(200, 3000))
+            ptr = np.zeros(V + 1, np.int32)
+            ptr[1:] = np.cumsum(deg)
+            idx = rng.integers(0, V, int(ptr[-1])).astype(np.int32)
+            E = int(ptr[-1])
+        x = rng.standard_normal((V, F)).astype(np.float32)
+        val = rng.standard_normal(E).astype(np.float32) if rng.random() < 0.7 else None
+        off = int(rng.choice([0, 0, 1, 2]))  # element offset of the feature buffers inside their allocation
+        xb = torch.zeros(V * F + 4, device=DEV)
+        yb = torch.full((V * F + 4,), 7.0, device=DEV)
+        dx = xb[off:off + V * F].view(V, F)
+        dy = yb[off:off + V * F].view(V, F)
+        dx.copy_(dev(x))
+        agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if val is None else dev(val), F, F)
+        mode = str(rng.choice(["rows", "scheduled", "balanced"]))
+        reduce = str(rng.choice(["sum", "mean", "max"]))
+        ng = int(rng.choice([1, 3, 16, 32, 64]))
+        if mode == "scheduled":
+            agg.schedule(gnc.Schedule.neighbor_grouping, [ng])
+        elif mode == "balanced":
+            agg.schedule_balanced(int(rng.choice([0, 4, 64])))
+        agg.run(dx, dy, 512, mode, reduce=reduce)
+        got = dy.cpu().numpy()
+        what = "case %d V=%d E=%d F=%d %s %s off=%d" % (case, V, E, F, mode, reduce, off)
+        if reduce == "max":
+            assert np.array_equal(got, orc.gcn_max(ptr, idx, val, x)), what
+            continue
+        if mode == "rows":
+            ref = orc.gcn_seq(ptr, idx, val, x) if reduce == "sum" else orc.gcn_mean(ptr, idx, val, x)
+            assert np.array_equal(got, ref), what
+            continue
+        if mode == "scheduled":
+            ps, tg = orc.neighbor_grouping(ptr, ng)
+            ref = orc.gcn_grouped(ps, tg, idx, val, x, V)
+        else:
+            ch, sg = agg.balanced_params()
+            ps, tg = orc.neighbor_grouping(ptr, ch)
+            ref = orc.gcn_grouped(ps, tg, idx, val, x, V, seg=sg)
+        if reduce == "mean":
+            ref = ref / np.maximum(np.diff(ptr), 1)[:, None].astype(np.float32)
+        assert np.array_equal(got, ref), what
+        assert float(yb[:off].sum()) == 7.0 * off and float(yb[off + V * F:].sum()) == 7.0 * (4 - off), what + " (out of bounds write)"
