@@ -748,3 +748,43 @@ def test_fuzz_gcn_modes_reductions_alignment():
             ref = ref / np.maximum(np.diff(ptr), 1)[:, None].astype(np.float32)
         assert np.array_equal(got, ref), what
         assert float(yb[:off].sum()) == 7.0 * off and float(yb[off + V * F:].sum()) == 7.0 * (4 - off), what + " (out of bounds write)"
+
+
+def test_fuzz_gat_modes_heads():
+    """Randomised GAT sweep: heads, head width (incl. widths that force the scalar path), mode, hub rows."""
+    rng = np.random.default_rng(4242)
+    for case in range(40):
+        V = int(rng.integers(2, 300))
+        E = int(rng.integers(1, 20 * V))
+        H = int(rng.choice([1, 2, 3, 4, 8]))
+        D = int(rng.choice([1, 2, 4, 5, 8, 16, 32, 64]))
+        F = H * D
+        ptr, idx = gnc.graph.uniform_random_csr(V, E, seed=3000 + case)
+        if rng.random() < 0.3:
+            deg = np.diff(ptr).astype(np.int64)
+            deg[int(rng.integers(0, V))] += int(rng.integers(300, 2500))
+            ptr = np.zeros(V + 1, np.int32)
+            ptr[1:] = np.cumsum(deg)
+            idx = rng.integers(0, V, int(ptr[-1])).astype(np.int32)
+            E = int(ptr[-1])
+        x = rng.standard_normal((V, F)).astype(np.float32)
+        att = (rng.standard_normal((V, H, 2)) * 0.5).astype(np.float32)
+        gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+        mode = str(rng.choice(["rows", "scheduled", "balanced"]))
+        ng = int(rng.choice([2, 16, 32]))
+        if mode == "scheduled":
+            gat.schedule(gnc.Schedule.neighbor_grouping, [ng])
+        elif mode == "balanced":
+            gat.schedule_balanced(int(rng.choice([0, 4, 64])))
+        y = torch.full((V, F), 7.0, device=DEV)
+        gat.run(dev(x), dev(att), y, 128, mode, heads=H)
+        if mode == "rows":
+            ref = orc.gat_fused(ptr, idx, att, x, H)
+        elif mode == "scheduled":
+            ref = orc.gat_grouped(*orc.neighbor_grouping(ptr, ng), idx, att, x, V, H)[0]
+        else:
+            ch, sg = gat.balanced_params()
+            ref = orc.gat_grouped(*orc.neighbor_grouping(ptr, ch), idx, att, x, V, H, seg=sg)[0]
+        what = "case %d V=%d E=%d H=%d D=%d %s" % (case, V, E, H, D, mode)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=5e-6, atol=2e-6, err_msg=what)
+        assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0), what
