@@ -138,7 +138,7 @@ def run_single(args, dev):
     # sanity: the timed kernel's output matches the oracle on this very input (outside the timed region)
     from oracle import oracle as orc
     ps, ix, tg = agg1.get_schedule(mode) if mode != "rows" else (None, None, None)
-    seg = agg1.balanced_params()[1] if mode == "balanced" else 0
+    seg = agg1.mode_params(mode)[1] if mode != "rows" else 0
     ref = (orc.gcn_seq(nptr, nidx, val, x[rows]) if mode == "rows"
            else orc.gcn_grouped(ps, tg, nidx, val, x[rows], V, seg=seg))
     assert np.array_equal(y.cpu().numpy(), ref), "bench output differs from the oracle"

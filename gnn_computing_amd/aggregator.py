@@ -93,6 +93,12 @@ class Aggregator:
         check(lib().gnnagg_balanced_params(self._h, ctypes.byref(ch), ctypes.byref(sg)))
         return ch.value, sg.value
 
+    def mode_params(self, mode="scheduled"):
+        """(chunk, seg_chunks) of any mode's summation order (gnnagg_mode_params)."""
+        ch, sg = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib().gnnagg_mode_params(self._h, MODE[mode], ctypes.byref(ch), ctypes.byref(sg)))
+        return ch.value, sg.value
+
     @property
     def num_target(self):
         """aggregator.h:126"""

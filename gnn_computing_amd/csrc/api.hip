@@ -135,7 +135,8 @@ struct Ctx {
     std::vector<int> h_ptr;  // host mirror, fetched on first schedule (reference ctor: aggregator.h:50)
     Schedule sched[2];       // [0] user schedule (MODE_SCHEDULED), [1] balanced (MODE_BALANCED; GAT, and the
                              //     host arrays that describe the GCN plan's summation order)
-    BalancedPlan plan;       // GCN balanced mode
+    BalancedPlan plan;       // balanced mode
+    BalancedPlan plan_sched; // `scheduled = 1` with a neighbor-grouping schedule, when the plan kernel suits that NG
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -270,11 +271,10 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
     return finalize_schedule(c, s);
 }
 
-static int build_balanced_plan(Ctx *c, int chunk)
+static int build_plan_into(Ctx *c, BalancedPlan &p, int chunk, bool describe_in_sched1, double *padding_ratio)
 {
     int rc = fetch_host_ptr(c);
     if (rc) return rc;
-    BalancedPlan &p = c->plan;
     p.reset();
     p.chunk = chunk;
     const int V = c->V;
@@ -316,18 +316,32 @@ static int build_balanced_plan(Ctx *c, int chunk)
     if ((rc = p.mrow_id.upload(mrow_id))) return rc;
     if ((rc = p.mrow_ptr.upload(mrow_ptr))) return rc;
     if ((rc = p.big_rows.upload(big))) return rc;
-    // host description of the summation order (chunks of `chunk` edges per row) for get_schedule()
-    Schedule &s = c->sched[1];
-    s.reset();
-    s.kind = GNNAGG_SCHED_NEIGHBOR_GROUPING;
-    const int G = neighbor_grouping(c->h_ptr.data(), chunk, V, nullptr, nullptr);
-    s.h_ptr_s.resize((size_t)G + 1);
-    s.h_target.resize((size_t)G);
-    neighbor_grouping(c->h_ptr.data(), chunk, V, s.h_ptr_s.data(), s.h_target.data());
-    s.num_target = G;
+    if (padding_ratio) {
+        // lane groups a segment workgroup occupies (rounds x groups, taken as 8 groups) vs the chunks it really has
+        long padded = 0, chunks = p.n0;
+        for (const Seg &sg : segs) {
+            const long nch = ((long)sg.end - sg.beg + chunk - 1) / chunk;
+            padded += 8 * ((nch + 7) / 8);
+            chunks += nch;
+        }
+        *padding_ratio = chunks > 0 ? (double)(padded + p.n0) / (double)chunks : 1.0;
+    }
+    if (describe_in_sched1) {
+        // host description of the summation order (chunks of `chunk` edges per row) for get_schedule()
+        Schedule &s = c->sched[1];
+        s.reset();
+        s.kind = GNNAGG_SCHED_NEIGHBOR_GROUPING;
+        const int G = neighbor_grouping(c->h_ptr.data(), chunk, V, nullptr, nullptr);
+        s.h_ptr_s.resize((size_t)G + 1);
+        s.h_target.resize((size_t)G);
+        neighbor_grouping(c->h_ptr.data(), chunk, V, s.h_ptr_s.data(), s.h_target.data());
+        s.num_target = G;
+    }
     p.valid = true;
     return GNNAGG_OK;
 }
+
+static int build_balanced_plan(Ctx *c, int chunk) { return build_plan_into(c, c->plan, chunk, true, nullptr); }
 
 static int build_rows_plan(Ctx *c)
 {
@@ -413,8 +427,8 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
-    if (mode == GNNAGG_MODE_BALANCED && c->use_plan) {
-        BalancedPlan &p = c->plan;
+    if ((mode == GNNAGG_MODE_BALANCED && c->use_plan) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
+        BalancedPlan &p = mode == GNNAGG_MODE_BALANCED ? c->plan : c->plan_sched;
         GcnPlanLaunch P;
         P.t0 = p.t0.p; P.t1 = p.t1.p; P.n0 = p.n0; P.n1 = p.n1; P.chunk = p.chunk;
         P.t0_cost_prefix = p.t0_cost_prefix.data();
@@ -490,8 +504,8 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
-    if (mode == GNNAGG_MODE_BALANCED && c->use_plan) {
-        BalancedPlan &p = c->plan;
+    if ((mode == GNNAGG_MODE_BALANCED && c->use_plan) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
+        BalancedPlan &p = mode == GNNAGG_MODE_BALANCED ? c->plan : c->plan_sched;
         GatPlanLaunch P;
         P.t0 = p.t0.p; P.t1 = p.t1.p; P.n0 = p.n0; P.n1 = p.n1; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
         P.hubs.mrow_id = p.mrow_id.p; P.hubs.mrow_ptr = p.mrow_ptr.p; P.hubs.n_mrows = p.n_mrows;
@@ -590,14 +604,27 @@ static int do_schedule(Ctx *c, int kind, const int *param, int total_v)
 {
     if (!param) return fail(GNNAGG_ERR_ARG, "null schedule parameter array");
     switch (kind) {
-        case GNNAGG_SCHED_NEIGHBOR_GROUPING:
-            return build_grouping(c, c->sched[0], param[0], kind);
+        case GNNAGG_SCHED_NEIGHBOR_GROUPING: {
+            int rc = build_grouping(c, c->sched[0], param[0], kind);
+            c->plan_sched.reset();
+            if (rc == GNNAGG_OK && c->use_plan) {
+                // the reference's groups of NG edges are the plan's chunks; use the plan kernel (in-workgroup ordered
+                // fold) unless NG is so small that most rows would occupy a whole workgroup for a handful of edges
+                double ratio = 0.0;
+                rc = build_plan_into(c, c->plan_sched, param[0], false, &ratio);
+                if (rc == GNNAGG_OK && ratio > 1.5) c->plan_sched.reset();
+            }
+            return rc;
+        }
         case GNNAGG_SCHED_LOCALITY:
+            c->plan_sched.reset();
             return build_locality(c, c->sched[0], param[0], 0, total_v, kind);
         case GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING:
             if (param[1] <= 0) return fail(GNNAGG_ERR_ARG, "neighbor group size must be >= 1");
+            c->plan_sched.reset();
             return build_locality(c, c->sched[0], param[0], param[1], total_v, kind);
         case GNNAGG_SCHED_NOP:
+            c->plan_sched.reset();
             c->sched[0].reset();
             return GNNAGG_OK;
         default:
@@ -712,21 +739,31 @@ int gnnagg_schedule_balanced(gnnagg_handle h, int chunk)
     return build_grouping(c, c->sched[1], chunk > 0 ? chunk : pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
 }
 
-int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks)
+int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks)
 {
     GET_CTX(h);
+    if (mode == GNNAGG_MODE_ROWS) {
+        if (chunk) *chunk = 0x7fffffff;
+        if (seg_chunks) *seg_chunks = 0;
+        return GNNAGG_OK;
+    }
     Schedule *s = nullptr;
-    int rc = get_sched(c, GNNAGG_MODE_BALANCED, &s);
+    int rc = get_sched(c, mode, &s);
     if (rc) return rc;
-    const bool plan = c->use_plan != 0;
+    const bool plan = mode == GNNAGG_MODE_BALANCED ? c->use_plan != 0 : c->plan_sched.valid;
     if (chunk) {
         int mx = 0;
-        if (plan) mx = c->plan.chunk;
+        if (plan) mx = mode == GNNAGG_MODE_BALANCED ? c->plan.chunk : c->plan_sched.chunk;
         else for (int g = 0; g < s->num_target; ++g) mx = std::max(mx, s->h_ptr_s[g + 1] - s->h_ptr_s[g]);
         *chunk = mx;
     }
     if (seg_chunks) *seg_chunks = plan ? kSegChunksHost : 0;
     return GNNAGG_OK;
+}
+
+int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks)
+{
+    return gnnagg_mode_params(h, GNNAGG_MODE_BALANCED, chunk, seg_chunks);
 }
 
 int gnnagg_num_target(gnnagg_handle h, int mode, int *out)

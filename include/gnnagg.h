@@ -109,6 +109,12 @@ int gnnagg_schedule_balanced(gnnagg_handle h, int chunk);
  * in ascending order inside segments of seg_chunks chunks and the segment sums are then added in ascending
  * order; 0 means one flat ascending fold.  (Rows of at most seg_chunks chunks are identical either way.) */
 int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks);
+/* The same for any mode.  GNNAGG_MODE_SCHEDULED with a neighbor-grouping schedule: *chunk = NG and *seg_chunks = 16
+ * when the plan kernel runs it (the reference adds the group partials with fp32 atomics in arbitrary order,
+ * aggr_gcn.h:112, so every fixed order is one of its outcomes up to association), 0 (flat ascending fold) when NG is
+ * so small that the one-item-per-lane-group kernel is used, and always 0 for the locality schedules.
+ * GNNAGG_MODE_ROWS: one chain per row (*chunk = INT_MAX, *seg_chunks = 0). */
+int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks);
 /* Aggregator::num_target (aggregator.h:126), and the scheduled arrays copied to host buffers
  * (any may be NULL): ptr_s[num_target+1], idx_s[ptr_s[num_target]], target[num_target], val_s. */
 int gnnagg_num_target(gnnagg_handle h, int mode, int *out);

@@ -76,7 +76,9 @@ def test_gcn_neighbor_grouping_bit_exact(V, E, F, ng):
     assert np.array_equal(ps, ps_ref) and np.array_equal(tg, tg_ref) and np.array_equal(ix, idx)
     y = torch.full((V, F), 7.0, device=DEV)
     agg.run(dev(x), y, 512, 1)
-    ref = orc.gcn_grouped(ps_ref, tg_ref, idx, val, x, V)
+    chunk, seg = agg.mode_params("scheduled")  # (NG, 16) on the plan kernel, (NG, 0) on the item kernel (tiny NG)
+    assert chunk == ng
+    ref = orc.gcn_grouped(ps_ref, tg_ref, idx, val, x, V, seg=seg)
     assert np.array_equal(y.cpu().numpy(), ref)
     # and against the canonical CSR-order chain within the fp32 bound
     assert_within(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x), "NG vs CSR order")
@@ -164,7 +166,7 @@ def test_gcn_update_val_aliases():
     assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, v2, x))
     agg.run(dev(x), y, 128, 1)
     ps, tg = orc.neighbor_grouping(ptr, 16)
-    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, v2, x, V))
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, v2, x, V, seg=agg.mode_params("scheduled")[1]))
 
 
 def test_csr2edgelist_and_edgewise():
@@ -246,7 +248,7 @@ def test_gat_scheduled(F, H, ng):
     newval = torch.full((E, H), 7.0, device=DEV)
     agg.run(dev(x), dev(att), y, 128, 1, heads=H, newval=newval)
     ps, tg = orc.neighbor_grouping(ptr, ng)
-    ref, ref_newval, _ = orc.gat_grouped(ps, tg, idx, att, x, V, H)
+    ref, ref_newval, _ = orc.gat_grouped(ps, tg, idx, att, x, V, H, seg=agg.mode_params("scheduled")[1])
     assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "gat scheduled")
     np.testing.assert_allclose(newval.cpu().numpy(), ref_newval, rtol=1e-6)
     # the fused result agrees with the unscheduled one (same math, different association)
@@ -321,7 +323,10 @@ def test_flat_reference_api():
     L.GCN_run_impl(at, dx.data_ptr(), y.data_ptr(), 128, 1, F)
     torch.cuda.synchronize()
     ps, tg = orc.neighbor_grouping(ptr, 32)
-    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+    ch, sg = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(L.gnnagg_mode_params(at, _lib.MODE_SCHEDULED, ctypes.byref(ch), ctypes.byref(sg)))
+    assert ch.value == 32
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=sg.value))
     L.GCN_run_impl(at, dx.data_ptr(), y.data_ptr(), 128, 0, F)
     torch.cuda.synchronize()
     assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x))
@@ -425,7 +430,7 @@ def test_hub_rows_block_cooperative_combine(F, ng):
     ps, tg = orc.neighbor_grouping(ptr, ng)
     y = torch.full((V, F), 7.0, device=DEV)
     agg.run(dev(x), y, 512, 1)
-    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V))
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=agg.mode_params("scheduled")[1]))
     agg.run(dev(x), y, 512, 1, reduce="max")
     assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))
     # rows mode keeps the canonical CSR-order chain even for the hubs (workgroup-per-row path), all reductions
@@ -450,7 +455,7 @@ def test_hub_rows_block_cooperative_combine(F, ng):
         gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
         gat.schedule(gnc.Schedule.neighbor_grouping, [ng])
         gat.run(dev(x), dev(att), y, 128, 1, heads=H)
-        ref, _, _ = orc.gat_grouped(ps, tg, idx, att, x, V, H)
+        ref, _, _ = orc.gat_grouped(ps, tg, idx, att, x, V, H, seg=gat.mode_params("scheduled")[1])
         np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
 
 
@@ -533,7 +538,7 @@ def test_run_with_nn():
     t = torch.full((V, OUT), 7.0, device=DEV)
     agg.run_with_nn(dev(x), y, dev(w), t, 128, 1)
     ps, tg = orc.neighbor_grouping(ptr, 16)
-    y_ref = orc.gcn_grouped(ps, tg, idx, val, x, V)
+    y_ref = orc.gcn_grouped(ps, tg, idx, val, x, V, seg=agg.mode_params("scheduled")[1])
     assert np.array_equal(y.cpu().numpy(), y_ref)
     assert np.array_equal(t.cpu().numpy(), orc.matmul_nn(y_ref, w))
 
@@ -652,7 +657,7 @@ def test_hipgraph_capture_and_replay(mode):
     if mode == "rows":
         ref = orc.gcn_seq(ptr, idx, val, x2)
     elif mode == "scheduled":
-        ref = orc.gcn_grouped(*orc.neighbor_grouping(ptr, 16), idx, val, x2, V)
+        ref = orc.gcn_grouped(*orc.neighbor_grouping(ptr, 16), idx, val, x2, V, seg=agg.mode_params("scheduled")[1])
     else:
         ch, sg = agg.balanced_params()
         ref = orc.gcn_grouped(*orc.neighbor_grouping(ptr, ch), idx, val, x2, V, seg=sg)
@@ -739,7 +744,7 @@ def test_fuzz_gcn_modes_reductions_alignment():
             continue
         if mode == "scheduled":
             ps, tg = orc.neighbor_grouping(ptr, ng)
-            ref = orc.gcn_grouped(ps, tg, idx, val, x, V)
+            ref = orc.gcn_grouped(ps, tg, idx, val, x, V, seg=agg.mode_params("scheduled")[1])
         else:
             ch, sg = agg.balanced_params()
             ps, tg = orc.neighbor_grouping(ptr, ch)
@@ -781,7 +786,7 @@ def test_fuzz_gat_modes_heads():
         if mode == "rows":
             ref = orc.gat_fused(ptr, idx, att, x, H)
         elif mode == "scheduled":
-            ref = orc.gat_grouped(*orc.neighbor_grouping(ptr, ng), idx, att, x, V, H)[0]
+            ref = orc.gat_grouped(*orc.neighbor_grouping(ptr, ng), idx, att, x, V, H, seg=gat.mode_params("scheduled")[1])[0]
         else:
             ch, sg = gat.balanced_params()
             ref = orc.gat_grouped(*orc.neighbor_grouping(ptr, ch), idx, att, x, V, H, seg=sg)[0]
