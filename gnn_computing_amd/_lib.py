@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnnagg.so")
+LIB_PATH = os.environ.get("GNNAGG_LIB", os.path.join(_HERE, "libgnnagg.so"))  # override: A/B builds in scripts/
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_IO = 0, 1, 2, 3, 4
 SCHED_LOCALITY, SCHED_NEIGHBOR_GROUPING, SCHED_LOCALITY_NEIGHBOR_GROUPING, SCHED_NOP = 0, 1, 2, 3
