@@ -123,7 +123,7 @@ static constexpr int kSegChunksHost = 16;  // kSegChunks in kernels.hip
 struct RowsPlan {
     bool valid = false;
     int n0 = 0, n1 = 0, long_deg = 256;
-    DevBuf<int> r0, r1;
+    DevBuf<int> r0, r1, r1_rows;
     std::vector<long> r0_cost_prefix;
 };
 
@@ -412,6 +412,11 @@ static int build_rows_plan(Ctx *c)
     p.n1 = (int)(r1.size() / 4);
     if ((rc = p.r0.upload(r0))) return rc;
     if ((rc = p.r1.upload(r1))) return rc;
+    {
+        std::vector<int> rows;
+        for (const Long &l : longs) rows.push_back(l.row);
+        if ((rc = p.r1_rows.upload(rows))) return rc;
+    }
     p.valid = true;
     return GNNAGG_OK;
 }
@@ -449,7 +454,13 @@ static int get_sched(Ctx *c, int mode, Schedule **out)
     return GNNAGG_OK;
 }
 
-static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0)
+struct NnRequest {  // run_with_nn: transformed[V, cols] = y . weight[feat, cols]
+    const float *weight;
+    float *out;
+    int cols;
+};
+
+static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0, const NnRequest *nn = nullptr)
 {
     if ((flags & GNNAGG_FLAG_ACCUMULATE) && (mode != GNNAGG_MODE_BALANCED || reduce != GNNAGG_REDUCE_SUM || !c->use_plan))
         return fail(GNNAGG_ERR_ARG, "GNNAGG_FLAG_ACCUMULATE needs GNNAGG_MODE_BALANCED and GNNAGG_REDUCE_SUM");
@@ -477,6 +488,9 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             if ((rc = c->partial.reserve((size_t)p.n_slots * feat))) return rc;
             P.partial = c->partial.p;
         }
+        if (nn) {
+            P.nn_weight = nn->weight; P.nn_out = nn->out; P.nn_cols = nn->cols;
+        }
         return launch_gcn_plan(P, c->stream);
     }
     if (mode == GNNAGG_MODE_ROWS && c->use_plan) {
@@ -499,8 +513,16 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         P.t0 = p.r0.p; P.n0 = p.n0; P.t0_cost_prefix = p.r0_cost_prefix.data();
         P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
         P.xcd_remap = c->xcd_remap; P.num_rows = c->V;
+        const bool nn_rows_ok = nn && (p.n1 == 0 || feat <= 15000);
+        if (nn_rows_ok) {  // short rows: epilogue of the plan kernel (or the GEMM right behind it)
+            P.nn_weight = nn->weight; P.nn_out = nn->out; P.nn_cols = nn->cols;
+        }
         rc = launch_gcn_plan(P, c->stream);
         if (p.n1 > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // join
+        if (rc || !nn) return rc;
+        if (!nn_rows_ok) return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
+        if (p.n1 > 0)  // the long rows' products, once their chains have joined
+            rc = launch_dense_rows(p.r1_rows.p, p.n1, y, nn->weight, nn->out, feat, nn->cols, c->stream);
         return rc;
     }
     GcnLaunch L;
@@ -529,7 +551,9 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             L.partial = c->partial.p;
         }
     }
-    return launch_gcn(L, c->stream);
+    rc = launch_gcn(L, c->stream);
+    if (rc || !nn) return rc;
+    return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
 }
 
 static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat, int heads, float slope, int mode,
@@ -862,9 +886,8 @@ int gnnagg_gcn_run_with_nn(gnnagg_handle h, const float *d_x, float *d_y, const 
 {
     GET_CTX(h);
     if (!d_weight || !d_transformed || feat_out <= 0) return fail(GNNAGG_ERR_ARG, "bad run_with_nn arguments");
-    int rc = gcn_run(c, d_x, d_y, feat_in, mode, GNNAGG_REDUCE_SUM);
-    if (rc) return rc;
-    return launch_dense_nn(d_y, d_weight, d_transformed, c->V, feat_out, feat_in, c->stream);
+    const NnRequest nn = {d_weight, d_transformed, feat_out};
+    return gcn_run(c, d_x, d_y, feat_in, mode, GNNAGG_REDUCE_SUM, 0, &nn);
 }
 
 int gnnagg_gcn_run_clock(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, unsigned long long *d_timer,

@@ -86,6 +86,10 @@ struct GcnPlanLaunch {
     int xcd_remap = 2;
     int accumulate = 0;  // y += A.x (sum only); rows without edges keep their value
     int num_rows = 0;    // rows of y
+    // dense combine as the epilogue (run_with_nn): nn_out[V, nn_cols] = y . nn_weight[feat, nn_cols]
+    const float *nn_weight = nullptr;
+    float *nn_out = nullptr;
+    int nn_cols = 0;
 };
 
 // Long rows of the rows mode (`scheduled = 0`, canonical CSR-order chains): k_gcn_rows_long.
@@ -162,6 +166,7 @@ int launch_spmm_naive(const int *ptr, const int *idx, const float *val, const fl
 int launch_validate(const float *ref, const float *ans, int num, int *d_diff, void *stream);
 int launch_validate_reordered(const float *ref, const float *ans, const int *map, int V, int feat, int *d_diff,
                               void *stream);
+int launch_dense_rows(const int *rows, int n_rows, const float *Y, const float *W, float *out, int K, int N, void *stream);
 int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream);
 int launch_check_csr(const int *ptr, const int *idx, int V, int E, int num_cols, int *d_counts, void *stream);
 int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out, void *stream);

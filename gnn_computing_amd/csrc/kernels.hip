@@ -377,6 +377,224 @@ __global__ __launch_bounds__(kBlock) void k_gcn_plan(const PlanArgs a)
     else store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
 }
 
+// ------------------------------------------------- aggregation with the dense combine as its epilogue
+// transformed[V,N] = (A . X)[V,K] . W[K,N] in one pass (reference aggr_gcn_nn, aggr_gcn.h:304-359, called by
+// run_with_nn :491-499).  The aggregation spreads the K columns of a row over the lanes of a group while the matrix
+// cores want rows across lanes, so finished rows meet in LDS: a workgroup aggregates 32 short rows (32/GPB passes
+// of the plan kernel's descriptor path), stages them as a [32][K] tile (odd pitch: conflict-free operand reads),
+// and after ONE barrier its 4 wavefronts each take 16x16 output sub-tiles and run the full-K chain on
+// v_mfma_f32_16x16x4_f32 -- f32 in / f32 accumulate, an ascending-k fmaf chain, so the result is bit-for-bit the
+// separate GEMM's (and the oracle's).  W (K*N*4 bytes, 16 KB at 128x32) is read through L1/L2, not staged.
+// Unlike the reference (partial . W added with atomics per neighbor group) W is applied to the FINAL row: rows that
+// are folded from several chunks (segment path, k_combine) get their product from k_dense_rows afterwards.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef NN_ROWS
+#define NN_ROWS 16
+#endif
+static constexpr int kNnRows = NN_ROWS;  // short rows a workgroup of the fused kernel aggregates and multiplies
+
+// out_row[j] = sum_k yrow[k] * W[k, j] for j = tid, tid + nthreads, ...: one ascending-k fmaf chain per output (the order of
+// the MFMA tiles and of the oracle's GEMM); yrow lives in LDS.  For the few rows that are finished one at a time.
+__device__ __forceinline__ void row_times_weight(const float *yrow, int K, const float *__restrict__ W, int N, float *out_row,
+                                                 int tid, int nthreads)
+{
+    for (int j = tid; j < N; j += nthreads) {
+        float o = 0.0f;
+        int k = 0;
+        for (; k + 8 <= K; k += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = W[(size_t)(k + u) * N + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o = fmaf(yrow[k + u], wv[u], o);
+        }
+        for (; k < K; ++k) o = fmaf(yrow[k], W[(size_t)k * N + j], o);
+        out_row[j] = o;
+    }
+}
+
+struct NnArgs {
+    const float *weight;  // [K, N] row-major
+    float *out;           // [V, N]
+    int n_out;
+};
+
+// tile: [32][pitch] floats in LDS, columns [K, roundup4(K)) zero; tile_rows[32] = output row or -1.
+// Call right after this thread's tile writes: the function holds the barrier that completes the tile, and issues the
+// first W operands BEFORE it so their latency overlaps the wait for the slowest wavefront.  KB = MFMAs per operand
+// batch; the batch is branch-free (k-quads past K are clamped loads with zeroed operands: 0 * 0 leaves the chain as is).
+template <int KB, int ROWS>
+__device__ __forceinline__ void tile_times_weight(const float *tile, int pitch, const int *tile_rows, const float *W, int K,
+                                                  int Kw, int N, float *out)
+{
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int ncb = (N + 15) >> 4;
+    const int Kf = K & ~3;     // k covered by whole quads
+    const int kq = lane >> 4;  // k offset inside one MFMA (A: row = lane % 16, k = lane / 16; B: k = lane / 16, col = lane % 16)
+    // W operands as buffer loads: the per-lane byte offset in one VGPR (out of range for the padding columns, which
+    // then read 0), the k step in an SGPR -- no per-load address registers
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W), 0, Kw * N * 4, 0x00020000);
+    bool synced = false;
+    constexpr int RH = ROWS / 16;  // 16-row halves of the tile
+#pragma unroll 1
+    for (int st = wave; st < RH * ncb; st += 4) {
+        const int rh = st % RH, cb = st / RH;
+        const int col = cb * 16 + (lane & 15);
+        const bool cok = col < N;
+        const float *arow = tile + (rh * 16 + (lane & 15)) * pitch + kq;
+        const int voff = cok ? (kq * N + col) * 4 : 0x7ffffff0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int k0 = 0; k0 < Kf; k0 += 4 * KB) {
+            float av[KB], bv[KB];
+#pragma unroll
+            for (int t = 0; t < KB; ++t) {
+                const int kk = k0 + 4 * t, kc = kk < Kf ? kk : Kf - 4;
+                const float b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, voff, kc * N * 4, 0));
+                bv[t] = kk < Kf ? b : 0.f;
+            }
+            if (!synced) {
+                __syncthreads();
+                synced = true;
+            }
+#pragma unroll
+            for (int t = 0; t < KB; ++t) {
+                const int kk = k0 + 4 * t, kc = kk < Kf ? kk : Kf - 4;
+                const float v = arow[kc];
+                av[t] = kk < Kf ? v : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < KB; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], acc, 0, 0, 0);
+        }
+        if (!synced) {
+            __syncthreads();
+            synced = true;
+        }
+        if (K != Kf) {  // ragged last quad: k = Kf + kq valid only below K (the tile's padding columns hold 0)
+            const float b = (cok && Kf + kq < K) ? W[(size_t)(Kf + kq) * N + col] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[Kf], b, acc, 0, 0, 0);
+        }
+        // D layout: col = lane % 16, row = 4 * (lane / 16) + reg
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = tile_rows[rh * 16 + 4 * kq + v];
+            if (r >= 0 && cok) out[(size_t)r * N + col] = acc[v];
+        }
+    }
+    if (!synced) __syncthreads();
+}
+
+template <int VEC, int GROUP, bool IS_MAX>
+__global__ __launch_bounds__(kBlock) void k_gcn_plan_nn(const PlanArgs a, const NnArgs w)
+{
+    constexpr int GPB = kBlock / GROUP;
+    constexpr int ROWS = GPB > kNnRows ? GPB : kNnRows;  // rows of the tile
+    constexpr int PITCH = GROUP * VEC + 1;
+    constexpr int kTile = ROWS * PITCH, kStage = kSegChunks * GROUP * VEC;
+    __shared__ float lds[kTile > kStage ? kTile : kStage];
+    __shared__ int tile_rows[ROWS];
+    const int F = a.feat;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int grp = (int)threadIdx.x / GROUP;
+    const int col = lane * VEC;
+    const bool col_ok = col < F;
+    if ((int)blockIdx.x < a.n1) {  // one segment of a long row: as in k_gcn_plan (ntiles == 1 here)
+        const int4 d = a.t1[blockIdx.x];
+        const int nch = (d.y - d.x + a.chunk - 1) / a.chunk;
+        for (int c = grp; c < nch; c += GPB) {
+            float acc[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+            const int cb = d.x + c * a.chunk;
+            const int ce = cb + a.chunk < d.y ? cb + a.chunk : d.y;
+            chain_edges<VEC, GROUP, IS_MAX>(acc, cb, ce, lane, col_ok, a.idx, a.val, a.x + col, F);
+            store_pack<VEC>(&lds[(c * GROUP + lane) * VEC], acc);
+        }
+        __syncthreads();
+        if (grp == 0 && col_ok) {
+            float acc[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+#pragma unroll
+            for (int c = 0; c < kSegChunks; ++c)
+                if (c < nch) {
+                    const Pack<VEC> p = load_pack<VEC>(&lds[(c * GROUP + lane) * VEC]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        if (IS_MAX) acc[k] = p.v[k] > acc[k] ? p.v[k] : acc[k];
+                        else acc[k] += p.v[k];
+                    }
+                }
+            if (d.z >= 0) {
+                if (a.mean) {
+                    const float dg = (float)(d.y - d.x);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
+                }
+                store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
+                store_pack<VEC>(&lds[col], acc);  // chunk 0's slot of this lane: read by nobody else
+            } else {
+                store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
+            }
+        }
+        if (d.z < 0) return;  // a hub's segment: k_combine finishes the row, k_dense_rows multiplies it
+        __syncthreads();
+        // the row is final: its product, one thread per output column
+        row_times_weight(lds, F, w.weight, w.n_out, w.out + (size_t)d.z * w.n_out, (int)threadIdx.x, kBlock);
+        return;
+    }
+    const int b = logical_block((int)blockIdx.x - a.n1, a.nblocks0, 1, a.remap, a.xr);
+    if (b < 0) return;
+#pragma unroll 1
+    for (int pass = 0; pass < ROWS / GPB; ++pass) {
+        const int slot = pass * GPB + grp;
+        const int item = b * ROWS + slot;
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+        int row = -1;
+        if (item < a.n0) {
+            const int4 d = a.t0[item];
+            row = d.z;
+            if (d.x != d.y) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+                chain_edges<VEC, GROUP, IS_MAX>(acc, d.x, d.y, lane, col_ok, a.idx, a.val, a.x + col, F);
+                if (a.mean) {
+                    const float dg = (float)(d.y - d.x);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
+                }
+            }
+            if (col_ok) {
+                if (a.wt) store_pack_wt<VEC>(a.y, a.ybytes, (size_t)row * F + col, acc);
+                else store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+            }
+        }
+#if !defined(NN_DBG) || NN_DBG != 1
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) lds[slot * PITCH + col + k] = col_ok ? acc[k] : 0.0f;
+        if (lane == 0) tile_rows[slot] = row;
+#endif
+    }
+#if defined(NN_DBG) && (NN_DBG == 1 || NN_DBG == 2)
+    return;
+#endif
+    tile_times_weight<(GROUP * VEC >= 128 ? 32 : GROUP * VEC / 4), ROWS>(lds, PITCH, tile_rows, w.weight, F, F, w.n_out, w.out);
+}
+
+// out[rows[i], :] = Y[rows[i], :] . W for a short list of rows (the rows-mode long rows, finished on the auxiliary
+// stream): one workgroup per row, the row staged in LDS, one chain per output column.
+__global__ __launch_bounds__(kBlock) void k_dense_rows(const int *__restrict__ rows, const float *__restrict__ Y,
+                                                       const float *__restrict__ W, float *__restrict__ out, int K, int N)
+{
+    extern __shared__ float yrow[];
+    const int row = rows[blockIdx.x];
+    for (int k = threadIdx.x; k < K; k += kBlock) yrow[k] = Y[(size_t)row * K + k];
+    __syncthreads();
+    row_times_weight(yrow, K, W, N, out + (size_t)row * N, (int)threadIdx.x, kBlock);
+}
+
 // ---------------------------------------------------------- GCN / SAGE, rows mode (canonical order)
 // `scheduled = 0` keeps the reference's summation order exactly -- one sequential FMA chain per (row, column)
 // in CSR order (aggr_gcn.h:13-35) -- but does not serialise a hub row on one lane group the way a
@@ -492,6 +710,10 @@ struct CombineArgs {
     const int *big_rows;  // indices into mrow_* of the rows with more than kCombineBatch partials
     int n_big, nblocks_small;
     int accumulate;  // 1: y += (sum of partials)
+    // run_with_nn: nn_out[row, :] = (finished row) . nn_weight for the rows finished here (ntiles == 1)
+    const float *nn_weight;
+    float *nn_out;
+    int nn_cols;
     const float *partial;
     const float *partial_den;  // GAT only
     float *y;
@@ -508,12 +730,13 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
 {
     constexpr int ITEMS = kBlock / GROUP;
     const int F = a.feat;
+    __shared__ float stage[kCombineStage * GROUP * VEC];
+    __shared__ float stage_den[IS_GAT ? kCombineStage * 64 : 1];
+    const bool nn = !IS_GAT && a.nn_weight != nullptr;
     if ((int)blockIdx.x >= a.nblocks_small) {
         // ---- big rows (hubs: hundreds of partials): one workgroup per (row, column tile).  All lane
         // groups fetch partial rows in parallel into LDS (kCombineStage rows per round, kCombineBatch
         // loads in flight per group), then each column is summed from LDS in ascending slot order.
-        __shared__ float stage[kCombineStage * GROUP * VEC];
-        __shared__ float stage_den[IS_GAT ? kCombineStage * 64 : 1];
         const int bb = (int)blockIdx.x - a.nblocks_small;
         const int tile = bb % a.ntiles;
         const int m = a.big_rows[bb / a.ntiles];
@@ -562,71 +785,89 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
             }
             __syncthreads();
         }
-        if (!sum_ok) return;
-        if (IS_GAT) {
-            if (den != 0.0f) acc = acc / den;
-        } else if (a.mean) {
-            acc = acc / (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
+        if (sum_ok) {
+            if (IS_GAT) {
+                if (den != 0.0f) acc = acc / den;
+            } else if (a.mean) {
+                acc = acc / (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
+            }
+            if (a.accumulate) acc = a.y[(size_t)row * F + col0 + c] + acc;
+            a.y[(size_t)row * F + col0 + c] = acc;
+            if (nn) stage[c] = acc;  // the staging rounds are over
         }
-        if (a.accumulate) acc = a.y[(size_t)row * F + col0 + c] + acc;
-        a.y[(size_t)row * F + col0 + c] = acc;
+        if (!nn) return;
+        __syncthreads();
+        row_times_weight(stage, F, a.nn_weight, a.nn_cols, a.nn_out + (size_t)row * a.nn_cols, (int)threadIdx.x, kBlock);
         return;
     }
     const int tile = blockIdx.x % a.ntiles;
-    const int m = (blockIdx.x / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
+    const int grp = (int)threadIdx.x / GROUP;
+    const int m = (blockIdx.x / a.ntiles) * ITEMS + grp;
     const int lane = threadIdx.x & (GROUP - 1);
     const int col = (tile * GROUP + lane) * VEC;
-    if (m >= a.n_mrows || col >= a.feat) return;
-    const int s0 = a.mrow_ptr[m], s1 = a.mrow_ptr[m + 1];
-    if (a.n_big > 0 && s1 - s0 > kCombineBatch) return;  // handled by the workgroup-per-row path
-    const int row = a.mrow_id[m];
-    float acc[VEC];
+    bool here = m < a.n_mrows;  // this lane group finishes row m (lane-group uniform)
+    int s0 = 0, s1 = 0;
+    if (here) {
+        s0 = a.mrow_ptr[m];
+        s1 = a.mrow_ptr[m + 1];
+        if (a.n_big > 0 && s1 - s0 > kCombineBatch) here = false;  // handled by the workgroup-per-row path
+    }
+    const bool active = here && col < a.feat;
+    if (!nn && !active) return;
+    const int row = here ? a.mrow_id[m] : 0;
+    if (active) {
+        float acc[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
-    float den = 0.0f;
-    const int h = IS_GAT ? col / a.dhead : 0;
-    // the adds stay in ascending slot order; only the loads are batched (a hub row of a power-law
-    // graph has hundreds of partials -- one dependent load per iteration made this kernel slower
-    // than the aggregation itself)
-    constexpr int CU = kCombineBatch;
-    for (int sb = s0; sb < s1; sb += CU) {
-        Pack<VEC> p[CU];
-        float pd[CU];
+        for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+        float den = 0.0f;
+        const int h = IS_GAT ? col / a.dhead : 0;
+        // the adds stay in ascending slot order; only the loads are batched (a hub row of a power-law
+        // graph has hundreds of partials -- one dependent load per iteration made this kernel slower
+        // than the aggregation itself)
+        constexpr int CU = kCombineBatch;
+        for (int sb = s0; sb < s1; sb += CU) {
+            Pack<VEC> p[CU];
+            float pd[CU];
 #pragma unroll
-        for (int u = 0; u < CU; ++u)
-            if (sb + u < s1) {
-                p[u] = load_pack<VEC>(a.partial + (size_t)(sb + u) * F + col);
-                if (IS_GAT) pd[u] = a.partial_den[(size_t)(sb + u) * a.heads + h];
-            }
-#pragma unroll
-        for (int u = 0; u < CU; ++u)
-            if (sb + u < s1) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if (IS_MAX)
-                        acc[k] = p[u].v[k] > acc[k] ? p[u].v[k] : acc[k];
-                    else
-                        acc[k] += p[u].v[k];
+            for (int u = 0; u < CU; ++u)
+                if (sb + u < s1) {
+                    p[u] = load_pack<VEC>(a.partial + (size_t)(sb + u) * F + col);
+                    if (IS_GAT) pd[u] = a.partial_den[(size_t)(sb + u) * a.heads + h];
                 }
-                if (IS_GAT) den += pd[u];
-            }
-    }
-    if (IS_GAT) {
-        if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+            for (int u = 0; u < CU; ++u)
+                if (sb + u < s1) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        if (IS_MAX)
+                            acc[k] = p[u].v[k] > acc[k] ? p[u].v[k] : acc[k];
+                        else
+                            acc[k] += p[u].v[k];
+                    }
+                    if (IS_GAT) den += pd[u];
+                }
         }
-    } else if (a.mean) {
-        const float d = (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
+        if (IS_GAT) {
+            if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
-    }
-    if (a.accumulate) {
-        const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)row * F + col);
+                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+            }
+        } else if (a.mean) {
+            const float d = (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
+            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
+        }
+        if (a.accumulate) {
+            const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)row * F + col);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
+        }
+        store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+        if (nn) store_pack<VEC>(&stage[grp * GROUP * VEC + col], acc);  // ntiles == 1: col = lane * VEC
     }
-    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+    if (!nn) return;
+    __syncthreads();
+    if (here) row_times_weight(&stage[grp * GROUP * VEC], F, a.nn_weight, a.nn_cols, a.nn_out + (size_t)row * a.nn_cols, lane, GROUP);
 }
 
 // ------------------------------------------------------------------------------- GAT items
@@ -924,7 +1165,8 @@ static int fill_xcd_ranges(const long *cost_prefix, int n_items, int items_per_b
     return longest;
 }
 
-static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max, hipStream_t stream)
+static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max, hipStream_t stream,
+                              const float *nn_weight = nullptr, float *nn_out = nullptr, int nn_cols = 0)
 {
     if (L.wl.n_mrows > 0) {
         CombineArgs c;
@@ -932,6 +1174,7 @@ static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max
         c.partial_den = nullptr; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
         c.heads = 1; c.dhead = L.feat; c.mean = L.reduce == GNNAGG_REDUCE_MEAN;
         c.accumulate = L.accumulate;
+        c.nn_weight = nn_weight; c.nn_out = nn_out; c.nn_cols = nn_cols;
         c.big_rows = L.wl.big_rows; c.n_big = L.wl.n_big;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
         const int nb = c.nblocks_small + c.n_big * g.ntiles;
@@ -942,6 +1185,24 @@ static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max
 #undef CALL_COMB
         HIP_TRY(hipGetLastError());
     }
+    return GNNAGG_OK;
+}
+
+int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream_v);
+
+static bool nn_fusion_enabled()
+{
+    static const int on = getenv("GNNAGG_FUSE_NN") ? atoi(getenv("GNNAGG_FUSE_NN")) : 1;
+    return on != 0;
+}
+
+int launch_dense_rows(const int *rows, int n_rows, const float *Y, const float *W, float *out, int K, int N, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (n_rows <= 0 || N <= 0) return GNNAGG_OK;
+    if ((size_t)K * sizeof(float) > 60 * 1024) return fail(GNNAGG_ERR_ARG, "dense_rows: feature length too large");
+    hipLaunchKernelGGL(k_dense_rows, dim3(n_rows), dim3(kBlock), (size_t)K * sizeof(float), stream, rows, Y, W, out, K, N);
+    HIP_TRY(hipGetLastError());
     return GNNAGG_OK;
 }
 
@@ -962,7 +1223,10 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
         a.wt = (wt_env && !L.accumulate && ybytes < 0x7fffffffULL) ? 1 : 0;
         a.ybytes = (unsigned)ybytes;
     }
-    const int gpb = kBlock / g.group;
+    // dense combine fused as the epilogue when one lane group spans the row and the [32][K] tile fits LDS
+    const bool want_nn = L.nn_weight != nullptr;
+    const bool fuse_nn = want_nn && g.ntiles == 1 && !L.accumulate && nn_fusion_enabled();
+    const int gpb = fuse_nn ? std::max(kNnRows, kBlock / g.group) : kBlock / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
     a.nblocks0 = item_blocks * g.ntiles;
     if (a.remap && a.nblocks0 < 64) a.remap = 0;
@@ -972,6 +1236,21 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
         else grid0 = 8 * fill_xcd_ranges(L.t0_cost_prefix, a.n0, gpb, item_blocks, a.xr) * g.ntiles;
     }
     const int grid = a.n1 * g.ntiles + grid0;
+    if (fuse_nn) {
+        NnArgs w;
+        w.weight = L.nn_weight; w.out = L.nn_out; w.n_out = L.nn_cols;
+        if (grid > 0) {
+#define CALL_PLAN_NN                                                                                                 \
+            if (is_max) hipLaunchKernelGGL((k_gcn_plan_nn<VEC, GROUP, true>), dim3(grid), dim3(kBlock), 0, stream, a, w);   \
+            else        hipLaunchKernelGGL((k_gcn_plan_nn<VEC, GROUP, false>), dim3(grid), dim3(kBlock), 0, stream, a, w);
+            DISPATCH_GEOM(g, CALL_PLAN_NN)
+#undef CALL_PLAN_NN
+            HIP_TRY(hipGetLastError());
+        }
+        GcnLaunch C;
+        C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
+        return launch_combine_gcn(C, g, is_max, stream, L.nn_weight, L.nn_out, L.nn_cols);  // hubs: product in the combine
+    }
     if (grid > 0) {
 #define CALL_PLAN                                                                                            \
         if (is_max) hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, true>), dim3(grid), dim3(kBlock), 0, stream, a);      \
@@ -983,7 +1262,9 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     GcnLaunch C;
     C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
     C.accumulate = L.accumulate;
-    return launch_combine_gcn(C, g, is_max, stream);
+    const int rc = launch_combine_gcn(C, g, is_max, stream);
+    if (rc || !want_nn) return rc;
+    return launch_dense_nn(L.y, L.nn_weight, L.nn_out, L.num_rows, L.nn_cols, L.feat, stream);
 }
 
 int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)

@@ -543,6 +543,45 @@ def test_run_with_nn():
     assert np.array_equal(t.cpu().numpy(), orc.matmul_nn(y_ref, w))
 
 
+@pytest.mark.parametrize("mode", ["rows", "scheduled", "balanced"])
+@pytest.mark.parametrize("F,OUT", [(128, 32), (32, 32), (64, 16), (100, 7), (256, 64), (30, 33), (602, 32), (7, 5)])
+def test_run_with_nn_fused_epilogue(mode, F, OUT):
+    """run_with_nn with the dense combine as the aggregation's epilogue (aggr_gcn.h:304-359,491-499): vout must equal
+    the plain run and transformed must be BIT-exact the ascending-k chain of vout . W -- for short rows (fused tile),
+    segment rows and hubs (row-list kernel), and the widths that fall back to the separate GEMM."""
+    V, E = 3000, 60000
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=5, alpha=1.0)   # a few hub rows with many segments
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    x, val, w = rand((V, F), 1), rand(E, 2), rand((F, OUT), 3)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, OUT)
+    m = {"rows": 0, "scheduled": 1, "balanced": "balanced"}[mode]
+    if mode == "scheduled":
+        agg.schedule(gnc.Schedule.neighbor_grouping, [32])
+    dx, dw = dev(x), dev(w)
+    y_plain = torch.empty((V, F), device=DEV)
+    agg.run(dx, y_plain, 128, m)
+    y = torch.full((V, F), 7.0, device=DEV)
+    t = torch.full((V, OUT), 7.0, device=DEV)
+    agg.run_with_nn(dx, y, dw, t, 128, m)
+    assert torch.equal(y, y_plain)
+    assert np.array_equal(t.cpu().numpy(), orc.matmul_nn(y.cpu().numpy(), w))
+
+
+def test_run_with_nn_mean_empty_rows():
+    V, F, OUT = 70, 64, 32
+    ptr = np.zeros(V + 1, np.int32)
+    ptr[10:] = 3            # rows 0..8 empty, row 9 has 3 edges, the rest empty
+    idx = np.array([1, 2, 3], np.int32)
+    x, w = rand((V, F), 1), rand((F, OUT), 3)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, F, OUT)
+    y = torch.full((V, F), 7.0, device=DEV)
+    t = torch.full((V, OUT), 7.0, device=DEV)
+    agg.run_with_nn(dev(x), y, dev(w), t, 128, "balanced")
+    y_ref = orc.gcn_seq(ptr, idx, np.ones(3, np.float32), x)
+    assert np.array_equal(y.cpu().numpy(), y_ref)
+    assert np.array_equal(t.cpu().numpy(), orc.matmul_nn(y_ref, w))
+
+
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("overlap", [False, True])
 def test_partitioned_gcn_single_gpu_emulation(world, overlap):
