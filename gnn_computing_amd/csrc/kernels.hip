@@ -36,6 +36,14 @@ namespace gnnagg {
     } while (0)
 
 static constexpr int kBlock = 256;  // 4 wavefronts
+// Aggregation kernels: 8 lane groups per workgroup, at most 4 wavefronts -- 64 threads for 8-lane groups (F <= 32),
+// 128 for 16-lane groups, 256 above.  A workgroup's slots are released when its slowest row is done, so narrow
+// features (8 or 4 rows per wavefront) want small workgroups: on the arxiv-shaped input F=32 37.3 -> 30.8 us and
+// F=64 51.0 -> 48.9 us against 256 threads everywhere; F >= 128 is unchanged (and 64 threads there loses the
+// segment path's parallelism: F=256 172 -> 234 us).
+template <int GROUP>
+constexpr int block_of() { return GROUP * 8 < kBlock ? GROUP * 8 : kBlock; }
+static inline int block_for(int group) { return group * 8 < kBlock ? group * 8 : kBlock; }
 // neighbor gathers in flight per lane group.  Measured on the arxiv-shaped input: 4 and 8 tie (73.7 / 74.5 us in community
 // order, 87.9 / 86.8 us un-reordered), 16 loses (96 us, register pressure), and forcing 8 waves/SIMD with
 // __launch_bounds__ spills (137 us): the kernel sits at the memory system's ceiling, not at an occupancy cliff.
@@ -200,7 +208,7 @@ __device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end,
 template <int VEC, int GROUP, bool IS_MAX, bool LIST>
 __device__ __forceinline__ void gcn_items_body(const GcnArgs &a)
 {
-    constexpr int ITEMS = kBlock / GROUP;
+    constexpr int ITEMS = block_of<GROUP>() / GROUP;
     const int b = logical_block(blockIdx.x, a.nblocks, a.ntiles, a.remap, a.xr);
     if (b < 0) return;
     const int tile = b % a.ntiles;
@@ -244,7 +252,7 @@ __device__ __forceinline__ void gcn_items_body(const GcnArgs &a)
 // constant-rate wall clock (s_memrealtime) before and after the work: timer[3b] = earliest start, timer[3b+1] =
 // latest end, timer[3b+2] = hardware CU id (__smid: XCC / SE / CU bits of HW_ID).
 template <int VEC, int GROUP, bool IS_MAX, bool LIST>
-__global__ __launch_bounds__(kBlock) void k_gcn_items(const GcnArgs a)
+__global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_items(const GcnArgs a)
 {
     if (a.timer && (threadIdx.x & 63) == 0) {
         atomicMin(&a.timer[3 * (size_t)blockIdx.x], (unsigned long long)wall_clock64());
@@ -292,9 +300,9 @@ struct PlanArgs {
 };
 
 template <int VEC, int GROUP, bool IS_MAX>
-__global__ __launch_bounds__(kBlock) void k_gcn_plan(const PlanArgs a)
+__global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a)
 {
-    constexpr int GPB = kBlock / GROUP;
+    constexpr int GPB = block_of<GROUP>() / GROUP;
     const int F = a.feat;
     const int lane = threadIdx.x & (GROUP - 1);
     const int grp = (int)threadIdx.x / GROUP;
@@ -437,7 +445,7 @@ __device__ __forceinline__ void tile_times_weight(const float *tile, int pitch, 
     bool synced = false;
     constexpr int RH = ROWS / 16;  // 16-row halves of the tile
 #pragma unroll 1
-    for (int st = wave; st < RH * ncb; st += 4) {
+    for (int st = wave; st < RH * ncb; st += (int)blockDim.x >> 6) {
         const int rh = st % RH, cb = st / RH;
         const int col = cb * 16 + (lane & 15);
         const bool cok = col < N;
@@ -485,9 +493,9 @@ __device__ __forceinline__ void tile_times_weight(const float *tile, int pitch, 
 }
 
 template <int VEC, int GROUP, bool IS_MAX>
-__global__ __launch_bounds__(kBlock) void k_gcn_plan_nn(const PlanArgs a, const NnArgs w)
+__global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan_nn(const PlanArgs a, const NnArgs w)
 {
-    constexpr int GPB = kBlock / GROUP;
+    constexpr int GPB = block_of<GROUP>() / GROUP;
     constexpr int ROWS = GPB > kNnRows ? GPB : kNnRows;  // rows of the tile
     constexpr int PITCH = GROUP * VEC + 1;
     constexpr int kTile = ROWS * PITCH, kStage = kSegChunks * GROUP * VEC;
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(kBlock) void k_gcn_plan_nn(const PlanArgs a, const 
         if (d.z < 0) return;  // a hub's segment: k_combine finishes the row, k_dense_rows multiplies it
         __syncthreads();
         // the row is final: its product, one thread per output column
-        row_times_weight(lds, F, w.weight, w.n_out, w.out + (size_t)d.z * w.n_out, (int)threadIdx.x, kBlock);
+        row_times_weight(lds, F, w.weight, w.n_out, w.out + (size_t)d.z * w.n_out, (int)threadIdx.x, block_of<GROUP>());
         return;
     }
     const int b = logical_block((int)blockIdx.x - a.n1, a.nblocks0, 1, a.remap, a.xr);
@@ -892,9 +900,9 @@ __device__ __forceinline__ float edge_weight(float a_dst, float a_src, float slo
 
 // LIST = false: reference aggr_gat (aggr_gat.h:116-164); LIST = true: aggr_gat_fine (:167-205).
 template <int VEC, int GROUP, bool LIST>
-__global__ __launch_bounds__(kBlock) void k_gat_items(const GatArgs a)
+__global__ __launch_bounds__(block_of<GROUP>()) void k_gat_items(const GatArgs a)
 {
-    constexpr int ITEMS = kBlock / GROUP;
+    constexpr int ITEMS = block_of<GROUP>() / GROUP;
     const int b = a.remap ? xcd_remap(blockIdx.x, a.nblocks) : (int)blockIdx.x;
     const int tile = b % a.ntiles;
     const int item = (b / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
@@ -1013,9 +1021,9 @@ struct GatPlanArgs {
 };
 
 template <int VEC, int GROUP>
-__global__ __launch_bounds__(kBlock) void k_gat_plan(const GatPlanArgs a)
+__global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArgs a)
 {
-    constexpr int GPB = kBlock / GROUP;
+    constexpr int GPB = block_of<GROUP>() / GROUP;
     const int F = a.feat, H = a.heads;
     const int lane = threadIdx.x & (GROUP - 1);
     const int grp = (int)threadIdx.x / GROUP;
@@ -1225,8 +1233,10 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     }
     // dense combine fused as the epilogue when one lane group spans the row and the [32][K] tile fits LDS
     const bool want_nn = L.nn_weight != nullptr;
-    const bool fuse_nn = want_nn && g.ntiles == 1 && !L.accumulate && nn_fusion_enabled();
-    const int gpb = fuse_nn ? std::max(kNnRows, kBlock / g.group) : kBlock / g.group;
+    // (8-lane groups, F <= 32: the GEMM is ~11 us on the arxiv-shaped input and the epilogue costs as much -- not fused)
+    const bool fuse_nn = want_nn && g.ntiles == 1 && g.group >= 16 && !L.accumulate && nn_fusion_enabled();
+    const int blk = block_for(g.group);
+    const int gpb = fuse_nn ? std::max(kNnRows, blk / g.group) : blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
     a.nblocks0 = item_blocks * g.ntiles;
     if (a.remap && a.nblocks0 < 64) a.remap = 0;
@@ -1241,8 +1251,8 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
         w.weight = L.nn_weight; w.out = L.nn_out; w.n_out = L.nn_cols;
         if (grid > 0) {
 #define CALL_PLAN_NN                                                                                                 \
-            if (is_max) hipLaunchKernelGGL((k_gcn_plan_nn<VEC, GROUP, true>), dim3(grid), dim3(kBlock), 0, stream, a, w);   \
-            else        hipLaunchKernelGGL((k_gcn_plan_nn<VEC, GROUP, false>), dim3(grid), dim3(kBlock), 0, stream, a, w);
+            if (is_max) hipLaunchKernelGGL((k_gcn_plan_nn<VEC, GROUP, true>), dim3(grid), dim3(blk), 0, stream, a, w);     \
+            else        hipLaunchKernelGGL((k_gcn_plan_nn<VEC, GROUP, false>), dim3(grid), dim3(blk), 0, stream, a, w);
             DISPATCH_GEOM(g, CALL_PLAN_NN)
 #undef CALL_PLAN_NN
             HIP_TRY(hipGetLastError());
@@ -1253,8 +1263,8 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     }
     if (grid > 0) {
 #define CALL_PLAN                                                                                            \
-        if (is_max) hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, true>), dim3(grid), dim3(kBlock), 0, stream, a);      \
-        else        hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+        if (is_max) hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, true>), dim3(grid), dim3(blk), 0, stream, a);        \
+        else        hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, false>), dim3(grid), dim3(blk), 0, stream, a);
         DISPATCH_GEOM(g, CALL_PLAN)
 #undef CALL_PLAN
         HIP_TRY(hipGetLastError());
@@ -1312,11 +1322,12 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
     a.timer = reinterpret_cast<unsigned long long *>(L.timer);
     if (L.timer || L.timer_blocks_out) a.remap = 0;  // natural block order for the load-balance study
     if (L.timer_blocks_out) {
-        *L.timer_blocks_out = a.n_total > 0 ? ceil_div(a.n_total, kBlock / g.group) * g.ntiles : 0;
+        *L.timer_blocks_out = a.n_total > 0 ? ceil_div(a.n_total, block_for(g.group) / g.group) * g.ntiles : 0;
         if (!L.timer) return GNNAGG_OK;  // size query only
     }
     if (a.n_total > 0) {
-        const int items_per_block = kBlock / g.group;
+        const int blk = block_for(g.group);
+        const int items_per_block = blk / g.group;
         const int item_blocks = ceil_div(a.n_total, items_per_block);
         a.nblocks = item_blocks * g.ntiles;
         if (a.remap && a.nblocks < 64) a.remap = 0;
@@ -1329,7 +1340,7 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
             }
         }
         if (a.timer) hipLaunchKernelGGL(k_timer_init, dim3(ceil_div(grid, 256)), dim3(256), 0, stream, a.timer, grid);
-#define LAUNCH_GCN(MAXF, LISTF) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, MAXF, LISTF>), dim3(grid), dim3(kBlock), 0, stream, a)
+#define LAUNCH_GCN(MAXF, LISTF) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, MAXF, LISTF>), dim3(grid), dim3(blk), 0, stream, a)
 #define CALL_GCN                                                                                  \
         if (list) { if (is_max) LAUNCH_GCN(true, true); else LAUNCH_GCN(false, true); }           \
         else      { if (is_max) LAUNCH_GCN(true, false); else LAUNCH_GCN(false, false); }
@@ -1356,11 +1367,12 @@ int launch_gat(const GatLaunch &L, void *stream_v)
     a.newval = L.newval; a.n_items = L.wl.n_items; a.n_total = L.wl.n_items + L.wl.n_empty; a.feat = L.feat;
     a.ntiles = g.ntiles; a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope;
     if (a.n_total > 0) {
-        a.nblocks = ceil_div(a.n_total, kBlock / g.group) * g.ntiles;
+        const int blk = block_for(g.group);
+        a.nblocks = ceil_div(a.n_total, blk / g.group) * g.ntiles;
         if (a.remap && a.nblocks < 64) a.remap = 0;
 #define CALL_GAT                                                                                             \
-        if (list) hipLaunchKernelGGL((k_gat_items<VEC, GROUP, true>), dim3(a.nblocks), dim3(kBlock), 0, stream, a);  \
-        else      hipLaunchKernelGGL((k_gat_items<VEC, GROUP, false>), dim3(a.nblocks), dim3(kBlock), 0, stream, a);
+        if (list) hipLaunchKernelGGL((k_gat_items<VEC, GROUP, true>), dim3(a.nblocks), dim3(blk), 0, stream, a);    \
+        else      hipLaunchKernelGGL((k_gat_items<VEC, GROUP, false>), dim3(a.nblocks), dim3(blk), 0, stream, a);
         DISPATCH_GEOM(g, CALL_GAT)
 #undef CALL_GAT
         HIP_TRY(hipGetLastError());
@@ -1393,7 +1405,8 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     a.idx = L.idx; a.att = L.att; a.x = L.x; a.y = L.y; a.partial = L.partial; a.partial_den = L.partial_den;
     a.newval = L.newval; a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
     a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope; a.rows_semantics = L.rows_semantics;
-    const int gpb = kBlock / g.group;
+    const int blk = block_for(g.group);
+    const int gpb = blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
     a.nblocks0 = item_blocks * g.ntiles;
     if (a.remap && a.nblocks0 < 64) a.remap = 0;
@@ -1404,7 +1417,7 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     }
     const int grid = a.n1 * g.ntiles + grid0;
     if (grid > 0) {
-#define CALL_GP hipLaunchKernelGGL((k_gat_plan<VEC, GROUP>), dim3(grid), dim3(kBlock), 0, stream, a);
+#define CALL_GP hipLaunchKernelGGL((k_gat_plan<VEC, GROUP>), dim3(grid), dim3(blk), 0, stream, a);
         DISPATCH_GEOM(g, CALL_GP)
 #undef CALL_GP
         HIP_TRY(hipGetLastError());
