@@ -103,7 +103,7 @@ struct BalancedPlan {
     bool valid = false;
     int chunk = 64;
     int n0 = 0, n1 = 0, n_mrows = 0, n_slots = 0, n_big = 0;
-    DevBuf<int> t0, t1, mrow_id, mrow_ptr, big_rows;
+    DevBuf<int> t0, t1, mrow_id, mrow_ptr, big_rows, slot_hub;
     std::vector<long> t0_cost_prefix;
     // the same short-row descriptors, degree-sorted inside windows (built on first use by a narrow-feature run)
     std::vector<int> h_t0;
@@ -112,7 +112,7 @@ struct BalancedPlan {
     void reset()
     {
         valid = false;
-        t0.release(); t1.release(); mrow_id.release(); mrow_ptr.release(); big_rows.release();
+        t0.release(); t1.release(); mrow_id.release(); mrow_ptr.release(); big_rows.release(); slot_hub.release();
         t0_cost_prefix.clear(); h_t0.clear(); t0_sorted.release(); t0s_cost_prefix.clear();
         n0 = n1 = n_mrows = n_slots = n_big = 0;
     }
@@ -149,6 +149,8 @@ struct Ctx {
     DevBuf<float> partial, partial_den;
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
     int xcd_remap = 2;         // 0 identity, 1 equal-count XCD ranges, 2 work-balanced XCD ranges
+    DevBuf<int> hub_count;  // arrival counters of the in-kernel hub fold (zero between launches)
+    int inkernel_combine = 1;  // GNNAGG_INKERNEL_COMBINE=0: hubs through k_combine (A/B)
     int sort_window = 2048;    // narrow features: short-row descriptors degree-sorted inside windows of this many rows
     int use_plan = 1;          // GCN balanced mode runs k_gcn_plan (0: items + combine, the round-1 first design)
     std::vector<long> row_cost_prefix;  // MODE_ROWS work items
@@ -322,6 +324,12 @@ static int build_plan_into(Ctx *c, BalancedPlan &p, int chunk, bool describe_in_
     if ((rc = p.mrow_id.upload(mrow_id))) return rc;
     if ((rc = p.mrow_ptr.upload(mrow_ptr))) return rc;
     if ((rc = p.big_rows.upload(big))) return rc;
+    {
+        std::vector<int> slot_hub((size_t)nslots);
+        for (size_t m = 0; m + 1 < mrow_ptr.size(); ++m)
+            for (int sl = mrow_ptr[m]; sl < mrow_ptr[m + 1]; ++sl) slot_hub[sl] = (int)m;
+        if ((rc = p.slot_hub.upload(slot_hub))) return rc;
+    }
     if (padding_ratio) {
         // lane groups a segment workgroup occupies (rounds x groups, taken as 8 groups) vs the chunks it really has
         long padded = 0, chunks = p.n0;
@@ -454,6 +462,20 @@ static int get_sched(Ctx *c, int mode, Schedule **out)
     return GNNAGG_OK;
 }
 
+// Arrival counters of the in-kernel hub fold: zero whenever no launch is in flight (the last arriver resets its own).
+static int reserve_hub_counters(Ctx *c, int n_mrows, int feat, int *stride_out)
+{
+    const int stride = feat / 64 + 2;  // >= column tiles of any lane geometry
+    const size_t want = (size_t)n_mrows * stride;
+    if (c->hub_count.n < want) {
+        int rc = c->hub_count.reserve(want);
+        if (rc) return rc;
+        HIP_TRY(hipMemset(c->hub_count.p, 0, c->hub_count.n * sizeof(int)));
+    }
+    *stride_out = stride;
+    return GNNAGG_OK;
+}
+
 struct NnRequest {  // run_with_nn: transformed[V, cols] = y . weight[feat, cols]
     const float *weight;
     float *out;
@@ -490,6 +512,10 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         }
         if (nn) {
             P.nn_weight = nn->weight; P.nn_out = nn->out; P.nn_cols = nn->cols;
+        }
+        if (p.n_mrows > 0 && c->inkernel_combine) {
+            if ((rc = reserve_hub_counters(c, p.n_mrows, feat, &P.hub_count_stride))) return rc;
+            P.slot_hub = p.slot_hub.p; P.hub_count = c->hub_count.p;
         }
         return launch_gcn_plan(P, c->stream);
     }
@@ -582,6 +608,10 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
             if ((rc = c->partial_den.reserve((size_t)p.n_slots * heads))) return rc;
             P.partial = c->partial.p;
             P.partial_den = c->partial_den.p;
+        }
+        if (p.n_mrows > 0 && c->inkernel_combine) {
+            if ((rc = reserve_hub_counters(c, p.n_mrows, feat, &P.hub_count_stride))) return rc;
+            P.slot_hub = p.slot_hub.p; P.hub_count = c->hub_count.p;
         }
         return launch_gat_plan(P, c->stream);
     }
@@ -737,6 +767,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_XCD_REMAP")) c->xcd_remap = atoi(e);
     if (const char *e = getenv("GNNAGG_PLAN")) c->use_plan = atoi(e);
     if (const char *e = getenv("GNNAGG_SORT_WINDOW")) c->sort_window = atoi(e);
+    if (const char *e = getenv("GNNAGG_INKERNEL_COMBINE")) c->inkernel_combine = atoi(e);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);

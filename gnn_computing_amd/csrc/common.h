@@ -86,6 +86,10 @@ struct GcnPlanLaunch {
     int xcd_remap = 2;
     int accumulate = 0;  // y += A.x (sum only); rows without edges keep their value
     int num_rows = 0;    // rows of y
+    // hubs finished inside the plan kernel by the last segment workgroup to arrive (no k_combine launch)
+    const int *slot_hub = nullptr;  // device: scratch slot -> index into hubs.mrow_*
+    int *hub_count = nullptr;       // device: arrival counters, zero between launches; n_mrows * hub_count_stride ints
+    int hub_count_stride = 0;       // counters per hub (>= column tiles of the launch)
     // dense combine as the epilogue (run_with_nn): nn_out[V, nn_cols] = y . nn_weight[feat, nn_cols]
     const float *nn_weight = nullptr;
     float *nn_out = nullptr;
@@ -152,6 +156,10 @@ struct GatPlanLaunch {
     float slope = 0.2f;
     int xcd_remap = 2;
     int rows_semantics = 0;  // 1: `scheduled = 0` semantics (aggr_gat: divide by the denominator unconditionally)
+    // hubs folded inside the plan kernel (see GcnPlanLaunch)
+    const int *slot_hub = nullptr;
+    int *hub_count = nullptr;
+    int hub_count_stride = 0;
 };
 int launch_gat_plan(const GatPlanLaunch &a, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);

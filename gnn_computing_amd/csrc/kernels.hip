@@ -104,6 +104,27 @@ __device__ __forceinline__ void store_pack_wt(float *ybase, unsigned nbytes, siz
     }
 }
 
+// Device-scope (sc1) load: sees what other XCDs' workgroups wrote with store_pack_wt, whatever this XCD's L2 holds.
+template <int VEC>
+__device__ __forceinline__ Pack<VEC> load_pack_sc1(const float *base, unsigned nbytes, size_t off)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)nbytes, 0x00020000);
+    const int voff = (int)(off * sizeof(float));
+    Pack<VEC> r;
+    if constexpr (VEC == 4) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 16);
+        r.v[0] = __uint_as_float(v[0]); r.v[1] = __uint_as_float(v[1]); r.v[2] = __uint_as_float(v[2]); r.v[3] = __uint_as_float(v[3]);
+    } else if constexpr (VEC == 2) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 16);
+        r.v[0] = __uint_as_float(v[0]); r.v[1] = __uint_as_float(v[1]);
+    } else {
+        r.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 16));
+    }
+    return r;
+}
+
 // Block b runs on XCD b % 8 (observed dispatch rule).  Give every XCD a contiguous range of
 // logical blocks; bijective for any nb (q = nb/8, r = nb%8: the first r XCDs get q+1 blocks).
 __device__ __forceinline__ int xcd_remap(int b, int nb)
@@ -296,8 +317,83 @@ struct PlanArgs {
     int accumulate;  // 1: y += result (rows without edges are left untouched); sum only
     int wt;          // 1: write-through (sc1) stores of the short-row results
     unsigned ybytes;
+    // hubs (rows with several segments) folded by the last segment workgroup to arrive; hub_count == nullptr: k_combine
+    const int *slot_hub, *mrow_ptr, *mrow_id, *row_ptr;
+    int *hub_count;
+    int hub_count_stride;
+    unsigned partial_bytes;
     XcdRanges xr;
 };
+
+// Tail of a hub's segment workgroup.  Its segment sum goes to scratch with a write-through (device-scope) store; once
+// the store has completed the workgroup bumps the hub's arrival counter, and the workgroup that finds all other
+// segments already in folds the scratch rows in ascending slot order (device-scope loads; the order of k_combine --
+// so which workgroup arrives last does not matter) and writes the row.  Returns true in that workgroup, with the
+// finished row in acc (group 0's lanes).  `stage` = the segment's LDS stage (kSegChunks rows), free by now.
+template <int VEC, int GROUP, bool IS_MAX>
+__device__ __forceinline__ bool hub_arrive_and_fold(const PlanArgs &a, const int4 d, int tile, int col, bool col_ok, int grp,
+                                                    int lane, float (&acc)[VEC], float *stage, int &row_out)
+{
+    constexpr int GPB = block_of<GROUP>() / GROUP;
+    const int F = a.feat;
+    const int slot = ~d.z;
+    if (grp == 0 && col_ok) store_pack_wt<VEC>(a.partial, a.partial_bytes, (size_t)slot * F + col, acc);
+    __builtin_amdgcn_s_waitcnt(0);  // the write-through store has reached the device coherence point
+    __shared__ int s_hub;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int m = a.slot_hub[slot];
+        const int nseg = a.mrow_ptr[m + 1] - a.mrow_ptr[m];
+        int *cnt = a.hub_count + (size_t)m * a.hub_count_stride + tile;
+        const int old = atomicAdd(cnt, 1);
+        if (old == nseg - 1) *cnt = 0;  // everybody is in: ready for the next launch
+        s_hub = old == nseg - 1 ? m : -1;
+    }
+    __syncthreads();
+    const int m = s_hub;
+    if (m < 0) return false;
+    const int s0 = a.mrow_ptr[m], s1 = a.mrow_ptr[m + 1];
+    const int row = a.mrow_id[m];
+    row_out = row;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+    for (int sb = s0; sb < s1; sb += kSegChunks) {
+        const int nst = s1 - sb < kSegChunks ? s1 - sb : kSegChunks;
+        for (int p = grp; p < nst; p += GPB)
+            if (col_ok) {
+                const Pack<VEC> v = load_pack_sc1<VEC>(a.partial, a.partial_bytes, (size_t)(sb + p) * F + col);
+                store_pack<VEC>(&stage[(p * GROUP + lane) * VEC], v.v);
+            }
+        __syncthreads();
+        if (grp == 0 && col_ok) {
+#pragma unroll
+            for (int p = 0; p < kSegChunks; ++p)
+                if (p < nst) {
+                    const Pack<VEC> v = load_pack<VEC>(&stage[(p * GROUP + lane) * VEC]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        if (IS_MAX) acc[k] = v.v[k] > acc[k] ? v.v[k] : acc[k];
+                        else acc[k] += v.v[k];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && col_ok) {
+        if (a.mean) {
+            const float dg = (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
+        }
+        if (a.accumulate) {
+            const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)row * F + col);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
+        }
+        store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+    }
+    return true;
+}
 
 template <int VEC, int GROUP, bool IS_MAX>
 __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a)
@@ -324,21 +420,27 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
             store_pack<VEC>(&stage[(c * GROUP + lane) * VEC], acc);
         }
         __syncthreads();
-        if (grp != 0 || !col_ok) return;
+        const bool hub_here = d.z < 0 && a.hub_count != nullptr;  // workgroup-uniform
+        if (!hub_here && (grp != 0 || !col_ok)) return;
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+        if (grp == 0 && col_ok) {
 #pragma unroll
-        for (int c = 0; c < kSegChunks; ++c)
-            if (c < nch) {
-                const Pack<VEC> p = load_pack<VEC>(&stage[(c * GROUP + lane) * VEC]);
+            for (int c = 0; c < kSegChunks; ++c)
+                if (c < nch) {
+                    const Pack<VEC> p = load_pack<VEC>(&stage[(c * GROUP + lane) * VEC]);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if (IS_MAX) acc[k] = p.v[k] > acc[k] ? p.v[k] : acc[k];
-                    else acc[k] += p.v[k];
+                    for (int k = 0; k < VEC; ++k) {
+                        if (IS_MAX) acc[k] = p.v[k] > acc[k] ? p.v[k] : acc[k];
+                        else acc[k] += p.v[k];
+                    }
                 }
-            }
-        if (d.z >= 0) {
+        }
+        if (hub_here) {
+            int row;
+            hub_arrive_and_fold<VEC, GROUP, IS_MAX>(a, d, tile, col, col_ok, grp, lane, acc, stage, row);
+        } else if (d.z >= 0) {
             if (a.mean) {
                 const float dg = (float)(d.y - d.x);
 #pragma unroll
@@ -519,6 +621,9 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan_nn(const PlanArg
             store_pack<VEC>(&lds[(c * GROUP + lane) * VEC], acc);
         }
         __syncthreads();
+        float hub_acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) hub_acc[k] = 0.0f;
         if (grp == 0 && col_ok) {
             float acc[VEC];
 #pragma unroll
@@ -541,14 +646,22 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan_nn(const PlanArg
                 }
                 store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
                 store_pack<VEC>(&lds[col], acc);  // chunk 0's slot of this lane: read by nobody else
-            } else {
+            } else if (a.hub_count == nullptr) {
                 store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) hub_acc[k] = acc[k];
             }
         }
-        if (d.z < 0) return;  // a hub's segment: k_combine finishes the row, k_dense_rows multiplies it
+        int row = d.z;
+        if (d.z < 0) {  // a hub's segment
+            if (a.hub_count == nullptr) return;  // k_combine finishes the row and multiplies it
+            if (!hub_arrive_and_fold<VEC, GROUP, IS_MAX>(a, d, 0, col, col_ok, grp, lane, hub_acc, lds, row)) return;
+            if (grp == 0 && col_ok) store_pack<VEC>(&lds[col], hub_acc);
+        }
         __syncthreads();
         // the row is final: its product, one thread per output column
-        row_times_weight(lds, F, w.weight, w.n_out, w.out + (size_t)d.z * w.n_out, (int)threadIdx.x, block_of<GROUP>());
+        row_times_weight(lds, F, w.weight, w.n_out, w.out + (size_t)row * w.n_out, (int)threadIdx.x, block_of<GROUP>());
         return;
     }
     const int b = logical_block((int)blockIdx.x - a.n1, a.nblocks0, 1, a.remap, a.xr);
@@ -1017,8 +1130,77 @@ struct GatPlanArgs {
     float *partial, *partial_den, *newval;
     int n0, n1, feat, ntiles, chunk, heads, dhead, remap, nblocks0, rows_semantics;
     float slope;
+    // hubs folded by the last segment workgroup to arrive (hub_count == nullptr: k_combine), as in PlanArgs
+    const int *slot_hub, *mrow_ptr, *mrow_id;
+    int *hub_count;
+    int hub_count_stride;
+    unsigned partial_bytes, partial_den_bytes;
     XcdRanges xr;
 };
+
+// GAT counterpart of hub_arrive_and_fold: numerator rows and per-head denominators of the hub's segments, ascending
+// slot order, one division at the end (scaleArray, aggr_gat.h:207-213) -- the order of k_combine<.., IS_GAT>.
+template <int VEC, int GROUP>
+__device__ __forceinline__ void hub_arrive_and_fold_gat(const GatPlanArgs &a, int slot, int tile, int col, bool col_ok, int h,
+                                                        bool head_leader, int grp, int lane, float (&acc)[VEC], float den,
+                                                        float *stage, float *stage_den)
+{
+    constexpr int GPB = block_of<GROUP>() / GROUP;
+    const int F = a.feat, H = a.heads;
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(a.partial_den, 0, (int)a.partial_den_bytes, 0x00020000);
+    if (grp == 0 && col_ok) {
+        store_pack_wt<VEC>(a.partial, a.partial_bytes, (size_t)slot * F + col, acc);
+        if (head_leader) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(den), drsrc, (int)(((size_t)slot * H + h) * 4), 0, 16);
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // the write-through stores have reached the device coherence point
+    __shared__ int s_hub;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int m = a.slot_hub[slot];
+        const int nseg = a.mrow_ptr[m + 1] - a.mrow_ptr[m];
+        int *cnt = a.hub_count + (size_t)m * a.hub_count_stride + tile;
+        const int old = atomicAdd(cnt, 1);
+        if (old == nseg - 1) *cnt = 0;
+        s_hub = old == nseg - 1 ? m : -1;
+    }
+    __syncthreads();
+    const int m = s_hub;
+    if (m < 0) return;
+    const int s0 = a.mrow_ptr[m], s1 = a.mrow_ptr[m + 1];
+    const int row = a.mrow_id[m];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    den = 0.0f;
+    for (int sb = s0; sb < s1; sb += kSegChunks) {
+        const int nst = s1 - sb < kSegChunks ? s1 - sb : kSegChunks;
+        for (int p = grp; p < nst; p += GPB)
+            if (col_ok) {
+                const Pack<VEC> v = load_pack_sc1<VEC>(a.partial, a.partial_bytes, (size_t)(sb + p) * F + col);
+                store_pack<VEC>(&stage[(p * GROUP + lane) * VEC], v.v);
+                stage_den[p * GROUP + lane] =
+                    __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(drsrc, (int)(((size_t)(sb + p) * H + h) * 4), 0, 16));
+            }
+        __syncthreads();
+        if (grp == 0 && col_ok) {
+#pragma unroll
+            for (int p = 0; p < kSegChunks; ++p)
+                if (p < nst) {
+                    const Pack<VEC> v = load_pack<VEC>(&stage[(p * GROUP + lane) * VEC]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += v.v[k];
+                    den += stage_den[p * GROUP + lane];
+                }
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && col_ok) {
+        if (den != 0.0f) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+        }
+        store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+    }
+}
 
 template <int VEC, int GROUP>
 __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArgs a)
@@ -1066,17 +1248,25 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
             stage_den[c * GROUP + lane] = den;
         }
         __syncthreads();
-        if (grp != 0 || !col_ok) return;
+        const bool hub_here = row_or_dest < 0 && a.hub_count != nullptr;  // workgroup-uniform
+        if (!hub_here && (grp != 0 || !col_ok)) return;
         float acc[VEC] = {};
         float den = 0.0f;
+        if (grp == 0 && col_ok) {
 #pragma unroll
-        for (int c = 0; c < kSegChunks; ++c)
-            if (c < nch) {
-                const Pack<VEC> p = load_pack<VEC>(&stage[(c * GROUP + lane) * VEC]);
+            for (int c = 0; c < kSegChunks; ++c)
+                if (c < nch) {
+                    const Pack<VEC> p = load_pack<VEC>(&stage[(c * GROUP + lane) * VEC]);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] += p.v[k];
-                den += stage_den[c * GROUP + lane];
-            }
+                    for (int k = 0; k < VEC; ++k) acc[k] += p.v[k];
+                    den += stage_den[c * GROUP + lane];
+                }
+        }
+        if (hub_here) {
+            hub_arrive_and_fold_gat<VEC, GROUP>(a, ~row_or_dest, tile, col, col_ok, h, head_leader, grp, lane, acc, den, stage,
+                                                stage_den);
+            return;
+        }
         if (row_or_dest >= 0) {
             if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
 #pragma unroll
@@ -1225,6 +1415,14 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
     a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
     a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap; a.accumulate = L.accumulate;
+    a.slot_hub = L.slot_hub; a.mrow_ptr = L.hubs.mrow_ptr; a.mrow_id = L.hubs.mrow_id; a.row_ptr = L.row_ptr;
+    a.hub_count = L.hub_count; a.hub_count_stride = L.hub_count_stride; a.partial_bytes = 0;
+    {
+        const size_t pbytes = (size_t)L.hubs.n_slots * L.feat * sizeof(float);
+        if (L.hubs.n_mrows == 0 || pbytes >= 0x7fffffffULL || g.ntiles > L.hub_count_stride) a.hub_count = nullptr;
+        else a.partial_bytes = (unsigned)pbytes;
+    }
+    const bool hubs_in_kernel = a.hub_count != nullptr;
     {
         static const int wt_env = getenv("GNNAGG_WT_STORES") ? atoi(getenv("GNNAGG_WT_STORES")) : 1;
         const size_t ybytes = (size_t)L.num_rows * L.feat * sizeof(float);
@@ -1259,6 +1457,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
         }
         GcnLaunch C;
         C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
+        if (hubs_in_kernel) return GNNAGG_OK;
         return launch_combine_gcn(C, g, is_max, stream, L.nn_weight, L.nn_out, L.nn_cols);  // hubs: product in the combine
     }
     if (grid > 0) {
@@ -1272,7 +1471,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     GcnLaunch C;
     C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
     C.accumulate = L.accumulate;
-    const int rc = launch_combine_gcn(C, g, is_max, stream);
+    const int rc = hubs_in_kernel ? GNNAGG_OK : launch_combine_gcn(C, g, is_max, stream);
     if (rc || !want_nn) return rc;
     return launch_dense_nn(L.y, L.nn_weight, L.nn_out, L.num_rows, L.nn_cols, L.feat, stream);
 }
@@ -1405,6 +1604,16 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     a.idx = L.idx; a.att = L.att; a.x = L.x; a.y = L.y; a.partial = L.partial; a.partial_den = L.partial_den;
     a.newval = L.newval; a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
     a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope; a.rows_semantics = L.rows_semantics;
+    a.slot_hub = L.slot_hub; a.mrow_ptr = L.hubs.mrow_ptr; a.mrow_id = L.hubs.mrow_id;
+    a.hub_count = L.hub_count; a.hub_count_stride = L.hub_count_stride; a.partial_bytes = a.partial_den_bytes = 0;
+    {
+        // one column tile only: with several, a head's denominator is written by the tile that holds its first column
+        // and the other tiles' last arrivers could not know that store is done
+        const size_t pbytes = (size_t)L.hubs.n_slots * L.feat * sizeof(float);
+        if (L.hubs.n_mrows == 0 || pbytes >= 0x7fffffffULL || g.ntiles != 1 || L.hub_count_stride < 1) a.hub_count = nullptr;
+        else { a.partial_bytes = (unsigned)pbytes; a.partial_den_bytes = (unsigned)((size_t)L.hubs.n_slots * L.heads * sizeof(float)); }
+    }
+    const bool hubs_in_kernel = a.hub_count != nullptr;
     const int blk = block_for(g.group);
     const int gpb = blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
@@ -1422,7 +1631,7 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
 #undef CALL_GP
         HIP_TRY(hipGetLastError());
     }
-    if (L.hubs.n_mrows > 0) {
+    if (L.hubs.n_mrows > 0 && !hubs_in_kernel) {
         CombineArgs c;
         c.mrow_id = L.hubs.mrow_id; c.mrow_ptr = L.hubs.mrow_ptr; c.row_ptr = nullptr; c.partial = L.partial;
         c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.hubs.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;

@@ -543,6 +543,34 @@ def test_run_with_nn():
     assert np.array_equal(t.cpu().numpy(), orc.matmul_nn(y_ref, w))
 
 
+@pytest.mark.parametrize("F", [128, 48, 602])
+def test_hub_fold_in_kernel_alternating_inputs(F):
+    """Hubs are folded by the last segment workgroup to arrive, reading scratch rows other XCDs wrote (device-scope
+    stores/loads, arrival counters reset in-kernel).  Alternate two inputs on one handle for many launches: a stale
+    L2 line, a missed arrival or a counter left non-zero shows up as a mismatch against the oracle."""
+    V, E = 6000, 400000
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=9, alpha=1.1)   # several rows with thousands of edges
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    val = rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.schedule_balanced(16)
+    chunk, seg = agg.balanced_params()
+    assert chunk == 16 and int(np.diff(ptr).max()) > 20 * chunk * seg     # hubs with > 16 segments exist
+    ps, tg = orc.neighbor_grouping(ptr, chunk)
+    xs = [rand((V, F), 10 + i) for i in range(2)]
+    refs = [orc.gcn_grouped(ps, tg, idx, val, x, V, seg=seg) for x in xs]
+    dxs = [dev(x) for x in xs]
+    y = torch.empty((V, F), device=DEV)
+    for it in range(60):
+        agg.run(dxs[it & 1], y, 128, "balanced")
+        if it % 7 == 0 or it >= 56:
+            assert np.array_equal(y.cpu().numpy(), refs[it & 1]), "launch %d" % it
+    for red, fn in (("mean", orc.gcn_mean), ("max", orc.gcn_max)):
+        agg.run(dxs[0], y, 128, "balanced", reduce=red)
+        ref = fn(ptr, idx, val, xs[0])
+        assert np.allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("mode", ["rows", "scheduled", "balanced"])
 @pytest.mark.parametrize("F,OUT", [(128, 32), (32, 32), (64, 16), (100, 7), (256, 64), (30, 33), (602, 32), (7, 5)])
 def test_run_with_nn_fused_epilogue(mode, F, OUT):
@@ -647,6 +675,29 @@ def test_gat_balanced_plan_with_hubs(F, H, chunk):
     np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=3e-6, atol=1e-6)
     np.testing.assert_allclose(newval.cpu().numpy(), ref_newval, rtol=1e-6)
     assert np.all(y.cpu().numpy()[deg == 0] == 0)
+
+
+@pytest.mark.parametrize("F,H", [(128, 1), (256, 8), (96, 4)])
+def test_gat_hub_fold_in_kernel_alternating_inputs(F, H):
+    """GAT counterpart of test_hub_fold_in_kernel_alternating_inputs: numerators and per-head denominators of the hubs'
+    segments cross XCDs through scratch; two inputs alternate on one handle."""
+    V, E = 5000, 300000
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=19, alpha=1.1)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.schedule_balanced(16)
+    chunk, seg = gat.balanced_params()
+    assert int(np.diff(ptr).max()) > 17 * chunk * seg
+    ps, tg = orc.neighbor_grouping(ptr, chunk)
+    xs = [rand((V, F), 30 + i) for i in range(2)]
+    atts = [rand((V, H, 2), 40 + i) * 0.4 for i in range(2)]
+    refs = [orc.gat_grouped(ps, tg, idx, atts[i], xs[i], V, H, seg=seg)[0] for i in range(2)]
+    dxs, datts = [dev(x) for x in xs], [dev(a) for a in atts]
+    y = torch.empty((V, F), device=DEV)
+    for it in range(40):
+        gat.run(dxs[it & 1], datts[it & 1], y, 128, "balanced", heads=H)
+        if it % 5 == 0 or it >= 37:
+            np.testing.assert_allclose(y.cpu().numpy(), refs[it & 1], rtol=3e-6, atol=1e-6, err_msg="launch %d" % it)
 
 
 def test_run_clock_instrumentation():
