@@ -165,7 +165,7 @@ def run_single(args, dev):
         "achieved_gbps": achieved,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
-                     "kernel": "k_gcn_plan (+k_combine)", "algorithmic_bytes": B,
+                     "kernel": "k_gcn_plan", "algorithmic_bytes": B,
                      "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6},
         other: {"value": E / (results[other][0] / args.steps), "avg_launch_us": results[other][1] * 1e6,
                 "achieved_gbps": B / results[other][1] / 1e9},
