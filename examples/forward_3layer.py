@@ -29,6 +29,11 @@ def main():
     ap.add_argument("--gpu", type=int, default=0)
     ap.add_argument("--neighbor-num", type=int, default=32)   # our.py:84
     ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--fused-relu", action="store_true",
+                    help="GCN: apply the ReLU inside the aggregation kernel (GNNAGG_FLAG_RELU) instead of F.relu")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="capture one forward in a HIP graph and replay it (the 9-12 launches of a forward are short "
+                         "enough on the arxiv-sized graph for launch gaps to show)")
     args = ap.parse_args()
     dev = torch.device("cuda", args.gpu)
     torch.manual_seed(123)                                   # our.py:76
@@ -55,6 +60,9 @@ def main():
 
     def gcn_layer(feat, out, w):                             # our.py:171-176
         feat2 = torch.mm(feat, w)
+        if args.fused_relu:
+            gnc.gcn_run(at, feat2, out, 128, 1, relu=True)
+            return out
         gnc.gcn_run(at, feat2, out, 128, 1)
         return F.relu(out)
 
@@ -70,17 +78,32 @@ def main():
             x = gcn_layer(x, outs[k], weights[k]) if args.model == "our_GCN" else gat_layer(x, outs[k], weights[k], weights_lr[k])
         return x
 
+    step, result = forward, None
+    if args.hip_graph:
+        forward()                                            # plans, scratch and rocBLAS workspaces exist before capture
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            forward()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            result = forward()
+        step = graph.replay
     for _ in range(args.iters):
-        forward()
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.iters):
-        forward()
+        step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.iters
     y = forward()
+    if result is not None:
+        assert torch.equal(result, y), "graph replay differs from the eager forward"
     print(json.dumps({"model": args.model, "dataset": args.dataset, "num_v": num_v, "num_e": num_e,
-                      "seconds_per_forward": dt, "finite": bool(torch.isfinite(y).all().item())}))
+                      "seconds_per_forward": dt, "hip_graph": bool(args.hip_graph), "fused_relu": bool(args.fused_relu), "finite": bool(torch.isfinite(y).all().item())}))
 
 
 if __name__ == "__main__":

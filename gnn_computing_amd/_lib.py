@@ -14,6 +14,7 @@ SCHED_LOCALITY, SCHED_NEIGHBOR_GROUPING, SCHED_LOCALITY_NEIGHBOR_GROUPING, SCHED
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX = 0, 1, 2
 MODE_ROWS, MODE_SCHEDULED, MODE_BALANCED = 0, 1, 2
 FLAG_ACCUMULATE = 1
+FLAG_RELU = 2
 
 c_int, c_float, c_void_p, c_char_p, c_int64 = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_char_p,
                                                 ctypes.c_int64)

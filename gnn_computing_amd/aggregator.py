@@ -146,12 +146,13 @@ class Aggregator_GCN(Aggregator):
                                       _dev_ptr(val, torch.float32, "val"), self.num_v, self.num_e,
                                       ctypes.byref(self._h)))
 
-    def run(self, vin, vout, BLOCK_SIZE=512, scheduled=0, reduce="sum", accumulate=False):
+    def run(self, vin, vout, BLOCK_SIZE=512, scheduled=0, reduce="sum", accumulate=False, relu=False):
         """aggr_gcn.h:379-410.  BLOCK_SIZE is accepted for signature parity and ignored.
-        accumulate=True (balanced mode, sum): vout += A.vin."""
-        return self.run_with_feat(vin, vout, BLOCK_SIZE, scheduled, int(vin.shape[1]), reduce, accumulate)
+        accumulate=True (balanced mode, sum): vout += A.vin.  relu=True: vout = max(result, 0) in the same kernel
+        (the F.relu that follows gcn_run in Figure7/our.py:176)."""
+        return self.run_with_feat(vin, vout, BLOCK_SIZE, scheduled, int(vin.shape[1]), reduce, accumulate, relu)
 
-    def run_with_feat(self, vin, vout, BLOCK_SIZE, scheduled, feat, reduce="sum", accumulate=False):
+    def run_with_feat(self, vin, vout, BLOCK_SIZE, scheduled, feat, reduce="sum", accumulate=False, relu=False):
         """aggr_gcn.h:411-444"""
         if vout.numel() < self.num_v * feat:
             raise ValueError("vout must hold num_v * feat floats")
@@ -159,7 +160,7 @@ class Aggregator_GCN(Aggregator):
         self._use_current_stream()
         check(lib().gnnagg_gcn_run_ex(self._h, _dev_ptr(vin, torch.float32, "vin"), _dev_ptr(vout, torch.float32, "vout"),
                                       int(feat), _mode(scheduled), REDUCE[reduce],
-                                      _lib.FLAG_ACCUMULATE if accumulate else 0))
+                                      (_lib.FLAG_ACCUMULATE if accumulate else 0) | (_lib.FLAG_RELU if relu else 0)))
         return 0.0
 
     def run_clock(self, vin, vout, BLOCK_SIZE=64, scheduled=0):
@@ -297,8 +298,9 @@ def gcn_update_val(at, val):
     at.updateval(val)
 
 
-def gcn_run(at, feat, outfeat, blocksize, scheduled):
-    at.run_with_feat(feat, outfeat, blocksize, scheduled, int(feat.shape[1]))
+def gcn_run(at, feat, outfeat, blocksize, scheduled, relu=False):
+    """Figure7/kernel.cpp:97-106; relu=True fuses the F.relu that follows it in our.py:176 (extension)."""
+    at.run_with_feat(feat, outfeat, blocksize, scheduled, int(feat.shape[1]), relu=relu)
 
 
 def gcn_schedule(at, neighbor_num):

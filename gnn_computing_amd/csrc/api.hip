@@ -487,6 +487,8 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     if ((flags & GNNAGG_FLAG_ACCUMULATE) && (mode != GNNAGG_MODE_BALANCED || reduce != GNNAGG_REDUCE_SUM || !c->use_plan))
         return fail(GNNAGG_ERR_ARG, "GNNAGG_FLAG_ACCUMULATE needs GNNAGG_MODE_BALANCED and GNNAGG_REDUCE_SUM");
     if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
+    if ((flags & GNNAGG_FLAG_RELU) && nn) return fail(GNNAGG_ERR_ARG, "GNNAGG_FLAG_RELU is not available in run_with_nn");
+    if (flags & ~(GNNAGG_FLAG_ACCUMULATE | GNNAGG_FLAG_RELU)) return fail(GNNAGG_ERR_ARG, "unknown flag bits");
     if (!x || !y) return fail(GNNAGG_ERR_ARG, "null feature pointer");
     if (reduce < GNNAGG_REDUCE_SUM || reduce > GNNAGG_REDUCE_MAX) return fail(GNNAGG_ERR_ARG, "bad reduce");
     if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
@@ -505,7 +507,8 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         P.hubs.mrow_id = p.mrow_id.p; P.hubs.mrow_ptr = p.mrow_ptr.p; P.hubs.n_mrows = p.n_mrows;
         P.hubs.n_slots = p.n_slots; P.hubs.big_rows = p.big_rows.p; P.hubs.n_big = p.n_big;
         P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
-        P.xcd_remap = c->xcd_remap; P.accumulate = (flags & GNNAGG_FLAG_ACCUMULATE) ? 1 : 0; P.num_rows = c->V;
+        P.xcd_remap = c->xcd_remap; P.accumulate = (flags & GNNAGG_FLAG_ACCUMULATE) ? 1 : 0; P.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
+        P.num_rows = c->V;
         if (p.n_slots > 0) {
             if ((rc = c->partial.reserve((size_t)p.n_slots * feat))) return rc;
             P.partial = c->partial.p;
@@ -532,13 +535,14 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
             GcnRowsLongLaunch R;
             R.r1 = p.r1.p; R.n1 = p.n1; R.idx = c->d_idx; R.val = c->d_val; R.x = x; R.y = y; R.feat = feat; R.reduce = reduce;
+            R.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
             if ((rc = launch_gcn_rows_long(R, c->aux_stream))) return rc;
             HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
         }
         GcnPlanLaunch P;  // short rows: the descriptor path of the plan kernel (no segments, no hubs)
         P.t0 = p.r0.p; P.n0 = p.n0; P.t0_cost_prefix = p.r0_cost_prefix.data();
         P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
-        P.xcd_remap = c->xcd_remap; P.num_rows = c->V;
+        P.xcd_remap = c->xcd_remap; P.num_rows = c->V; P.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
         const bool nn_rows_ok = nn && (p.n1 == 0 || feat <= 15000);
         if (nn_rows_ok) {  // short rows: epilogue of the plan kernel (or the GEMM right behind it)
             P.nn_weight = nn->weight; P.nn_out = nn->out; P.nn_cols = nn->cols;
@@ -553,7 +557,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     }
     GcnLaunch L;
     L.row_ptr = c->d_ptr; L.x = x; L.y = y; L.feat = feat; L.reduce = reduce;
-    L.xcd_remap = c->xcd_remap;
+    L.xcd_remap = c->xcd_remap; L.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
     if (!s) {
         L.wl.ptr = c->d_ptr;
         L.wl.n_items = c->V;

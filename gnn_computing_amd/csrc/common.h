@@ -62,6 +62,7 @@ struct GcnLaunch {
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 1;
     int accumulate = 0;  // combine only: y += sum of partials
+    int relu = 0;        // y = max(result, 0)
     void *timer = nullptr;          // run_clock: unsigned long long[3 * blocks]
     int *timer_blocks_out = nullptr;  // run_clock: receives the number of workgroups of the items kernel
     // host array [n_items + n_empty + 1]: prefix sums of the per-item cost, for xcd_remap == 2
@@ -85,6 +86,7 @@ struct GcnPlanLaunch {
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 2;
     int accumulate = 0;  // y += A.x (sum only); rows without edges keep their value
+    int relu = 0;        // y = max(result, 0)
     int num_rows = 0;    // rows of y
     // hubs finished inside the plan kernel by the last segment workgroup to arrive (no k_combine launch)
     const int *slot_hub = nullptr;  // device: scratch slot -> index into hubs.mrow_*
@@ -106,6 +108,7 @@ struct GcnRowsLongLaunch {
     float *y = nullptr;
     int feat = 0;
     int reduce = GNNAGG_REDUCE_SUM;
+    int relu = 0;  // y = max(result, 0) (GCN flavour)
     const float *att = nullptr;  // non-null: GAT flavour (fused edge softmax), needs (feat / heads) % 32 == 0
     int heads = 1;
     float slope = 0.2f;

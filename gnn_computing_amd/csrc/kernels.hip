@@ -71,6 +71,15 @@ __device__ __forceinline__ Pack<VEC> load_pack(const float *p)
     return r;
 }
 
+// GNNAGG_FLAG_RELU: the activation that follows the aggregation in the 3-layer models (Figure7/our.py:176), applied to the
+// finished row in the producing kernel instead of a separate elementwise pass over Y.
+template <int VEC>
+__device__ __forceinline__ void relu_pack(float (&a)[VEC])
+{
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) a[k] = a[k] > 0.0f ? a[k] : 0.0f;
+}
+
 template <int VEC>
 __device__ __forceinline__ void store_pack(float *p, const float (&a)[VEC])
 {
@@ -162,7 +171,7 @@ struct GcnArgs {
     const float *x;
     float *y;
     float *partial;
-    int n_items, n_total, feat, ntiles, nblocks, mean, remap;
+    int n_items, n_total, feat, ntiles, nblocks, mean, remap, relu;
     unsigned long long *timer;  // run_clock: per workgroup {first wave start, last wave end, CU id}; null otherwise
     XcdRanges xr;
 };
@@ -265,6 +274,7 @@ __device__ __forceinline__ void gcn_items_body(const GcnArgs &a)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
     }
+    if (a.relu) relu_pack<VEC>(acc);
     store_pack<VEC>(a.y + (size_t)row * F + col, acc);
 }
 
@@ -315,6 +325,7 @@ struct PlanArgs {
     float *partial;
     int n0, n1, feat, ntiles, chunk, mean, remap, nblocks0;
     int accumulate;  // 1: y += result (rows without edges are left untouched); sum only
+    int relu;        // 1: y = max(result, 0)
     int wt;          // 1: write-through (sc1) stores of the short-row results
     unsigned ybytes;
     // hubs (rows with several segments) folded by the last segment workgroup to arrive; hub_count == nullptr: k_combine
@@ -390,6 +401,7 @@ __device__ __forceinline__ bool hub_arrive_and_fold(const PlanArgs &a, const int
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
         }
+        if (a.relu) relu_pack<VEC>(acc);
         store_pack<VEC>(a.y + (size_t)row * F + col, acc);
     }
     return true;
@@ -451,6 +463,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
             }
+            if (a.relu) relu_pack<VEC>(acc);
             store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
         } else {
             store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
     const int col = (tile * GROUP + lane) * VEC;
     const bool col_ok = col < F;
     const int4 d = a.t0[item];
-    if (a.accumulate && d.x == d.y) return;  // y += 0
+    if (a.accumulate && !a.relu && d.x == d.y) return;  // y += 0
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
@@ -483,6 +496,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
     }
+    if (a.relu) relu_pack<VEC>(acc);
     if (a.wt) store_pack_wt<VEC>(a.y, a.ybytes, (size_t)d.z * F + col, acc);
     else store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
 }
@@ -737,7 +751,7 @@ struct RowsLongArgs {
     const float *val;
     const float *x;
     float *y;
-    int n1, feat, ntiles32, mean;
+    int n1, feat, ntiles32, mean, relu;
     // GAT flavour (reference aggr_gat, aggr_gat.h:116-164): the edge weight is exp(leaky(att[row,h,0] + att[src,h,1]))
     // computed by the gathering lanes; the consumer also runs the denominator chain.  Needs dhead % 32 == 0 so
     // that a 32-column tile lies inside one head.
@@ -822,6 +836,7 @@ __global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs
     if (consumer) {
         if (IS_GAT) acc = acc / den;  // aggr_gat.h:163 (rows here are never empty)
         else if (a.mean) acc = acc / (float)(d.y - d.x);
+        if (!IS_GAT && a.relu) acc = acc > 0.0f ? acc : 0.0f;
         a.y[(size_t)d.z * F + tile * 32 + c] = acc;
     }
 }
@@ -831,6 +846,7 @@ struct CombineArgs {
     const int *big_rows;  // indices into mrow_* of the rows with more than kCombineBatch partials
     int n_big, nblocks_small;
     int accumulate;  // 1: y += (sum of partials)
+    int relu = 0;    // 1: y = max(result, 0) (GCN)
     // run_with_nn: nn_out[row, :] = (finished row) . nn_weight for the rows finished here (ntiles == 1)
     const float *nn_weight;
     float *nn_out;
@@ -913,6 +929,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
                 acc = acc / (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
             }
             if (a.accumulate) acc = a.y[(size_t)row * F + col0 + c] + acc;
+            if (!IS_GAT && a.relu) acc = acc > 0.0f ? acc : 0.0f;
             a.y[(size_t)row * F + col0 + c] = acc;
             if (nn) stage[c] = acc;  // the staging rounds are over
         }
@@ -983,6 +1000,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
         }
+        if (!IS_GAT && a.relu) relu_pack<VEC>(acc);
         store_pack<VEC>(a.y + (size_t)row * F + col, acc);
         if (nn) store_pack<VEC>(&stage[grp * GROUP * VEC + col], acc);  // ntiles == 1: col = lane * VEC
     }
@@ -1371,7 +1389,7 @@ static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max
         c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = L.row_ptr; c.partial = L.partial;
         c.partial_den = nullptr; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
         c.heads = 1; c.dhead = L.feat; c.mean = L.reduce == GNNAGG_REDUCE_MEAN;
-        c.accumulate = L.accumulate;
+        c.accumulate = L.accumulate; c.relu = L.relu;
         c.nn_weight = nn_weight; c.nn_out = nn_out; c.nn_cols = nn_cols;
         c.big_rows = L.wl.big_rows; c.n_big = L.wl.n_big;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
@@ -1414,7 +1432,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     a.t0 = reinterpret_cast<const int4 *>(L.t0); a.t1 = reinterpret_cast<const int4 *>(L.t1);
     a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
     a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
-    a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap; a.accumulate = L.accumulate;
+    a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap; a.accumulate = L.accumulate; a.relu = L.relu;
     a.slot_hub = L.slot_hub; a.mrow_ptr = L.hubs.mrow_ptr; a.mrow_id = L.hubs.mrow_id; a.row_ptr = L.row_ptr;
     a.hub_count = L.hub_count; a.hub_count_stride = L.hub_count_stride; a.partial_bytes = 0;
     {
@@ -1432,7 +1450,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     // dense combine fused as the epilogue when one lane group spans the row and the [32][K] tile fits LDS
     const bool want_nn = L.nn_weight != nullptr;
     // (8-lane groups, F <= 32: the GEMM is ~11 us on the arxiv-shaped input and the epilogue costs as much -- not fused)
-    const bool fuse_nn = want_nn && g.ntiles == 1 && g.group >= 16 && !L.accumulate && nn_fusion_enabled();
+    const bool fuse_nn = want_nn && g.ntiles == 1 && g.group >= 16 && !L.accumulate && !L.relu && nn_fusion_enabled();
     const int blk = block_for(g.group);
     const int gpb = fuse_nn ? std::max(kNnRows, blk / g.group) : blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
@@ -1470,7 +1488,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     }
     GcnLaunch C;
     C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
-    C.accumulate = L.accumulate;
+    C.accumulate = L.accumulate; C.relu = L.relu;
     const int rc = hubs_in_kernel ? GNNAGG_OK : launch_combine_gcn(C, g, is_max, stream);
     if (rc || !want_nn) return rc;
     return launch_dense_nn(L.y, L.nn_weight, L.nn_out, L.num_rows, L.nn_cols, L.feat, stream);
@@ -1486,7 +1504,7 @@ int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)
     else if (L.feat % 2 == 0 && aligned(L.x, 8)) vec = 2;
     RowsLongArgs a;
     a.r1 = reinterpret_cast<const int4 *>(L.r1); a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y;
-    a.n1 = L.n1; a.feat = L.feat; a.ntiles32 = ceil_div(L.feat, 32); a.mean = L.reduce == GNNAGG_REDUCE_MEAN;
+    a.n1 = L.n1; a.feat = L.feat; a.ntiles32 = ceil_div(L.feat, 32); a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.relu = L.relu;
     a.att = L.att; a.heads = L.heads; a.dhead = L.heads > 0 ? L.feat / L.heads : L.feat; a.slope = L.slope;
     const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
     const bool is_gat = L.att != nullptr;
@@ -1517,7 +1535,7 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
     a.ptr = L.wl.ptr; a.target = L.wl.target; a.slot = L.wl.slot; a.empty_rows = L.wl.empty_rows;
     a.row_ptr = L.row_ptr; a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
     a.n_items = L.wl.n_items; a.n_total = L.wl.n_items + L.wl.n_empty; a.feat = L.feat; a.ntiles = g.ntiles;
-    a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap;
+    a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap; a.relu = L.relu;
     a.timer = reinterpret_cast<unsigned long long *>(L.timer);
     if (L.timer || L.timer_blocks_out) a.remap = 0;  // natural block order for the load-balance study
     if (L.timer_blocks_out) {

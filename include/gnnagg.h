@@ -127,6 +127,11 @@ int gnnagg_gcn_run(gnnagg_handle h, const float *d_x, float *d_y, int feat, int 
  * usual and added to the value already in y with one fp32 add; rows without edges are left untouched.  Used by the
  * row-partitioned path to add the halo-column part after the local-column part. */
 #define GNNAGG_FLAG_ACCUMULATE 1
+/* GNNAGG_FLAG_RELU (any mode / reduce): y = max(result, 0) -- the activation that follows the aggregation in the
+ * reference's 3-layer model (Figure7/our.py:176, F.relu on the output of gcn_run), applied to the finished row by the
+ * producing kernel instead of one more pass over y.  With GNNAGG_FLAG_ACCUMULATE: y = max(y + A.x, 0), rows without
+ * edges included. */
+#define GNNAGG_FLAG_RELU 2
 int gnnagg_gcn_run_ex(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce, int flags);
 /* Aggregator_GCN::run_clock, aggr_gcn.h:462-489 (Figure 8 load-balance study).  Runs the one-item-per-lane-group
  * kernel of mode rows (the reference's aggr_gcn_clock) or scheduled (aggr_gcn_target_clock) with per-workgroup

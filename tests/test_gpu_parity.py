@@ -543,6 +543,47 @@ def test_run_with_nn():
     assert np.array_equal(t.cpu().numpy(), orc.matmul_nn(y_ref, w))
 
 
+@pytest.mark.parametrize("mode", ["rows", "scheduled", "balanced", "scheduled_items"])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+def test_gcn_fused_relu(mode, reduce):
+    """GNNAGG_FLAG_RELU: y = max(A.x, 0) written by the aggregation kernels themselves -- short rows, segment rows, hubs
+    folded in-kernel, the rows-mode long rows, and the item kernels + k_combine (NG = 2 schedule)."""
+    V, E, F = 3000, 120000, 128
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=5, alpha=1.1)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    x, val = rand((V, F), 1), rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    m = {"rows": 0, "scheduled": 1, "balanced": "balanced", "scheduled_items": 1}[mode]
+    if mode == "scheduled":
+        agg.schedule(gnc.Schedule.neighbor_grouping, [32])
+    if mode == "scheduled_items":
+        agg.schedule(gnc.Schedule.neighbor_grouping, [2])
+    if mode == "balanced":
+        agg.schedule_balanced(16)
+    dx = dev(x)
+    y_plain = torch.empty((V, F), device=DEV)
+    agg.run(dx, y_plain, 128, m, reduce=reduce)
+    y = torch.full((V, F), -7.0, device=DEV)
+    agg.run(dx, y, 128, m, reduce=reduce, relu=True)
+    assert torch.equal(y, torch.clamp_min(y_plain, 0.0))
+    assert float(y_plain.min()) < 0.0
+
+
+def test_gcn_fused_relu_with_accumulate():
+    V, E, F = 2000, 50000, 64
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=6, alpha=1.1)
+    ptr, idx = ptr_t.numpy().copy(), idx_t.numpy()
+    x, val = rand((V, F), 1), rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.schedule_balanced(16)
+    base = rand((V, F), 3)
+    y_sum = torch.empty((V, F), device=DEV)
+    agg.run(dev(x), y_sum, 128, "balanced")
+    y = dev(base).clone()
+    agg.run(dev(x), y, 128, "balanced", accumulate=True, relu=True)
+    assert torch.equal(y, torch.clamp_min(dev(base) + y_sum, 0.0))
+
+
 @pytest.mark.parametrize("F", [128, 48, 602])
 def test_hub_fold_in_kernel_alternating_inputs(F):
     """Hubs are folded by the last segment workgroup to arrive, reading scratch rows other XCDs wrote (device-scope
