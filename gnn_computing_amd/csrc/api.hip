@@ -393,7 +393,8 @@ static int build_rows_plan(Ctx *c)
     // many lane groups walking their own rows, so it is used only for rows far above the average degree and only
     // when those rows hold a small share of the edges (reddit-shaped graphs, where hub rows dominate, measured
     // slower with it).
-    p.long_deg = std::max(1024, 4 * c->avg_deg());
+    static const int long_min = getenv("GNNAGG_LONG_DEG") ? atoi(getenv("GNNAGG_LONG_DEG")) : 1024;
+    p.long_deg = std::max(long_min, 4 * c->avg_deg());
     {
         long long_edges = 0;
         for (int r = 0; r < c->V; ++r)

@@ -760,84 +760,175 @@ struct RowsLongArgs {
     float slope;
 };
 
+static constexpr int kLongGatherThreads = kLongBlock - 64;  // wavefront 0 only consumes
+static constexpr int kLongU = 8;                            // neighbors per gather group per round
+
+template <int VEC>
+constexpr int long_round_edges() { return (kLongGatherThreads / (32 / VEC)) * kLongU; }
+
 template <int VEC, bool IS_MAX, bool IS_GAT>
 __global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs a)
 {
-    constexpr int GL = 32 / VEC;           // lanes of one gather group: GL * VEC = 32 columns = 128 bytes
-    constexpr int NG = kLongBlock / GL;    // gather groups per workgroup
-    constexpr int U = 8;                   // neighbors per group per round
-    constexpr int RE = NG * U;             // edges per round
-    extern __shared__ float lds[];         // stage[RE * 32] (edge-major) then wstage[RE]
-    float *stage = lds, *wstage = lds + RE * 32;
+    constexpr int GL = 32 / VEC;                 // lanes of one gather group: GL * VEC = 32 columns = 128 bytes
+    constexpr int NG = kLongGatherThreads / GL;  // gather groups per workgroup
+    constexpr int U = kLongU;
+    constexpr int RE = NG * U;                   // edges per round
+    // two stage buffers + two weight buffers [RE]: round r+1 is written while round r is consumed, so one barrier per
+    // round orders everything (the buffer written in round r+1 was last read in round r-1).  Stage layout: the values of
+    // 4 consecutive edges of one column are contiguous -- element (edge k, column c) at ((k/4) * 32 + (c ^ swz(k/4))) * 4
+    // + k % 4 -- so the consumer fetches 4 chain steps with one ds_read_b128, and a gather thread, which holds 8 edges x
+    // VEC columns in registers, writes each (column, 4 edges) quad with one ds_write_b128 (a register transpose, no
+    // shuffles).  swz(q) = (q >> 1) & 3 XORs the column inside its row of quads: without it the 8 groups of a gather
+    // wavefront write 64-byte-strided quads that all fall on the same 8 of the 32 banks (4x slower stores, which also
+    // delay the consumer's reads); with it one store instruction covers every bank evenly.
+    extern __shared__ float lds[];
+    float *stage0 = lds, *stage1 = lds + RE * 32, *wst0 = lds + 2 * RE * 32, *wst1 = wst0 + RE;
     const int F = a.feat;
     const int tile = (int)blockIdx.x % a.ntiles32;
     const int4 d = a.r1[(int)blockIdx.x / a.ntiles32];
-    const int g = (int)threadIdx.x / GL, lane = threadIdx.x & (GL - 1);
+    const int nrounds = (d.y - d.x + RE - 1) / RE;
+    const int head = IS_GAT ? (tile * 32) / a.dhead : 0;
+    if (threadIdx.x < 64) {
+        // ---- consumer wavefront: lane c < 32 owns column tile*32 + c and runs its chain from LDS in edge order
+        const int c = (int)threadIdx.x;
+        const bool consumer = c < 32 && tile * 32 + c < F;
+        float acc = IS_MAX ? -INFINITY : 0.0f, den = 0.0f;
+        auto step = [&](float xs, float ws) {
+            if (IS_MAX) {
+                const float p = xs * ws;
+                acc = p > acc ? p : acc;
+            } else {
+                acc = __builtin_fmaf(xs, ws, acc);
+                if (IS_GAT) den += ws;
+            }
+        };
+        for (int r = 0; r < nrounds; ++r) {
+            __syncthreads();  // round r is staged
+            if (!consumer) continue;
+            const float *stage = (r & 1) ? stage1 : stage0, *wst = (r & 1) ? wst1 : wst0;
+            const int base = d.x + r * RE;
+            const int n = d.y - base < RE ? d.y - base : RE;
+            // 32 chain steps per batch = 8 + 8 ds_read_b128; the reads of batch b+1 are issued before the steps of batch b
+            // (two register sets), so the chain never waits for LDS latency
+            auto load32 = [&](float4 (&xs)[8], float4 (&ws)[8], int k) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {  // k % 32 == 0: swz(k/4 + q) == (q >> 1) & 3
+                    xs[q] = *reinterpret_cast<const float4 *>(&stage[(((k >> 2) + q) * 32 + (c ^ ((q >> 1) & 3))) * 4]);
+                    ws[q] = *reinterpret_cast<const float4 *>(&wst[k + 4 * q]);
+                }
+            };
+            auto steps32 = [&](const float4 (&xs)[8], const float4 (&ws)[8]) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    step(xs[q].x, ws[q].x);
+                    step(xs[q].y, ws[q].y);
+                    step(xs[q].z, ws[q].z);
+                    step(xs[q].w, ws[q].w);
+                }
+            };
+            const int nfull = n & ~31;
+            int k0 = 0;
+            if (nfull > 0) {
+                float4 xa[8], wa[8], xb[8], wb[8];
+                load32(xa, wa, 0);
+                while (true) {
+                    if (k0 + 32 < nfull) load32(xb, wb, k0 + 32);
+                    steps32(xa, wa);
+                    k0 += 32;
+                    if (k0 >= nfull) break;
+                    if (k0 + 32 < nfull) load32(xa, wa, k0 + 32);
+                    steps32(xb, wb);
+                    k0 += 32;
+                    if (k0 >= nfull) break;
+                }
+            }
+            for (; k0 < n; ++k0) step(stage[((k0 >> 2) * 32 + (c ^ ((k0 >> 3) & 3))) * 4 + (k0 & 3)], wst[k0]);
+        }
+        if (consumer) {
+            if (IS_GAT) acc = acc / den;  // aggr_gat.h:163 (rows here are never empty)
+            else if (a.mean) acc = acc / (float)(d.y - d.x);
+            if (!IS_GAT && a.relu) acc = acc > 0.0f ? acc : 0.0f;
+            a.y[(size_t)d.z * F + tile * 32 + c] = acc;
+        }
+        return;
+    }
+    // ---- gather wavefronts: group g fetches the 128-byte tile segments of edges base + g*U .. +U of every round
+    const int t = (int)threadIdx.x - 64;
+    const int g = t / GL, lane = t & (GL - 1);
     const int col = tile * 32 + lane * VEC;
     const bool col_ok = col < F;
-    const int c = (int)threadIdx.x;  // consumer thread <-> column tile*32 + c (c < 32)
-    const bool consumer = c < 32 && tile * 32 + c < F;
-    float acc = IS_MAX ? -INFINITY : 0.0f, den = 0.0f;
     const float *__restrict__ xcol = a.x + col;
-    const int head = IS_GAT ? (tile * 32) / a.dhead : 0;
     const float a_dst = IS_GAT ? a.att[((size_t)d.z * a.heads + head) * 2] : 0.0f;
-    Pack<VEC> xv[U];
-    float wv[U];
-    auto issue = [&](int base) {  // gathers of the round starting at edge `base`; this group's edges: base + g*U + u
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = base + g * U + u;
-            if (e < d.y) {
-                const int s = a.idx[e];
-                if (IS_GAT) wv[u] = a.att[((size_t)s * a.heads + head) * 2 + 1];  // source term; exp() after it landed
-                else wv[u] = a.val ? a.val[e] : 1.0f;
-                if (col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s * F);
-            }
-        }
+    // Two rounds of gathers are in flight (register sets A: even rounds, B: odd rounds) on top of the round in LDS, and
+    // the neighbor ids / weights are fetched two rounds before their gathers: under the load of the short-row kernel
+    // running beside this one every dependent load costs microseconds.  Every lane of a group loads the group's U ids
+    // (same addresses: one request each, no LDS shuffles -- the LDS pipe belongs to the stage); lane u < U also carries
+    // the u-th edge's weight and writes it to LDS.  Everything is branch-free: edges past the row's end are clamped to
+    // the last edge (their stage slots are never read).
+    const int mlane = lane < U ? lane : U - 1;
+    struct Meta {
+        int sid[U];  // neighbor ids of the group's U edges (same addresses in every lane of the group: one request each)
+        float w;     // this lane's edge (lane < U): its value (GCN)
     };
-    auto step = [&](float xs, float ws) {
-        if (IS_MAX) {
-            const float p = xs * ws;
-            acc = p > acc ? p : acc;
+    auto meta_load = [&](int base, Meta &m) {
+        const int e0 = base + g * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) m.sid[u] = a.idx[e0 + u < d.y ? e0 + u : d.y - 1];
+        if (!IS_GAT) m.w = a.val ? a.val[e0 + mlane < d.y ? e0 + mlane : d.y - 1] : 1.0f;
+    };
+    auto issue = [&](const Meta &m, Pack<VEC> (&xv)[U], float &wv) {
+        if (IS_GAT) {  // source term of this lane's edge; exp() once it has landed
+            int sl = m.sid[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) sl = mlane == u ? m.sid[u] : sl;
+            wv = a.att[((size_t)sl * a.heads + head) * 2 + 1];
         } else {
-            acc = __builtin_fmaf(xs, ws, acc);
-            if (IS_GAT) den += ws;
+            wv = m.w;
+        }
+        if (col_ok) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = load_pack<VEC>(xcol + (size_t)m.sid[u] * F);
         }
     };
-    issue(d.x);
-    for (int base = d.x; base < d.y; base += RE) {
+    // registers -> LDS: quads of 4 consecutive edges per column
+    auto stage_round = [&](const Pack<VEC> (&xv)[U], float wv, float *stage, float *wst) {
+        if (col_ok) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {  // registers -> LDS in edge order
-            const int k = g * U + u;
-            if (base + k < d.y) {
-                if (col_ok) store_pack<VEC>(&stage[k * 32 + lane * VEC], xv[u].v);
-                if (lane == 0) wstage[k] = IS_GAT ? edge_weight(a_dst, wv[u], a.slope) : wv[u];
+            for (int hq = 0; hq < U / 4; ++hq) {
+                const int kq = (g * U + 4 * hq) >> 2;
+                const int swz = (kq >> 1) & 3;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    *reinterpret_cast<float4 *>(&stage[(kq * 32 + ((lane * VEC + j) ^ swz)) * 4]) =
+                        make_float4(xv[4 * hq].v[j], xv[4 * hq + 1].v[j], xv[4 * hq + 2].v[j], xv[4 * hq + 3].v[j]);
             }
         }
-        __syncthreads();
-        if (base + RE < d.y) issue(base + RE);  // next round travels while this one is consumed
-        if (consumer) {
-            const int n = d.y - base < RE ? d.y - base : RE;
-            int k0 = 0;
-            for (; k0 + 16 <= n; k0 += 16) {  // 16 independent LDS reads (no per-element branches), then 16 chain steps
-                float xs[16], ws[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    xs[u] = stage[(k0 + u) * 32 + c];
-                    ws[u] = wstage[k0 + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) step(xs[u], ws[u]);
-            }
-            for (; k0 < n; ++k0) step(stage[k0 * 32 + c], wstage[k0]);
+        if (lane < U) wst[g * U + lane] = IS_GAT ? edge_weight(a_dst, wv, a.slope) : wv;
+    };
+    Pack<VEC> xa[U], xb[U];
+    float wa = 0.0f, wb = 0.0f;
+    Meta ma, mb;  // metadata of the next issue of set A / set B
+    meta_load(d.x, ma);
+    meta_load(d.x + RE, mb);
+    issue(ma, xa, wa);
+    meta_load(d.x + 2 * RE, ma);
+    issue(mb, xb, wb);
+    meta_load(d.x + 3 * RE, mb);
+    for (int r = 0; r < nrounds; r += 2) {
+        const int base = d.x + r * RE;
+        stage_round(xa, wa, stage0, wst0);
+        if (r + 2 < nrounds) {
+            issue(ma, xa, wa);                 // round r+2
+            meta_load(base + 4 * RE, ma);      // round r+4
+        }
+        __syncthreads();  // round r is staged (and the consumer is done with round r-1's buffer, which r+1 overwrites)
+        if (r + 1 >= nrounds) break;
+        stage_round(xb, wb, stage1, wst1);
+        if (r + 3 < nrounds) {
+            issue(mb, xb, wb);                 // round r+3
+            meta_load(base + 5 * RE, mb);      // round r+5
         }
         __syncthreads();
-    }
-    if (consumer) {
-        if (IS_GAT) acc = acc / den;  // aggr_gat.h:163 (rows here are never empty)
-        else if (a.mean) acc = acc / (float)(d.y - d.x);
-        if (!IS_GAT && a.relu) acc = acc > 0.0f ? acc : 0.0f;
-        a.y[(size_t)d.z * F + tile * 32 + c] = acc;
     }
 }
 
@@ -1512,13 +1603,22 @@ int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)
     const int grid = a.n1 * a.ntiles32;
 #define LAUNCH_LONG(V)                                                                                               \
     {                                                                                                                \
-        const size_t re = (size_t)(kLongBlock / (32 / V)) * 8;                                                       \
-        const size_t lds = (32 * re + re) * sizeof(float);                                 \
-        if (is_gat)      hipLaunchKernelGGL((k_gcn_rows_long<V, false, true>), dim3(grid), dim3(kLongBlock), lds, stream, a);  \
-        else if (is_max) hipLaunchKernelGGL((k_gcn_rows_long<V, true, false>), dim3(grid), dim3(kLongBlock), lds, stream, a);  \
-        else             hipLaunchKernelGGL((k_gcn_rows_long<V, false, false>), dim3(grid), dim3(kLongBlock), lds, stream, a); \
+        const size_t lds = (size_t)long_round_edges<V>() * (2 * 32 + 2) * sizeof(float);                             \
+        if (is_gat)      LAUNCH_LONG_K((k_gcn_rows_long<V, false, true>))                                            \
+        else if (is_max) LAUNCH_LONG_K((k_gcn_rows_long<V, true, false>))                                            \
+        else             LAUNCH_LONG_K((k_gcn_rows_long<V, false, false>))                                           \
+    }
+#define LAUNCH_LONG_K(K)                                                                                             \
+    {                                                                                                                \
+        static bool big_lds_ok = false; /* > 64 KB of dynamic LDS needs the attribute, once per instantiation */    \
+        if (!big_lds_ok) {                                                                                           \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            big_lds_ok = true;                                                                                       \
+        }                                                                                                            \
+        hipLaunchKernelGGL(K, dim3(grid), dim3(kLongBlock), lds, stream, a);                                         \
     }
     if (vec == 4) LAUNCH_LONG(4) else if (vec == 2) LAUNCH_LONG(2) else LAUNCH_LONG(1)
+#undef LAUNCH_LONG_K
 #undef LAUNCH_LONG
     HIP_TRY(hipGetLastError());
     return GNNAGG_OK;
