@@ -389,18 +389,14 @@ static int build_rows_plan(Ctx *c)
     int rc = fetch_host_ptr(c);
     if (rc) return rc;
     RowsPlan &p = c->rows_plan;
-    // The workgroup-per-row kernel wins on latency for isolated hubs but has less memory parallelism per CU than
-    // many lane groups walking their own rows, so it is used only for rows far above the average degree and only
-    // when those rows hold a small share of the edges (reddit-shaped graphs, where hub rows dominate, measured
-    // slower with it).
+    // The workgroup-per-row kernel finishes a long chain sooner (parallel gathers, one lane per column consuming), but a CU
+    // holds one such workgroup while it could hold dozens of lane groups walking their own rows, so it only takes rows far
+    // above the average degree: max(1024, 16 * avg).  Measured (rows mode, ms): reddit-shaped SAGE F=602 56.3 with every
+    // row on lane groups, 45.8 at 4 * avg, 41.0 at 16 * avg, 40.0 at 32 * avg; reddit-shaped GAT 47.2 / 19.8 / 16.8 / 16.5;
+    // products-shaped 9.8 at 1024 but 89 at 256 (the short rows starve).  GNNAGG_LONG_DEG / GNNAGG_LONG_MULT override.
     static const int long_min = getenv("GNNAGG_LONG_DEG") ? atoi(getenv("GNNAGG_LONG_DEG")) : 1024;
-    p.long_deg = std::max(long_min, 4 * c->avg_deg());
-    {
-        long long_edges = 0;
-        for (int r = 0; r < c->V; ++r)
-            if (c->h_ptr[r + 1] - c->h_ptr[r] > p.long_deg) long_edges += c->h_ptr[r + 1] - c->h_ptr[r];
-        if (long_edges * 4 > (long)c->E) p.long_deg = 0x7fffffff;
-    }
+    static const int long_mult = getenv("GNNAGG_LONG_MULT") ? atoi(getenv("GNNAGG_LONG_MULT")) : 16;
+    p.long_deg = std::max(long_min, long_mult * c->avg_deg());
     std::vector<int> r0;
     struct Long { int beg, end, row; };
     std::vector<Long> longs;

@@ -357,7 +357,7 @@ __device__ __forceinline__ bool hub_arrive_and_fold(const PlanArgs &a, const int
         const int nseg = a.mrow_ptr[m + 1] - a.mrow_ptr[m];
         int *cnt = a.hub_count + (size_t)m * a.hub_count_stride + tile;
         const int old = atomicAdd(cnt, 1);
-        if (old == nseg - 1) *cnt = 0;  // everybody is in: ready for the next launch
+        if (old == nseg - 1) atomicExch(cnt, 0);  // everybody is in: ready for the next launch (same path as the adds)
         s_hub = old == nseg - 1 ? m : -1;
     }
     __syncthreads();
@@ -1269,7 +1269,7 @@ __device__ __forceinline__ void hub_arrive_and_fold_gat(const GatPlanArgs &a, in
         const int nseg = a.mrow_ptr[m + 1] - a.mrow_ptr[m];
         int *cnt = a.hub_count + (size_t)m * a.hub_count_stride + tile;
         const int old = atomicAdd(cnt, 1);
-        if (old == nseg - 1) *cnt = 0;
+        if (old == nseg - 1) atomicExch(cnt, 0);
         s_hub = old == nseg - 1 ? m : -1;
     }
     __syncthreads();
