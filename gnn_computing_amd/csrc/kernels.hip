@@ -505,7 +505,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
 // transformed[V,N] = (A . X)[V,K] . W[K,N] in one pass (reference aggr_gcn_nn, aggr_gcn.h:304-359, called by
 // run_with_nn :491-499).  The aggregation spreads the K columns of a row over the lanes of a group while the matrix
 // cores want rows across lanes, so finished rows meet in LDS: a workgroup aggregates 32 short rows (32/GPB passes
-// of the plan kernel's descriptor path), stages them as a [32][K] tile (odd pitch: conflict-free operand reads),
+// of the plan kernel's descriptor path), stages them as a [rows][K] tile (pitch K + 4: aligned 16-byte row stores, operand reads two per bank),
 // and after ONE barrier its 4 wavefronts each take 16x16 output sub-tiles and run the full-K chain on
 // v_mfma_f32_16x16x4_f32 -- f32 in / f32 accumulate, an ascending-k fmaf chain, so the result is bit-for-bit the
 // separate GEMM's (and the oracle's).  W (K*N*4 bytes, 16 KB at 128x32) is read through L1/L2, not staged.
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan_nn(const PlanArg
 {
     constexpr int GPB = block_of<GROUP>() / GROUP;
     constexpr int ROWS = GPB > kNnRows ? GPB : kNnRows;  // rows of the tile
-    constexpr int PITCH = GROUP * VEC + 1;
+    constexpr int PITCH = GROUP * VEC + 4;  // rows stay 16-byte aligned; operand reads (row = lane % 16, k = lane / 16) fall 2 per bank
     constexpr int kTile = ROWS * PITCH, kStage = kSegChunks * GROUP * VEC;
     __shared__ float lds[kTile > kStage ? kTile : kStage];
     __shared__ int tile_rows[ROWS];
@@ -707,8 +707,11 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan_nn(const PlanArg
             }
         }
 #if !defined(NN_DBG) || NN_DBG != 1
+        if (!col_ok) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) lds[slot * PITCH + col + k] = col_ok ? acc[k] : 0.0f;
+            for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+        }
+        store_pack<VEC>(&lds[slot * PITCH + col], acc);
         if (lane == 0) tile_rows[slot] = row;
 #endif
     }
