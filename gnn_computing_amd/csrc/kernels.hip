@@ -2153,10 +2153,109 @@ __global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, c
     }
 }
 
+// Tall-skinny variant for the aggregation widths (K <= 128, K % 4 == 0): every wavefront keeps its B operands -- the
+// whole W[K, 32] column block, 64 VGPRs -- in registers for the life of the kernel and walks 32-row tiles of A on its own:
+// 16 coalesced 16-byte loads per lane fetch the NEXT tile while the current one is multiplied; the tile passes through a
+// per-wavefront LDS image (pitch K + 4: aligned ds_write_b128, operand reads two per bank) only to turn rows-over-lanes
+// into the MFMA operand layout; no workgroup barrier anywhere.  Four 16x16 sub-tiles per tile, each the full ascending-k
+// chain on v_mfma_f32_16x16x4_f32 (bit-exact as k_dense_nn).
+static constexpr int kTallWaves = 2;  // wavefronts per workgroup (one 16.9 KB LDS image each at K = 128)
+
+__global__ __launch_bounds__(64 * kTallWaves) void k_dense_nn_tall(const float *__restrict__ A, const float *__restrict__ B,
+                                                                   float *__restrict__ C, int M, int N, int K, int ntiles)
+{
+    extern __shared__ float lds[];
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int pitch = K + 4, q4 = K >> 2;  // K % 4 == 0
+    float *tile = lds + wave * 32 * pitch;
+    const int col0 = blockIdx.y * 32;
+    const int kq = lane >> 4, cl = lane & 15;
+    // B operands: lane (c = lane % 16, k = lane / 16) of MFMA t holds W[4t + k][col]; two column halves
+    float b0[32], b1[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const int k = 4 * t + kq;
+        b0[t] = (k < K && col0 + cl < N) ? B[(size_t)k * N + col0 + cl] : 0.0f;
+        b1[t] = (k < K && col0 + 16 + cl < N) ? B[(size_t)k * N + col0 + 16 + cl] : 0.0f;
+    }
+    const int wstride = gridDim.x * kTallWaves;
+    int t_idx = blockIdx.x * kTallWaves + wave;
+    float4 pre[16];
+    // float4 number e = lane + 64 i of a tile is (row e / q4, quad e % q4); stepping e by 64 advances (row, quad) by
+    // (64 / q4, 64 % q4) with one carry -- no division in the loops
+    const int step_r = 64 / q4, step_c = 64 - step_r * q4;
+    const int r0 = lane / q4, c0 = lane - r0 * q4;
+    auto fetch = [&](int ti) {
+        int r = r0, c4 = c0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = ti * 32 + r;
+            pre[i] = (r < 32 && row < M) ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + 4 * c4)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            r += step_r; c4 += step_c;
+            if (c4 >= q4) { c4 -= q4; ++r; }
+        }
+    };
+    if (t_idx < ntiles) fetch(t_idx);
+    for (; t_idx < ntiles; t_idx += wstride) {
+        {
+            int r = r0, c4 = c0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (r < 32) *reinterpret_cast<float4 *>(&tile[r * pitch + 4 * c4]) = pre[i];
+                r += step_r; c4 += step_c;
+                if (c4 >= q4) { c4 -= q4; ++r; }
+            }
+        }
+        if (t_idx + wstride < ntiles) fetch(t_idx + wstride);  // travels during the MFMA chains below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float *arow = tile + (rh * 16 + cl) * pitch + kq;
+            float av[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) av[t] = 4 * t < K ? arow[4 * t] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                if (4 * t < K) {  // wave-uniform
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b0[t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b1[t], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {  // D layout: col = lane % 16, row = 4 * (lane / 16) + reg
+                const int row = t_idx * 32 + rh * 16 + 4 * kq + v;
+                if (row < M) {
+                    if (col0 + cl < N) C[(size_t)row * N + col0 + cl] = acc0[v];
+                    if (col0 + 16 + cl < N) C[(size_t)row * N + col0 + 16 + cl] = acc1[v];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the image is rewritten next iteration
+    }
+}
+
 int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
     if (M <= 0 || N <= 0) return GNNAGG_OK;
+    {
+        static const int tall = getenv("GNNAGG_GEMM_TALL") ? atoi(getenv("GNNAGG_GEMM_TALL")) : 1;
+        // measured against k_dense_nn (N = 32): K = 128: M = 300 k 48.2 vs 46.4 us, 600 k 92.4 vs 99.9, 1.2 M 169 vs 184,
+        // 2.45 M 307 vs 352; K = 100, M = 2.45 M: 268 vs 363 (torch.mm 427); K = 64 loses at every M -> large M, wide K only
+        if (tall && K > 64 && K <= 128 && (K & 3) == 0 && M >= 500000 && ((uintptr_t)A & 15) == 0) {
+            const int ntiles = ceil_div(M, 32);
+            const size_t lds = (size_t)kTallWaves * 32 * (K + 4) * sizeof(float);
+            const int wgs = std::min(ceil_div(ntiles, kTallWaves), 256 * 4);
+            hipLaunchKernelGGL(k_dense_nn_tall, dim3(wgs, ceil_div(N, 32)), dim3(64 * kTallWaves), lds, stream, A, B, C, M, N, K,
+                               ntiles);
+            HIP_TRY(hipGetLastError());
+            return GNNAGG_OK;
+        }
+    }
     if (K <= 0) {
         HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream));
         return GNNAGG_OK;

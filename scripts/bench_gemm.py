@@ -24,7 +24,10 @@ def t(fn, it=20):
     return a.elapsed_time(b) * 1e3 / it
 
 
-for (M, K, N) in [(169343, 128, 32), (169343, 128, 64), (169343, 512, 128), (232965, 602, 128), (2449029, 100, 32)]:
+shapes = [(169343, 128, 32), (169343, 128, 64), (169343, 512, 128), (232965, 602, 128), (2449029, 100, 32)]
+if os.environ.get("GEMM_SHAPES"):
+    shapes = [tuple(int(v) for v in t_.split("x")) for t_ in os.environ["GEMM_SHAPES"].split(",")]
+for (M, K, N) in shapes:
     A, B = torch.randn((M, K), device=dev), torch.randn((K, N), device=dev)
     C = gnc.matmul_NN(A, B)
     ref = A @ B

@@ -528,6 +528,16 @@ def test_matmul_nn_bit_exact(M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), A.astype(np.float64) @ B.astype(np.float64), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(500001, 33, 100), (520000, 32, 128), (500017, 7, 68)])
+def test_matmul_nn_tall_kernel_bit_exact(M, N, K):
+    """The large-M kernel (k_dense_nn_tall: W held in registers, per-wavefront tiles, taken for M >= 500 k and 64 < K <= 128):
+    same ascending-k chain as the oracle, ragged last tile / column block included."""
+    A, B = rand((M, K), 5), rand((K, N), 6)
+    C = gnc.matmul_NN(dev(A), dev(B))
+    torch.cuda.synchronize()
+    assert np.array_equal(C.cpu().numpy(), orc.matmul_nn(A, B))
+
+
 def test_run_with_nn():
     V, E, F, OUT = 500, 9000, 128, 32
     ptr, idx = make_graph(V, E, seed=77)
