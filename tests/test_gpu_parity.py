@@ -832,6 +832,30 @@ def test_rows_mode_isolated_hub_gcn_and_gat(F, H):
     assert np.all(y.cpu().numpy()[deg == 0] == 0)
 
 
+@pytest.mark.parametrize("F", [30, 33, 130, 602])
+@pytest.mark.parametrize("weights", [True, False])
+def test_rows_mode_long_rows_odd_widths_and_reductions(F, weights):
+    """Rows mode with several long rows (1.5 k - 9 k edges: 4 - 21 rounds of the long-row kernel, ragged last round) at
+    widths that take the 1- and 2-float lane packs and a ragged last 32-column tile; sum / mean / max, bit-exact."""
+    V = 3000
+    rng = np.random.default_rng(23)
+    deg = rng.integers(0, 10, V)
+    deg[[5, 700, 1500, 2999]] = [9001, 1500, 4097, 2240]
+    ptr = np.zeros(V + 1, np.int32)
+    ptr[1:] = np.cumsum(deg)
+    E = int(ptr[-1])
+    idx = rng.integers(0, V, E).astype(np.int32)
+    x = rand((V, F), 1)
+    val = rand(E, 2) if weights else None
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if val is None else dev(val), F, F)
+    oval = val if val is not None else np.ones(E, np.float32)
+    y = torch.full((V, F), 7.0, device=DEV)
+    for red, fn in (("sum", orc.gcn_seq), ("mean", orc.gcn_mean), ("max", orc.gcn_max)):
+        y.fill_(7.0)
+        agg.run(dev(x), y, 512, 0, reduce=red)
+        assert np.array_equal(y.cpu().numpy(), fn(ptr, idx, oval, x)), red
+
+
 def test_check_csr_flags_bad_input():
     ptr = np.array([0, 2, 1, 4], np.int32)           # row 1 has ptr[1] > ptr[2]
     idx = np.array([0, 5, 2, -1], np.int32)          # 5 and -1 are outside [0, 3)
