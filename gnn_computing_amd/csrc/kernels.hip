@@ -1233,6 +1233,56 @@ __device__ __forceinline__ void chain_edges_gat(float (&acc)[VEC], float &den, i
     }
 }
 
+// Single head (the reference's only case, aggr_gat.h:116-205): the weight of an edge is the same for every column, so lane j
+// of the group computes it ONCE for edge cb + j -- its own coalesced id, one source-term gather, one exp -- and the group
+// shares it with ds_bpermute like the edge values of the GCN chain, instead of every lane gathering and exponentiating
+// every edge.  Ids are fetched two windows ahead and source terms one window ahead, so nothing dependent sits on the path;
+// the first feature gathers of a window are issued before its weights are needed.  Same values, same order as
+// chain_edges_gat (bit-identical results).
+template <int VEC, int GROUP>
+__device__ __forceinline__ void chain_edges_gat1(float (&acc)[VEC], float &den, int beg, int end, int lane, bool col_ok,
+                                                 const int *__restrict__ idx, const float *__restrict__ att_src, float a_dst,
+                                                 float slope, const float *__restrict__ xcol, int F, float *newval,
+                                                 bool first_tile)
+{
+    int s0 = 0, s1 = 0;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (beg + lane < end) s0 = idx[beg + lane];
+    if (beg + GROUP + lane < end) s1 = idx[beg + GROUP + lane];
+    if (beg + lane < end) a0 = att_src[(size_t)s0 * 2];
+    for (int cb = beg; cb < end; cb += GROUP) {
+        int s2 = 0;
+        if (cb + 2 * GROUP + lane < end) s2 = idx[cb + 2 * GROUP + lane];
+        if (cb + GROUP + lane < end) a1 = att_src[(size_t)s1 * 2];
+        const int n = end - cb < GROUP ? end - cb : GROUP;
+        float my_w = 0.0f;
+        for (int j = 0; j < n; j += kUnroll) {
+            int s[kUnroll];
+            float w[kUnroll];
+            Pack<VEC> xv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) s[u] = __shfl(s0, j + u, GROUP);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+            if (j == 0) {  // this lane's edge of the window
+                my_w = lane < n ? edge_weight(a_dst, a0, slope) : 0.0f;
+                if (newval && first_tile && lane < n) newval[cb + lane] = my_w;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) w[u] = __shfl(my_w, j + u, GROUP);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
+                    den += w[u];
+                }
+        }
+        s0 = s1; s1 = s2; a0 = a1;
+    }
+}
+
 struct GatPlanArgs {
     const int4 *t0, *t1;
     const int *idx;
@@ -1314,7 +1364,7 @@ __device__ __forceinline__ void hub_arrive_and_fold_gat(const GatPlanArgs &a, in
     }
 }
 
-template <int VEC, int GROUP>
+template <int VEC, int GROUP, bool SINGLE>
 __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArgs a)
 {
     constexpr int GPB = block_of<GROUP>() / GROUP;
@@ -1354,8 +1404,12 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
             float den = 0.0f;
             const int cb = d.x + c * a.chunk;
             const int ce = cb + a.chunk < d.y ? cb + a.chunk : d.y;
-            chain_edges_gat<VEC, GROUP>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval, h,
-                                        head_leader);
+            if constexpr (SINGLE)
+                chain_edges_gat1<VEC, GROUP>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, F, a.newval,
+                                             tile == 0);
+            else
+                chain_edges_gat<VEC, GROUP>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval,
+                                            h, head_leader);
             store_pack<VEC>(&stage[(c * GROUP + lane) * VEC], acc);
             stage_den[c * GROUP + lane] = den;
         }
@@ -1396,8 +1450,12 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
     float den = 0.0f;
     if (d.x < d.y) {
         const float a_dst = a.att[((size_t)row * H + h) * 2];
-        chain_edges_gat<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval, h,
-                                    head_leader);
+        if constexpr (SINGLE)
+            chain_edges_gat1<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, F, a.newval,
+                                         tile == 0);
+        else
+            chain_edges_gat<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval, h,
+                                        head_leader);
     }
     if (!col_ok) return;
     if (d.x < d.y && (den != 0.0f || a.rows_semantics)) {
@@ -1747,7 +1805,9 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     }
     const int grid = a.n1 * g.ntiles + grid0;
     if (grid > 0) {
-#define CALL_GP hipLaunchKernelGGL((k_gat_plan<VEC, GROUP>), dim3(grid), dim3(blk), 0, stream, a);
+#define CALL_GP                                                                                              \
+        if (a.heads == 1) hipLaunchKernelGGL((k_gat_plan<VEC, GROUP, true>), dim3(grid), dim3(blk), 0, stream, a);   \
+        else              hipLaunchKernelGGL((k_gat_plan<VEC, GROUP, false>), dim3(grid), dim3(blk), 0, stream, a);
         DISPATCH_GEOM(g, CALL_GP)
 #undef CALL_GP
         HIP_TRY(hipGetLastError());
