@@ -1364,6 +1364,7 @@ __device__ __forceinline__ void hub_arrive_and_fold_gat(const GatPlanArgs &a, in
     }
 }
 
+// (forcing 6 waves/SIMD -- 80 VGPRs, 5-9 spilled -- changes nothing: 100.8 vs 101.5 us on fig10a, 13.8 vs 13.6 ms on config G)
 template <int VEC, int GROUP, bool SINGLE>
 __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArgs a)
 {
