@@ -1,0 +1,459 @@
+// agg_gat.hip -- GAT kernels (fused edge softmax + weighted SpMM: items and balanced plan) and their launchers.
+#include "combine.cuh"
+
+namespace gnnagg {
+
+// ------------------------------------------------------------------------------- GAT items
+struct GatArgs {
+    const int *ptr, *target, *slot, *empty_rows;
+    const int *idx;
+    const float *att;
+    const float *x;
+    float *y;
+    float *partial, *partial_den, *newval;
+    int n_items, n_total, feat, ntiles, nblocks, heads, dhead, remap;
+    float slope;
+};
+
+
+// LIST = false: reference aggr_gat (aggr_gat.h:116-164); LIST = true: aggr_gat_fine (:167-205).
+template <int VEC, int GROUP, bool LIST>
+__global__ __launch_bounds__(block_of<GROUP>()) void k_gat_items(const GatArgs a)
+{
+    constexpr int ITEMS = block_of<GROUP>() / GROUP;
+    const int b = a.remap ? xcd_remap(blockIdx.x, a.nblocks) : (int)blockIdx.x;
+    const int tile = b % a.ntiles;
+    const int item = (b / a.ntiles) * ITEMS + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int col = (tile * GROUP + lane) * VEC;
+    if (item >= a.n_total || col >= a.feat) return;
+    const int F = a.feat, H = a.heads;
+
+    if (LIST && item >= a.n_items) {
+        const float z[VEC] = {};
+        store_pack<VEC>(a.y + (size_t)a.empty_rows[item - a.n_items] * F + col, z);
+        return;
+    }
+    const int beg = a.ptr[item], end = a.ptr[item + 1];
+    const int row = (LIST && a.target) ? a.target[item] : item;
+    const int h = col / a.dhead;
+    const bool head_leader = (col % a.dhead) == 0;
+    const int *__restrict__ idx = a.idx;
+    const float *__restrict__ att_src = a.att + (size_t)h * 2 + 1;
+    const float *__restrict__ xcol = a.x + col;
+    const float a_dst = a.att[((size_t)row * H + h) * 2];
+
+    float acc[VEC] = {};
+    float den = 0.0f;
+    for (int e = beg; e < end; e += kUnroll) {
+        int s[kUnroll];
+        float as[kUnroll];
+        Pack<VEC> xv[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (e + u < end) s[u] = idx[e + u];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (e + u < end) {
+                as[u] = att_src[(size_t)s[u] * H * 2];
+                xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+            }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (e + u < end) {
+                const float w = edge_weight(a_dst, as[u], a.slope);
+                if (a.newval && head_leader) a.newval[(size_t)(e + u) * H + h] = w;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
+                den += w;
+            }
+    }
+    const int sl = (LIST && a.slot) ? a.slot[item] : -1;
+    if (sl >= 0) {
+        store_pack<VEC>(a.partial + (size_t)sl * F + col, acc);
+        if (head_leader) a.partial_den[(size_t)sl * H + h] = den;
+        return;
+    }
+    if (beg == end) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    } else if (!LIST || den != 0.0f) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+    }
+    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+}
+
+// --------------------------------------------------------------------------- GAT, balanced plan
+// The fused edge-softmax + weighted SpMM (reference aggr_gat / aggr_gat_fine, aggr_gat.h:116-205) on the same
+// plan as k_gcn_plan: short rows one lane group each, long rows one workgroup per <= 16-chunk segment with the
+// numerator AND denominator partials folded in ascending chunk order in LDS, hubs through scratch + k_combine.
+template <int VEC, int GROUP>
+__device__ __forceinline__ void chain_edges_gat(float (&acc)[VEC], float &den, int beg, int end, int lane, bool col_ok,
+                                                const int *__restrict__ idx, const float *__restrict__ att_src, int H,
+                                                float a_dst, float slope, const float *__restrict__ xcol, int F,
+                                                float *newval, int h, bool head_leader)
+{
+    int my_s = 0;
+    if (beg + lane < end) my_s = idx[beg + lane];
+    for (int cb = beg; cb < end; cb += GROUP) {
+        int nx_s = 0;
+        if (cb + GROUP + lane < end) nx_s = idx[cb + GROUP + lane];
+        const int n = end - cb < GROUP ? end - cb : GROUP;
+        for (int j = 0; j < n; j += kUnroll) {
+            int s[kUnroll];
+            float as[kUnroll];
+            Pack<VEC> xv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) s[u] = __shfl(my_s, j + u, GROUP);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+                    as[u] = att_src[(size_t)s[u] * H * 2];
+                    xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+                }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+                    const float w = edge_weight(a_dst, as[u], slope);
+                    if (newval && head_leader) newval[(size_t)(cb + j + u) * H + h] = w;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
+                    den += w;
+                }
+        }
+        my_s = nx_s;
+    }
+}
+
+// Single head (the reference's only case, aggr_gat.h:116-205): the weight of an edge is the same for every column, so lane j
+// of the group computes it ONCE for edge cb + j -- its own coalesced id, one source-term gather, one exp -- and the group
+// shares it with ds_bpermute like the edge values of the GCN chain, instead of every lane gathering and exponentiating
+// every edge.  Ids are fetched two windows ahead and source terms one window ahead, so nothing dependent sits on the path;
+// the first feature gathers of a window are issued before its weights are needed.  Same values, same order as
+// chain_edges_gat (bit-identical results).
+template <int VEC, int GROUP>
+__device__ __forceinline__ void chain_edges_gat1(float (&acc)[VEC], float &den, int beg, int end, int lane, bool col_ok,
+                                                 const int *__restrict__ idx, const float *__restrict__ att_src, float a_dst,
+                                                 float slope, const float *__restrict__ xcol, int F, float *newval,
+                                                 bool first_tile)
+{
+    int s0 = 0, s1 = 0;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (beg + lane < end) s0 = idx[beg + lane];
+    if (beg + GROUP + lane < end) s1 = idx[beg + GROUP + lane];
+    if (beg + lane < end) a0 = att_src[(size_t)s0 * 2];
+    for (int cb = beg; cb < end; cb += GROUP) {
+        int s2 = 0;
+        if (cb + 2 * GROUP + lane < end) s2 = idx[cb + 2 * GROUP + lane];
+        if (cb + GROUP + lane < end) a1 = att_src[(size_t)s1 * 2];
+        const int n = end - cb < GROUP ? end - cb : GROUP;
+        float my_w = 0.0f;
+        for (int j = 0; j < n; j += kUnroll) {
+            int s[kUnroll];
+            float w[kUnroll];
+            Pack<VEC> xv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) s[u] = __shfl(s0, j + u, GROUP);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+            if (j == 0) {  // this lane's edge of the window
+                my_w = lane < n ? edge_weight(a_dst, a0, slope) : 0.0f;
+                if (newval && first_tile && lane < n) newval[cb + lane] = my_w;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) w[u] = __shfl(my_w, j + u, GROUP);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
+                    den += w[u];
+                }
+        }
+        s0 = s1; s1 = s2; a0 = a1;
+    }
+}
+
+struct GatPlanArgs {
+    const int4 *t0, *t1;
+    const int *idx;
+    const float *att;
+    const float *x;
+    float *y;
+    float *partial, *partial_den, *newval;
+    int n0, n1, feat, ntiles, chunk, heads, dhead, remap, nblocks0, rows_semantics;
+    float slope;
+    // hubs folded by the last segment workgroup to arrive (hub_count == nullptr: k_combine), as in PlanArgs
+    const int *slot_hub, *mrow_ptr, *mrow_id;
+    int *hub_count;
+    int hub_count_stride;
+    unsigned partial_bytes, partial_den_bytes;
+    XcdRanges xr;
+};
+
+// GAT counterpart of hub_arrive_and_fold: numerator rows and per-head denominators of the hub's segments, ascending
+// slot order, one division at the end (scaleArray, aggr_gat.h:207-213) -- the order of k_combine<.., IS_GAT>.
+template <int VEC, int GROUP>
+__device__ __forceinline__ void hub_arrive_and_fold_gat(const GatPlanArgs &a, int slot, int tile, int col, bool col_ok, int h,
+                                                        bool head_leader, int grp, int lane, float (&acc)[VEC], float den,
+                                                        float *stage, float *stage_den)
+{
+    constexpr int GPB = block_of<GROUP>() / GROUP;
+    const int F = a.feat, H = a.heads;
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(a.partial_den, 0, (int)a.partial_den_bytes, 0x00020000);
+    if (grp == 0 && col_ok) {
+        store_pack_wt<VEC>(a.partial, a.partial_bytes, (size_t)slot * F + col, acc);
+        if (head_leader) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(den), drsrc, (int)(((size_t)slot * H + h) * 4), 0, 16);
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // the write-through stores have reached the device coherence point
+    __shared__ int s_hub;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int m = a.slot_hub[slot];
+        const int nseg = a.mrow_ptr[m + 1] - a.mrow_ptr[m];
+        int *cnt = a.hub_count + (size_t)m * a.hub_count_stride + tile;
+        const int old = atomicAdd(cnt, 1);
+        if (old == nseg - 1) atomicExch(cnt, 0);
+        s_hub = old == nseg - 1 ? m : -1;
+    }
+    __syncthreads();
+    const int m = s_hub;
+    if (m < 0) return;
+    const int s0 = a.mrow_ptr[m], s1 = a.mrow_ptr[m + 1];
+    const int row = a.mrow_id[m];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    den = 0.0f;
+    for (int sb = s0; sb < s1; sb += kSegChunks) {
+        const int nst = s1 - sb < kSegChunks ? s1 - sb : kSegChunks;
+        for (int p = grp; p < nst; p += GPB)
+            if (col_ok) {
+                const Pack<VEC> v = load_pack_sc1<VEC>(a.partial, a.partial_bytes, (size_t)(sb + p) * F + col);
+                store_pack<VEC>(&stage[(p * GROUP + lane) * VEC], v.v);
+                stage_den[p * GROUP + lane] =
+                    __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(drsrc, (int)(((size_t)(sb + p) * H + h) * 4), 0, 16));
+            }
+        __syncthreads();
+        if (grp == 0 && col_ok) {
+#pragma unroll
+            for (int p = 0; p < kSegChunks; ++p)
+                if (p < nst) {
+                    const Pack<VEC> v = load_pack<VEC>(&stage[(p * GROUP + lane) * VEC]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += v.v[k];
+                    den += stage_den[p * GROUP + lane];
+                }
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && col_ok) {
+        if (den != 0.0f) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+        }
+        store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+    }
+}
+
+// (forcing 6 waves/SIMD -- 80 VGPRs, 5-9 spilled -- changes nothing: 100.8 vs 101.5 us on fig10a, 13.8 vs 13.6 ms on config G)
+template <int VEC, int GROUP, bool SINGLE>
+__global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArgs a)
+{
+    constexpr int GPB = block_of<GROUP>() / GROUP;
+    const int F = a.feat, H = a.heads;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int grp = (int)threadIdx.x / GROUP;
+    const int nb1 = a.n1 * a.ntiles;
+    const bool seg_block = (int)blockIdx.x < nb1;
+    int tile, row_or_dest;
+    int4 d;
+    if (seg_block) {
+        tile = (int)blockIdx.x % a.ntiles;
+        d = a.t1[(int)blockIdx.x / a.ntiles];
+    } else {
+        const int b = logical_block((int)blockIdx.x - nb1, a.nblocks0, a.ntiles, a.remap, a.xr);
+        if (b < 0) return;
+        tile = b % a.ntiles;
+        const int item = (b / a.ntiles) * GPB + grp;
+        if (item >= a.n0) return;
+        d = a.t0[item];
+    }
+    row_or_dest = d.z;
+    const int col = (tile * GROUP + lane) * VEC;
+    const bool col_ok = col < F;
+    const int h = col_ok ? col / a.dhead : 0;
+    const bool head_leader = col_ok && (col % a.dhead) == 0;
+    const float *__restrict__ att_src = a.att + (size_t)h * 2 + 1;
+    const float *__restrict__ xcol = a.x + col;
+    if (seg_block) {
+        __shared__ float stage[kSegChunks * GROUP * VEC];
+        __shared__ float stage_den[kSegChunks * GROUP];
+        const int row = d.w;  // destination row of this segment (its attention centre term)
+        const float a_dst = a.att[((size_t)row * H + h) * 2];
+        const int nch = (d.y - d.x + a.chunk - 1) / a.chunk;
+        for (int c = grp; c < nch; c += GPB) {
+            float acc[VEC] = {};
+            float den = 0.0f;
+            const int cb = d.x + c * a.chunk;
+            const int ce = cb + a.chunk < d.y ? cb + a.chunk : d.y;
+            if constexpr (SINGLE)
+                chain_edges_gat1<VEC, GROUP>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, F, a.newval,
+                                             tile == 0);
+            else
+                chain_edges_gat<VEC, GROUP>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval,
+                                            h, head_leader);
+            store_pack<VEC>(&stage[(c * GROUP + lane) * VEC], acc);
+            stage_den[c * GROUP + lane] = den;
+        }
+        __syncthreads();
+        const bool hub_here = row_or_dest < 0 && a.hub_count != nullptr;  // workgroup-uniform
+        if (!hub_here && (grp != 0 || !col_ok)) return;
+        float acc[VEC] = {};
+        float den = 0.0f;
+        if (grp == 0 && col_ok) {
+#pragma unroll
+            for (int c = 0; c < kSegChunks; ++c)
+                if (c < nch) {
+                    const Pack<VEC> p = load_pack<VEC>(&stage[(c * GROUP + lane) * VEC]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += p.v[k];
+                    den += stage_den[c * GROUP + lane];
+                }
+        }
+        if (hub_here) {
+            hub_arrive_and_fold_gat<VEC, GROUP>(a, ~row_or_dest, tile, col, col_ok, h, head_leader, grp, lane, acc, den, stage,
+                                                stage_den);
+            return;
+        }
+        if (row_or_dest >= 0) {
+            if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+            }
+            store_pack<VEC>(a.y + (size_t)row_or_dest * F + col, acc);
+        } else {
+            store_pack<VEC>(a.partial + (size_t)(~row_or_dest) * F + col, acc);
+            if (head_leader) a.partial_den[(size_t)(~row_or_dest) * H + h] = den;
+        }
+        return;
+    }
+    const int row = d.z;
+    float acc[VEC] = {};
+    float den = 0.0f;
+    if (d.x < d.y) {
+        const float a_dst = a.att[((size_t)row * H + h) * 2];
+        if constexpr (SINGLE)
+            chain_edges_gat1<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, F, a.newval,
+                                         tile == 0);
+        else
+            chain_edges_gat<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval, h,
+                                        head_leader);
+    }
+    if (!col_ok) return;
+    if (d.x < d.y && (den != 0.0f || a.rows_semantics)) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+    }
+    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+}
+
+int launch_gat(const GatLaunch &L, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (L.feat <= 0 || L.heads <= 0 || L.feat % L.heads != 0)
+        return fail(GNNAGG_ERR_ARG, "GAT needs feat >= 1 and feat % heads == 0");
+    const bool list = L.wl.target != nullptr || L.wl.slot != nullptr || L.wl.n_empty > 0;
+    const int dhead = L.feat / L.heads;
+    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, dhead);
+    GatArgs a;
+    a.ptr = L.wl.ptr; a.target = L.wl.target; a.slot = L.wl.slot; a.empty_rows = L.wl.empty_rows;
+    a.idx = L.idx; a.att = L.att; a.x = L.x; a.y = L.y; a.partial = L.partial; a.partial_den = L.partial_den;
+    a.newval = L.newval; a.n_items = L.wl.n_items; a.n_total = L.wl.n_items + L.wl.n_empty; a.feat = L.feat;
+    a.ntiles = g.ntiles; a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope;
+    if (a.n_total > 0) {
+        const int blk = block_for(g.group);
+        a.nblocks = ceil_div(a.n_total, blk / g.group) * g.ntiles;
+        if (a.remap && a.nblocks < 64) a.remap = 0;
+#define CALL_GAT                                                                                             \
+        if (list) hipLaunchKernelGGL((k_gat_items<VEC, GROUP, true>), dim3(a.nblocks), dim3(blk), 0, stream, a);    \
+        else      hipLaunchKernelGGL((k_gat_items<VEC, GROUP, false>), dim3(a.nblocks), dim3(blk), 0, stream, a);
+        DISPATCH_GEOM(g, CALL_GAT)
+#undef CALL_GAT
+        HIP_TRY(hipGetLastError());
+    }
+    if (L.wl.n_mrows > 0) {
+        CombineArgs c;
+        c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = nullptr; c.partial = L.partial;
+        c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
+        c.heads = L.heads; c.dhead = dhead; c.mean = 0; c.accumulate = 0;
+        c.big_rows = L.wl.big_rows; c.n_big = L.heads <= 64 ? L.wl.n_big : 0;
+        c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
+        const int nb = c.nblocks_small + c.n_big * g.ntiles;
+#define CALL_COMB hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true>), dim3(nb), dim3(kBlock), 0, stream, c);
+        DISPATCH_GEOM(g, CALL_COMB)
+#undef CALL_COMB
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
+int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (L.feat <= 0 || L.heads <= 0 || L.feat % L.heads != 0)
+        return fail(GNNAGG_ERR_ARG, "GAT needs feat >= 1 and feat % heads == 0");
+    const int dhead = L.feat / L.heads;
+    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, dhead);
+    GatPlanArgs a;
+    a.t0 = reinterpret_cast<const int4 *>(L.t0); a.t1 = reinterpret_cast<const int4 *>(L.t1);
+    a.idx = L.idx; a.att = L.att; a.x = L.x; a.y = L.y; a.partial = L.partial; a.partial_den = L.partial_den;
+    a.newval = L.newval; a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
+    a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope; a.rows_semantics = L.rows_semantics;
+    a.slot_hub = L.slot_hub; a.mrow_ptr = L.hubs.mrow_ptr; a.mrow_id = L.hubs.mrow_id;
+    a.hub_count = L.hub_count; a.hub_count_stride = L.hub_count_stride; a.partial_bytes = a.partial_den_bytes = 0;
+    {
+        // one column tile only: with several, a head's denominator is written by the tile that holds its first column
+        // and the other tiles' last arrivers could not know that store is done
+        const size_t pbytes = (size_t)L.hubs.n_slots * L.feat * sizeof(float);
+        if (L.hubs.n_mrows == 0 || pbytes >= 0x7fffffffULL || g.ntiles != 1 || L.hub_count_stride < 1) a.hub_count = nullptr;
+        else { a.partial_bytes = (unsigned)pbytes; a.partial_den_bytes = (unsigned)((size_t)L.hubs.n_slots * L.heads * sizeof(float)); }
+    }
+    const bool hubs_in_kernel = a.hub_count != nullptr;
+    const int blk = block_for(g.group);
+    const int gpb = blk / g.group;
+    const int item_blocks = ceil_div(a.n0, gpb);
+    a.nblocks0 = item_blocks * g.ntiles;
+    if (a.remap && a.nblocks0 < 64) a.remap = 0;
+    int grid0 = a.nblocks0;
+    if (a.remap == 2) {
+        if (!L.t0_cost_prefix) a.remap = 1;
+        else grid0 = 8 * fill_xcd_ranges(L.t0_cost_prefix, a.n0, gpb, item_blocks, a.xr) * g.ntiles;
+    }
+    const int grid = a.n1 * g.ntiles + grid0;
+    if (grid > 0) {
+#define CALL_GP                                                                                              \
+        if (a.heads == 1) hipLaunchKernelGGL((k_gat_plan<VEC, GROUP, true>), dim3(grid), dim3(blk), 0, stream, a);   \
+        else              hipLaunchKernelGGL((k_gat_plan<VEC, GROUP, false>), dim3(grid), dim3(blk), 0, stream, a);
+        DISPATCH_GEOM(g, CALL_GP)
+#undef CALL_GP
+        HIP_TRY(hipGetLastError());
+    }
+    if (L.hubs.n_mrows > 0 && !hubs_in_kernel) {
+        CombineArgs c;
+        c.mrow_id = L.hubs.mrow_id; c.mrow_ptr = L.hubs.mrow_ptr; c.row_ptr = nullptr; c.partial = L.partial;
+        c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.hubs.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
+        c.heads = L.heads; c.dhead = dhead; c.mean = 0; c.accumulate = 0;
+        c.big_rows = L.hubs.big_rows; c.n_big = L.heads <= 64 ? L.hubs.n_big : 0;
+        c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
+        const int nb = c.nblocks_small + c.n_big * g.ntiles;
+#define CALL_COMB hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true>), dim3(nb), dim3(kBlock), 0, stream, c);
+        DISPATCH_GEOM(g, CALL_COMB)
+#undef CALL_COMB
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
+}  // namespace gnnagg

@@ -117,7 +117,7 @@ struct BalancedPlan {
         n0 = n1 = n_mrows = n_slots = n_big = 0;
     }
 };
-static constexpr int kSegChunksHost = 16;  // kSegChunks in kernels.hip
+static constexpr int kSegChunksHost = 16;  // kSegChunks in kernel_util.cuh
 
 // GNNAGG_MODE_ROWS plan of a GCN aggregator (k_gcn_rows_plan): short rows per lane group, long rows per workgroup.
 struct RowsPlan {
@@ -221,7 +221,7 @@ static int finalize_schedule(Ctx *c, Schedule &s)
     {
         std::vector<int> big;
         for (int m = 0; m < (int)mrow_id.size(); ++m)
-            if (mrow_ptr[m + 1] - mrow_ptr[m] > 16) big.push_back(m);  // kCombineBatch in kernels.hip
+            if (mrow_ptr[m + 1] - mrow_ptr[m] > 16) big.push_back(m);  // kCombineBatch in combine.cuh
         s.n_big = (int)big.size();
         if ((rc = s.big_rows.upload(big))) return rc;
     }
@@ -304,7 +304,7 @@ static int build_plan_into(Ctx *c, BalancedPlan &p, int chunk, bool describe_in_
                 const long sb = beg + (long)j * seg_edges;
                 segs.push_back({(int)sb, (int)std::min<long>(sb + seg_edges, end), ~(nslots + j), r});
             }
-            if (nseg > 16) big.push_back((int)mrow_id.size());  // kCombineBatch in kernels.hip
+            if (nseg > 16) big.push_back((int)mrow_id.size());  // kCombineBatch in combine.cuh
             nslots += nseg;
             mrow_id.push_back(r);
             mrow_ptr.push_back(nslots);

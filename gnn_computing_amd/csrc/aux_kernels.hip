@@ -1,0 +1,552 @@
+// aux_kernels.hip -- everything beside the two aggregation families: CSR -> edge list, the unfused edge-softmax stages,
+// the edge-wise and naive SpMM baselines, validators, the dense combine GEMM, the CSR check and the halo pack.
+#include "kernel_util.cuh"
+
+namespace gnnagg {
+
+// ------------------------------------------------------------------------- CSR -> edge list
+// A lane group strides over the edges of one row; group size follows the average degree so short
+// rows do not idle a whole wavefront.
+static int edge_group(int avg_deg)
+{
+    int g = 8;
+    while (g < 64 && g < avg_deg) g <<= 1;
+    return g;
+}
+
+template <int GROUP>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int m = GROUP / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, GROUP);
+    return v;
+}
+
+// reference convertCSRToEdgelist, aggregator.h:11-23 ((src,dst) written as one 8-byte store)
+template <int GROUP>
+__global__ __launch_bounds__(kBlock) void k_csr2edgelist(const int *__restrict__ ptr, const int *__restrict__ idx,
+                                                        int2 *__restrict__ edgelist, int V)
+{
+    const int row = blockIdx.x * (kBlock / GROUP) + threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (row >= V) return;
+    for (int e = ptr[row] + lane; e < ptr[row + 1]; e += GROUP) edgelist[e] = make_int2(idx[e], row);
+}
+
+#define DISPATCH_EDGE_GROUP(G, CALL)                      \
+    switch (G) {                                          \
+        case 8:  { constexpr int GROUP = 8;  CALL; } break;  \
+        case 16: { constexpr int GROUP = 16; CALL; } break;  \
+        case 32: { constexpr int GROUP = 32; CALL; } break;  \
+        default: { constexpr int GROUP = 64; CALL; } break;  \
+    }
+
+int launch_csr2edgelist(const int *ptr, const int *idx, int *edgelist, int V, int avg_deg, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (V <= 0) return GNNAGG_OK;
+    const int G = edge_group(avg_deg);
+    const int nb = ceil_div(V, kBlock / G);
+    DISPATCH_EDGE_GROUP(G, hipLaunchKernelGGL((k_csr2edgelist<GROUP>), dim3(nb), dim3(kBlock), 0, stream, ptr, idx,
+                                              reinterpret_cast<int2 *>(edgelist), V))
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// ------------------------------------------------- edge kernels on chunked work items (hub-safe)
+// Giving one lane group a whole row (the reference's warp-per-row attGat / u_add_v / add_to_center / each_div,
+// aggr_gat.h:5-92) serialises on a 15 k-edge hub row: 860 us for attGat on the arxiv-shaped graph in the first
+// version of this file.  These kernels run on the work items of the balanced
+// neighbor grouping (<= chunk edges each): pass 1 writes the edge values and per-item sums (straight to
+// den[row] when the row has one item, to partial_den[slot] otherwise), an ordered combine finishes the
+// split rows, pass 2 normalises.  Lanes walk the flattened (edge, head) pairs of an item, so out[e,h]
+// stores are fully coalesced and a lane keeps one head when GROUP % H == 0.
+struct EdgeItemArgs {
+    const int *ptr_s, *target, *slot, *empty_rows, *idx;
+    const float *att;   // [V,H,2]
+    const float *in;    // per-edge input (add_to_center) / per-row divisor (div)
+    float *out;         // per-edge output [E,H]
+    float *den;         // per-row sums [V,H]
+    float *partial_den; // [n_slots,H]
+    int n_items, n_empty, H;
+    float slope;
+};
+
+// OP 0: attGat pass 1 (w = exp(leaky(a_dst + a_src)) -> out, item sums)   aggr_gat.h:13-19
+// OP 1: add_to_center (item sums of in[e])                                 aggr_gat.h:62-73
+template <int GROUP, int OP>
+__global__ __launch_bounds__(kBlock) void k_edge_items_sum(const EdgeItemArgs a)
+{
+    const int item = blockIdx.x * (kBlock / GROUP) + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int H = a.H;
+    if (item >= a.n_items + a.n_empty) return;
+    if (item >= a.n_items) {  // rows without edges: sum = 0
+        const int row = a.empty_rows[item - a.n_items];
+        for (int h = lane; h < H; h += GROUP) a.den[(size_t)row * H + h] = 0.0f;
+        return;
+    }
+    const int beg = a.ptr_s[item], end = a.ptr_s[item + 1];
+    const int row = a.target[item];
+    const int sl = a.slot[item];
+    float *dst = sl >= 0 ? a.partial_den + (size_t)sl * H : a.den + (size_t)row * H;
+    const int n = (end - beg) * H;
+    if (H <= GROUP && (GROUP % H) == 0) {
+        const int h = lane % H;  // fixed head per lane: the stride GROUP is a multiple of H
+        const float a_dst = OP == 0 ? a.att[((size_t)row * H + h) * 2] : 0.0f;
+        float part = 0.0f;
+        for (int j = lane; j < n; j += GROUP) {
+            const int e = beg + j / H;
+            float w;
+            if (OP == 0) {
+                w = edge_weight(a_dst, a.att[((size_t)a.idx[e] * H + h) * 2 + 1], a.slope);
+                a.out[(size_t)beg * H + j] = w;
+            } else {
+                w = a.in[(size_t)beg * H + j];
+            }
+            part += w;
+        }
+        for (int msk = GROUP / 2; msk >= H; msk >>= 1) part += __shfl_xor(part, msk, GROUP);
+        if (lane < H) dst[lane] = part;
+    } else {
+        for (int h = 0; h < H; ++h) {  // odd head counts: one head at a time
+            const float a_dst = OP == 0 ? a.att[((size_t)row * H + h) * 2] : 0.0f;
+            float part = 0.0f;
+            for (int e = beg + lane; e < end; e += GROUP) {
+                float w;
+                if (OP == 0) {
+                    w = edge_weight(a_dst, a.att[((size_t)a.idx[e] * H + h) * 2 + 1], a.slope);
+                    a.out[(size_t)e * H + h] = w;
+                } else {
+                    w = a.in[(size_t)e * H + h];
+                }
+                part += w;
+            }
+            part = group_sum<GROUP>(part);
+            if (lane == 0) dst[h] = part;
+        }
+    }
+}
+
+// ordered sum of the item sums of split rows
+__global__ void k_den_combine(const int *__restrict__ mrow_id, const int *__restrict__ mrow_ptr,
+                              const float *__restrict__ partial_den, float *__restrict__ den, int n_mrows, int H)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_mrows * H) return;
+    const int m = t / H, h = t % H;
+    float s = 0.0f;
+    for (int p = mrow_ptr[m]; p < mrow_ptr[m + 1]; ++p) s += partial_den[(size_t)p * H + h];
+    den[(size_t)mrow_id[m] * H + h] = s;
+}
+
+// OP 0: out[e,h] /= den[row,h]   (attGat pass 2 aggr_gat.h:26-29, each_div aggr_gat.h:84-90)
+// OP 1: out[e] = att[row,0] + att[idx[e],1]   (u_add_v aggr_gat.h:44-46)
+template <int GROUP, int OP>
+__global__ __launch_bounds__(kBlock) void k_edge_items_map(const EdgeItemArgs a)
+{
+    const int item = blockIdx.x * (kBlock / GROUP) + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (item >= a.n_items) return;
+    const int beg = a.ptr_s[item], end = a.ptr_s[item + 1];
+    const int row = a.target[item];
+    const int H = a.H;
+    if (OP == 0) {
+        const int n = (end - beg) * H;
+        for (int j = lane; j < n; j += GROUP) a.out[(size_t)beg * H + j] /= a.in[(size_t)row * H + j % H];
+    } else {
+        const float a_dst = a.att[(size_t)row * 2];
+        for (int e = beg + lane; e < end; e += GROUP) a.out[e] = a_dst + a.att[(size_t)a.idx[e] * 2 + 1];
+    }
+}
+
+static int edge_item_group(long avg_pairs)
+{
+    return avg_pairs <= 8 ? 8 : (avg_pairs <= 32 ? 32 : 64);
+}
+
+#define DISPATCH_EIG(G, CALL)                               \
+    switch (G) {                                            \
+        case 8:  { constexpr int GROUP = 8;  CALL; } break; \
+        case 32: { constexpr int GROUP = 32; CALL; } break; \
+        default: { constexpr int GROUP = 64; CALL; } break; \
+    }
+
+static void fill_edge_args(EdgeItemArgs &a, const EdgeItemLaunch &L)
+{
+    a.ptr_s = L.wl.ptr; a.target = L.wl.target; a.slot = L.wl.slot; a.empty_rows = L.wl.empty_rows; a.idx = L.idx;
+    a.att = L.att; a.in = L.in; a.out = L.out; a.den = L.den; a.partial_den = L.partial_den;
+    a.n_items = L.wl.n_items; a.n_empty = L.wl.n_empty; a.H = L.heads; a.slope = L.slope;
+}
+
+// sums: op 0 = attGat weights + row sums, op 1 = add_to_center
+int launch_edge_items_sum(const EdgeItemLaunch &L, int op, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    EdgeItemArgs a;
+    fill_edge_args(a, L);
+    const int total = a.n_items + a.n_empty;
+    if (total > 0) {
+        const int G = edge_item_group((long)L.avg_item_edges * L.heads);
+        const int nb = ceil_div(total, kBlock / G);
+        if (op == 0) { DISPATCH_EIG(G, hipLaunchKernelGGL((k_edge_items_sum<GROUP, 0>), dim3(nb), dim3(kBlock), 0, stream, a)) }
+        else         { DISPATCH_EIG(G, hipLaunchKernelGGL((k_edge_items_sum<GROUP, 1>), dim3(nb), dim3(kBlock), 0, stream, a)) }
+        HIP_TRY(hipGetLastError());
+    }
+    if (L.wl.n_mrows > 0) {
+        const int n = L.wl.n_mrows * L.heads;
+        hipLaunchKernelGGL(k_den_combine, dim3(ceil_div(n, 256)), dim3(256), 0, stream, L.wl.mrow_id, L.wl.mrow_ptr,
+                           L.partial_den, L.den, L.wl.n_mrows, L.heads);
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
+// maps: op 0 = divide by the row value, op 1 = u_add_v
+int launch_edge_items_map(const EdgeItemLaunch &L, int op, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    EdgeItemArgs a;
+    fill_edge_args(a, L);
+    if (a.n_items <= 0) return GNNAGG_OK;
+    const int G = edge_item_group((long)L.avg_item_edges * L.heads);
+    const int nb = ceil_div(a.n_items, kBlock / G);
+    if (op == 0) { DISPATCH_EIG(G, hipLaunchKernelGGL((k_edge_items_map<GROUP, 0>), dim3(nb), dim3(kBlock), 0, stream, a)) }
+    else         { DISPATCH_EIG(G, hipLaunchKernelGGL((k_edge_items_map<GROUP, 1>), dim3(nb), dim3(kBlock), 0, stream, a)) }
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// ------------------------------------------------------------------------ edge-wise variant
+// reference aggr_gcn_edgewise, aggr_gcn.h:291-302 (which covers only 32 columns and reads one edge
+// past the end, :296); here one 64-lane wavefront per edge strides over all F columns.
+__global__ __launch_bounds__(kBlock) void k_edgewise(const int2 *__restrict__ edgelist, const float *__restrict__ val,
+                                                    const float *__restrict__ x, float *__restrict__ y, int E,
+                                                    int F)
+{
+    const int e = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (e >= E) return;
+    const int2 sd = edgelist[e];
+    const float w = val ? val[e] : 1.0f;
+    for (int c = lane; c < F; c += 64) atomicAdd(&y[(size_t)sd.y * F + c], x[(size_t)sd.x * F + c] * w);
+}
+
+int launch_edgewise(const int *edgelist, const float *val, const float *x, float *y, int E, int V, int feat,
+                    void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(y, 0, (size_t)V * feat * sizeof(float), stream));  // aggr_gcn.h:448
+    if (E <= 0) return GNNAGG_OK;
+    hipLaunchKernelGGL(k_edgewise, dim3(ceil_div(E, kBlock / 64)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const int2 *>(edgelist), val, x, y, E, feat);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// --------------------------------------------------------------------- naive SpMM + validators
+// reference spmm<L>, spmm.h:223-265: thread per row, first edge a plain product, the rest FMAs,
+// empty rows left untouched.  Columns are walked in register tiles of 8 (any F, not a template).
+__global__ __launch_bounds__(128) void k_spmm_naive(const int *__restrict__ ptr, const int *__restrict__ idx,
+                                                   const float *__restrict__ val, const float *__restrict__ x,
+                                                   float *__restrict__ y, int V, int F)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= V) return;
+    const int beg = ptr[r], end = ptr[r + 1];
+    if (beg == end) return;
+    for (int c0 = 0; c0 < F; c0 += 8) {
+        float ans[8];
+        const int n = F - c0 < 8 ? F - c0 : 8;
+        {
+            const float v = val[beg];
+            const float *xr = x + (size_t)idx[beg] * F + c0;
+            for (int j = 0; j < n; ++j) ans[j] = v * xr[j];
+        }
+        for (int e = beg + 1; e < end; ++e) {
+            const float v = val[e];
+            const float *xr = x + (size_t)idx[e] * F + c0;
+            for (int j = 0; j < n; ++j) ans[j] = __builtin_fmaf(v, xr[j], ans[j]);
+        }
+        for (int j = 0; j < n; ++j) y[(size_t)r * F + c0 + j] = ans[j];
+    }
+}
+
+int launch_spmm_naive(const int *ptr, const int *idx, const float *val, const float *x, float *y, int V, int feat,
+                      void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (V <= 0) return GNNAGG_OK;
+    hipLaunchKernelGGL(k_spmm_naive, dim3(ceil_div(V, 128)), dim3(128), 0, stream, ptr, idx, val, x, y, V, feat);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// reference validate2, spmm.h:11-21
+__global__ void k_validate(const float *__restrict__ ref, const float *__restrict__ ans, int num, int *diff)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < num && fabsf((ref[t] - ans[t]) / ref[t]) > 1e-2f) atomicAdd(diff, 1);
+}
+
+// reference validateReordered, spmm.h:23-33
+__global__ void k_validate_reordered(const float *__restrict__ ref, const float *__restrict__ ans,
+                                     const int *__restrict__ map, int V, int F, int *diff)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (long)V * F && fabsf(ref[t] - ans[(size_t)map[t / F] * F + t % F]) > 1e-2f) atomicAdd(diff, 1);
+}
+
+int launch_validate(const float *ref, const float *ans, int num, int *d_diff, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(d_diff, 0, sizeof(int), stream));
+    if (num > 0) hipLaunchKernelGGL(k_validate, dim3(ceil_div(num, 256)), dim3(256), 0, stream, ref, ans, num, d_diff);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_validate_reordered(const float *ref, const float *ans, const int *map, int V, int feat, int *d_diff,
+                              void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(d_diff, 0, sizeof(int), stream));
+    if ((long)V * feat > 0)
+        hipLaunchKernelGGL(k_validate_reordered, dim3(ceil_div((long)V * feat, 256)), dim3(256), 0, stream, ref, ans,
+                           map, V, feat, d_diff);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// ------------------------------------------------------------------- dense combine GEMM (MFMA)
+// C[M,N] = A[M,K] . B[K,N], all row-major fp32 -- the reference's matmul_NN (include/dense.h:4-23: cuBLAS
+// Sgemm(T,T) + Sgeam transpose) and the dense half of aggr_gcn_nn (aggr_gcn.h:304-359).  Tall-skinny in this
+// path (M = |V|, K = feat_in, N = feat_out <= a few hundred): HBM-bound on reading A once.
+// One wavefront owns a 32x32 output tile and accumulates it with v_mfma_f32_32x32x2_f32 (f32 in / f32
+// accumulate; bit-for-bit an ascending-k fmaf chain, so the result equals the oracle's chain exactly).
+// A workgroup = 4 wavefronts = 128 rows x 32 columns; K is walked in chunks of 32 staged through LDS:
+// A chunk with coalesced 128-byte row segments into a pitch-33 image (conflict-free operand reads:
+// lane l reads row l&31, k = l>>5), B chunk as is (lane reads consecutive columns).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+static constexpr int kGemmRows = 128, kGemmCols = 32, kGemmKC = 32, kGemmPitch = 33;
+
+__global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, const float *__restrict__ B,
+                                                  float *__restrict__ C, int M, int N, int K)
+{
+    __shared__ float As[kGemmRows * kGemmPitch];
+    __shared__ float Bs[kGemmKC * kGemmCols];
+    const int row0 = blockIdx.x * kGemmRows, col0 = blockIdx.y * kGemmCols;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += kGemmKC) {
+        // stage A[row0 .. +128, k0 .. +32): thread t loads rows t/8 + 32*j, floats (t%8)*4 .. +4
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (threadIdx.x >> 3) + 32 * j, kq = (threadIdx.x & 7) * 4;
+            const int gr = row0 + r, gk = k0 + kq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gr < M) {
+                const float *src = A + (size_t)gr * K + gk;
+                if (gk + 3 < K && ((uintptr_t)src & 15) == 0) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (gk + q < K) v[q] = src[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) As[r * kGemmPitch + kq + q] = v[q];
+        }
+        // stage B[k0 .. +32, col0 .. +32): 1024 floats, 4 per thread
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = threadIdx.x + 256 * j, kk = e >> 5, cc = e & 31;
+            Bs[e] = (k0 + kk < K && col0 + cc < N) ? B[(size_t)(k0 + kk) * N + col0 + cc] : 0.0f;
+        }
+        __syncthreads();
+        // all 16 operand pairs of the chunk into registers first, then 16 back-to-back MFMAs
+        float av[kGemmKC / 2], bv[kGemmKC / 2];
+#pragma unroll
+        for (int t = 0; t < kGemmKC / 2; ++t) {
+            av[t] = As[(wave * 32 + (lane & 31)) * kGemmPitch + 2 * t + (lane >> 5)];
+            bv[t] = Bs[(2 * t + (lane >> 5)) * kGemmCols + (lane & 31)];
+        }
+#pragma unroll
+        for (int t = 0; t < kGemmKC / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col = col0 + (lane & 31);
+    if (col < N) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (row < M) C[(size_t)row * N + col] = acc[reg];
+        }
+    }
+}
+
+// Tall-skinny variant for the aggregation widths (K <= 128, K % 4 == 0): every wavefront keeps its B operands -- the
+// whole W[K, 32] column block, 64 VGPRs -- in registers for the life of the kernel and walks 32-row tiles of A on its own:
+// 16 coalesced 16-byte loads per lane fetch the NEXT tile while the current one is multiplied; the tile passes through a
+// per-wavefront LDS image (pitch K + 4: aligned ds_write_b128, operand reads two per bank) only to turn rows-over-lanes
+// into the MFMA operand layout; no workgroup barrier anywhere.  Four 16x16 sub-tiles per tile, each the full ascending-k
+// chain on v_mfma_f32_16x16x4_f32 (bit-exact as k_dense_nn).
+static constexpr int kTallWaves = 2;  // wavefronts per workgroup (one 16.9 KB LDS image each at K = 128)
+
+__global__ __launch_bounds__(64 * kTallWaves) void k_dense_nn_tall(const float *__restrict__ A, const float *__restrict__ B,
+                                                                   float *__restrict__ C, int M, int N, int K, int ntiles)
+{
+    extern __shared__ float lds[];
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int pitch = K + 4, q4 = K >> 2;  // K % 4 == 0
+    float *tile = lds + wave * 32 * pitch;
+    const int col0 = blockIdx.y * 32;
+    const int kq = lane >> 4, cl = lane & 15;
+    // B operands: lane (c = lane % 16, k = lane / 16) of MFMA t holds W[4t + k][col]; two column halves
+    float b0[32], b1[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const int k = 4 * t + kq;
+        b0[t] = (k < K && col0 + cl < N) ? B[(size_t)k * N + col0 + cl] : 0.0f;
+        b1[t] = (k < K && col0 + 16 + cl < N) ? B[(size_t)k * N + col0 + 16 + cl] : 0.0f;
+    }
+    const int wstride = gridDim.x * kTallWaves;
+    int t_idx = blockIdx.x * kTallWaves + wave;
+    float4 pre[16];
+    // float4 number e = lane + 64 i of a tile is (row e / q4, quad e % q4); stepping e by 64 advances (row, quad) by
+    // (64 / q4, 64 % q4) with one carry -- no division in the loops
+    const int step_r = 64 / q4, step_c = 64 - step_r * q4;
+    const int r0 = lane / q4, c0 = lane - r0 * q4;
+    auto fetch = [&](int ti) {
+        int r = r0, c4 = c0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = ti * 32 + r;
+            pre[i] = (r < 32 && row < M) ? *reinterpret_cast<const float4 *>(A + (size_t)row * K + 4 * c4)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            r += step_r; c4 += step_c;
+            if (c4 >= q4) { c4 -= q4; ++r; }
+        }
+    };
+    if (t_idx < ntiles) fetch(t_idx);
+    for (; t_idx < ntiles; t_idx += wstride) {
+        {
+            int r = r0, c4 = c0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (r < 32) *reinterpret_cast<float4 *>(&tile[r * pitch + 4 * c4]) = pre[i];
+                r += step_r; c4 += step_c;
+                if (c4 >= q4) { c4 -= q4; ++r; }
+            }
+        }
+        if (t_idx + wstride < ntiles) fetch(t_idx + wstride);  // travels during the MFMA chains below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float *arow = tile + (rh * 16 + cl) * pitch + kq;
+            float av[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) av[t] = 4 * t < K ? arow[4 * t] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                if (4 * t < K) {  // wave-uniform
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b0[t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], b1[t], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {  // D layout: col = lane % 16, row = 4 * (lane / 16) + reg
+                const int row = t_idx * 32 + rh * 16 + 4 * kq + v;
+                if (row < M) {
+                    if (col0 + cl < N) C[(size_t)row * N + col0 + cl] = acc0[v];
+                    if (col0 + 16 + cl < N) C[(size_t)row * N + col0 + 16 + cl] = acc1[v];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the image is rewritten next iteration
+    }
+}
+
+int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (M <= 0 || N <= 0) return GNNAGG_OK;
+    {
+        static const int tall = getenv("GNNAGG_GEMM_TALL") ? atoi(getenv("GNNAGG_GEMM_TALL")) : 1;
+        // measured against k_dense_nn (N = 32): K = 128: M = 300 k 48.2 vs 46.4 us, 600 k 92.4 vs 99.9, 1.2 M 169 vs 184,
+        // 2.45 M 307 vs 352; K = 100, M = 2.45 M: 268 vs 363 (torch.mm 427); K = 64 loses at every M -> large M, wide K only
+        if (tall && K > 64 && K <= 128 && (K & 3) == 0 && M >= 500000 && ((uintptr_t)A & 15) == 0) {
+            const int ntiles = ceil_div(M, 32);
+            const size_t lds = (size_t)kTallWaves * 32 * (K + 4) * sizeof(float);
+            const int wgs = std::min(ceil_div(ntiles, kTallWaves), 256 * 4);
+            hipLaunchKernelGGL(k_dense_nn_tall, dim3(wgs, ceil_div(N, 32)), dim3(64 * kTallWaves), lds, stream, A, B, C, M, N, K,
+                               ntiles);
+            HIP_TRY(hipGetLastError());
+            return GNNAGG_OK;
+        }
+    }
+    if (K <= 0) {
+        HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream));
+        return GNNAGG_OK;
+    }
+    const dim3 grid(ceil_div(M, kGemmRows), ceil_div(N, kGemmCols));
+    hipLaunchKernelGGL(k_dense_nn, grid, dim3(256), 0, stream, A, B, C, M, N, K);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// --------------------------------------------------------------------------------- CSR check
+// The reference trusts its inputs (an out-of-range neighbor id is a silent out-of-bounds gather).  counts[0] = rows with
+// ptr[r] > ptr[r+1], counts[1] = neighbor ids outside [0, num_cols).
+__global__ void k_check_csr(const int *__restrict__ ptr, const int *__restrict__ idx, int V, int E, int num_cols, int *counts)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < V && ptr[t] > ptr[t + 1]) atomicAdd(&counts[0], 1);
+    if (t < E && (idx[t] < 0 || idx[t] >= num_cols)) atomicAdd(&counts[1], 1);
+}
+
+int launch_check_csr(const int *ptr, const int *idx, int V, int E, int num_cols, int *d_counts, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), stream));
+    const long n = std::max<long>(V, E);
+    if (n > 0) hipLaunchKernelGGL(k_check_csr, dim3(ceil_div(n, 256)), dim3(256), 0, stream, ptr, idx, V, E, num_cols, d_counts);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// ----------------------------------------------------------------------------- halo packing
+// out[i,:] = x[ids[i],:]  -- send buffer of the halo all-to-all (gnnagg.h Section D)
+template <int VEC, int GROUP>
+__global__ __launch_bounds__(kBlock) void k_pack_rows(const float *__restrict__ x, const int *__restrict__ ids, int n,
+                                                     int F, int ntiles, float *__restrict__ out)
+{
+    const int tile = blockIdx.x % ntiles;
+    const int i = (blockIdx.x / ntiles) * (kBlock / GROUP) + threadIdx.x / GROUP;
+    const int col = (tile * GROUP + (threadIdx.x & (GROUP - 1))) * VEC;
+    if (i >= n || col >= F) return;
+    const Pack<VEC> p = load_pack<VEC>(x + (size_t)ids[i] * F + col);
+    store_pack<VEC>(out + (size_t)i * F + col, p.v);
+}
+
+int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (n <= 0) return GNNAGG_OK;
+    const Geometry g = pick_geometry(feat, x, out, nullptr, feat);
+    const int nb = ceil_div(n, kBlock / g.group) * g.ntiles;
+#define CALL_PACK hipLaunchKernelGGL((k_pack_rows<VEC, GROUP>), dim3(nb), dim3(kBlock), 0, stream, x, ids, n, feat, g.ntiles, out);
+    DISPATCH_GEOM(g, CALL_PACK)
+#undef CALL_PACK
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+}  // namespace gnnagg

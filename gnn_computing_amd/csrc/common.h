@@ -26,7 +26,7 @@ int halo_plan(const int *ptr, const int *idx, int V, const int *bounds, int npar
 int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int num_perm, int cap, uint64_t seed,
                     int max_bucket, int *rows_out, int *num_clusters_out);
 
-// ---- kernels.hip : launch descriptors (all pointers are device pointers)
+// ---- agg_gcn.hip / agg_gat.hip / aux_kernels.hip : launch descriptors (all pointers are device pointers)
 
 // A work list: item g covers edges [ptr[g], ptr[g+1]) of output row (target ? target[g] : g).
 //   slot == nullptr : every item owns its whole row -> direct store.
@@ -69,7 +69,7 @@ struct GcnLaunch {
     const long *xcd_item_cost_prefix = nullptr;
 };
 
-// Balanced plan (GNNAGG_MODE_BALANCED, GCN): see k_gcn_plan in kernels.hip.
+// Balanced plan (GNNAGG_MODE_BALANCED, GCN): see k_gcn_plan in agg_gcn.hip.
 struct GcnPlanLaunch {
     const void *t0 = nullptr;  // int4 {beg,end,row,-} per short row
     const void *t1 = nullptr;  // int4 {beg,end,dest,-} per long-row segment

@@ -1,0 +1,337 @@
+#pragma once
+// kernel_util.cuh -- shared device helpers of the hand-written CDNA4 (gfx950) kernels of the neighbor-aggregation hot
+// path (agg_gcn.hip, agg_gat.hip, aux_kernels.hip).
+//
+// Design (wave64, HBM/L2-bound integer+fp32 gather work; no MFMA -- 0.25 flop/B):
+//  * A "lane group" of GROUP = 8/16/32/64 lanes owns one work item (a CSR row, or a chunk of a
+//    long row) and one column tile of GROUP*VEC floats; each lane keeps VEC accumulators and
+//    loads VEC*4 bytes per neighbor, so a group reads a contiguous GROUP*VEC*4-byte segment of
+//    the neighbor's feature row (512 B for F=128: four 128-B lines, one dwordx4 per lane).
+//    GROUP < 64 packs several short rows into one wavefront (avg degree of arxiv is 6.9), which
+//    is what keeps lanes busy where the reference's warp-per-row scheme idles.
+//  * The FMA chain of an item runs in CSR order (bit-exact against the oracle); memory-level
+//    parallelism comes from issuing the U=8 neighbor gathers of a batch before the first FMA;
+//    (idx,val) of GROUP edges arrive with ONE coalesced load and are broadcast with ds_bpermute.
+//  * Long rows are split into several items by the schedule; their partial sums go to a scratch
+//    slab and a second kernel adds them in ascending order (deterministic; the reference uses
+//    fp32 atomics in arbitrary order, aggr_gcn.h:112).
+//  * Workgroup -> item-block mapping is XCD-aware: consecutive item blocks (which share
+//    neighbors after the locality reorder) are placed on the same XCD / L2 (8 XCDs, block b runs
+//    on XCD b % 8), using the bijective remap so any grid size works.
+//  * Wide feature rows (F > GROUP*VEC) are covered by several column tiles; tiles of one item
+//    block are adjacent in the remapped block order so they hit the same DRAM pages / L2 lines.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace gnnagg {
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(GNNAGG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+static constexpr int kBlock = 256;  // 4 wavefronts
+// Aggregation kernels: 8 lane groups per workgroup, at most 4 wavefronts -- 64 threads for 8-lane groups (F <= 32),
+// 128 for 16-lane groups, 256 above.  A workgroup's slots are released when its slowest row is done, so narrow
+// features (8 or 4 rows per wavefront) want small workgroups: on the arxiv-shaped input F=32 37.3 -> 30.8 us and
+// F=64 51.0 -> 48.9 us against 256 threads everywhere; F >= 128 is unchanged (and 64 threads there loses the
+// segment path's parallelism: F=256 172 -> 234 us).
+template <int GROUP>
+constexpr int block_of() { return GROUP * 8 < kBlock ? GROUP * 8 : kBlock; }
+static inline int block_for(int group) { return group * 8 < kBlock ? group * 8 : kBlock; }
+// neighbor gathers in flight per lane group.  Measured on the arxiv-shaped input: 4 and 8 tie (73.7 / 74.5 us in community
+// order, 87.9 / 86.8 us un-reordered), 16 loses (96 us, register pressure), and forcing 8 waves/SIMD with
+// __launch_bounds__ spills (137 us): the kernel sits at the memory system's ceiling, not at an occupancy cliff.
+static constexpr int kUnroll = 8;
+static constexpr int kSegChunks = 16;  // chunks of a long row that one segment workgroup folds in LDS (plan kernels)
+
+// ---------------------------------------------------------------------------------- helpers
+template <int VEC>
+struct Pack {
+    float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ Pack<VEC> load_pack(const float *p)
+{
+    Pack<VEC> r;
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else if constexpr (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        r.v[0] = t.x; r.v[1] = t.y;
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+
+// GNNAGG_FLAG_RELU: the activation that follows the aggregation in the 3-layer models (Figure7/our.py:176), applied to the
+// finished row in the producing kernel instead of a separate elementwise pass over Y.
+template <int VEC>
+__device__ __forceinline__ void relu_pack(float (&a)[VEC])
+{
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) a[k] = a[k] > 0.0f ? a[k] : 0.0f;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_pack(float *p, const float (&a)[VEC])
+{
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(a[0], a[1], a[2], a[3]);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(a[0], a[1]);
+    } else {
+        *p = a[0];
+    }
+}
+
+// Output rows are written once and never re-read by this kernel: a write-through (sc1) store leaves the XCD's L2
+// to the gathered feature rows instead of parking 87 MB of results in it.  Buffer store so the cache bits can be
+// given (aux 16 = sc1); `yoff` is the element offset from `ybase` (callers guarantee the byte offset fits 31 bits).
+template <int VEC>
+__device__ __forceinline__ void store_pack_wt(float *ybase, unsigned nbytes, size_t yoff, const float (&a)[VEC])
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, (int)nbytes, 0x00020000);
+    const int voff = (int)(yoff * sizeof(float));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    if constexpr (VEC == 4) {
+        u4 v = {__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 16);
+    } else if constexpr (VEC == 2) {
+        u2 v = {__float_as_uint(a[0]), __float_as_uint(a[1])};
+        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, 0, 16);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[0]), rsrc, voff, 0, 16);
+    }
+}
+
+// Device-scope (sc1) load: sees what other XCDs' workgroups wrote with store_pack_wt, whatever this XCD's L2 holds.
+template <int VEC>
+__device__ __forceinline__ Pack<VEC> load_pack_sc1(const float *base, unsigned nbytes, size_t off)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)nbytes, 0x00020000);
+    const int voff = (int)(off * sizeof(float));
+    Pack<VEC> r;
+    if constexpr (VEC == 4) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 16);
+        r.v[0] = __uint_as_float(v[0]); r.v[1] = __uint_as_float(v[1]); r.v[2] = __uint_as_float(v[2]); r.v[3] = __uint_as_float(v[3]);
+    } else if constexpr (VEC == 2) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 16);
+        r.v[0] = __uint_as_float(v[0]); r.v[1] = __uint_as_float(v[1]);
+    } else {
+        r.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 16));
+    }
+    return r;
+}
+
+// Block b runs on XCD b % 8 (observed dispatch rule).  Give every XCD a contiguous range of
+// logical blocks; bijective for any nb (q = nb/8, r = nb%8: the first r XCDs get q+1 blocks).
+__device__ __forceinline__ int xcd_remap(int b, int nb)
+{
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// Work-balanced XCD ranges: XCD x owns item blocks [first[x], first[x] + count[x]); ranges are cut so
+// that every XCD gets about the same number of edges (not the same number of blocks): a locality
+// reorder clusters the hub rows, and equal-count ranges would pile them onto one XCD.
+struct XcdRanges {
+    int first[8];
+    int count[8];
+};
+
+// remap == 0: identity.  remap == 1: equal-count contiguous ranges.  remap == 2: XcdRanges.
+// Returns the logical (item block * ntiles + tile) index, or -1 when this workgroup has no work.
+__device__ __forceinline__ int logical_block(int b, int nblocks, int ntiles, int remap, const XcdRanges &xr)
+{
+    if (remap == 0) return b;
+    if (remap == 1) return xcd_remap(b, nblocks);
+    const int xcd = b & 7, k = b >> 3;
+    const int ib = k / ntiles;
+    if (ib >= xr.count[xcd]) return -1;
+    return (xr.first[xcd] + ib) * ntiles + (k - ib * ntiles);
+}
+
+struct GcnArgs {
+    const int *ptr, *target, *slot, *empty_rows;
+    const int *row_ptr;
+    const int *idx;
+    const float *val;
+    const float *x;
+    float *y;
+    float *partial;
+    int n_items, n_total, feat, ntiles, nblocks, mean, remap, relu;
+    unsigned long long *timer;  // run_clock: per workgroup {first wave start, last wave end, CU id}; null otherwise
+    XcdRanges xr;
+};
+
+// The FMA (or max) chain of one work item over edges [beg,end) in CSR order.  Lane j of the group fetches
+// (idx,val) of edge cb+j with ONE coalesced load per GROUP edges (next window prefetched); each edge's
+// pair is broadcast inside the group with ds_bpermute (LDS crossbar, no memory traffic; nontemporal loads of
+// this once-streamed metadata were measured 1-5 % SLOWER, and nontemporal feature gathers 30 % slower at an
+// unchanged L2 hit rate -- `nt` does not bypass L2 allocation here; neither is used), kUnroll feature
+// gathers are issued before the first FMA.  Lanes with col_ok == false still carry metadata.
+template <int VEC, int GROUP, bool IS_MAX>
+__device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end, int lane, bool col_ok,
+                                            const int *__restrict__ idx, const float *__restrict__ val,
+                                            const float *__restrict__ xcol, int F)
+{
+    int my_s = 0;
+    float my_w = 1.0f;
+    if (beg + lane < end) {
+        my_s = idx[beg + lane];
+        if (val) my_w = val[beg + lane];
+    }
+    for (int cb = beg; cb < end; cb += GROUP) {
+        int nx_s = 0;
+        float nx_w = 1.0f;
+        if (cb + GROUP + lane < end) {
+            nx_s = idx[cb + GROUP + lane];
+            if (val) nx_w = val[cb + GROUP + lane];
+        }
+        const int n = end - cb < GROUP ? end - cb : GROUP;
+        for (int j = 0; j < n; j += kUnroll) {
+            int s[kUnroll];
+            float w[kUnroll];
+            Pack<VEC> xv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                s[u] = __shfl(my_s, j + u, GROUP);
+                w[u] = __shfl(my_w, j + u, GROUP);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        if (IS_MAX) {
+                            const float p = xv[u].v[k] * w[u];
+                            acc[k] = p > acc[k] ? p : acc[k];
+                        } else {
+                            acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
+                        }
+                    }
+                }
+        }
+        my_s = nx_s;
+        my_w = nx_w;
+    }
+}
+
+// exp(leaky_relu(a_dst + a_src)): the un-normalised attention weight of an edge (aggr_gat.h:138-143)
+__device__ __forceinline__ float edge_weight(float a_dst, float a_src, float slope)
+{
+    // reference aggr_gat.h:138-143: exp(max(s, s*slope)), no max-subtraction
+    const float sc = a_dst + a_src;
+    const float l = sc * slope;
+    return expf(sc > l ? sc : l);
+}
+
+// out_row[j] = sum_k yrow[k] * W[k, j] for j = tid, tid + nthreads, ...: one ascending-k fmaf chain per output (the order of
+// the MFMA tiles and of the oracle's GEMM); yrow lives in LDS.  For the few rows that are finished one at a time.
+__device__ __forceinline__ void row_times_weight(const float *yrow, int K, const float *__restrict__ W, int N, float *out_row,
+                                                 int tid, int nthreads)
+{
+    for (int j = tid; j < N; j += nthreads) {
+        float o = 0.0f;
+        int k = 0;
+        for (; k + 8 <= K; k += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = W[(size_t)(k + u) * N + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o = fmaf(yrow[k + u], wv[u], o);
+        }
+        for (; k < K; ++k) o = fmaf(yrow[k], W[(size_t)k * N + j], o);
+        out_row[j] = o;
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// --------------------------------------------------------------------- geometry + dispatch
+struct Geometry {
+    int vec, group, ntiles;
+};
+
+static Geometry pick_geometry(int F, const void *p0, const void *p1, const void *p2, int dhead)
+{
+    auto aligned = [](const void *p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; };
+    int vec = 1;
+    if (F % 4 == 0 && dhead % 4 == 0 && aligned(p0, 16) && aligned(p1, 16) && aligned(p2, 16))
+        vec = 4;
+    else if (F % 2 == 0 && dhead % 2 == 0 && aligned(p0, 8) && aligned(p1, 8) && aligned(p2, 8))
+        vec = 2;
+    const int lanes = (F + vec - 1) / vec;
+    int group = 8;
+    while (group < 64 && group < lanes) group <<= 1;
+    const int ntiles = (lanes + group - 1) / group;
+    return {vec, group, ntiles};
+}
+
+#define DISPATCH_GEOM(g, KERNEL_CALL)                                            \
+    switch ((g).vec * 100 + (g).group) {                                         \
+        case 108: { constexpr int VEC = 1, GROUP = 8;  KERNEL_CALL; } break;     \
+        case 116: { constexpr int VEC = 1, GROUP = 16; KERNEL_CALL; } break;     \
+        case 132: { constexpr int VEC = 1, GROUP = 32; KERNEL_CALL; } break;     \
+        case 164: { constexpr int VEC = 1, GROUP = 64; KERNEL_CALL; } break;     \
+        case 208: { constexpr int VEC = 2, GROUP = 8;  KERNEL_CALL; } break;     \
+        case 216: { constexpr int VEC = 2, GROUP = 16; KERNEL_CALL; } break;     \
+        case 232: { constexpr int VEC = 2, GROUP = 32; KERNEL_CALL; } break;     \
+        case 264: { constexpr int VEC = 2, GROUP = 64; KERNEL_CALL; } break;     \
+        case 408: { constexpr int VEC = 4, GROUP = 8;  KERNEL_CALL; } break;     \
+        case 416: { constexpr int VEC = 4, GROUP = 16; KERNEL_CALL; } break;     \
+        case 432: { constexpr int VEC = 4, GROUP = 32; KERNEL_CALL; } break;     \
+        case 464: { constexpr int VEC = 4, GROUP = 64; KERNEL_CALL; } break;     \
+        default: return fail(GNNAGG_ERR_ARG, "unsupported lane geometry");       \
+    }
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// cost_prefix[i] = total cost of items [0,i) (host array, n_items+1 entries).  Cuts the item blocks
+// into 8 contiguous ranges of about equal cost; returns the longest range (in blocks).
+static int fill_xcd_ranges(const long *cost_prefix, int n_items, int items_per_block, int item_blocks, XcdRanges &xr)
+{
+    const long total = cost_prefix[n_items];
+    int start = 0, longest = 0;
+    for (int x = 0; x < 8; ++x) {
+        int stop;
+        if (x == 7) {
+            stop = item_blocks;
+        } else {
+            const long want = total * (x + 1) / 8;
+            // first block boundary whose prefix cost reaches `want`
+            int lo = start, hi = item_blocks;
+            while (lo < hi) {
+                const int mid = (lo + hi) / 2;
+                const long c = cost_prefix[std::min((long)mid * items_per_block, (long)n_items)];
+                if (c < want) lo = mid + 1; else hi = mid;
+            }
+            stop = lo;
+        }
+        xr.first[x] = start;
+        xr.count[x] = stop - start;
+        longest = std::max(longest, stop - start);
+        start = stop;
+    }
+    return longest;
+}
+
+}  // namespace gnnagg
