@@ -82,7 +82,8 @@ __global__ void k_timer_init(unsigned long long *timer, int nblocks)
 //    workgroup.  Lane group g computes the partial chains of chunks g, g+GPB, ...; the partials meet in
 //    LDS and group 0 folds them in ascending chunk order (deterministic; the reference's
 //    aggr_gcn_target adds them with fp32 atomics in arbitrary order, aggr_gcn.h:112).  A row that fits one
-//    segment is written straight to Y; only rows with several segments (hubs) go through scratch + k_combine.
+//    segment is written straight to Y; only rows with several segments (hubs) go through scratch: the last of their
+//    segment workgroups to arrive folds them (hub_arrive_and_fold), or k_combine when that is switched off.
 //  * the remaining blocks: GPB short rows each (deg <= chunk, empty rows included), one lane group per
 //    row, descriptor {beg,end,row} fetched with ONE 16-byte load; XCD-aware work-balanced block ranges.
 
@@ -275,13 +276,14 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
 // ------------------------------------------------- aggregation with the dense combine as its epilogue
 // transformed[V,N] = (A . X)[V,K] . W[K,N] in one pass (reference aggr_gcn_nn, aggr_gcn.h:304-359, called by
 // run_with_nn :491-499).  The aggregation spreads the K columns of a row over the lanes of a group while the matrix
-// cores want rows across lanes, so finished rows meet in LDS: a workgroup aggregates 32 short rows (32/GPB passes
+// cores want rows across lanes, so finished rows meet in LDS: a workgroup aggregates kNnRows = 16 short rows (16/GPB passes
 // of the plan kernel's descriptor path), stages them as a [rows][K] tile (pitch K + 4: aligned 16-byte row stores, operand reads two per bank),
 // and after ONE barrier its 4 wavefronts each take 16x16 output sub-tiles and run the full-K chain on
 // v_mfma_f32_16x16x4_f32 -- f32 in / f32 accumulate, an ascending-k fmaf chain, so the result is bit-for-bit the
 // separate GEMM's (and the oracle's).  W (K*N*4 bytes, 16 KB at 128x32) is read through L1/L2, not staged.
 // Unlike the reference (partial . W added with atomics per neighbor group) W is applied to the FINAL row: rows that
-// are folded from several chunks (segment path, k_combine) get their product from k_dense_rows afterwards.
+// are folded from several chunks get their product where the fold ends (segment workgroup, hub fold, k_combine: one fmaf
+// chain per output column, row_times_weight); the rows-mode long rows from k_dense_rows after the join.
 #ifndef NN_ROWS
 #define NN_ROWS 16
 #endif
