@@ -242,6 +242,18 @@ class Aggregator_GAT(Aggregator):
         check(lib().gnnagg_gat_run_div_each(self._h, _dev_ptr(in_att, torch.float32, "in_att"),
                                             _dev_ptr(in_out_val, torch.float32, "in_out_val")))
 
+    def run_bwd(self, output, doutput, newval, div, infeat, d_a_b, d_feat, relu_l=0.2, BLOCK_SIZE=128):
+        """aggr_gat.h:426-434 (kernel :222-296).  Backward of the single-head fused aggregation from the forward pass's
+        un-normalised edge weights `newval` [E] and denominators `div` [V]: d_feat [V,F] (through the aggregation) and
+        d_a_b [V,2] (centre / source attention terms) are overwritten.  See gnnagg_gat_run_bwd for what the reference
+        kernel leaves out."""
+        self._use_current_stream()
+        check(lib().gnnagg_gat_run_bwd(self._h, _dev_ptr(output, torch.float32, "output"),
+                                       _dev_ptr(doutput, torch.float32, "doutput"), _dev_ptr(newval, torch.float32, "newval"),
+                                       _dev_ptr(div, torch.float32, "div"), _dev_ptr(infeat, torch.float32, "infeat"),
+                                       _dev_ptr(d_a_b, torch.float32, "d_a_b"), _dev_ptr(d_feat, torch.float32, "d_feat"),
+                                       float(relu_l), int(infeat.shape[1])))
+
 
 # ------------------------------------------------------------------------------------------
 # Flat functions with the reference pybind names (Figure7/kernel.cpp:166-179).  Handles are

@@ -456,4 +456,182 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     return GNNAGG_OK;
 }
 
+// ------------------------------------------------------------ backward of the single-head fused aggregation
+// Reference: aggr_gat_fine_bwd (aggr_gat.h:222-296, marked "Experiment"; run_bwd :426-434).  With w_e = newval[e] and
+// D_r = div[r] saved by the forward pass, p_e = w_e / D_r:
+//     dz_e      = p_e * (dout_r . x_s  -  dout_r . out_r) * lrelu'(z_e)        (z_e < 0  <=>  w_e < 1)
+//     d_a_b[r,0] = sum_{e in row r} dz_e,   d_a_b[s,1] = sum_{e: src(e) = s} dz_e,   d_feat[s,:] = sum_{e: src = s} p_e dout_r
+// The reference scatters with fp32 atomics from a warp per neighbor group (and covers 32 columns, no centre term);
+// here every sum is a gather in a fixed order: the per-edge stage below runs on the hub-safe chunked work items of the
+// edge-softmax kernels, the row sums reuse add_to_center, and the source-side sums and d_feat run on the TRANSPOSED
+// CSR (api.hip builds it once per handle) -- d_feat is then simply the balanced GCN aggregation of dout over A^T with
+// edge values p.  Deterministic; compared with orc_gat_bwd within the fp32 tolerance.
+struct GatBwdArgs {
+    const int *ptr_s, *target, *idx;
+    const float *out, *dout, *newval, *div, *x, *rowdot;
+    float *dz;
+    int n_items, V, F;
+    float slope;
+};
+
+// rowdot[r] = dout[r,:] . out[r,:]
+template <int GROUP, int VEC>
+__global__ __launch_bounds__(kBlock) void k_rowdot(const float *__restrict__ a, const float *__restrict__ b,
+                                                   float *__restrict__ out, int V, int F)
+{
+    const int row = blockIdx.x * (kBlock / GROUP) + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (row >= V) return;
+    float part = 0.0f;
+    for (int c = lane * VEC; c < F; c += GROUP * VEC) {
+        const Pack<VEC> x = load_pack<VEC>(a + (size_t)row * F + c), y = load_pack<VEC>(b + (size_t)row * F + c);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) part = __builtin_fmaf(x.v[k], y.v[k], part);
+    }
+    part = group_sum<GROUP>(part);
+    if (lane == 0) out[row] = part;
+}
+
+// One lane group (32 lanes x VEC columns per tile) per work item (<= chunk edges of one row).  As in the forward chains, lane
+// j carries (id, weight) of edge cb + j from one coalesced load (next window prefetched) and 8 edges' gathers are in
+// flight.  The 8 per-edge dot products are reduced together: a butterfly that halves the number of values a lane keeps
+// at each step (4 + 2 + 1 + 1 + 1 = 9 shuffles for 8 edges instead of 40), after which lane 4u holds edge u's dot and
+// finishes it -- eight lanes write eight consecutive dz.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_gat_bwd_edges(const GatBwdArgs a)
+{
+    constexpr int GROUP = 32, U = 8;
+    const int item = blockIdx.x * (kBlock / GROUP) + (int)threadIdx.x / GROUP;
+    const int lane = threadIdx.x & (GROUP - 1);
+    if (item >= a.n_items) return;
+    const int beg = a.ptr_s[item], end = a.ptr_s[item + 1];
+    const int row = a.target[item];
+    const int F = a.F;
+    const float D = a.div[row];
+    const float rd = a.rowdot[row];
+    const float *__restrict__ drow = a.dout + (size_t)row * F;
+    int my_s = 0;
+    float my_w = 0.0f;
+    if (beg + lane < end) {
+        my_s = a.idx[beg + lane];
+        my_w = a.newval[beg + lane];
+    }
+    for (int cb = beg; cb < end; cb += GROUP) {
+        int nx_s = 0;
+        float nx_w = 0.0f;
+        if (cb + GROUP + lane < end) {
+            nx_s = a.idx[cb + GROUP + lane];
+            nx_w = a.newval[cb + GROUP + lane];
+        }
+        const int n = end - cb < GROUP ? end - cb : GROUP;
+        for (int j = 0; j < n; j += U) {
+            float part[U];
+            int s[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                part[u] = 0.0f;
+                s[u] = __shfl(my_s, j + u, GROUP);  // past the item's end: id 0, a valid row; its result is dropped
+            }
+            for (int col = lane * VEC; col < F; col += GROUP * VEC) {
+                const Pack<VEC> d = load_pack<VEC>(drow + col);
+                Pack<VEC> xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = load_pack<VEC>(a.x + (size_t)s[u] * F + col);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) part[u] = __builtin_fmaf(d.v[k], xv[u].v[k], part[u]);
+            }
+            float q[4], r2[2];
+            const bool h16 = (lane & 16) != 0, h8 = (lane & 8) != 0, h4 = (lane & 4) != 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // lanes 0-15 keep edges 0-3, lanes 16-31 edges 4-7
+                const float recv = __shfl_xor(h16 ? part[u] : part[u + 4], 16, GROUP);
+                q[u] = (h16 ? part[u + 4] : part[u]) + recv;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float recv = __shfl_xor(h8 ? q[u] : q[u + 2], 8, GROUP);
+                r2[u] = (h8 ? q[u + 2] : q[u]) + recv;
+            }
+            float tsum = (h4 ? r2[1] : r2[0]) + __shfl_xor(h4 ? r2[0] : r2[1], 4, GROUP);
+            tsum += __shfl_xor(tsum, 2, GROUP);
+            tsum += __shfl_xor(tsum, 1, GROUP);
+            const int ul = lane >> 2;  // the edge of the batch whose dot this lane now holds
+            const float w = __shfl(my_w, j + ul, GROUP);
+            if ((lane & 3) == 0 && j + ul < n) {
+                float g = D != 0.0f ? (w / D) * (tsum - rd) : 0.0f;
+                if (w < 1.0f) g *= a.slope;
+                a.dz[cb + j + ul] = g;
+            }
+        }
+        my_s = nx_s;
+        my_w = nx_w;
+    }
+}
+
+// transposed side: dzT[e'] = dz[perm[e']], valT[e'] = newval[perm[e']] / div[idxT[e']]  (idxT[e'] = destination row of the edge)
+__global__ void k_gat_bwd_permute(const int *__restrict__ perm, const int *__restrict__ idx_t, const float *__restrict__ dz,
+                                  const float *__restrict__ newval, const float *__restrict__ div, float *__restrict__ dz_t,
+                                  float *__restrict__ val_t, int E)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int o = perm[e];
+    const float D = div[idx_t[e]];
+    dz_t[e] = dz[o];
+    val_t[e] = D != 0.0f ? newval[o] / D : 0.0f;
+}
+
+__global__ void k_interleave2(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reinterpret_cast<float2 *>(out)[i] = make_float2(a[i], b[i]);
+}
+
+int launch_gat_bwd_edges(const GatBwdLaunch &L, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (L.V > 0) {
+        auto al = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+        if (L.feat % 4 == 0 && al(L.dout) && al(L.out))
+            hipLaunchKernelGGL((k_rowdot<16, 4>), dim3(ceil_div(L.V, kBlock / 16)), dim3(kBlock), 0, stream, L.dout, L.out, L.rowdot, L.V, L.feat);
+        else
+            hipLaunchKernelGGL((k_rowdot<16, 1>), dim3(ceil_div(L.V, kBlock / 16)), dim3(kBlock), 0, stream, L.dout, L.out, L.rowdot, L.V, L.feat);
+        HIP_TRY(hipGetLastError());
+    }
+    if (L.wl.n_items > 0) {
+        GatBwdArgs a;
+        a.ptr_s = L.wl.ptr; a.target = L.wl.target; a.idx = L.idx; a.out = L.out; a.dout = L.dout; a.newval = L.newval;
+        a.div = L.div; a.x = L.x; a.rowdot = L.rowdot; a.dz = L.dz; a.n_items = L.wl.n_items; a.V = L.V; a.F = L.feat;
+        a.slope = L.slope;
+        auto aligned = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+        const int nb = ceil_div(a.n_items, kBlock / 32);
+        if (L.feat % 4 == 0 && aligned(L.x) && aligned(L.dout))
+            hipLaunchKernelGGL((k_gat_bwd_edges<4>), dim3(nb), dim3(kBlock), 0, stream, a);
+        else
+            hipLaunchKernelGGL((k_gat_bwd_edges<1>), dim3(nb), dim3(kBlock), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
+int launch_gat_bwd_permute(const int *perm, const int *idx_t, const float *dz, const float *newval, const float *div, float *dz_t,
+                           float *val_t, int E, void *stream_v)
+{
+    if (E <= 0) return GNNAGG_OK;
+    hipLaunchKernelGGL(k_gat_bwd_permute, dim3(ceil_div(E, 256)), dim3(256), 0, (hipStream_t)stream_v, perm, idx_t, dz, newval,
+                       div, dz_t, val_t, E);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_interleave2(const float *a, const float *b, float *out, int n, void *stream_v)
+{
+    if (n <= 0) return GNNAGG_OK;
+    hipLaunchKernelGGL(k_interleave2, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream_v, a, b, out, n);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
 }  // namespace gnnagg

@@ -154,6 +154,14 @@ struct Ctx {
     int sort_window = 2048;    // narrow features: short-row descriptors degree-sorted inside windows of this many rows
     int use_plan = 1;          // GCN balanced mode runs k_gcn_plan (0: items + combine, the round-1 first design)
     std::vector<long> row_cost_prefix;  // MODE_ROWS work items
+    // GAT backward (run_bwd): the transposed graph -- row s of A^T lists the destination rows of the edges whose source is
+    // s, in ascending original edge order; perm[e'] = original edge id -- and a GCN aggregator over it
+    struct Transposed {
+        bool valid = false;
+        DevBuf<int> ptr_t, idx_t, perm;
+        DevBuf<float> val_t, dz, dz_t, rowdot, da, db;
+        gnnagg_handle agg = 0;
+    } tr;
     int avg_deg() const { return V > 0 ? (int)((long)E / V) : 0; }
 };
 
@@ -798,6 +806,7 @@ int gnnagg_destroy(gnnagg_handle h)
         g_live.erase(c);
     }
     (void)hipStreamSynchronize(c->stream);
+    if (c->tr.agg) (void)gnnagg_destroy(c->tr.agg);
     if (c->aux_stream) {
         (void)hipStreamSynchronize(c->aux_stream);
         (void)hipStreamDestroy(c->aux_stream);
@@ -1043,6 +1052,72 @@ int gnnagg_gat_run_add_to_center(gnnagg_handle h, const float *d_in_val, float *
     if (rc) return rc;
     L.in = d_in_val; L.den = d_out_att;
     return launch_edge_items_sum(L, 1, c->stream);
+}
+
+static int build_transposed(Ctx *c)
+{
+    if (c->tr.valid) return GNNAGG_OK;
+    int rc = fetch_host_ptr(c);
+    if (rc) return rc;
+    const int V = c->V, E = c->E;
+    std::vector<int> h_idx((size_t)E);
+    if (E > 0) HIP_TRY(hipMemcpy(h_idx.data(), c->d_idx, (size_t)E * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> ptr_t((size_t)V + 1, 0), idx_t((size_t)E), perm((size_t)E);
+    for (int e = 0; e < E; ++e) {
+        if (h_idx[e] < 0 || h_idx[e] >= V) return fail(GNNAGG_ERR_ARG, "run_bwd: neighbor id outside [0, num_v)");
+        ++ptr_t[(size_t)h_idx[e] + 1];
+    }
+    for (int v = 0; v < V; ++v) ptr_t[v + 1] += ptr_t[v];
+    std::vector<int> fill(ptr_t.begin(), ptr_t.end() - 1);
+    for (int r = 0; r < V; ++r)
+        for (int e = c->h_ptr[r]; e < c->h_ptr[r + 1]; ++e) {  // counting sort: stable in the original edge order
+            const int pos = fill[h_idx[e]]++;
+            idx_t[pos] = r;
+            perm[pos] = e;
+        }
+    Ctx::Transposed &t = c->tr;
+    if ((rc = t.ptr_t.upload(ptr_t)) || (rc = t.idx_t.upload(idx_t)) || (rc = t.perm.upload(perm))) return rc;
+    if ((rc = t.val_t.reserve((size_t)std::max(E, 1))) || (rc = t.dz.reserve((size_t)std::max(E, 1))) ||
+        (rc = t.dz_t.reserve((size_t)std::max(E, 1))) || (rc = t.rowdot.reserve((size_t)std::max(V, 1))) ||
+        (rc = t.da.reserve((size_t)std::max(V, 1))) || (rc = t.db.reserve((size_t)std::max(V, 1))))
+        return rc;
+    if ((rc = gnnagg_gcn_create(t.ptr_t.p, t.idx_t.p, t.val_t.p, V, E, &t.agg))) return rc;
+    t.valid = true;
+    return GNNAGG_OK;
+}
+
+int gnnagg_gat_run_bwd(gnnagg_handle h, const float *d_output, const float *d_doutput, const float *d_newval, const float *d_div,
+                       const float *d_infeat, float *d_a_b_grad, float *d_feat_grad, float relu_slope, int feat)
+{
+    GET_CTX(h);
+    if (c->kind != Ctx::GAT) return fail(GNNAGG_ERR_ARG, "handle is not a GAT aggregator");
+    if (feat <= 0 || !d_output || !d_doutput || !d_div || !d_infeat || !d_a_b_grad || !d_feat_grad || (!d_newval && c->E > 0))
+        return fail(GNNAGG_ERR_ARG, "bad run_bwd arguments");
+    int rc = build_transposed(c);
+    if (rc) return rc;
+    Ctx::Transposed &t = c->tr;
+    Ctx *ct = lookup(t.agg);
+    if (!ct) return fail(GNNAGG_ERR_ARG, "run_bwd: transposed aggregator lost");
+    ct->stream = c->stream;
+    // 1. per-edge dz on the chunked work items of this graph
+    EdgeItemLaunch L;
+    if ((rc = edge_launch(c, L, 1))) return rc;
+    GatBwdLaunch B;
+    B.wl = L.wl; B.idx = c->d_idx; B.out = d_output; B.dout = d_doutput; B.newval = d_newval; B.div = d_div; B.x = d_infeat;
+    B.rowdot = t.rowdot.p; B.dz = t.dz.p; B.V = c->V; B.feat = feat; B.slope = relu_slope;
+    if ((rc = launch_gat_bwd_edges(B, c->stream))) return rc;
+    // 2. centre-term gradient: row sums of dz (the hub-safe, ordered add_to_center)
+    L.in = t.dz.p; L.den = t.da.p;
+    if ((rc = launch_edge_items_sum(L, 1, c->stream))) return rc;
+    // 3. the source side runs on the transposed graph
+    if ((rc = launch_gat_bwd_permute(t.perm.p, t.idx_t.p, t.dz.p, d_newval, d_div, t.dz_t.p, t.val_t.p, c->E, c->stream))) return rc;
+    EdgeItemLaunch LT;
+    if ((rc = edge_launch(ct, LT, 1))) return rc;
+    LT.in = t.dz_t.p; LT.den = t.db.p;
+    if ((rc = launch_edge_items_sum(LT, 1, c->stream))) return rc;
+    if ((rc = launch_interleave2(t.da.p, t.db.p, d_a_b_grad, c->V, c->stream))) return rc;
+    // 4. d_feat = A^T-aggregation of dout with edge values p (balanced GCN kernels)
+    return gcn_run(ct, d_doutput, d_feat_grad, feat, GNNAGG_MODE_BALANCED, GNNAGG_REDUCE_SUM);
 }
 
 int gnnagg_gat_run_div_each(gnnagg_handle h, const float *d_in_att, float *d_inout_val)

@@ -14,13 +14,6 @@ static int edge_group(int avg_deg)
     return g;
 }
 
-template <int GROUP>
-__device__ __forceinline__ float group_sum(float v)
-{
-#pragma unroll
-    for (int m = GROUP / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, GROUP);
-    return v;
-}
 
 // reference convertCSRToEdgelist, aggregator.h:11-23 ((src,dst) written as one 8-byte store)
 template <int GROUP>
@@ -135,8 +128,18 @@ __global__ void k_den_combine(const int *__restrict__ mrow_id, const int *__rest
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_mrows * H) return;
     const int m = t / H, h = t % H;
+    // ascending order kept; the loads of 16 partials are issued together (a hub has hundreds: one dependent load per
+    // step made this 16 us on the arxiv-shaped input)
     float s = 0.0f;
-    for (int p = mrow_ptr[m]; p < mrow_ptr[m + 1]; ++p) s += partial_den[(size_t)p * H + h];
+    const int p1 = mrow_ptr[m + 1];
+    for (int p = mrow_ptr[m]; p < p1; p += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p + u < p1 ? partial_den[(size_t)(p + u) * H + h] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (p + u < p1) s += v[u];
+    }
     den[(size_t)mrow_id[m] * H + h] = s;
 }
 

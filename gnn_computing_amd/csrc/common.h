@@ -165,6 +165,19 @@ struct GatPlanLaunch {
     int hub_count_stride = 0;
 };
 int launch_gat_plan(const GatPlanLaunch &a, void *stream);
+// Backward of the single-head fused GAT aggregation (k_rowdot + k_gat_bwd_edges); wl = chunked edge work items.
+struct GatBwdLaunch {
+    WorkList wl;
+    const int *idx = nullptr;
+    const float *out = nullptr, *dout = nullptr, *newval = nullptr, *div = nullptr, *x = nullptr;
+    float *rowdot = nullptr, *dz = nullptr;
+    int V = 0, feat = 0;
+    float slope = 0.2f;
+};
+int launch_gat_bwd_edges(const GatBwdLaunch &a, void *stream);
+int launch_gat_bwd_permute(const int *perm, const int *idx_t, const float *dz, const float *newval, const float *div, float *dz_t,
+                           float *val_t, int E, void *stream);
+int launch_interleave2(const float *a, const float *b, float *out, int n, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);
 int launch_gcn_plan(const GcnPlanLaunch &a, void *stream);
 int launch_gcn_rows_long(const GcnRowsLongLaunch &a, void *stream);

@@ -264,6 +264,15 @@ __device__ __forceinline__ void row_times_weight(const float *yrow, int K, const
     }
 }
 
+// sum over the lanes of a group (xor butterfly: a fixed association, every lane gets the total)
+template <int GROUP>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int m = GROUP / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, GROUP);
+    return v;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // --------------------------------------------------------------------- geometry + dispatch

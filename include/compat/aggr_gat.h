@@ -63,5 +63,12 @@ public:
         (void)BLOCK_SIZE;
         checkGnnagg(gnnagg_gat_run_div_each(handle, in_att, in_out_val));
     }
+    // aggr_gat.h:426-434.  Same argument order as the reference; d_a_b / d_feat are overwritten (see gnnagg.h).
+    void run_bwd(float *output, float *doutput, float *newval, float *div, float *infeat, float *d_a_b, float *d_feat,
+                 float relu_l, int BLOCK_SIZE)
+    {
+        (void)BLOCK_SIZE;
+        checkGnnagg(gnnagg_gat_run_bwd(handle, output, doutput, newval, div, infeat, d_a_b, d_feat, relu_l, feat_in));
+    }
 };
 #endif

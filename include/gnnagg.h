@@ -164,6 +164,17 @@ int gnnagg_gat_run(gnnagg_handle h, const float *d_x, const float *d_att, float 
                    float slope, int mode, float *d_newval);
 /* Aggregator_GAT::run_att, aggr_gat.h:395-401 (attGat :5-31): out_val[E,heads] = softmax weights */
 int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, int heads, float slope);
+/* Aggregator_GAT::run_bwd, aggr_gat.h:426-434 (kernel aggr_gat_fine_bwd :222-296, marked "Experiment" in the reference and
+ * called by none of its drivers).  Backward of the single-head fused aggregation out_r = sum_e w_e x_s / D_r given the
+ * forward pass's un-normalised edge weights newval[E] (w_e) and denominators div[V] (D_r):
+ *   d_feat_grad[V,feat]  = gradient w.r.t. the input features through the aggregation (attention held constant)
+ *   d_a_b_grad[V,2]      = gradient w.r.t. att: [.,0] centre term, [.,1] source term
+ * Differences from the reference kernel, which stops short of its own comments: all `feat` columns (not 32), the
+ * leaky-ReLU slope applied where z_e < 0 (the reference tests newval < 0, never true), the centre-term gradient is
+ * produced, and both outputs are OVERWRITTEN with deterministic sums (the reference atomically accumulates into
+ * caller-zeroed buffers).  heads == 1 only. */
+int gnnagg_gat_run_bwd(gnnagg_handle h, const float *d_output, const float *d_doutput, const float *d_newval, const float *d_div,
+                       const float *d_infeat, float *d_a_b_grad, float *d_feat_grad, float relu_slope, int feat);
 /* aggr_gat.h:402-425, single head as in the reference */
 int gnnagg_gat_run_u_add_v(gnnagg_handle h, const float *d_att, float *d_out_val);
 int gnnagg_gat_run_add_to_center(gnnagg_handle h, const float *d_in_val, float *d_out_att);

@@ -507,3 +507,44 @@ ORC_API void orc_gcn_abs_scale(const int *ptr, const int *idx, const float *val,
             S[(size_t)r * F + c] = (float)s;
         }
 }
+
+/* include/aggr_gat.h:222-296 aggr_gat_fine_bwd (marked "Experiment" in the reference, called by run_bwd :426-434):
+ * backward of the single-head fused GAT aggregation  out_r = sum_e w_e x_{s_e} / D_r,  w_e = exp(lrelu(z_e)),
+ * z_e = a_r + b_{s_e},  D_r = sum_e w_e, with newval[e] = w_e and div[r] = D_r saved by the forward pass:
+ *   d_feat[s,:]  += (w_e / D_r) * dout[r,:]                                   (:263, through the aggregation only)
+ *   dL/dw_e       = (dout_r . x_s) / D_r  -  (dout_r . out_r) / D_r           (:264-283: shared_write_cache + res)
+ *   dL/dz_e       = dL/dw_e * w_e * lrelu'(z_e)                               (:288-290)
+ *   d_a_b[s,1]   += dL/dz_e                                                    (:291)
+ * Restated as the mathematics the reference's comments describe, for all F columns; where its code stops short the
+ * restatement completes it and says so: the reference covers 32 columns only (col = lane, :229), tests
+ * `newval < 0` for the leaky slope (never true for an exponential; z_e < 0 <=> w_e < 1 is used here), and never
+ * writes the centre-term gradient d_a_b[r,0] = sum_e dL/dz_e (computed here).  Outputs are overwritten, not
+ * accumulated.  Double accumulation: this is the checker, tolerance-compared. */
+ORC_API void orc_gat_bwd(const int *ptr, const int *idx, const float *output, const float *doutput, const float *newval,
+                         const float *div, const float *infeat, float *d_a_b, float *d_feat, int num_v, int F, float slope)
+{
+    double *dfe = (double *)calloc((size_t)num_v * F, sizeof(double));
+    double *dab = (double *)calloc((size_t)num_v * 2, sizeof(double));
+    for (int r = 0; r < num_v; ++r) {
+        const double D = div[r];
+        if (ptr[r] == ptr[r + 1] || D == 0.0) continue;
+        double rowdot = 0.0;
+        for (int c = 0; c < F; ++c) rowdot += (double)doutput[(size_t)r * F + c] * (double)output[(size_t)r * F + c];
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e) {
+            const int s = idx[e];
+            const double w = newval[e], p = w / D;
+            double dot = 0.0;
+            for (int c = 0; c < F; ++c) {
+                dfe[(size_t)s * F + c] += p * (double)doutput[(size_t)r * F + c];
+                dot += (double)doutput[(size_t)r * F + c] * (double)infeat[(size_t)s * F + c];
+            }
+            double g = p * (dot - rowdot);
+            if (w < 1.0) g *= (double)slope;
+            dab[(size_t)r * 2] += g;
+            dab[(size_t)s * 2 + 1] += g;
+        }
+    }
+    for (size_t i = 0; i < (size_t)num_v * F; ++i) d_feat[i] = (float)dfe[i];
+    for (size_t i = 0; i < (size_t)num_v * 2; ++i) d_a_b[i] = (float)dab[i];
+    free(dfe); free(dab);
+}

@@ -223,6 +223,18 @@ def gat_div_each(ptr, center, newval):
     return out
 
 
+def gat_bwd(ptr, idx, output, doutput, newval, div, infeat, slope=0.2):
+    """Backward of the single-head fused GAT aggregation (orc_gat_bwd).  Returns (d_a_b[V,2], d_feat[V,F])."""
+    ptr, idx = _ci(ptr), _ci(idx)
+    output, doutput, newval, div, infeat = _cf(output), _cf(doutput), _cf(newval).ravel(), _cf(div).ravel(), _cf(infeat)
+    V, F = len(ptr) - 1, infeat.shape[1]
+    d_a_b = np.empty((V, 2), np.float32)
+    d_feat = np.empty((V, F), np.float32)
+    lib().orc_gat_bwd(_i(ptr), _i(idx), _f(output), _f(doutput), _f(newval), _f(div), _f(infeat), _f(d_a_b), _f(d_feat), V, F,
+                      ctypes.c_float(slope))
+    return d_a_b, d_feat
+
+
 def gat_grouped(ptr_s, target, idx, att, X, num_v, heads=1, slope=0.2, seg=0):
     """Returns (Y, newval[E,H] un-normalised, scalar[V,H]); seg as in gcn_grouped."""
     ptr_s, target, idx, att, X = _ci(ptr_s), _ci(target), _ci(idx), _cf(att), _cf(X)

@@ -751,6 +751,36 @@ def test_gat_hub_fold_in_kernel_alternating_inputs(F, H):
             np.testing.assert_allclose(y.cpu().numpy(), refs[it & 1], rtol=3e-6, atol=1e-6, err_msg="launch %d" % it)
 
 
+@pytest.mark.parametrize("F", [128, 32, 100, 33])
+def test_gat_run_bwd(F):
+    """run_bwd (aggr_gat.h:426-434): gradients of the single-head fused aggregation w.r.t. the input features and both
+    attention terms, from the forward pass's newval / div -- hub rows on both the destination side (long rows) and the
+    source side (popular nodes) -- against the double-precision oracle (itself checked by finite differences in
+    tests/test_oracle_bwd.py)."""
+    V, E = 3000, 90000
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=41, alpha=1.1)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    x, att, g = rand((V, F), 1), rand((V, 1, 2), 2) * 0.5, rand((V, F), 3)
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.schedule_balanced(0)
+    out = torch.empty((V, F), device=DEV)
+    newval = torch.empty((E, 1), device=DEV)
+    gat.run(dev(x), dev(att), out, 128, "balanced", heads=1, newval=newval)
+    div = torch.empty(V, device=DEV)
+    gat.run_add_to_center(newval, div)
+    d_a_b = torch.full((V, 2), 7.0, device=DEV)
+    d_feat = torch.full((V, F), 7.0, device=DEV)
+    for _ in range(2):   # second call: cached transpose, same result
+        gat.run_bwd(out, dev(g), newval, div, dev(x), d_a_b, d_feat, 0.2)
+    ref_ab, ref_feat = orc.gat_bwd(ptr, idx, out.cpu().numpy(), g, newval.cpu().numpy(), div.cpu().numpy(), x, 0.2)
+    scale_f = np.abs(ref_feat).max()
+    scale_a = np.abs(ref_ab).max()
+    np.testing.assert_allclose(d_feat.cpu().numpy(), ref_feat, rtol=1e-4, atol=1e-5 * scale_f)
+    np.testing.assert_allclose(d_a_b.cpu().numpy(), ref_ab, rtol=1e-3, atol=2e-5 * scale_a)
+    assert np.diff(ptr).max() > 1500                                  # destination hubs
+    assert np.bincount(idx, minlength=V).max() > 500                  # source hubs
+
+
 def test_run_clock_instrumentation():
     """run_clock (reference aggr_gcn.h:462-489, Figure 8): per-workgroup (start, end, CU id) stamps, results unchanged."""
     V, E, F = 3000, 40000, 64
