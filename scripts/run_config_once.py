@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""A few balanced-mode launches of one named config (R, G or P1) -- the command rocprofv3 wraps for per-config counters."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gnn_computing_amd as gnc  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "R"
+dev = torch.device("cuda", 0)
+name, F = {"R": ("reddit", 602), "G": ("reddit", 256), "P1": ("products", 100)}[cfg]
+ptr, idx = gnc.graph.dataset(name, device=dev)
+V = ptr.numel() - 1
+x = torch.randn((V, F), device=dev)
+y = torch.empty((V, F), device=dev)
+if cfg == "G":
+    agg = gnc.Aggregator_GAT(ptr, idx, F, F)
+    att = torch.randn((V, 8, 2), device=dev) * 0.3
+    agg.schedule_balanced(0)
+    run = lambda: agg.run(x, att, y, 128, "balanced", heads=8)  # noqa: E731
+else:
+    agg = gnc.Aggregator_GCN(ptr, idx, None, F, F)
+    agg.schedule_balanced(0)
+    run = lambda: agg.run(x, y, 128, "balanced", reduce="mean" if cfg == "R" else "sum")  # noqa: E731
+for _ in range(5):
+    run()
+torch.cuda.synchronize()
