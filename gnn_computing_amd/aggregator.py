@@ -93,6 +93,12 @@ class Aggregator:
         check(lib().gnnagg_balanced_params(self._h, ctypes.byref(ch), ctypes.byref(sg)))
         return ch.value, sg.value
 
+    def balanced_partitions(self):
+        """0, or the number of source partitions when the balanced mode chose the partitioned order (gnnagg_balanced_partitions)."""
+        n = ctypes.c_int(0)
+        check(lib().gnnagg_balanced_partitions(self._h, ctypes.byref(n)))
+        return n.value
+
     def mode_params(self, mode="scheduled"):
         """(chunk, seg_chunks) of any mode's summation order (gnnagg_mode_params)."""
         ch, sg = ctypes.c_int(0), ctypes.c_int(0)

@@ -153,6 +153,7 @@ struct Ctx {
     int inkernel_combine = 1;  // GNNAGG_INKERNEL_COMBINE=0: hubs through k_combine (A/B)
     int sort_window = 2048;    // narrow features: short-row descriptors degree-sorted inside windows of this many rows
     int use_plan = 1;          // GCN balanced mode runs k_gcn_plan (0: items + combine, the round-1 first design)
+    int partitions = 0;        // > 0: the balanced mode is SOURCE-PARTITIONED (high-degree graphs, see auto_partitions)
     std::vector<long> row_cost_prefix;  // MODE_ROWS work items
     // GAT backward (run_bwd): the transposed graph -- row s of A^T lists the destination rows of the edges whose source is
     // s, in ascending original edge order; perm[e'] = original edge id -- and a GCN aggregator over it
@@ -364,6 +365,9 @@ static int build_plan_into(Ctx *c, BalancedPlan &p, int chunk, bool describe_in_
 }
 
 static int build_balanced_plan(Ctx *c, int chunk) { return build_plan_into(c, c->plan, chunk, true, nullptr); }
+static int pick_chunk(const Ctx *c);
+// the plan alone, leaving sched[1] (a source-partitioned schedule) untouched: GNNAGG_FLAG_ACCUMULATE on such a handle
+static int build_balanced_plan_keep(Ctx *c) { return build_plan_into(c, c->plan, pick_chunk(c), false, nullptr); }
 
 // Narrow features (8- and 16-lane groups): a wavefront holds 8 or 4 rows and runs for the longest of them, so rows of
 // similar degree should share a wavefront.  Sorting by degree inside windows of `sort_window` rows equalises them while
@@ -444,6 +448,31 @@ static int pick_chunk(const Ctx *c)
     return chunk;
 }
 
+// Source-partitioned balanced mode.  On high-degree graphs the aggregation is bound by L2-miss traffic (every config
+// runs at ~7.4 TB/s of it) and the 4 MB L2 of an XCD holds a sliver of X; the reference's locality schedule
+// (graph_schedule.h:156-243: per column range, per row, the sub-row of edges whose source falls in the range, cut every
+// NG edges) maps onto the 8 XCDs directly: with 16 ranges every XCD walks two source slices one after the other, so its
+// L2 only ever serves 1/16 of X -- reddit-shaped SAGE F=602: L2 hit rate 0.08 -> 0.41, fabric traffic 273 -> 198 GB,
+// 36.9 -> 30.2 ms; GAT 8x32: 13.4 -> 11.5 ms.  The price is one partial row per (row, range) and their ordered combine
+// (V * 16 scratch rows), which only pays when a row has many edges per range: products-shaped (avg degree 50) 7.8 -> 21 ms,
+// so it is chosen for avg degree >= 256 only.  16 (a multiple of the 8 XCDs: 20 or 24 ranges straddle XCDs and lose,
+// 46 ms) beats 8 (33.1 ms) and 32 (48 ms: sub-rows too short).  GNNAGG_PARTITIONS = 0 / N overrides.
+static int auto_partitions(const Ctx *c)
+{
+    static const int env = getenv("GNNAGG_PARTITIONS") ? atoi(getenv("GNNAGG_PARTITIONS")) : -1;
+    if (env >= 0) return env;
+    return c->avg_deg() >= 256 ? 16 : 0;
+}
+
+static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind);
+
+static int build_partitioned(Ctx *c, int parts)
+{
+    c->plan.reset();
+    c->partitions = parts;
+    return build_locality(c, c->sched[1], parts, pick_chunk(c), c->V, GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING);
+}
+
 static int get_sched(Ctx *c, int mode, Schedule **out)
 {
     if (mode == GNNAGG_MODE_SCHEDULED) {
@@ -451,7 +480,12 @@ static int get_sched(Ctx *c, int mode, Schedule **out)
             return fail(GNNAGG_ERR_STATE, "scheduled run without schedule() (reference: assert aggr_gcn.h:392)");
         *out = &c->sched[0];
     } else if (mode == GNNAGG_MODE_BALANCED) {
-        if (c->use_plan) {
+        if (c->partitions > 0 || (c->use_plan && !c->plan.valid && auto_partitions(c) > 0)) {
+            if (!c->sched[1].valid) {
+                int rc = build_partitioned(c, c->partitions > 0 ? c->partitions : auto_partitions(c));
+                if (rc) return rc;
+            }
+        } else if (c->use_plan) {
             if (!c->plan.valid) {
                 int rc = build_balanced_plan(c, pick_chunk(c));
                 if (rc) return rc;
@@ -500,7 +534,10 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
-    if ((mode == GNNAGG_MODE_BALANCED && c->use_plan) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
+    const bool acc_on_partitioned = (flags & GNNAGG_FLAG_ACCUMULATE) && c->partitions > 0;
+    if (acc_on_partitioned && !c->plan.valid && (rc = build_balanced_plan_keep(c))) return rc;  // y += A.x needs the plan kernel
+    if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && (c->partitions == 0 || acc_on_partitioned)) ||
+        (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
         BalancedPlan &p = mode == GNNAGG_MODE_BALANCED ? c->plan : c->plan_sched;
         GcnPlanLaunch P;
         P.t0 = p.t0.p; P.t1 = p.t1.p; P.n0 = p.n0; P.n1 = p.n1; P.chunk = p.chunk;
@@ -600,7 +637,7 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
-    if ((mode == GNNAGG_MODE_BALANCED && c->use_plan) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
+    if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && c->partitions == 0) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
         BalancedPlan &p = mode == GNNAGG_MODE_BALANCED ? c->plan : c->plan_sched;
         GatPlanLaunch P;
         P.t0 = p.t0.p; P.t1 = p.t1.p; P.n0 = p.n0; P.n1 = p.n1; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
@@ -842,6 +879,9 @@ int gnnagg_schedule_balanced(gnnagg_handle h, int chunk)
 {
     GET_CTX(h);
     if (chunk < 0) return fail(GNNAGG_ERR_ARG, "chunk must be >= 0");
+    c->partitions = 0;
+    c->sched[1].reset();
+    if (chunk == 0 && c->use_plan && auto_partitions(c) > 0) return build_partitioned(c, auto_partitions(c));
     if (c->use_plan) return build_balanced_plan(c, chunk > 0 ? chunk : pick_chunk(c));
     return build_grouping(c, c->sched[1], chunk > 0 ? chunk : pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
 }
@@ -857,7 +897,7 @@ int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks)
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
-    const bool plan = mode == GNNAGG_MODE_BALANCED ? c->use_plan != 0 : c->plan_sched.valid;
+    const bool plan = mode == GNNAGG_MODE_BALANCED ? (c->use_plan != 0 && c->partitions == 0) : c->plan_sched.valid;
     if (chunk) {
         int mx = 0;
         if (plan) mx = mode == GNNAGG_MODE_BALANCED ? c->plan.chunk : c->plan_sched.chunk;
@@ -871,6 +911,17 @@ int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks)
 int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks)
 {
     return gnnagg_mode_params(h, GNNAGG_MODE_BALANCED, chunk, seg_chunks);
+}
+
+int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions)
+{
+    GET_CTX(h);
+    if (!partitions) return fail(GNNAGG_ERR_ARG, "null output");
+    Schedule *s = nullptr;
+    int rc = get_sched(c, GNNAGG_MODE_BALANCED, &s);
+    if (rc) return rc;
+    *partitions = c->partitions;
+    return GNNAGG_OK;
 }
 
 int gnnagg_num_target(gnnagg_handle h, int mode, int *out)

@@ -115,6 +115,11 @@ int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks);
  * so small that the one-item-per-lane-group kernel is used, and always 0 for the locality schedules.
  * GNNAGG_MODE_ROWS: one chain per row (*chunk = INT_MAX, *seg_chunks = 0). */
 int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks);
+/* Source partitions of the balanced mode: 0 for the chunked order reported by gnnagg_balanced_params; P > 0 when the library
+ * chose the source-partitioned order for a high-degree graph (avg degree >= 256): the groups are those of
+ * gnnagg_locality_schedule(par_num = P, neighbor_num = chunk, total = num_v) -- partition-major, row-minor, CSR order inside a
+ * sub-row -- folded flat in ascending group order per row; gnnagg_get_schedule(h, GNNAGG_MODE_BALANCED, ...) returns them. */
+int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions);
 /* Aggregator::num_target (aggregator.h:126), and the scheduled arrays copied to host buffers
  * (any may be NULL): ptr_s[num_target+1], idx_s[ptr_s[num_target]], target[num_target], val_s. */
 int gnnagg_num_target(gnnagg_handle h, int mode, int *out);

@@ -781,6 +781,58 @@ def test_gat_run_bwd(F):
     assert np.bincount(idx, minlength=V).max() > 500                  # source hubs
 
 
+def test_balanced_mode_source_partitioned_on_high_degree_graph():
+    """avg degree >= 256: the balanced mode picks the source-partitioned order (16 column ranges, the reference's
+    localityNeighborGrouping arrays, graph_schedule.h:156-243) -- GCN sum/mean/max, fused ReLU, accumulate (falls back to
+    the chunked plan), run_with_nn and GAT, all against the oracle on the schedule the library reports."""
+    V, E, F, H = 600, 200000, 64, 2
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=77, alpha=0.9)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    x, val = rand((V, F), 1), rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    assert agg.balanced_partitions() == 16
+    chunk, seg = agg.balanced_params()
+    assert seg == 0
+    ps, ix, tg, vs = agg.get_schedule("balanced", with_val=True)
+    ops, oix, otg, ovs = orc.locality_schedule(ptr, idx, 16, V, ng=chunk, val=val)
+    assert np.array_equal(ps, ops) and np.array_equal(ix, oix) and np.array_equal(tg, otg) and np.array_equal(vs, ovs)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), y, 128, "balanced")
+    ref = orc.gcn_grouped(ops, otg, oix, ovs, x, V, seg=0)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    agg.run(dev(x), y, 128, "balanced", relu=True)
+    assert np.array_equal(y.cpu().numpy(), np.maximum(ref, 0))
+    deg = np.maximum(np.diff(ptr), 1)[:, None].astype(np.float32)
+    agg.run(dev(x), y, 128, "balanced", reduce="mean")
+    assert np.array_equal(y.cpu().numpy()[np.diff(ptr) > 0], (ref / deg)[np.diff(ptr) > 0])
+    agg.run(dev(x), y, 128, "balanced", reduce="max")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))
+    # y += A.x: the chunked plan takes over for that call
+    base = rand((V, F), 5)
+    y.copy_(dev(base))
+    agg.run(dev(x), y, 128, "balanced", accumulate=True)
+    scale = orc.gcn_abs_scale(ptr, idx, val, x)
+    assert np.all(np.abs(y.cpu().numpy() - (base + ref)) <= 1e-5 * (scale + np.abs(base)) + 1e-30)
+    assert agg.balanced_partitions() == 16
+    # dense combine behind it
+    w = rand((F, 32), 6)
+    t = torch.empty((V, 32), device=DEV)
+    agg.run_with_nn(dev(x), y, dev(w), t, 128, "balanced")
+    assert np.array_equal(y.cpu().numpy(), ref) and np.array_equal(t.cpu().numpy(), orc.matmul_nn(ref, w))
+    # an explicit chunk asks for the chunked order
+    agg.schedule_balanced(64)
+    assert agg.balanced_partitions() == 0 and agg.balanced_params() == (64, 16)
+    # GAT
+    att = rand((V, H, 2), 3) * 0.4
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    assert gat.balanced_partitions() == 16
+    yg = torch.full((V, F), 7.0, device=DEV)
+    gat.run(dev(x), dev(att), yg, 128, "balanced", heads=H)
+    gps, gix, gtg = gat.get_schedule("balanced")
+    refg, _, _ = orc.gat_grouped(gps, gtg, gix, att, x, V, H, seg=0)
+    np.testing.assert_allclose(yg.cpu().numpy(), refg, rtol=3e-6, atol=1e-6)
+
+
 def test_run_clock_instrumentation():
     """run_clock (reference aggr_gcn.h:462-489, Figure 8): per-workgroup (start, end, CU id) stamps, results unchanged."""
     V, E, F = 3000, 40000, 64
