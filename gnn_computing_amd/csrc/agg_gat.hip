@@ -339,7 +339,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
         }
         return;
     }
-    const int row = d.z;
+    const int row = d.w;  // destination row (attention centre term); d.z = where the result goes
     float acc[VEC] = {};
     float den = 0.0f;
     if (d.x < d.y) {
@@ -352,6 +352,11 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
                                         head_leader);
     }
     if (!col_ok) return;
+    if (d.z < 0) {  // one of several groups of its row (source-partitioned order): numerator and denominator to scratch
+        store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
+        if (head_leader) a.partial_den[(size_t)(~d.z) * H + h] = den;
+        return;
+    }
     if (d.x < d.y && (den != 0.0f || a.rows_semantics)) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;

@@ -256,6 +256,10 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
     for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
     chain_edges<VEC, GROUP, IS_MAX>(acc, d.x, d.y, lane, col_ok, a.idx, a.val, a.x + col, F);
     if (!col_ok) return;
+    if (d.z < 0) {  // one of several groups of its row (source-partitioned order): raw partial to its scratch slot
+        store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
+        return;
+    }
     if (a.accumulate) {
         const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)d.z * F + col);
 #pragma unroll
@@ -755,7 +759,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     // dense combine fused as the epilogue when one lane group spans the row and the [32][K] tile fits LDS
     const bool want_nn = L.nn_weight != nullptr;
     // (8-lane groups, F <= 32: the GEMM is ~11 us on the arxiv-shaped input and the epilogue costs as much -- not fused)
-    const bool fuse_nn = want_nn && g.ntiles == 1 && g.group >= 16 && !L.accumulate && !L.relu && nn_fusion_enabled();
+    const bool fuse_nn = want_nn && g.ntiles == 1 && g.group >= 16 && !L.accumulate && !L.relu && !L.t0_partials && nn_fusion_enabled();
     const int blk = block_for(g.group);
     const int gpb = fuse_nn ? std::max(kNnRows, blk / g.group) : blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);

@@ -69,7 +69,7 @@ struct Schedule {
     int kind = GNNAGG_SCHED_NOP;
     int num_target = 0;
     bool permuted = false;  // locality schedules permute idx/val; neighbor grouping aliases them
-    std::vector<int> h_ptr_s, h_target, h_idx_s;
+    std::vector<int> h_ptr_s, h_target, h_idx_s, h_slot, h_empty;
     std::vector<float> h_val_s;
     DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s, big_rows;
     int n_big = 0;
@@ -82,7 +82,7 @@ struct Schedule {
         valid = false;
         ptr_s.release(); target.release(); slot.release(); empty_rows.release();
         mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release(); big_rows.release(); n_big = 0;
-        h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear();
+        h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear(); h_slot.clear(); h_empty.clear();
         cost_prefix.clear();
         num_target = n_empty = n_mrows = n_slots = 0;
         permuted = false;
@@ -141,6 +141,7 @@ struct Ctx {
                              //     host arrays that describe the GCN plan's summation order)
     BalancedPlan plan;       // balanced mode
     BalancedPlan plan_sched; // `scheduled = 1` with a neighbor-grouping schedule, when the plan kernel suits that NG
+    BalancedPlan plan_part;  // source-partitioned balanced mode: one short-row descriptor per group of sched[1]
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -154,6 +155,7 @@ struct Ctx {
     int sort_window = 2048;    // narrow features: short-row descriptors degree-sorted inside windows of this many rows
     int use_plan = 1;          // GCN balanced mode runs k_gcn_plan (0: items + combine, the round-1 first design)
     int partitions = 0;        // > 0: the balanced mode is SOURCE-PARTITIONED (high-degree graphs, see auto_partitions)
+    int part_descriptors = 1;  // run it on the plan kernels' descriptor path (GNNAGG_PART_DESC=0: item kernels)
     std::vector<long> row_cost_prefix;  // MODE_ROWS work items
     // GAT backward (run_bwd): the transposed graph -- row s of A^T lists the destination rows of the edges whose source is
     // s, in ascending original edge order; perm[e'] = original edge id -- and a GCN aggregator over it
@@ -225,6 +227,8 @@ static int finalize_schedule(Ctx *c, Schedule &s)
     if ((rc = s.target.upload(s.h_target))) return rc;
     if ((rc = s.slot.upload(slot))) return rc;
     if ((rc = s.empty_rows.upload(empty))) return rc;
+    s.h_slot = slot;
+    s.h_empty = empty;
     if ((rc = s.mrow_id.upload(mrow_id))) return rc;
     if ((rc = s.mrow_ptr.upload(mrow_ptr))) return rc;
     {
@@ -303,7 +307,7 @@ static int build_plan_into(Ctx *c, BalancedPlan &p, int chunk, bool describe_in_
     for (int r = 0; r < V; ++r) {
         const int beg = c->h_ptr[r], end = c->h_ptr[r + 1], deg = end - beg;
         if (deg <= chunk) {
-            t0.insert(t0.end(), {beg, end, r, 0});
+            t0.insert(t0.end(), {beg, end, r, r});
             p.t0_cost_prefix.push_back(p.t0_cost_prefix.back() + deg + kItemCost);
         } else if (deg <= seg_edges) {
             segs.push_back({beg, end, r, r});
@@ -416,7 +420,7 @@ static int build_rows_plan(Ctx *c)
     for (int r = 0; r < c->V; ++r) {
         const int beg = c->h_ptr[r], end = c->h_ptr[r + 1];
         if (end - beg <= p.long_deg) {
-            r0.insert(r0.end(), {beg, end, r, 0});
+            r0.insert(r0.end(), {beg, end, r, r});
             p.r0_cost_prefix.push_back(p.r0_cost_prefix.back() + (end - beg) + kItemCost);
         } else {
             longs.push_back({beg, end, r});
@@ -469,8 +473,28 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
 static int build_partitioned(Ctx *c, int parts)
 {
     c->plan.reset();
+    c->plan_part.reset();
     c->partitions = parts;
-    return build_locality(c, c->sched[1], parts, pick_chunk(c), c->V, GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING);
+    Schedule &s = c->sched[1];
+    int rc = build_locality(c, s, parts, pick_chunk(c), c->V, GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING);
+    if (rc) return rc;
+    // the same groups as 16-byte descriptors {beg, end, dest, row} for the plan kernels' short-row path (dest < 0: ~scratch
+    // slot of a row with several groups), rows without edges behind them; the order and the XCD costs are the schedule's
+    BalancedPlan &p = c->plan_part;
+    const int G = s.num_target;
+    std::vector<int> t0;
+    t0.reserve(((size_t)G + s.h_empty.size()) * 4);
+    for (int g = 0; g < G; ++g) {
+        const int r = s.h_target[g];
+        t0.insert(t0.end(), {s.h_ptr_s[g], s.h_ptr_s[g + 1], s.h_slot[g] >= 0 ? ~s.h_slot[g] : r, r});
+    }
+    for (int r : s.h_empty) t0.insert(t0.end(), {0, 0, r, r});
+    p.n0 = (int)(t0.size() / 4);
+    p.chunk = pick_chunk(c);
+    p.t0_cost_prefix = s.cost_prefix;
+    if ((rc = p.t0.upload(t0))) return rc;
+    p.valid = true;
+    return GNNAGG_OK;
 }
 
 static int get_sched(Ctx *c, int mode, Schedule **out)
@@ -562,6 +586,22 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             if ((rc = reserve_hub_counters(c, p.n_mrows, feat, &P.hub_count_stride))) return rc;
             P.slot_hub = p.slot_hub.p; P.hub_count = c->hub_count.p;
         }
+        return launch_gcn_plan(P, c->stream);
+    }
+    if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors) {
+        // source-partitioned order on the plan kernel's short-row path: every group of sched[1] is a descriptor, rows with
+        // several groups meet in scratch and k_combine folds them in ascending group order
+        BalancedPlan &p = c->plan_part;
+        GcnPlanLaunch P;
+        P.t0 = p.t0.p; P.n0 = p.n0; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
+        P.hubs = s->worklist();
+        P.row_ptr = c->d_ptr; P.idx = s->idx_s.p; P.val = s->val_s.p; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
+        P.xcd_remap = c->xcd_remap; P.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0; P.num_rows = c->V; P.t0_partials = 1;
+        if (s->n_slots > 0) {
+            if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
+            P.partial = c->partial.p;
+        }
+        if (nn) { P.nn_weight = nn->weight; P.nn_out = nn->out; P.nn_cols = nn->cols; }
         return launch_gcn_plan(P, c->stream);
     }
     if (mode == GNNAGG_MODE_ROWS && c->use_plan) {
@@ -658,6 +698,21 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
         if (p.n_mrows > 0 && c->inkernel_combine) {
             if ((rc = reserve_hub_counters(c, p.n_mrows, feat, &P.hub_count_stride))) return rc;
             P.slot_hub = p.slot_hub.p; P.hub_count = c->hub_count.p;
+        }
+        return launch_gat_plan(P, c->stream);
+    }
+    if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors) {
+        BalancedPlan &p = c->plan_part;  // source-partitioned order on the descriptor path, as in gcn_run
+        GatPlanLaunch P;
+        P.t0 = p.t0.p; P.n0 = p.n0; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
+        P.hubs = s->worklist();
+        P.idx = s->idx_s.p; P.att = att; P.x = x; P.y = y; P.newval = newval; P.feat = feat; P.heads = heads; P.slope = slope;
+        P.xcd_remap = c->xcd_remap;
+        if (s->n_slots > 0) {
+            if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
+            if ((rc = c->partial_den.reserve((size_t)s->n_slots * heads))) return rc;
+            P.partial = c->partial.p;
+            P.partial_den = c->partial_den.p;
         }
         return launch_gat_plan(P, c->stream);
     }
@@ -814,6 +869,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_PLAN")) c->use_plan = atoi(e);
     if (const char *e = getenv("GNNAGG_SORT_WINDOW")) c->sort_window = atoi(e);
     if (const char *e = getenv("GNNAGG_INKERNEL_COMBINE")) c->inkernel_combine = atoi(e);
+    if (const char *e = getenv("GNNAGG_PART_DESC")) c->part_descriptors = atoi(e);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);

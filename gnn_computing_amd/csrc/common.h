@@ -88,6 +88,7 @@ struct GcnPlanLaunch {
     int accumulate = 0;  // y += A.x (sum only); rows without edges keep their value
     int relu = 0;        // y = max(result, 0)
     int num_rows = 0;    // rows of y
+    int t0_partials = 0; // short-row descriptors may carry scratch slots (dest < 0): source-partitioned order
     // hubs finished inside the plan kernel by the last segment workgroup to arrive (no k_combine launch)
     const int *slot_hub = nullptr;  // device: scratch slot -> index into hubs.mrow_*
     int *hub_count = nullptr;       // device: arrival counters, zero between launches; n_mrows * hub_count_stride ints
