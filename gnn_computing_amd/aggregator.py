@@ -96,8 +96,14 @@ class Aggregator:
     def balanced_partitions(self):
         """0, or the number of source partitions when the balanced mode chose the partitioned order (gnnagg_balanced_partitions)."""
         n = ctypes.c_int(0)
-        check(lib().gnnagg_balanced_partitions(self._h, ctypes.byref(n)))
+        check(lib().gnnagg_balanced_partitions(self._h, ctypes.byref(n), None))
         return n.value
+
+    def balanced_partition_columns(self):
+        """Column count the source ranges are cut from (largest neighbor id + 1), 0 when not partitioned."""
+        n, t = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib().gnnagg_balanced_partitions(self._h, ctypes.byref(n), ctypes.byref(t)))
+        return t.value
 
     def mode_params(self, mode="scheduled"):
         """(chunk, seg_chunks) of any mode's summation order (gnnagg_mode_params)."""

@@ -69,6 +69,7 @@ struct Schedule {
     int kind = GNNAGG_SCHED_NOP;
     int num_target = 0;
     bool permuted = false;  // locality schedules permute idx/val; neighbor grouping aliases them
+    int total_cols = 0;     // locality schedules: the column count the ranges were cut from
     std::vector<int> h_ptr_s, h_target, h_idx_s, h_slot, h_empty;
     std::vector<float> h_val_s;
     DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s, big_rows;
@@ -272,9 +273,16 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
         h_val.resize((size_t)c->E);
         HIP_TRY(hipMemcpy(h_val.data(), c->d_val, (size_t)c->E * sizeof(float), hipMemcpyDeviceToHost));
     }
+    if (total_v < 0) {  // library-chosen partitioning: the ranges must cover every column that occurs (the CSR need not be
+                        // square: a rank's local graph indexes [X_local ; X_halo])
+        int mx = 0;
+        for (int v : h_idx) mx = std::max(mx, v);
+        total_v = std::max(mx + 1, par_num);
+    }
     s.reset();
     s.kind = kind;
     s.permuted = true;
+    s.total_cols = total_v;
     std::vector<int> ptr_s((size_t)c->E + 2), tgt((size_t)c->E + 1);
     s.h_idx_s.resize((size_t)c->E);
     if (!h_val.empty()) s.h_val_s.resize((size_t)c->E);
@@ -476,7 +484,7 @@ static int build_partitioned(Ctx *c, int parts)
     c->plan_part.reset();
     c->partitions = parts;
     Schedule &s = c->sched[1];
-    int rc = build_locality(c, s, parts, pick_chunk(c), c->V, GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING);
+    int rc = build_locality(c, s, parts, pick_chunk(c), -1, GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING);
     if (rc) return rc;
     // the same groups as 16-byte descriptors {beg, end, dest, row} for the plan kernels' short-row path (dest < 0: ~scratch
     // slot of a row with several groups), rows without edges behind them; the order and the XCD costs are the schedule's
@@ -969,7 +977,7 @@ int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks)
     return gnnagg_mode_params(h, GNNAGG_MODE_BALANCED, chunk, seg_chunks);
 }
 
-int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions)
+int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions, int *total_cols)
 {
     GET_CTX(h);
     if (!partitions) return fail(GNNAGG_ERR_ARG, "null output");
@@ -977,6 +985,7 @@ int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions)
     int rc = get_sched(c, GNNAGG_MODE_BALANCED, &s);
     if (rc) return rc;
     *partitions = c->partitions;
+    if (total_cols) *total_cols = c->partitions > 0 ? c->sched[1].total_cols : 0;
     return GNNAGG_OK;
 }
 

@@ -117,9 +117,11 @@ int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks);
 int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks);
 /* Source partitions of the balanced mode: 0 for the chunked order reported by gnnagg_balanced_params; P > 0 when the library
  * chose the source-partitioned order for a high-degree graph (avg degree >= 256): the groups are those of
- * gnnagg_locality_schedule(par_num = P, neighbor_num = chunk, total = num_v) -- partition-major, row-minor, CSR order inside a
- * sub-row -- folded flat in ascending group order per row; gnnagg_get_schedule(h, GNNAGG_MODE_BALANCED, ...) returns them. */
-int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions);
+ * gnnagg_locality_schedule(par_num = P, neighbor_num = chunk, total = *total_cols) -- partition-major, row-minor, CSR order
+ * inside a sub-row -- folded flat in ascending group order per row; gnnagg_get_schedule(h, GNNAGG_MODE_BALANCED, ...) returns
+ * them.  *total_cols (may be NULL) = largest neighbor id + 1: the column count the ranges are cut from (the CSR need not be
+ * square). */
+int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions, int *total_cols);
 /* Aggregator::num_target (aggregator.h:126), and the scheduled arrays copied to host buffers
  * (any may be NULL): ptr_s[num_target+1], idx_s[ptr_s[num_target]], target[num_target], val_s. */
 int gnnagg_num_target(gnnagg_handle h, int mode, int *out);

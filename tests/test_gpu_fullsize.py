@@ -55,7 +55,7 @@ def test_reddit_sage_mean_f602(reddit):
     chunk, seg = agg.balanced_params()
     parts = agg.balanced_partitions()
     assert parts == 16 and seg == 0   # avg degree 492: the library picks the source-partitioned order here
-    ps, ix, tg, _ = orc.locality_schedule(sp, si, parts, V, ng=chunk)   # the same order restated on the sampled rows
+    ps, ix, tg, _ = orc.locality_schedule(sp, si, parts, agg.balanced_partition_columns(), ng=chunk)   # the same order restated on the sampled rows
     ref_sum = orc.gcn_grouped(ps, tg, ix, None, xh, len(rows), seg=0)
     deg = np.maximum(np.diff(sp), 1)[:, None].astype(np.float32)
     got = y[torch.from_numpy(rows).to(DEV)].cpu().numpy()

@@ -794,7 +794,7 @@ def test_balanced_mode_source_partitioned_on_high_degree_graph():
     chunk, seg = agg.balanced_params()
     assert seg == 0
     ps, ix, tg, vs = agg.get_schedule("balanced", with_val=True)
-    ops, oix, otg, ovs = orc.locality_schedule(ptr, idx, 16, V, ng=chunk, val=val)
+    ops, oix, otg, ovs = orc.locality_schedule(ptr, idx, 16, agg.balanced_partition_columns(), ng=chunk, val=val)
     assert np.array_equal(ps, ops) and np.array_equal(ix, oix) and np.array_equal(tg, otg) and np.array_equal(vs, ovs)
     y = torch.full((V, F), 7.0, device=DEV)
     agg.run(dev(x), y, 128, "balanced")
@@ -819,6 +819,15 @@ def test_balanced_mode_source_partitioned_on_high_degree_graph():
     t = torch.empty((V, 32), device=DEV)
     agg.run_with_nn(dev(x), y, dev(w), t, 128, "balanced")
     assert np.array_equal(y.cpu().numpy(), ref) and np.array_equal(t.cpu().numpy(), orc.matmul_nn(ref, w))
+    # a non-square CSR (a rank's local graph indexes [X_local ; X_halo]): the ranges are cut from the real column count
+    Vc = 1500
+    idx2 = np.random.default_rng(3).integers(0, Vc, E).astype(np.int32)
+    x2 = rand((Vc, F), 8)
+    agg2 = gnc.Aggregator_GCN(dev(ptr), dev(idx2), dev(val), F, F)
+    assert agg2.balanced_partitions() == 16 and agg2.balanced_partition_columns() == int(idx2.max()) + 1
+    agg2.run(dev(x2), y, 128, "balanced")
+    s2 = orc.locality_schedule(ptr, idx2, 16, agg2.balanced_partition_columns(), ng=agg2.balanced_params()[0], val=val)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(s2[0], s2[2], s2[1], s2[3], x2, V, seg=0))
     # an explicit chunk asks for the chunked order
     agg.schedule_balanced(64)
     assert agg.balanced_partitions() == 0 and agg.balanced_params() == (64, 16)
