@@ -235,7 +235,7 @@ static int finalize_schedule(Ctx *c, Schedule &s)
     {
         std::vector<int> big;
         for (int m = 0; m < (int)mrow_id.size(); ++m)
-            if (mrow_ptr[m + 1] - mrow_ptr[m] > 16) big.push_back(m);  // kCombineBatch in combine.cuh
+            if (mrow_ptr[m + 1] - mrow_ptr[m] > kBigRowPartials) big.push_back(m);
         s.n_big = (int)big.size();
         if ((rc = s.big_rows.upload(big))) return rc;
     }
@@ -325,7 +325,7 @@ static int build_plan_into(Ctx *c, BalancedPlan &p, int chunk, bool describe_in_
                 const long sb = beg + (long)j * seg_edges;
                 segs.push_back({(int)sb, (int)std::min<long>(sb + seg_edges, end), ~(nslots + j), r});
             }
-            if (nseg > 16) big.push_back((int)mrow_id.size());  // kCombineBatch in combine.cuh
+            if (nseg > kBigRowPartials) big.push_back((int)mrow_id.size());
             nslots += nseg;
             mrow_id.push_back(r);
             mrow_ptr.push_back(nslots);
@@ -467,8 +467,8 @@ static int pick_chunk(const Ctx *c)
 // L2 only ever serves 1/16 of X -- reddit-shaped SAGE F=602: L2 hit rate 0.08 -> 0.41, fabric traffic 273 -> 198 GB,
 // 36.9 -> 30.2 ms; GAT 8x32: 13.4 -> 11.5 ms.  The price is one partial row per (row, range) and their ordered combine
 // (V * 16 scratch rows), which only pays when a row has many edges per range: products-shaped (avg degree 50) 7.8 -> 21 ms,
-// so it is chosen for avg degree >= 256 only.  16 (a multiple of the 8 XCDs: 20 or 24 ranges straddle XCDs and lose,
-// 46 ms) beats 8 (33.1 ms) and 32 (48 ms: sub-rows too short).  GNNAGG_PARTITIONS = 0 / N overrides.
+// so it is chosen for avg degree >= 256 only.  16 ranges (30.2 ms on the item kernels) against 8: 33.1, 24: 29.6, 32: 31.8,
+// 48: 38.6 ms -- shorter sub-rows and more partial rows eat the extra hits.  GNNAGG_PARTITIONS = 0 / N overrides.
 static int auto_partitions(const Ctx *c)
 {
     static const int env = getenv("GNNAGG_PARTITIONS") ? atoi(getenv("GNNAGG_PARTITIONS")) : -1;

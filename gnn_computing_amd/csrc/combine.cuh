@@ -6,7 +6,7 @@ namespace gnnagg {
 
 struct CombineArgs {
     const int *mrow_id, *mrow_ptr, *row_ptr;
-    const int *big_rows;  // indices into mrow_* of the rows with more than kCombineBatch partials
+    const int *big_rows;  // indices into mrow_* of the rows with more than kBigRowPartials partials
     int n_big, nblocks_small;
     int accumulate;  // 1: y += (sum of partials)
     int relu = 0;    // 1: y = max(result, 0) (GCN)
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
     if (here) {
         s0 = a.mrow_ptr[m];
         s1 = a.mrow_ptr[m + 1];
-        if (a.n_big > 0 && s1 - s0 > kCombineBatch) here = false;  // handled by the workgroup-per-row path
+        if (a.n_big > 0 && s1 - s0 > kBigRowPartials) here = false;  // handled by the workgroup-per-row path
     }
     const bool active = here && col < a.feat;
     if (!nn && !active) return;

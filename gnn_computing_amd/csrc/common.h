@@ -33,6 +33,10 @@ int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int
 //   slot[g] <  0    : item owns the whole row -> direct store
 //   slot[g] >= 0    : row is split over several items -> partial sums go to scratch row slot[g]
 // Items [n_items, n_items + n_empty) zero-fill the rows listed in empty_rows (rows with no item).
+// Split rows with more partial rows than this are combined by a whole workgroup (LDS-staged), the others by one lane group
+// in batches of 16 loads.  (The source-partitioned order gives EVERY row one partial per range: 16 or 32 of them.)
+static constexpr int kBigRowPartials = 64;
+
 struct WorkList {
     const int *ptr = nullptr;
     const int *target = nullptr;

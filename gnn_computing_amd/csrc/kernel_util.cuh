@@ -49,7 +49,10 @@ static inline int block_for(int group) { return group * 8 < kBlock ? group * 8 :
 // neighbor gathers in flight per lane group.  Measured on the arxiv-shaped input: 4 and 8 tie (73.7 / 74.5 us in community
 // order, 87.9 / 86.8 us un-reordered), 16 loses (96 us, register pressure), and forcing 8 waves/SIMD with
 // __launch_bounds__ spills (137 us): the kernel sits at the memory system's ceiling, not at an occupancy cliff.
-static constexpr int kUnroll = 8;
+#ifndef KUNROLL
+#define KUNROLL 8
+#endif
+static constexpr int kUnroll = KUNROLL;
 static constexpr int kSegChunks = 16;  // chunks of a long row that one segment workgroup folds in LDS (plan kernels)
 
 // ---------------------------------------------------------------------------------- helpers
