@@ -59,7 +59,8 @@ def main():
             agg = gnc.Aggregator_GCN(ptr, idx, None, F, F)
             nbytes = E * (4 * F + 4) + V * 4 * F + 4 * (V + 1)  # implicit weights: no val stream
             for mode in os.environ.get("MODES", "balanced,rows").split(","):
-                emit("R reddit SAGE mean F=602", mode, timeit(lambda: agg.run(x, y, 512, mode, reduce="mean")), V, E, F, nbytes)
+                emit("R reddit SAGE mean F=602", mode, timeit(lambda: agg.run(x, y, 512, mode, reduce="mean")), V, E, F, nbytes,
+                     source_partitions=agg.balanced_partitions() if mode == "balanced" else 0)
             del agg, x, y
         if "G" in WHICH:
             H, D = 8, 32
@@ -70,7 +71,8 @@ def main():
             gat = gnc.Aggregator_GAT(ptr, idx, F, F)
             nbytes = E * (4 * F + 4 + 4 * H) + V * (4 * F + 4 * H) + 4 * (V + 1)
             for mode in os.environ.get("MODES", "balanced,rows").split(","):
-                emit("G reddit GAT 8x32", mode, timeit(lambda: gat.run(x, att, y, 128, mode, heads=H)), V, E, F, nbytes)
+                emit("G reddit GAT 8x32", mode, timeit(lambda: gat.run(x, att, y, 128, mode, heads=H)), V, E, F, nbytes,
+                     source_partitions=gat.balanced_partitions() if mode == "balanced" else 0)
             del gat, x, y, att
         del ptr, idx
         torch.cuda.empty_cache()
@@ -84,7 +86,8 @@ def main():
         agg = gnc.Aggregator_GCN(ptr, idx, val, F, F)
         nbytes = E * (4 * F + 8) + V * 4 * F + 4 * (V + 1)
         for mode in os.environ.get("MODES", "balanced,rows").split(","):
-            emit("P1 products GCN F=100 (1 GPU)", mode, timeit(lambda: agg.run(x, y, 512, mode)), V, E, F, nbytes)
+            emit("P1 products GCN F=100 (1 GPU)", mode, timeit(lambda: agg.run(x, y, 512, mode)), V, E, F, nbytes,
+                 source_partitions=agg.balanced_partitions() if mode == "balanced" else 0)
 
 
 if __name__ == "__main__":
