@@ -467,13 +467,13 @@ static int pick_chunk(const Ctx *c)
 // L2 only ever serves 1/16 of X -- reddit-shaped SAGE F=602: L2 hit rate 0.08 -> 0.41, fabric traffic 273 -> 198 GB,
 // 36.9 -> 30.2 ms; GAT 8x32: 13.4 -> 11.5 ms.  The price is one partial row per (row, range) and their ordered combine
 // (V * 16 scratch rows), which only pays when a row has many edges per range: products-shaped (avg degree 50) 7.8 -> 21 ms,
-// so it is chosen for avg degree >= 256 only.  16 ranges (30.2 ms on the item kernels) against 8: 33.1, 24: 29.6, 32: 31.8,
+// so it is chosen for avg degree >= 192 only (V = 400 k sweep, F = 128: degree 150 3.68 vs 3.50 ms chunked, 200 4.26 vs 4.61, 300 5.41 vs 6.70).  16 ranges (30.2 ms on the item kernels) against 8: 33.1, 24: 29.6, 32: 31.8,
 // 48: 38.6 ms -- shorter sub-rows and more partial rows eat the extra hits.  GNNAGG_PARTITIONS = 0 / N overrides.
 static int auto_partitions(const Ctx *c)
 {
     static const int env = getenv("GNNAGG_PARTITIONS") ? atoi(getenv("GNNAGG_PARTITIONS")) : -1;
     if (env >= 0) return env;
-    return c->avg_deg() >= 256 ? 16 : 0;
+    return c->avg_deg() >= 192 ? 16 : 0;
 }
 
 static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind);

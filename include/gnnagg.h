@@ -116,7 +116,7 @@ int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks);
  * GNNAGG_MODE_ROWS: one chain per row (*chunk = INT_MAX, *seg_chunks = 0). */
 int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks);
 /* Source partitions of the balanced mode: 0 for the chunked order reported by gnnagg_balanced_params; P > 0 when the library
- * chose the source-partitioned order for a high-degree graph (avg degree >= 256): the groups are those of
+ * chose the source-partitioned order for a high-degree graph (avg degree >= 192): the groups are those of
  * gnnagg_locality_schedule(par_num = P, neighbor_num = chunk, total = *total_cols) -- partition-major, row-minor, CSR order
  * inside a sub-row -- folded flat in ascending group order per row; gnnagg_get_schedule(h, GNNAGG_MODE_BALANCED, ...) returns
  * them.  *total_cols (may be NULL) = largest neighbor id + 1: the column count the ranges are cut from (the CSR need not be
