@@ -295,6 +295,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # test hooks (not used by the driver): BENCH_ONE_GPU=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo swaps the
+    # transport, so the N > 1 code path can be exercised on a single-GPU box (RCCL needs one GPU per rank)
+    if os.environ.get("BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("BENCH_FORCE_MULTI") == "1":
@@ -303,7 +307,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         out = run_multi(args, dev, rank, world)
         dist.barrier()
         dist.destroy_process_group()
