@@ -64,6 +64,7 @@ SIGNATURES = {
     "gnnagg_gat_run_u_add_v": (c_int, [c_int64, c_void_p, c_void_p]),
     "gnnagg_gat_run_add_to_center": (c_int, [c_int64, c_void_p, c_void_p]),
     "gnnagg_gat_run_div_each": (c_int, [c_int64, c_void_p, c_void_p]),
+    "gnnagg_gcn_run_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_int]),
     "gnnagg_gat_run_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int]),
     "gnnagg_spmm_naive": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gnnagg_validate": (c_int, [c_void_p, c_void_p, c_int, P_INT, c_void_p]),

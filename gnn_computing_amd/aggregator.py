@@ -202,6 +202,13 @@ class Aggregator_GCN(Aggregator):
                                            _dev_ptr(transformed, torch.float32, "transformed"), int(vin.shape[1]),
                                            int(weight.shape[1]), _mode(scheduled)))
 
+    def run_bwd(self, doutput, dinput):
+        """d(input) = A^T . d(output) for the sum aggregation with this aggregator's edge values (extension: the reference
+        is forward-only).  Deterministic gather over the transposed CSR."""
+        self._use_current_stream()
+        check(lib().gnnagg_gcn_run_bwd(self._h, _dev_ptr(doutput, torch.float32, "doutput"),
+                                       _dev_ptr(dinput, torch.float32, "dinput"), int(doutput.shape[1])))
+
     def updateval(self, val):
         """aggr_gcn.h:540-544"""
         self.val = val

@@ -588,6 +588,13 @@ __global__ void k_gat_bwd_permute(const int *__restrict__ perm, const int *__res
     val_t[e] = D != 0.0f ? newval[o] / D : 0.0f;
 }
 
+// val_t[e'] = val[perm[e']] (1 when the aggregator has implicit unit weights): the edge values of the transposed graph
+__global__ void k_permute_val(const int *__restrict__ perm, const float *__restrict__ val, float *__restrict__ val_t, int E)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) val_t[e] = val ? val[perm[e]] : 1.0f;
+}
+
 __global__ void k_interleave2(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,6 +634,14 @@ int launch_gat_bwd_permute(const int *perm, const int *idx_t, const float *dz, c
     if (E <= 0) return GNNAGG_OK;
     hipLaunchKernelGGL(k_gat_bwd_permute, dim3(ceil_div(E, 256)), dim3(256), 0, (hipStream_t)stream_v, perm, idx_t, dz, newval,
                        div, dz_t, val_t, E);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_permute_val(const int *perm, const float *val, float *val_t, int E, void *stream_v)
+{
+    if (E <= 0) return GNNAGG_OK;
+    hipLaunchKernelGGL(k_permute_val, dim3(ceil_div(E, 256)), dim3(256), 0, (hipStream_t)stream_v, perm, val, val_t, E);
     HIP_TRY(hipGetLastError());
     return GNNAGG_OK;
 }

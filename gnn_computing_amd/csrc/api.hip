@@ -1236,6 +1236,22 @@ int gnnagg_gat_run_bwd(gnnagg_handle h, const float *d_output, const float *d_do
     return gcn_run(ct, d_doutput, d_feat_grad, feat, GNNAGG_MODE_BALANCED, GNNAGG_REDUCE_SUM);
 }
 
+int gnnagg_gcn_run_bwd(gnnagg_handle h, const float *d_doutput, float *d_dinput, int feat)
+{
+    GET_CTX(h);
+    if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
+    if (feat <= 0 || !d_doutput || !d_dinput) return fail(GNNAGG_ERR_ARG, "bad gcn_run_bwd arguments");
+    int rc = build_transposed(c);
+    if (rc) return rc;
+    Ctx::Transposed &t = c->tr;
+    Ctx *ct = lookup(t.agg);
+    if (!ct) return fail(GNNAGG_ERR_ARG, "gcn_run_bwd: transposed aggregator lost");
+    ct->stream = c->stream;
+    // the edge values follow their edges (re-gathered every call: updateval may have re-aliased them)
+    if ((rc = launch_permute_val(t.perm.p, c->d_val, t.val_t.p, c->E, c->stream))) return rc;
+    return gcn_run(ct, d_doutput, d_dinput, feat, GNNAGG_MODE_BALANCED, GNNAGG_REDUCE_SUM);
+}
+
 int gnnagg_gat_run_div_each(gnnagg_handle h, const float *d_in_att, float *d_inout_val)
 {
     GET_CTX(h);

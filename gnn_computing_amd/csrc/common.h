@@ -183,6 +183,7 @@ int launch_gat_bwd_edges(const GatBwdLaunch &a, void *stream);
 int launch_gat_bwd_permute(const int *perm, const int *idx_t, const float *dz, const float *newval, const float *div, float *dz_t,
                            float *val_t, int E, void *stream);
 int launch_interleave2(const float *a, const float *b, float *out, int n, void *stream);
+int launch_permute_val(const int *perm, const float *val, float *val_t, int E, void *stream);
 int launch_gcn(const GcnLaunch &a, void *stream);
 int launch_gcn_plan(const GcnPlanLaunch &a, void *stream);
 int launch_gcn_rows_long(const GcnRowsLongLaunch &a, void *stream);

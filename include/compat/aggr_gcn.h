@@ -89,6 +89,12 @@ public:
         d_val = out_d_val;
         checkGnnagg(gnnagg_update_val(handle, out_d_val));
     }
+    // extension (the reference is forward-only): d(input) = A^T . d(output) for the sum aggregation
+    void run_bwd(float *doutput, float *dinput, int BLOCK_SIZE)
+    {
+        (void)BLOCK_SIZE;
+        checkGnnagg(gnnagg_gcn_run_bwd(handle, doutput, dinput, feat_in));
+    }
 
 private:
     float *d_val = nullptr;

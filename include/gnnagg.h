@@ -171,6 +171,10 @@ int gnnagg_gat_run(gnnagg_handle h, const float *d_x, const float *d_att, float 
                    float slope, int mode, float *d_newval);
 /* Aggregator_GAT::run_att, aggr_gat.h:395-401 (attGat :5-31): out_val[E,heads] = softmax weights */
 int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, int heads, float slope);
+/* Backward of the GCN / SAGE sum aggregation y = A.x (no reference counterpart: the reference is forward-only):
+ * d_dinput[V, feat] = A^T . d_doutput with the aggregator's edge values, as a deterministic gather over the
+ * transposed CSR (built once per handle) on the balanced kernels.  Square graphs (neighbor ids < num_v). */
+int gnnagg_gcn_run_bwd(gnnagg_handle h, const float *d_doutput, float *d_dinput, int feat);
 /* Aggregator_GAT::run_bwd, aggr_gat.h:426-434 (kernel aggr_gat_fine_bwd :222-296, marked "Experiment" in the reference and
  * called by none of its drivers).  Backward of the single-head fused aggregation out_r = sum_e w_e x_s / D_r given the
  * forward pass's un-normalised edge weights newval[E] (w_e) and denominators div[V] (D_r):

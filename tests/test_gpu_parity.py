@@ -842,6 +842,33 @@ def test_balanced_mode_source_partitioned_on_high_degree_graph():
     np.testing.assert_allclose(yg.cpu().numpy(), refg, rtol=3e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("weights", [True, False])
+def test_gcn_run_bwd_is_the_transposed_aggregation(weights):
+    """d(input) = A^T d(output): checked through the adjoint identity <A x, g> == <x, A^T g> in float64 and against the
+    float64 transposed product directly; hub rows on the source side included."""
+    V, E, F = 4000, 120000, 96
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=51, alpha=1.1)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    val = rand(E, 2) if weights else None
+    x, g = rand((V, F), 1), rand((V, F), 3)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if val is None else dev(val), F, F)
+    dx = torch.full((V, F), 7.0, device=DEV)
+    for _ in range(2):
+        agg.run_bwd(dev(g), dx)
+    rows = np.repeat(np.arange(V), np.diff(ptr))
+    w = (val if val is not None else np.ones(E, np.float32)).astype(np.float64)
+    ref = np.zeros((V, F))
+    np.add.at(ref, idx, w[:, None] * g.astype(np.float64)[rows])
+    scale = np.zeros((V, F))
+    np.add.at(scale, idx, np.abs(w[:, None] * g.astype(np.float64)[rows]))
+    assert np.all(np.abs(dx.cpu().numpy() - ref) <= 1e-5 * scale + 1e-30)
+    y = torch.empty((V, F), device=DEV)
+    agg.run(dev(x), y, 128, "balanced")
+    lhs = float((y.cpu().numpy().astype(np.float64) * g).sum())
+    rhs = float((x.astype(np.float64) * dx.cpu().numpy()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * float(np.abs(ref).sum())
+
+
 def test_run_clock_instrumentation():
     """run_clock (reference aggr_gcn.h:462-489, Figure 8): per-workgroup (start, end, CU id) stamps, results unchanged."""
     V, E, F = 3000, 40000, 64
