@@ -157,6 +157,7 @@ struct Ctx {
     int use_plan = 1;          // GCN balanced mode runs k_gcn_plan (0: items + combine, the round-1 first design)
     int partitions = 0;        // > 0: the balanced mode is SOURCE-PARTITIONED (high-degree graphs, see auto_partitions)
     int part_descriptors = 1;  // run it on the plan kernels' descriptor path (GNNAGG_PART_DESC=0: item kernels)
+    int no_auto_partition = 0; // set when a run found the partial-row scratch too large: the handle stays on the chunked plan
     std::vector<long> row_cost_prefix;  // MODE_ROWS work items
     // GAT backward (run_bwd): the transposed graph -- row s of A^T lists the destination rows of the edges whose source is
     // s, in ascending original edge order; perm[e'] = original edge id -- and a GCN aggregator over it
@@ -472,6 +473,7 @@ static int pick_chunk(const Ctx *c)
 static int auto_partitions(const Ctx *c)
 {
     static const int env = getenv("GNNAGG_PARTITIONS") ? atoi(getenv("GNNAGG_PARTITIONS")) : -1;
+    if (c->no_auto_partition) return 0;
     if (env >= 0) return env;
     return c->avg_deg() >= 192 ? 16 : 0;
 }
@@ -503,6 +505,24 @@ static int build_partitioned(Ctx *c, int parts)
     if ((rc = p.t0.upload(t0))) return rc;
     p.valid = true;
     return GNNAGG_OK;
+}
+
+static int get_sched(Ctx *c, int mode, Schedule **out);
+// The partitioned order keeps one partial row per (row, range) in scratch: num_v * 16 * feat floats (9 GB for the reddit-shaped
+// F = 602 case).  When that exceeds a quarter of the device memory the handle is moved to the chunked plan for good
+// (gnnagg_balanced_partitions reports 0 from then on).
+static int demote_if_scratch_too_large(Ctx *c, int mode, int feat, int heads, Schedule **s)
+{
+    if (mode != GNNAGG_MODE_BALANCED || c->partitions == 0) return GNNAGG_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GNNAGG_OK;
+    const size_t need = (size_t)c->sched[1].n_slots * ((size_t)feat + (size_t)heads) * sizeof(float);
+    if (need <= total_b / 4) return GNNAGG_OK;
+    c->partitions = 0;
+    c->no_auto_partition = 1;
+    c->sched[1].reset();
+    c->plan_part.reset();
+    return get_sched(c, mode, s);
 }
 
 static int get_sched(Ctx *c, int mode, Schedule **out)
@@ -566,6 +586,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
+    if ((rc = demote_if_scratch_too_large(c, mode, feat, 0, &s))) return rc;
     const bool acc_on_partitioned = (flags & GNNAGG_FLAG_ACCUMULATE) && c->partitions > 0;
     if (acc_on_partitioned && !c->plan.valid && (rc = build_balanced_plan_keep(c))) return rc;  // y += A.x needs the plan kernel
     if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && (c->partitions == 0 || acc_on_partitioned)) ||
@@ -685,6 +706,7 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
+    if ((rc = demote_if_scratch_too_large(c, mode, feat, heads, &s))) return rc;
     if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && c->partitions == 0) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
         BalancedPlan &p = mode == GNNAGG_MODE_BALANCED ? c->plan : c->plan_sched;
         GatPlanLaunch P;
