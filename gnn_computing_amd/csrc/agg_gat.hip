@@ -395,8 +395,10 @@ int launch_gat(const GatLaunch &L, void *stream_v)
         c.heads = L.heads; c.dhead = dhead; c.mean = 0; c.accumulate = 0;
         c.big_rows = L.wl.big_rows; c.n_big = L.heads <= 64 ? L.wl.n_big : 0;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
-        const int nb = c.nblocks_small + c.n_big * g.ntiles;
-#define CALL_COMB hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true>), dim3(nb), dim3(kBlock), 0, stream, c);
+        const int nb_big = c.n_big * g.ntiles;
+#define CALL_COMB                                                                                                         \
+        hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true, false>), dim3(c.nblocks_small), dim3(kBlock), 0, stream, c);     \
+        if (nb_big > 0) hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true, true>), dim3(nb_big), dim3(kBlock), 0, stream, c);
         DISPATCH_GEOM(g, CALL_COMB)
 #undef CALL_COMB
         HIP_TRY(hipGetLastError());
@@ -452,8 +454,10 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
         c.heads = L.heads; c.dhead = dhead; c.mean = 0; c.accumulate = 0;
         c.big_rows = L.hubs.big_rows; c.n_big = L.heads <= 64 ? L.hubs.n_big : 0;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
-        const int nb = c.nblocks_small + c.n_big * g.ntiles;
-#define CALL_COMB hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true>), dim3(nb), dim3(kBlock), 0, stream, c);
+        const int nb_big = c.n_big * g.ntiles;
+#define CALL_COMB                                                                                                         \
+        hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true, false>), dim3(c.nblocks_small), dim3(kBlock), 0, stream, c);     \
+        if (nb_big > 0) hipLaunchKernelGGL((k_combine<VEC, GROUP, false, true, true>), dim3(nb_big), dim3(kBlock), 0, stream, c);
         DISPATCH_GEOM(g, CALL_COMB)
 #undef CALL_COMB
         HIP_TRY(hipGetLastError());

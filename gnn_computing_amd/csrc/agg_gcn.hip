@@ -702,10 +702,14 @@ static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max
         c.nn_weight = nn_weight; c.nn_out = nn_out; c.nn_cols = nn_cols;
         c.big_rows = L.wl.big_rows; c.n_big = L.wl.n_big;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
-        const int nb = c.nblocks_small + c.n_big * g.ntiles;
+        const int nb_big = c.n_big * g.ntiles;
 #define CALL_COMB                                                                                           \
-        if (is_max) hipLaunchKernelGGL((k_combine<VEC, GROUP, true, false>), dim3(nb), dim3(kBlock), 0, stream, c);  \
-        else        hipLaunchKernelGGL((k_combine<VEC, GROUP, false, false>), dim3(nb), dim3(kBlock), 0, stream, c);
+        if (is_max) hipLaunchKernelGGL((k_combine<VEC, GROUP, true, false, false>), dim3(c.nblocks_small), dim3(kBlock), 0, stream, c);  \
+        else        hipLaunchKernelGGL((k_combine<VEC, GROUP, false, false, false>), dim3(c.nblocks_small), dim3(kBlock), 0, stream, c); \
+        if (nb_big > 0) {                                                                                   \
+            if (is_max) hipLaunchKernelGGL((k_combine<VEC, GROUP, true, false, true>), dim3(nb_big), dim3(kBlock), 0, stream, c);  \
+            else        hipLaunchKernelGGL((k_combine<VEC, GROUP, false, false, true>), dim3(nb_big), dim3(kBlock), 0, stream, c); \
+        }
         DISPATCH_GEOM(g, CALL_COMB)
 #undef CALL_COMB
         HIP_TRY(hipGetLastError());

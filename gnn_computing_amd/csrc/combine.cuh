@@ -25,19 +25,22 @@ struct CombineArgs {
 static constexpr int kCombineBatch = 16;   // partial rows a lane group keeps in flight
 static constexpr int kCombineStage = 128;  // partial rows a workgroup stages in LDS per round (big rows)
 
-template <int VEC, int GROUP, bool IS_MAX, bool IS_GAT>
+// BIG = true: the workgroup-per-row path only (64 KB of LDS staging), launched over the rows of big_rows; BIG = false: the
+// lane-group path only, with 4 KB of LDS (the two used to be one kernel, and the staging array capped the lane-group path
+// at two workgroups per CU -- it now runs for every row of the source-partitioned mode).
+template <int VEC, int GROUP, bool IS_MAX, bool IS_GAT, bool BIG>
 __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
 {
     constexpr int ITEMS = kBlock / GROUP;
     const int F = a.feat;
-    __shared__ float stage[kCombineStage * GROUP * VEC];
-    __shared__ float stage_den[IS_GAT ? kCombineStage * 64 : 1];
+    __shared__ float stage[BIG ? kCombineStage * GROUP * VEC : kBlock * VEC];
+    __shared__ float stage_den[(BIG && IS_GAT) ? kCombineStage * 64 : 1];
     const bool nn = !IS_GAT && a.nn_weight != nullptr;
-    if ((int)blockIdx.x >= a.nblocks_small) {
+    if constexpr (BIG) {
         // ---- big rows (hubs: hundreds of partials): one workgroup per (row, column tile).  All lane
         // groups fetch partial rows in parallel into LDS (kCombineStage rows per round, kCombineBatch
         // loads in flight per group), then each column is summed from LDS in ascending slot order.
-        const int bb = (int)blockIdx.x - a.nblocks_small;
+        const int bb = (int)blockIdx.x;
         const int tile = bb % a.ntiles;
         const int m = a.big_rows[bb / a.ntiles];
         const int s0 = a.mrow_ptr[m], s1 = a.mrow_ptr[m + 1];
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
         __syncthreads();
         row_times_weight(stage, F, a.nn_weight, a.nn_cols, a.nn_out + (size_t)row * a.nn_cols, (int)threadIdx.x, kBlock);
         return;
-    }
+    } else {
     const int tile = blockIdx.x % a.ntiles;
     const int grp = (int)threadIdx.x / GROUP;
     const int m = (blockIdx.x / a.ntiles) * ITEMS + grp;
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
     if (!nn) return;
     __syncthreads();
     if (here) row_times_weight(&stage[grp * GROUP * VEC], F, a.nn_weight, a.nn_cols, a.nn_out + (size_t)row * a.nn_cols, lane, GROUP);
+    }
 }
 
 }  // namespace gnnagg
