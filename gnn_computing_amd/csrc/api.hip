@@ -514,9 +514,13 @@ static int get_sched(Ctx *c, int mode, Schedule **out);
 static int demote_if_scratch_too_large(Ctx *c, int mode, int feat, int heads, Schedule **s)
 {
     if (mode != GNNAGG_MODE_BALANCED || c->partitions == 0) return GNNAGG_OK;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GNNAGG_OK;
     const size_t need = (size_t)c->sched[1].n_slots * ((size_t)feat + (size_t)heads) * sizeof(float);
+    if (need <= (c->partial.n + c->partial_den.n) * sizeof(float)) return GNNAGG_OK;  // already allocated (no API call: capture-safe)
+    static size_t total_b = 0;
+    if (total_b == 0) {
+        size_t free_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { total_b = 0; return GNNAGG_OK; }
+    }
     if (need <= total_b / 4) return GNNAGG_OK;
     c->partitions = 0;
     c->no_auto_partition = 1;

@@ -828,6 +828,15 @@ def test_balanced_mode_source_partitioned_on_high_degree_graph():
     agg2.run(dev(x2), y, 128, "balanced")
     s2 = orc.locality_schedule(ptr, idx2, 16, agg2.balanced_partition_columns(), ng=agg2.balanced_params()[0], val=val)
     assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(s2[0], s2[2], s2[1], s2[3], x2, V, seg=0))
+    # the partitioned launch sequence (plan kernel + combine) captures into a hipGraph once the scratch is warm
+    gr = torch.cuda.CUDAGraph()
+    dx_in = dev(x)
+    with torch.cuda.graph(gr):
+        agg.run(dx_in, y, 128, "balanced")
+    y.fill_(7.0)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), ref)
     # an explicit chunk asks for the chunked order
     agg.schedule_balanced(64)
     assert agg.balanced_partitions() == 0 and agg.balanced_params() == (64, 16)
