@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--gpu", type=int, default=0)
     ap.add_argument("--neighbor-num", type=int, default=32)   # our.py:84
     ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--balanced", action="store_true",
+                    help="use the library-balanced mode instead of the reference's scheduled=1 on its neighbor-grouping "
+                         "schedule (on high-degree graphs that is the source-partitioned order)")
     ap.add_argument("--fused-relu", action="store_true",
                     help="GCN: apply the ReLU inside the aggregation kernel (GNNAGG_FLAG_RELU) instead of F.relu")
     ap.add_argument("--hip-graph", action="store_true",
@@ -50,6 +53,7 @@ def main():
     at_gat = gnc.gat_init(ptrs, idxs)
     gnc.gat_schedule(at_gat, args.neighbor_num)
 
+    sched = "balanced" if args.balanced else 1
     dims = [512, 128, 64, 32]                                # our.py:92-95
     # 1/sqrt(fan_in) scaling keeps activations O(1): the reference's GAT kernel exponentiates raw scores without a
     # max-subtraction (aggr_gat.h:138-143), so un-scaled randn weights overflow exp() in the deeper layers
@@ -61,15 +65,15 @@ def main():
     def gcn_layer(feat, out, w):                             # our.py:171-176
         feat2 = torch.mm(feat, w)
         if args.fused_relu:
-            gnc.gcn_run(at, feat2, out, 128, 1, relu=True)
+            gnc.gcn_run(at, feat2, out, 128, sched, relu=True)
             return out
-        gnc.gcn_run(at, feat2, out, 128, 1)
+        gnc.gcn_run(at, feat2, out, 128, sched)
         return F.relu(out)
 
     def gat_layer(feat, out, w, w_lr):                       # our.py:179-188
         feat2 = torch.mm(feat, w)
         att_lr = torch.mm(feat2, w_lr)
-        gnc.gat_run(at_gat, feat2, att_lr, out, 128, 1)
+        gnc.gat_run(at_gat, feat2, att_lr, out, 128, sched)
         return out
 
     def forward():
@@ -103,7 +107,7 @@ def main():
     if result is not None:
         assert torch.equal(result, y), "graph replay differs from the eager forward"
     print(json.dumps({"model": args.model, "dataset": args.dataset, "num_v": num_v, "num_e": num_e,
-                      "seconds_per_forward": dt, "hip_graph": bool(args.hip_graph), "fused_relu": bool(args.fused_relu), "finite": bool(torch.isfinite(y).all().item())}))
+                      "seconds_per_forward": dt, "hip_graph": bool(args.hip_graph), "fused_relu": bool(args.fused_relu), "balanced": bool(args.balanced), "finite": bool(torch.isfinite(y).all().item())}))
 
 
 if __name__ == "__main__":
