@@ -971,6 +971,7 @@ int gnnagg_schedule_balanced(gnnagg_handle h, int chunk)
     if (chunk < 0) return fail(GNNAGG_ERR_ARG, "chunk must be >= 0");
     c->partitions = 0;
     c->sched[1].reset();
+    c->plan_part.reset();
     if (chunk == 0 && c->use_plan && auto_partitions(c) > 0) return build_partitioned(c, auto_partitions(c));
     if (c->use_plan) return build_balanced_plan(c, chunk > 0 ? chunk : pick_chunk(c));
     return build_grouping(c, c->sched[1], chunk > 0 ? chunk : pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
