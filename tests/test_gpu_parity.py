@@ -920,6 +920,38 @@ def test_autograd_wrappers_match_a_dense_torch_reference():
     assert torch.allclose(aa.grad, ab.grad, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("chunk", [4, 64])
+def test_plan_boundaries_exact_multiples(chunk):
+    """Rows whose degree sits exactly on the plan's boundaries: chunk - 1, chunk, chunk + 1 (short row vs one segment),
+    16 * chunk - 1, 16 * chunk, 16 * chunk + 1 (one segment vs hub with two), 32 * chunk, 17 * 16 * chunk + 3 (more than
+    16 segments), next to empty rows -- GCN sum / max and GAT, bit-exact (GCN) against the oracle's restated order."""
+    degs = [chunk - 1, chunk, chunk + 1, 0, 16 * chunk - 1, 16 * chunk, 16 * chunk + 1, 0, 0, 32 * chunk,
+            17 * 16 * chunk + 3, 1, 2]
+    V, F, H = len(degs), 72, 2
+    ptr = np.zeros(V + 1, np.int32)
+    ptr[1:] = np.cumsum(degs)
+    E = int(ptr[-1])
+    rng = np.random.default_rng(chunk)
+    idx = rng.integers(0, V, E).astype(np.int32)
+    x, val, att = rand((V, F), 1), rand(E, 2), rand((V, H, 2), 3) * 0.3
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.schedule_balanced(chunk)
+    assert agg.balanced_params() == (chunk, 16) and agg.balanced_partitions() == 0
+    ps, tg = orc.neighbor_grouping(ptr, chunk)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), y, 128, "balanced")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=16))
+    agg.run(dev(x), y, 128, "balanced", reduce="max")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))
+    agg.run(dev(x), y, 128, 0)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x))
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.schedule_balanced(chunk)
+    gat.run(dev(x), dev(att), y, 128, "balanced", heads=H)
+    ref, _, _ = orc.gat_grouped(ps, tg, idx, att, x, V, H, seg=16)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=3e-6, atol=1e-6)
+
+
 def test_run_clock_instrumentation():
     """run_clock (reference aggr_gcn.h:462-489, Figure 8): per-workgroup (start, end, CU id) stamps, results unchanged."""
     V, E, F = 3000, 40000, 64
