@@ -73,6 +73,7 @@ struct Schedule {
     std::vector<int> h_ptr_s, h_target, h_idx_s, h_slot, h_empty;
     std::vector<float> h_val_s;
     DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s, big_rows;
+    DevBuf<int> eperm;      // library-built permuted schedules: original edge of every permuted position (val follows its edges)
     int n_big = 0;
     DevBuf<float> val_s;
     int n_empty = 0, n_mrows = 0, n_slots = 0;
@@ -82,7 +83,7 @@ struct Schedule {
     {
         valid = false;
         ptr_s.release(); target.release(); slot.release(); empty_rows.release();
-        mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release(); big_rows.release(); n_big = 0;
+        mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release(); big_rows.release(); eperm.release(); n_big = 0;
         h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear(); h_slot.clear(); h_empty.clear();
         cost_prefix.clear();
         num_target = n_empty = n_mrows = n_slots = 0;
@@ -262,7 +263,7 @@ static int build_grouping(Ctx *c, Schedule &s, int ng, int kind)
     return finalize_schedule(c, s);
 }
 
-static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind)
+static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind, bool keep_eid)
 {
     if (par_num <= 0) return fail(GNNAGG_ERR_ARG, "locality partition count must be >= 1");
     int rc = fetch_host_ptr(c);
@@ -287,12 +288,19 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
     std::vector<int> ptr_s((size_t)c->E + 2), tgt((size_t)c->E + 1);
     s.h_idx_s.resize((size_t)c->E);
     if (!h_val.empty()) s.h_val_s.resize((size_t)c->E);
+    std::vector<int> eid;
+    if (keep_eid) eid.resize((size_t)c->E);
     const int G = locality_schedule(c->h_ptr.data(), h_idx.data(), h_val.empty() ? nullptr : h_val.data(), par_num, ng,
                                     c->V, total_v, ptr_s.data(), s.h_idx_s.data(),
-                                    h_val.empty() ? nullptr : s.h_val_s.data(), tgt.data());
+                                    h_val.empty() ? nullptr : s.h_val_s.data(), tgt.data(), keep_eid ? eid.data() : nullptr);
     ptr_s.resize((size_t)G + 1);
     tgt.resize((size_t)G);
     const int kept = ptr_s[G];
+    if (keep_eid) {
+        eid.resize((size_t)kept);
+        int rc2 = s.eperm.upload(eid);
+        if (rc2) return rc2;
+    }
     s.h_idx_s.resize((size_t)kept);
     if (!s.h_val_s.empty()) s.h_val_s.resize((size_t)kept);
     s.h_ptr_s.swap(ptr_s);
@@ -478,7 +486,7 @@ static int auto_partitions(const Ctx *c)
     return c->avg_deg() >= 192 ? 16 : 0;
 }
 
-static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind);
+static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind, bool keep_eid = false);
 
 static int build_partitioned(Ctx *c, int parts)
 {
@@ -486,7 +494,7 @@ static int build_partitioned(Ctx *c, int parts)
     c->plan_part.reset();
     c->partitions = parts;
     Schedule &s = c->sched[1];
-    int rc = build_locality(c, s, parts, pick_chunk(c), -1, GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING);
+    int rc = build_locality(c, s, parts, pick_chunk(c), -1, GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING, true);
     if (rc) return rc;
     // the same groups as 16-byte descriptors {beg, end, dest, row} for the plan kernels' short-row path (dest < 0: ~scratch
     // slot of a row with several groups), rows without edges behind them; the order and the XCD costs are the schedule's
@@ -505,6 +513,18 @@ static int build_partitioned(Ctx *c, int parts)
     if ((rc = p.t0.upload(t0))) return rc;
     p.valid = true;
     return GNNAGG_OK;
+}
+
+// The source-partitioned order was chosen by the library, not by the caller, so the aliasing contract of updateval
+// (aggr_gcn.h:540-544: the aggregator reads the caller's array at run time) has to survive the permutation: the permuted
+// copy of the edge values is re-gathered from the caller's array before every run (E floats; 0.13 ms at 115 M edges).
+static int refresh_partitioned_val(Ctx *c, Schedule *s)
+{
+    if (c->kind != Ctx::GCN || !c->d_val || !s->eperm.p) return GNNAGG_OK;
+    const size_t kept = s->eperm.n;
+    int rc = s->val_s.reserve(kept);
+    if (rc) return rc;
+    return launch_permute_val(s->eperm.p, c->d_val, s->val_s.p, (int)kept, c->stream);
 }
 
 static int get_sched(Ctx *c, int mode, Schedule **out);
@@ -625,10 +645,11 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         // source-partitioned order on the plan kernel's short-row path: every group of sched[1] is a descriptor, rows with
         // several groups meet in scratch and k_combine folds them in ascending group order
         BalancedPlan &p = c->plan_part;
+        if ((rc = refresh_partitioned_val(c, s))) return rc;
         GcnPlanLaunch P;
         P.t0 = p.t0.p; P.n0 = p.n0; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
         P.hubs = s->worklist();
-        P.row_ptr = c->d_ptr; P.idx = s->idx_s.p; P.val = s->val_s.p; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
+        P.row_ptr = c->d_ptr; P.idx = s->idx_s.p; P.val = c->d_val ? s->val_s.p : nullptr; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
         P.xcd_remap = c->xcd_remap; P.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0; P.num_rows = c->V; P.t0_partials = 1;
         if (s->n_slots > 0) {
             if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
@@ -687,10 +708,11 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             L.xcd_item_cost_prefix = c->row_cost_prefix.data();
         }
     } else {
+        if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && (rc = refresh_partitioned_val(c, s))) return rc;
         L.xcd_item_cost_prefix = s->cost_prefix.data();
         L.wl = s->worklist();
         L.idx = s->permuted ? s->idx_s.p : c->d_idx;
-        L.val = s->permuted ? s->val_s.p : c->d_val;
+        L.val = s->permuted ? ((mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && !c->d_val) ? nullptr : s->val_s.p) : c->d_val;
         if (s->n_slots > 0) {
             if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
             L.partial = c->partial.p;

@@ -15,7 +15,7 @@ int fail(int code, const std::string &msg);
 void reorder_csr(const int *ptr, const int *idx, const int *map, const int *rmap, int V, int *newptr, int *newidx);
 int neighbor_grouping(const int *ptr, int ng, int V, int *ptr_out, int *target_out);
 int locality_schedule(const int *ptr, const int *idx, const float *val, int par_num, int ng, int V, int total_v,
-                      int *ptr_out, int *idx_out, float *val_out, int *target_out);
+                      int *ptr_out, int *idx_out, float *val_out, int *target_out, int *eid_out = nullptr);  // eid_out[pos] = original edge of permuted position pos
 int load_graph(const char *datadir, const char *dset, const char *suffix, int shuffle, int *num_v, int *num_e,
                int **ptr_o, int **idx_o, int **rows_o, int **rrows_o);
 void partition_rows(const int *ptr, int V, int nparts, int *bounds);

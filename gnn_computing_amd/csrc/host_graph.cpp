@@ -73,7 +73,7 @@ int neighbor_grouping(const int *ptr, int ng, int V, int *ptr_out, int *target_o
 // include/graph_schedule.h:17-63 and :156-211).  Pass 1 counts sub-row sizes per (partition,row),
 // pass 2 scatters; both passes are row-parallel.
 int locality_schedule(const int *ptr, const int *idx, const float *val, int par_num, int ng, int V, int total_v,
-                      int *ptr_out, int *idx_out, float *val_out, int *target_out)
+                      int *ptr_out, int *idx_out, float *val_out, int *target_out, int *eid_out)
 {
     const int width = total_v / par_num;
     auto part_of = [&](int col) {
@@ -115,6 +115,7 @@ int locality_schedule(const int *ptr, const int *idx, const float *val, int par_
             const int pos = eoff[k] + cursor[p]++;
             idx_out[pos] = idx[e];
             if (val && val_out) val_out[pos] = val[e];
+            if (eid_out) eid_out[pos] = e;
         }
         for (int p = 0; p < par_num; ++p) {
             const size_t k = (size_t)p * V + i;

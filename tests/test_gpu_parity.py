@@ -828,6 +828,22 @@ def test_balanced_mode_source_partitioned_on_high_degree_graph():
     agg2.run(dev(x2), y, 128, "balanced")
     s2 = orc.locality_schedule(ptr, idx2, 16, agg2.balanced_partition_columns(), ng=agg2.balanced_params()[0], val=val)
     assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(s2[0], s2[2], s2[1], s2[3], x2, V, seg=0))
+    # updateval aliasing (aggr_gcn.h:540-544) survives the library's permutation: values rewritten in place, then re-aliased
+    dval = dev(val)
+    agg3 = gnc.Aggregator_GCN(dev(ptr), dev(idx), dval, F, F)
+    agg3.run(dev(x), y, 128, "balanced")
+    assert np.array_equal(y.cpu().numpy(), ref)
+    val_b = rand(E, 12)
+    dval.copy_(dev(val_b))
+    agg3.run(dev(x), y, 128, "balanced")
+    sb = orc.locality_schedule(ptr, idx, 16, agg3.balanced_partition_columns(), ng=chunk, val=val_b)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(sb[0], sb[2], sb[1], sb[3], x, V, seg=0))
+    val_c = rand(E, 13)
+    dval_c = dev(val_c)
+    agg3.updateval(dval_c)
+    agg3.run(dev(x), y, 128, "balanced")
+    sc = orc.locality_schedule(ptr, idx, 16, agg3.balanced_partition_columns(), ng=chunk, val=val_c)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(sc[0], sc[2], sc[1], sc[3], x, V, seg=0))
     # the partitioned launch sequence (plan kernel + combine) captures into a hipGraph once the scratch is warm
     gr = torch.cuda.CUDAGraph()
     dx_in = dev(x)
