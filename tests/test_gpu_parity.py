@@ -1084,8 +1084,9 @@ def test_check_csr_flags_bad_input():
 def test_fuzz_gcn_modes_reductions_alignment():
     """Randomised sweep: graph shape, feature width (incl. odd widths), mode, reduction, weights on/off and
     deliberately mis-aligned feature buffers (forces the narrower vector paths) -- always against the oracle."""
-    rng = np.random.default_rng(2024)
-    for case in range(60):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "2024")))
+    for case in range(int(os.environ.get("FUZZ_CASES", "60"))):
         V = int(rng.integers(1, 400))
         E = int(rng.integers(0, 30 * V))
         F = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 31, 32, 33, 64, 100, 128, 130, 256]))
@@ -1127,6 +1128,11 @@ def test_fuzz_gcn_modes_reductions_alignment():
         if mode == "scheduled":
             ps, tg = orc.neighbor_grouping(ptr, ng)
             ref = orc.gcn_grouped(ps, tg, idx, val, x, V, seg=agg.mode_params("scheduled")[1])
+        elif agg.balanced_partitions() > 0:   # tiny V, hundreds of edges per row: the source-partitioned order
+            ch, sg = agg.balanced_params()
+            ps, ix, tg, vs = orc.locality_schedule(ptr, idx, agg.balanced_partitions(), agg.balanced_partition_columns(),
+                                                   ng=ch, val=val)
+            ref = orc.gcn_grouped(ps, tg, ix, vs, x, V, seg=0)
         else:
             ch, sg = agg.balanced_params()
             ps, tg = orc.neighbor_grouping(ptr, ch)
@@ -1139,8 +1145,9 @@ def test_fuzz_gcn_modes_reductions_alignment():
 
 def test_fuzz_gat_modes_heads():
     """Randomised GAT sweep: heads, head width (incl. widths that force the scalar path), mode, hub rows."""
-    rng = np.random.default_rng(4242)
-    for case in range(40):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "4242")))
+    for case in range(int(os.environ.get("FUZZ_CASES", "40"))):
         V = int(rng.integers(2, 300))
         E = int(rng.integers(1, 20 * V))
         H = int(rng.choice([1, 2, 3, 4, 8]))
@@ -1173,5 +1180,6 @@ def test_fuzz_gat_modes_heads():
             ch, sg = gat.balanced_params()
             ref = orc.gat_grouped(*orc.neighbor_grouping(ptr, ch), idx, att, x, V, H, seg=sg)[0]
         what = "case %d V=%d E=%d H=%d D=%d %s" % (case, V, E, H, D, mode)
-        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=5e-6, atol=2e-6, err_msg=what)
+        # device expf vs libm differ by ulps per edge; over a 2 k-edge row that reaches ~1e-5 of the row's magnitude
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=2e-5, atol=5e-6, err_msg=what)
         assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0), what
