@@ -20,6 +20,58 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnn_computing_amd as gnc  # noqa: E402
 
 
+DIMS = [512, 128, 64, 32]                                    # our.py:92-95
+
+
+class Model:
+    """The aggregators, weights and layer functions of Figure7/our.py for one graph (ptrs, idxs: int32 device CSR)."""
+
+    def __init__(self, ptrs, idxs, neighbor_num=32, sched=1, fused_relu=False, dense=torch.mm, seed=123):
+        dev = ptrs.device
+        torch.manual_seed(seed)                               # our.py:76
+        self.num_v, self.num_e = ptrs.numel() - 1, idxs.numel()
+        self.vals = torch.ones(self.num_e, device=dev)        # our.py:78
+        self.at = gnc.gcn_init(ptrs, idxs, self.vals)
+        gnc.gcn_schedule(self.at, neighbor_num)               # our.py:84
+        self.at_gat = gnc.gat_init(ptrs, idxs)
+        gnc.gat_schedule(self.at_gat, neighbor_num)
+        self.sched, self.fused_relu, self.dense = sched, fused_relu, dense
+        # 1/sqrt(fan_in) scaling keeps activations O(1): the reference's GAT kernel exponentiates raw scores without a
+        # max-subtraction (aggr_gat.h:138-143), so un-scaled randn weights overflow exp() in the deeper layers
+        self.weights = [torch.randn(DIMS[k], DIMS[k + 1], device=dev) / DIMS[k] ** 0.5 for k in range(3)]
+        self.weights_lr = [torch.randn(DIMS[k + 1], 2, device=dev) / DIMS[k + 1] ** 0.5 for k in range(3)]
+        self.h = torch.randn(self.num_v, DIMS[0], device=dev)
+        self.outs = [torch.empty(self.num_v, DIMS[k + 1], device=dev) for k in range(3)]
+        self.trace = None                                     # set to a list to record every layer's intermediates
+
+    def gcn_layer(self, feat, out, w):                        # our.py:171-176
+        feat2 = self.dense(feat, w)
+        if self.fused_relu:
+            gnc.gcn_run(self.at, feat2, out, 128, self.sched, relu=True)
+            res = out
+        else:
+            gnc.gcn_run(self.at, feat2, out, 128, self.sched)
+            res = F.relu(out)
+        if self.trace is not None:
+            self.trace.append(dict(feat=feat, w=w, feat2=feat2, out=res.clone()))
+        return res
+
+    def gat_layer(self, feat, out, w, w_lr):                  # our.py:179-188
+        feat2 = self.dense(feat, w)
+        att_lr = self.dense(feat2, w_lr)
+        gnc.gat_run(self.at_gat, feat2, att_lr, out, 128, self.sched)
+        if self.trace is not None:
+            self.trace.append(dict(feat=feat, w=w, w_lr=w_lr, feat2=feat2, att=att_lr, out=out.clone()))
+        return out
+
+    def forward(self, model="our_GCN"):
+        x = self.h
+        for k in range(3):
+            x = (self.gcn_layer(x, self.outs[k], self.weights[k]) if model == "our_GCN"
+                 else self.gat_layer(x, self.outs[k], self.weights[k], self.weights_lr[k]))
+        return x
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="our_GCN", choices=["our_GCN", "our_GAT"])
@@ -39,48 +91,16 @@ def main():
                          "enough on the arxiv-sized graph for launch gaps to show)")
     args = ap.parse_args()
     dev = torch.device("cuda", args.gpu)
-    torch.manual_seed(123)                                   # our.py:76
 
     if args.datadir:
         ptrs, idxs = gnc.new_load(args.dataset, args.reorder, args.gpu, datadir=args.datadir)
     else:
-        p, i = gnc.graph.dataset(args.dataset, device=dev)
-        ptrs, idxs = p, i
-    num_v, num_e = ptrs.numel() - 1, idxs.numel()
-    vals = torch.ones(num_e, device=dev)                     # our.py:78
-    at = gnc.gcn_init(ptrs, idxs, vals)
-    gnc.gcn_schedule(at, args.neighbor_num)
-    at_gat = gnc.gat_init(ptrs, idxs)
-    gnc.gat_schedule(at_gat, args.neighbor_num)
-
-    sched = "balanced" if args.balanced else 1
-    dims = [512, 128, 64, 32]                                # our.py:92-95
-    # 1/sqrt(fan_in) scaling keeps activations O(1): the reference's GAT kernel exponentiates raw scores without a
-    # max-subtraction (aggr_gat.h:138-143), so un-scaled randn weights overflow exp() in the deeper layers
-    weights = [torch.randn(dims[k], dims[k + 1], device=dev) / dims[k] ** 0.5 for k in range(3)]
-    weights_lr = [torch.randn(dims[k + 1], 2, device=dev) / dims[k + 1] ** 0.5 for k in range(3)]
-    h = torch.randn(num_v, 512, device=dev)
-    outs = [torch.empty(num_v, dims[k + 1], device=dev) for k in range(3)]
-
-    def gcn_layer(feat, out, w):                             # our.py:171-176
-        feat2 = torch.mm(feat, w)
-        if args.fused_relu:
-            gnc.gcn_run(at, feat2, out, 128, sched, relu=True)
-            return out
-        gnc.gcn_run(at, feat2, out, 128, sched)
-        return F.relu(out)
-
-    def gat_layer(feat, out, w, w_lr):                       # our.py:179-188
-        feat2 = torch.mm(feat, w)
-        att_lr = torch.mm(feat2, w_lr)
-        gnc.gat_run(at_gat, feat2, att_lr, out, 128, sched)
-        return out
+        ptrs, idxs = gnc.graph.dataset(args.dataset, device=dev)
+    m = Model(ptrs, idxs, args.neighbor_num, "balanced" if args.balanced else 1, args.fused_relu)
+    num_v, num_e = m.num_v, m.num_e
 
     def forward():
-        x = h
-        for k in range(3):
-            x = gcn_layer(x, outs[k], weights[k]) if args.model == "our_GCN" else gat_layer(x, outs[k], weights[k], weights_lr[k])
-        return x
+        return m.forward(args.model)
 
     step, result = forward, None
     if args.hip_graph:

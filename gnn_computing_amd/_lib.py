@@ -42,6 +42,7 @@ SIGNATURES = {
     "gnnagg_gat_create": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_int64)]),
     "gnnagg_destroy": (c_int, [c_int64]),
     "gnnagg_set_stream": (c_int, [c_int64, c_void_p]),
+    "gnnagg_set_option": (c_int, [c_int64, c_char_p, c_int]),
     "gnnagg_update_val": (c_int, [c_int64, c_void_p]),
     "gnnagg_schedule": (c_int, [c_int64, c_int, P_INT, c_int]),
     "gnnagg_schedule_balanced": (c_int, [c_int64, c_int]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "gnnagg_get_schedule": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gnnagg_gcn_run": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int]),
     "gnnagg_gcn_run_ex": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "gnnagg_gcn_probe_gather": (c_int, [c_int64, c_void_p, c_int, c_int]),
     "gnnagg_gcn_run_clock": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, P_INT, P_INT]),
     "gnnagg_wall_clock_hz": (ctypes.c_longlong, []),
     "gnnagg_gcn_run_edgewise": (c_int, [c_int64, c_void_p, c_void_p, c_int]),

@@ -79,6 +79,10 @@ class Aggregator:
     def _use_current_stream(self):
         check(lib().gnnagg_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    def set_option(self, name, value):
+        """Per-handle knob (gnnagg_set_option): "partitions", "tile_width", "slice_kb", "fast_rows", ..."""
+        check(lib().gnnagg_set_option(self._h, name.encode(), int(value)))
+
     # -- aggregator.h:67-99
     def schedule(self, s, param, total_num_v=None):
         arr = (ctypes.c_int * 2)(*(list(param) + [0])[:2])
@@ -174,6 +178,12 @@ class Aggregator_GCN(Aggregator):
                                       int(feat), _mode(scheduled), REDUCE[reduce],
                                       (_lib.FLAG_ACCUMULATE if accumulate else 0) | (_lib.FLAG_RELU if relu else 0)))
         return 0.0
+
+    def probe_gather(self, vin, scheduled="balanced"):
+        """Measurement aid (gnnagg_gcn_probe_gather): the loads of run(vin, ., ., scheduled) without the FMA chains and
+        without any store -- the gather ceiling of that launch."""
+        self._use_current_stream()
+        check(lib().gnnagg_gcn_probe_gather(self._h, _dev_ptr(vin, torch.float32, "vin"), int(vin.shape[1]), _mode(scheduled)))
 
     def run_clock(self, vin, vout, BLOCK_SIZE=64, scheduled=0):
         """aggr_gcn.h:462-489.  Returns an int64 tensor [blocks, 3] = (start tick, end tick, CU id) per workgroup of

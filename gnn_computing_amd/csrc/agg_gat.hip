@@ -92,7 +92,7 @@ template <int VEC, int GROUP>
 __device__ __forceinline__ void chain_edges_gat(float (&acc)[VEC], float &den, int beg, int end, int lane, bool col_ok,
                                                 const int *__restrict__ idx, const float *__restrict__ att_src, int H,
                                                 float a_dst, float slope, const float *__restrict__ xcol, int F,
-                                                float *newval, int h, bool head_leader)
+                                                float *newval, int h, bool head_leader, const int *__restrict__ eperm = nullptr)
 {
     int my_s = 0;
     if (beg + lane < end) my_s = idx[beg + lane];
@@ -116,7 +116,7 @@ __device__ __forceinline__ void chain_edges_gat(float (&acc)[VEC], float &den, i
             for (int u = 0; u < kUnroll; ++u)
                 if (j + u < n && col_ok) {
                     const float w = edge_weight(a_dst, as[u], slope);
-                    if (newval && head_leader) newval[(size_t)(cb + j + u) * H + h] = w;
+                    if (newval && head_leader) newval[(size_t)(eperm ? eperm[cb + j + u] : cb + j + u) * H + h] = w;
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
                     den += w;
@@ -136,7 +136,7 @@ template <int VEC, int GROUP>
 __device__ __forceinline__ void chain_edges_gat1(float (&acc)[VEC], float &den, int beg, int end, int lane, bool col_ok,
                                                  const int *__restrict__ idx, const float *__restrict__ att_src, float a_dst,
                                                  float slope, const float *__restrict__ xcol, int F, float *newval,
-                                                 bool first_tile)
+                                                 bool first_tile, const int *__restrict__ eperm = nullptr)
 {
     int s0 = 0, s1 = 0;
     float a0 = 0.0f, a1 = 0.0f;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void chain_edges_gat1(float (&acc)[VEC], float &den, 
                 if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
             if (j == 0) {  // this lane's edge of the window
                 my_w = lane < n ? edge_weight(a_dst, a0, slope) : 0.0f;
-                if (newval && first_tile && lane < n) newval[cb + lane] = my_w;
+                if (newval && first_tile && lane < n) newval[eperm ? eperm[cb + lane] : cb + lane] = my_w;
             }
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) w[u] = __shfl(my_w, j + u, GROUP);
@@ -190,6 +190,11 @@ struct GatPlanArgs {
     int *hub_count;
     int hub_count_stride;
     unsigned partial_bytes, partial_den_bytes;
+    // X / partial addressing and block order as in PlanArgs (agg_gcn.hip); eperm: see GatPlanLaunch
+    int xpitch, ppitch, yvec, tile_major, item_blocks;
+    long x_tile_stride, p_tile_stride;
+    unsigned ptile_bytes;
+    const int *eperm;
     XcdRanges xr;
 };
 
@@ -207,15 +212,17 @@ __device__ __forceinline__ void hub_arrive_and_fold_gat(const GatPlanArgs &a, in
         store_pack_wt<VEC>(a.partial, a.partial_bytes, (size_t)slot * F + col, acc);
         if (head_leader) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(den), drsrc, (int)(((size_t)slot * H + h) * 4), 0, 16);
     }
-    __builtin_amdgcn_s_waitcnt(0);  // the write-through stores have reached the device coherence point
+    // publication protocol: see hub_arrive_and_fold (agg_gcn.hip) -- sc1 payload, every storing wave drains, barrier, one
+    // agent-scope atomic; the last arriver reads with sc1 loads
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __shared__ int s_hub;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int m = a.slot_hub[slot];
         const int nseg = a.mrow_ptr[m + 1] - a.mrow_ptr[m];
         int *cnt = a.hub_count + (size_t)m * a.hub_count_stride + tile;
-        const int old = atomicAdd(cnt, 1);
-        if (old == nseg - 1) atomicExch(cnt, 0);
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nseg - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_hub = old == nseg - 1 ? m : -1;
     }
     __syncthreads();
@@ -273,7 +280,8 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
         tile = (int)blockIdx.x % a.ntiles;
         d = a.t1[(int)blockIdx.x / a.ntiles];
     } else {
-        const int b = logical_block((int)blockIdx.x - nb1, a.nblocks0, a.ntiles, a.remap, a.xr);
+        const int b = a.tile_major ? logical_block_tile_major((int)blockIdx.x - nb1, a.item_blocks, a.ntiles, a.xr)
+                                   : logical_block((int)blockIdx.x - nb1, a.nblocks0, a.ntiles, a.remap, a.xr);
         if (b < 0) return;
         tile = b % a.ntiles;
         const int item = (b / a.ntiles) * GPB + grp;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
     const int h = col_ok ? col / a.dhead : 0;
     const bool head_leader = col_ok && (col % a.dhead) == 0;
     const float *__restrict__ att_src = a.att + (size_t)h * 2 + 1;
-    const float *__restrict__ xcol = a.x + col;
+    const float *__restrict__ xcol = a.x + (size_t)tile * a.x_tile_stride + lane * VEC;
     if (seg_block) {
         __shared__ float stage[kSegChunks * GROUP * VEC];
         __shared__ float stage_den[kSegChunks * GROUP];
@@ -345,15 +353,17 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
     if (d.x < d.y) {
         const float a_dst = a.att[((size_t)row * H + h) * 2];
         if constexpr (SINGLE)
-            chain_edges_gat1<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, F, a.newval,
-                                         tile == 0);
+            chain_edges_gat1<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, a.xpitch, a.newval,
+                                         tile == 0, a.eperm);
         else
-            chain_edges_gat<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval, h,
-                                        head_leader);
+            chain_edges_gat<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, a.xpitch, a.newval,
+                                        h, head_leader, a.eperm);
     }
     if (!col_ok) return;
     if (d.z < 0) {  // one of several groups of its row (source-partitioned order): numerator and denominator to scratch
-        store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
+        const size_t poff = (size_t)(~d.z) * a.ppitch + lane * VEC;
+        if (a.ptile_bytes) store_pack_wt<VEC>(a.partial + (size_t)tile * a.p_tile_stride, a.ptile_bytes, poff, acc);
+        else store_pack<VEC>(a.partial + (size_t)tile * a.p_tile_stride + poff, acc);
         if (head_leader) a.partial_den[(size_t)(~d.z) * H + h] = den;
         return;
     }
@@ -361,7 +371,8 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
     }
-    store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+    if (a.yvec < VEC || F - col < VEC) store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
+    else store_pack<VEC>(a.y + (size_t)row * F + col, acc);
 }
 
 int launch_gat(const GatLaunch &L, void *stream_v)
@@ -390,6 +401,8 @@ int launch_gat(const GatLaunch &L, void *stream_v)
     }
     if (L.wl.n_mrows > 0) {
         CombineArgs c;
+        combine_strides(c, L.feat, g, nullptr);
+        c.nn_weight = nullptr; c.nn_out = nullptr; c.nn_cols = 0;
         c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = nullptr; c.partial = L.partial;
         c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
         c.heads = L.heads; c.dhead = dhead; c.mean = 0; c.accumulate = 0;
@@ -412,7 +425,9 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     if (L.feat <= 0 || L.heads <= 0 || L.feat % L.heads != 0)
         return fail(GNNAGG_ERR_ARG, "GAT needs feat >= 1 and feat % heads == 0");
     const int dhead = L.feat / L.heads;
-    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, dhead);
+    if (L.tile.on && (L.n1 > 0 || dhead % 4 != 0)) return fail(GNNAGG_ERR_STATE, "internal: tiled GAT launch with segments / odd heads");
+    const Geometry g = L.tile.on ? Geometry{4, L.tile.tile_w / 4, (L.feat + L.tile.tile_w - 1) / L.tile.tile_w}
+                                 : pick_geometry(L.feat, L.x, L.y, L.partial, dhead);
     GatPlanArgs a;
     a.t0 = reinterpret_cast<const int4 *>(L.t0); a.t1 = reinterpret_cast<const int4 *>(L.t1);
     a.idx = L.idx; a.att = L.att; a.x = L.x; a.y = L.y; a.partial = L.partial; a.partial_den = L.partial_den;
@@ -420,6 +435,14 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     a.heads = L.heads; a.dhead = dhead; a.remap = L.xcd_remap; a.slope = L.slope; a.rows_semantics = L.rows_semantics;
     a.slot_hub = L.slot_hub; a.mrow_ptr = L.hubs.mrow_ptr; a.mrow_id = L.hubs.mrow_id;
     a.hub_count = L.hub_count; a.hub_count_stride = L.hub_count_stride; a.partial_bytes = a.partial_den_bytes = 0;
+    a.xpitch = L.feat; a.ppitch = L.feat; a.x_tile_stride = a.p_tile_stride = g.group * g.vec; a.yvec = g.vec;
+    a.tile_major = 0; a.item_blocks = 0; a.ptile_bytes = 0; a.eperm = L.eperm;
+    if (L.tile.on) {
+        a.xpitch = L.tile.xpitch; a.x_tile_stride = L.tile.x_tile_stride; a.ppitch = L.tile.ppitch;
+        a.p_tile_stride = L.tile.p_tile_stride; a.yvec = L.tile.yvec; a.tile_major = 1;
+        const size_t tb = (size_t)L.hubs.n_slots * L.tile.ppitch * sizeof(float);
+        a.ptile_bytes = tb < 0x7fffffffULL ? (unsigned)tb : 0u;
+    }
     {
         // one column tile only: with several, a head's denominator is written by the tile that holds its first column
         // and the other tiles' last arrivers could not know that store is done
@@ -432,9 +455,13 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     const int gpb = blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
     a.nblocks0 = item_blocks * g.ntiles;
-    if (a.remap && a.nblocks0 < 64) a.remap = 0;
+    a.item_blocks = item_blocks;
+    if (a.remap && a.nblocks0 < 64 && !a.tile_major) a.remap = 0;
     int grid0 = a.nblocks0;
-    if (a.remap == 2) {
+    if (a.tile_major) {
+        if (!L.t0_cost_prefix) return fail(GNNAGG_ERR_STATE, "internal: tiled launch without item costs");
+        grid0 = 8 * fill_xcd_ranges_tile_major(L.t0_cost_prefix, a.n0, gpb, item_blocks, g.ntiles, a.xr);
+    } else if (a.remap == 2) {
         if (!L.t0_cost_prefix) a.remap = 1;
         else grid0 = 8 * fill_xcd_ranges(L.t0_cost_prefix, a.n0, gpb, item_blocks, a.xr) * g.ntiles;
     }
@@ -449,9 +476,11 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     }
     if (L.hubs.n_mrows > 0 && !hubs_in_kernel) {
         CombineArgs c;
+        combine_strides(c, L.feat, g, &L.tile);
         c.mrow_id = L.hubs.mrow_id; c.mrow_ptr = L.hubs.mrow_ptr; c.row_ptr = nullptr; c.partial = L.partial;
         c.partial_den = L.partial_den; c.y = L.y; c.n_mrows = L.hubs.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
         c.heads = L.heads; c.dhead = dhead; c.mean = 0; c.accumulate = 0;
+        c.nn_weight = nullptr; c.nn_out = nullptr; c.nn_cols = 0;
         c.big_rows = L.hubs.big_rows; c.n_big = L.heads <= 64 ? L.hubs.n_big : 0;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
         const int nb_big = c.n_big * g.ntiles;

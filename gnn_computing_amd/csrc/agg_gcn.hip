@@ -105,8 +105,59 @@ struct PlanArgs {
     int *hub_count;
     int hub_count_stride;
     unsigned partial_bytes;
+    // addressing of X and of the partial scratch (floats): row-major defaults (xpitch = ppitch = feat, tile strides = the lane
+    // group's column span) or the 2-D blocked mode's tile-major images (TileSpec); tile_major: block order of that mode
+    int xpitch, ppitch, yvec, tile_major, item_blocks;
+    long x_tile_stride, p_tile_stride;
+    unsigned ptile_bytes;  // bytes of one tile of the partial scratch when that fits a buffer descriptor, else 0
+    unsigned *probe_sink;  // PROBE instantiation only
     XcdRanges xr;
 };
+
+// Gather probe (bench.py's measured ceiling): everything chain_edges loads -- ids, values, feature segments, same
+// addresses, same batching -- consumed with integer XORs instead of the dependent FMA chain.
+template <int VEC, int GROUP>
+__device__ __forceinline__ unsigned probe_edges(int beg, int end, int lane, bool col_ok, const int *__restrict__ idx,
+                                                const float *__restrict__ val, const float *__restrict__ xcol, int F)
+{
+    unsigned sig = 0;
+    int my_s = 0;
+    float my_w = 1.0f;
+    if (beg + lane < end) {
+        my_s = idx[beg + lane];
+        if (val) my_w = val[beg + lane];
+    }
+    for (int cb = beg; cb < end; cb += GROUP) {
+        int nx_s = 0;
+        float nx_w = 1.0f;
+        if (cb + GROUP + lane < end) {
+            nx_s = idx[cb + GROUP + lane];
+            if (val) nx_w = val[cb + GROUP + lane];
+        }
+        const int n = end - cb < GROUP ? end - cb : GROUP;
+        for (int j = 0; j < n; j += kUnroll) {
+            int s[kUnroll];
+            Pack<VEC> xv[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                s[u] = __shfl(my_s, j + u, GROUP);
+                sig ^= __float_as_uint(__shfl(my_w, j + u, GROUP));
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (j + u < n && col_ok) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) sig ^= __float_as_uint(xv[u].v[k]);
+                }
+        }
+        my_s = nx_s;
+        my_w = nx_w;
+    }
+    return sig;
+}
 
 // Tail of a hub's segment workgroup.  Its segment sum goes to scratch with a write-through (device-scope) store; once
 // the store has completed the workgroup bumps the hub's arrival counter, and the workgroup that finds all other
@@ -120,16 +171,23 @@ __device__ __forceinline__ bool hub_arrive_and_fold(const PlanArgs &a, const int
     constexpr int GPB = block_of<GROUP>() / GROUP;
     const int F = a.feat;
     const int slot = ~d.z;
+    // Publication protocol = the write-through form of the inter-workgroup hand-off (cdna_hip_programming.md Guideline 16,
+    // recipe R1; MI355X_MICROARCH.md "Valid forms"): payload stored with sc1 (write-through, leaves this XCD's L2), EVERY
+    // storing wave drains its stores (asm wait: the one form the compiler can neither drop nor move memory operations
+    // across), workgroup barrier, ONE lane's agent-scope atomic on the arrival counter; the consumer -- the workgroup whose
+    // atomic returns nseg - 1 -- reads the payload with sc1 loads (L1-bypassing; valid without an acquire fence because the
+    // producers stored sc1).  Placement-independent: nothing assumes which XCD a segment workgroup runs on.
     if (grp == 0 && col_ok) store_pack_wt<VEC>(a.partial, a.partial_bytes, (size_t)slot * F + col, acc);
-    __builtin_amdgcn_s_waitcnt(0);  // the write-through store has reached the device coherence point
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __shared__ int s_hub;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int m = a.slot_hub[slot];
         const int nseg = a.mrow_ptr[m + 1] - a.mrow_ptr[m];
         int *cnt = a.hub_count + (size_t)m * a.hub_count_stride + tile;
-        const int old = atomicAdd(cnt, 1);
-        if (old == nseg - 1) atomicExch(cnt, 0);  // everybody is in: ready for the next launch (same path as the adds)
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // everybody is in: zero for the next launch (ordered behind this launch's adds by the kernel boundary)
+        if (old == nseg - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_hub = old == nseg - 1 ? m : -1;
     }
     __syncthreads();
@@ -179,7 +237,7 @@ __device__ __forceinline__ bool hub_arrive_and_fold(const PlanArgs &a, const int
     return true;
 }
 
-template <int VEC, int GROUP, bool IS_MAX>
+template <int VEC, int GROUP, bool IS_MAX, bool PROBE = false>
 __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a)
 {
     constexpr int GPB = block_of<GROUP>() / GROUP;
@@ -187,6 +245,20 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
     const int lane = threadIdx.x & (GROUP - 1);
     const int grp = (int)threadIdx.x / GROUP;
     const int nb1 = a.n1 * a.ntiles;
+    if (PROBE && (int)blockIdx.x < nb1) {  // segments: the chunks' loads, nothing else
+        const int tile = (int)blockIdx.x % a.ntiles;
+        const int4 d = a.t1[(int)blockIdx.x / a.ntiles];
+        const int col = (tile * GROUP + lane) * VEC;
+        const int nch = (d.y - d.x + a.chunk - 1) / a.chunk;
+        unsigned sig = 0;
+        for (int c = grp; c < nch; c += GPB) {
+            const int cb = d.x + c * a.chunk;
+            const int ce = cb + a.chunk < d.y ? cb + a.chunk : d.y;
+            sig ^= probe_edges<VEC, GROUP>(cb, ce, lane, col < F, a.idx, a.val, a.x + col, F);
+        }
+        if (sig == 0x9e3779b9u) a.probe_sink[0] = sig;  // practically never: keeps the loads alive
+        return;
+    }
     if ((int)blockIdx.x < nb1) {
         __shared__ float stage[kSegChunks * GROUP * VEC];
         const int tile = (int)blockIdx.x % a.ntiles;
@@ -242,7 +314,8 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
         }
         return;
     }
-    const int b = logical_block((int)blockIdx.x - nb1, a.nblocks0, a.ntiles, a.remap, a.xr);
+    const int b = a.tile_major ? logical_block_tile_major((int)blockIdx.x - nb1, a.item_blocks, a.ntiles, a.xr)
+                               : logical_block((int)blockIdx.x - nb1, a.nblocks0, a.ntiles, a.remap, a.xr);
     if (b < 0) return;
     const int tile = b % a.ntiles;
     const int item = (b / a.ntiles) * GPB + grp;
@@ -250,14 +323,24 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
     const int col = (tile * GROUP + lane) * VEC;
     const bool col_ok = col < F;
     const int4 d = a.t0[item];
+    const float *__restrict__ xcol = a.x + (size_t)tile * a.x_tile_stride + lane * VEC;
+    if constexpr (PROBE) {
+        const unsigned sig = probe_edges<VEC, GROUP>(d.x, d.y, lane, col_ok, a.idx, a.val, xcol, a.xpitch);
+        if (sig == 0x9e3779b9u) a.probe_sink[0] = sig;
+        return;
+    }
     if (a.accumulate && !a.relu && d.x == d.y) return;  // y += 0
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
-    chain_edges<VEC, GROUP, IS_MAX>(acc, d.x, d.y, lane, col_ok, a.idx, a.val, a.x + col, F);
+    chain_edges<VEC, GROUP, IS_MAX>(acc, d.x, d.y, lane, col_ok, a.idx, a.val, xcol, a.xpitch);
     if (!col_ok) return;
     if (d.z < 0) {  // one of several groups of its row (source-partitioned order): raw partial to its scratch slot
-        store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
+        // write-through when a descriptor can cover the tile: the partials are read back by k_combine only, and must not
+        // push the X slice out of this XCD's L2
+        const size_t poff = (size_t)(~d.z) * a.ppitch + lane * VEC;
+        if (a.ptile_bytes) store_pack_wt<VEC>(a.partial + (size_t)tile * a.p_tile_stride, a.ptile_bytes, poff, acc);
+        else store_pack<VEC>(a.partial + (size_t)tile * a.p_tile_stride + poff, acc);
         return;
     }
     if (a.accumulate) {
@@ -273,7 +356,8 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a
         for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
     }
     if (a.relu) relu_pack<VEC>(acc);
-    if (a.wt) store_pack_wt<VEC>(a.y, a.ybytes, (size_t)d.z * F + col, acc);
+    if (a.yvec < VEC || F - col < VEC) store_pack_any<VEC>(a.y + (size_t)d.z * F + col, acc, F - col, a.yvec);
+    else if (a.wt) store_pack_wt<VEC>(a.y, a.ybytes, (size_t)d.z * F + col, acc);
     else store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
 }
 
@@ -691,10 +775,12 @@ __global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs
 }
 
 static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max, hipStream_t stream,
-                              const float *nn_weight = nullptr, float *nn_out = nullptr, int nn_cols = 0)
+                              const float *nn_weight = nullptr, float *nn_out = nullptr, int nn_cols = 0,
+                              const TileSpec *tile = nullptr)
 {
     if (L.wl.n_mrows > 0) {
         CombineArgs c;
+        combine_strides(c, L.feat, g, tile);
         c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = L.row_ptr; c.partial = L.partial;
         c.partial_den = nullptr; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
         c.heads = 1; c.dhead = L.feat; c.mean = L.reduce == GNNAGG_REDUCE_MEAN;
@@ -735,11 +821,22 @@ int launch_dense_rows(const int *rows, int n_rows, const float *Y, const float *
     return GNNAGG_OK;
 }
 
+// geometry of a 2-D blocked launch: 16-byte lanes over tiles of tile_w floats
+static Geometry tile_geometry(const TileSpec &t, int feat) { return {4, t.tile_w / 4, (feat + t.tile_w - 1) / t.tile_w}; }
+
+static unsigned *probe_sink()
+{
+    static unsigned *p = nullptr;
+    if (!p && hipMalloc((void **)&p, sizeof(unsigned)) != hipSuccess) p = nullptr;
+    return p;
+}
+
 int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
     if (L.feat <= 0) return fail(GNNAGG_ERR_ARG, "feature length must be >= 1");
-    const Geometry g = pick_geometry(L.feat, L.x, L.y, L.partial, L.feat);
+    if (L.tile.on && (L.n1 > 0 || L.accumulate)) return fail(GNNAGG_ERR_STATE, "internal: tiled launch with segments");
+    const Geometry g = L.tile.on ? tile_geometry(L.tile, L.feat) : pick_geometry(L.feat, L.x, L.y, L.partial, L.feat);
     const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
     PlanArgs a;
     a.t0 = reinterpret_cast<const int4 *>(L.t0); a.t1 = reinterpret_cast<const int4 *>(L.t1);
@@ -748,6 +845,14 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap; a.accumulate = L.accumulate; a.relu = L.relu;
     a.slot_hub = L.slot_hub; a.mrow_ptr = L.hubs.mrow_ptr; a.mrow_id = L.hubs.mrow_id; a.row_ptr = L.row_ptr;
     a.hub_count = L.hub_count; a.hub_count_stride = L.hub_count_stride; a.partial_bytes = 0;
+    a.xpitch = L.feat; a.ppitch = L.feat; a.x_tile_stride = a.p_tile_stride = g.group * g.vec; a.yvec = g.vec;
+    a.tile_major = 0; a.item_blocks = 0; a.ptile_bytes = 0; a.probe_sink = nullptr;
+    if (L.tile.on) {
+        a.xpitch = L.tile.xpitch; a.x_tile_stride = L.tile.x_tile_stride; a.ppitch = L.tile.ppitch;
+        a.p_tile_stride = L.tile.p_tile_stride; a.yvec = L.tile.yvec; a.tile_major = 1;
+        const size_t tb = (size_t)L.hubs.n_slots * L.tile.ppitch * sizeof(float);
+        a.ptile_bytes = tb < 0x7fffffffULL ? (unsigned)tb : 0u;
+    }
     {
         const size_t pbytes = (size_t)L.hubs.n_slots * L.feat * sizeof(float);
         if (L.hubs.n_mrows == 0 || pbytes >= 0x7fffffffULL || g.ntiles > L.hub_count_stride) a.hub_count = nullptr;
@@ -763,18 +868,34 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     // dense combine fused as the epilogue when one lane group spans the row and the [32][K] tile fits LDS
     const bool want_nn = L.nn_weight != nullptr;
     // (8-lane groups, F <= 32: the GEMM is ~11 us on the arxiv-shaped input and the epilogue costs as much -- not fused)
-    const bool fuse_nn = want_nn && g.ntiles == 1 && g.group >= 16 && !L.accumulate && !L.relu && !L.t0_partials && nn_fusion_enabled();
+    const bool fuse_nn = want_nn && !L.tile.on && !L.probe && g.ntiles == 1 && g.group >= 16 && !L.accumulate && !L.relu && !L.t0_partials && nn_fusion_enabled();
     const int blk = block_for(g.group);
     const int gpb = fuse_nn ? std::max(kNnRows, blk / g.group) : blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
     a.nblocks0 = item_blocks * g.ntiles;
-    if (a.remap && a.nblocks0 < 64) a.remap = 0;
+    a.item_blocks = item_blocks;
+    if (a.remap && a.nblocks0 < 64 && !a.tile_major) a.remap = 0;
     int grid0 = a.nblocks0;
-    if (a.remap == 2) {
+    if (a.tile_major) {
+        if (!L.t0_cost_prefix) return fail(GNNAGG_ERR_STATE, "internal: tiled launch without item costs");
+        grid0 = 8 * fill_xcd_ranges_tile_major(L.t0_cost_prefix, a.n0, gpb, item_blocks, g.ntiles, a.xr);
+    } else if (a.remap == 2) {
         if (!L.t0_cost_prefix) a.remap = 1;
         else grid0 = 8 * fill_xcd_ranges(L.t0_cost_prefix, a.n0, gpb, item_blocks, a.xr) * g.ntiles;
     }
     const int grid = a.n1 * g.ntiles + grid0;
+    if (L.probe) {
+        if (is_max) return fail(GNNAGG_ERR_ARG, "probe: sum/mean only");
+        a.probe_sink = probe_sink();
+        if (!a.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
+        if (grid > 0) {
+#define CALL_PROBE hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, false, true>), dim3(grid), dim3(blk), 0, stream, a);
+            DISPATCH_GEOM(g, CALL_PROBE)
+#undef CALL_PROBE
+            HIP_TRY(hipGetLastError());
+        }
+        return GNNAGG_OK;
+    }
     if (fuse_nn) {
         NnArgs w;
         w.weight = L.nn_weight; w.out = L.nn_out; w.n_out = L.nn_cols;
@@ -802,7 +923,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     GcnLaunch C;
     C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
     C.accumulate = L.accumulate; C.relu = L.relu;
-    const int rc = hubs_in_kernel ? GNNAGG_OK : launch_combine_gcn(C, g, is_max, stream);
+    const int rc = hubs_in_kernel ? GNNAGG_OK : launch_combine_gcn(C, g, is_max, stream, nullptr, nullptr, 0, &L.tile);
     if (rc || !want_nn) return rc;
     return launch_dense_nn(L.y, L.nn_weight, L.nn_out, L.num_rows, L.nn_cols, L.feat, stream);
 }
@@ -862,7 +983,7 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
     if (L.timer || L.timer_blocks_out) a.remap = 0;  // natural block order for the load-balance study
     if (L.timer_blocks_out) {
         *L.timer_blocks_out = a.n_total > 0 ? ceil_div(a.n_total, block_for(g.group) / g.group) * g.ntiles : 0;
-        if (!L.timer) return GNNAGG_OK;  // size query only
+        if (!L.timer) return GNNAGG_OK;  // size query only (pass the run's x / y so the lane geometry is the run's)
     }
     if (a.n_total > 0) {
         const int blk = block_for(g.group);
@@ -878,6 +999,9 @@ int launch_gcn(const GcnLaunch &L, void *stream_v)
                 grid = 8 * fill_xcd_ranges(L.xcd_item_cost_prefix, a.n_total, items_per_block, item_blocks, a.xr) * g.ntiles;
             }
         }
+        // the size query saw no feature pointers: an unaligned x / y picks narrower lanes and a larger grid than it reported
+        if (a.timer && grid > L.timer_capacity)
+            return fail(GNNAGG_ERR_ARG, "run_clock: timer buffer too small for this launch (query num_blocks with the same x / y pointers)");
         if (a.timer) hipLaunchKernelGGL(k_timer_init, dim3(ceil_div(grid, 256)), dim3(256), 0, stream, a.timer, grid);
 #define LAUNCH_GCN(MAXF, LISTF) hipLaunchKernelGGL((k_gcn_items<VEC, GROUP, MAXF, LISTF>), dim3(grid), dim3(blk), 0, stream, a)
 #define CALL_GCN                                                                                  \

@@ -70,10 +70,15 @@ struct Schedule {
     int num_target = 0;
     bool permuted = false;  // locality schedules permute idx/val; neighbor grouping aliases them
     int total_cols = 0;     // locality schedules: the column count the ranges were cut from
+    int par_num = 0;        // locality schedules: the number of column ranges
     std::vector<int> h_ptr_s, h_target, h_idx_s, h_slot, h_empty;
     std::vector<float> h_val_s;
     DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s, big_rows;
     DevBuf<int> eperm;      // library-built permuted schedules: original edge of every permuted position (val follows its edges)
+    // segmented-stream form of a library-built partitioned order (agg_span.hip)
+    DevBuf<int> idx_f, span_g, crows, rg_ptr, rg_idx;
+    int n_spans = 0, n_crows = 0;
+    std::vector<long> span_cost_prefix;
     int n_big = 0;
     DevBuf<float> val_s;
     int n_empty = 0, n_mrows = 0, n_slots = 0;
@@ -84,6 +89,8 @@ struct Schedule {
         valid = false;
         ptr_s.release(); target.release(); slot.release(); empty_rows.release();
         mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release(); big_rows.release(); eperm.release(); n_big = 0;
+        idx_f.release(); span_g.release(); crows.release(); rg_ptr.release(); rg_idx.release(); n_spans = n_crows = 0;
+        span_cost_prefix.clear();
         h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear(); h_slot.clear(); h_empty.clear();
         cost_prefix.clear();
         num_target = n_empty = n_mrows = n_slots = 0;
@@ -150,6 +157,16 @@ struct Ctx {
     Schedule sched_edges;    // chunked work items of the edge kernels (run_att, u_add_v, add_to_center, div_each)
     DevBuf<float> den;       // [V,heads] row sums of run_att
     DevBuf<float> partial, partial_den;
+    DevBuf<float> xt;      // 2-D blocked mode: column-tiled image of X, rebuilt by every run (k_tile_x)
+    int tiled = 1;         // source-partitioned balanced mode runs tile-major on the tiled image (GNNAGG_TILED=0: r01 order)
+    // gnnagg_set_option knobs (defaults from the environment, see create())
+    int opt_partitions = -1;   // -1: library decides (avg degree >= opt_part_min_deg), 0: never partition, N: N source ranges
+    int opt_part_min_deg = 192;
+    int opt_tile_w = 64;       // floats per column tile of the 2-D blocked mode
+    int opt_slice_kb = 4096;   // target size of the X slice one XCD's L2 holds (measured optimum 4-6 MB on the reddit-shaped F=602 case)
+    int opt_retile = 1;        // 0: gather from the caller's X when its rows are 128-byte aligned
+    int use_spans = 1;         // GCN, tiled: the segmented-stream kernel (agg_span.hip); 0: one descriptor per lane group
+    int fast_rows = 0;         // 1: `scheduled = 0` runs the balanced order (within 1e-5) instead of CSR-order chains
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
     int xcd_remap = 2;         // 0 identity, 1 equal-count XCD ranges, 2 work-balanced XCD ranges
     DevBuf<int> hub_count;  // arrival counters of the in-kernel hub fold (zero between launches)
@@ -263,9 +280,12 @@ static int build_grouping(Ctx *c, Schedule &s, int ng, int kind)
     return finalize_schedule(c, s);
 }
 
+static int parts_for_cols(const Ctx *c, long cols);
+
+// par_num == -1 (library-chosen order only): the range count follows from the column count (parts_for_cols)
 static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind, bool keep_eid)
 {
-    if (par_num <= 0) return fail(GNNAGG_ERR_ARG, "locality partition count must be >= 1");
+    if (par_num <= 0 && !(par_num == -1 && total_v < 0)) return fail(GNNAGG_ERR_ARG, "locality partition count must be >= 1");
     int rc = fetch_host_ptr(c);
     if (rc) return rc;
     std::vector<int> h_idx((size_t)c->E);
@@ -279,8 +299,10 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
                         // square: a rank's local graph indexes [X_local ; X_halo])
         int mx = 0;
         for (int v : h_idx) mx = std::max(mx, v);
+        if (par_num == -1) par_num = parts_for_cols(c, (long)mx + 1);
         total_v = std::max(mx + 1, par_num);
     }
+    s.par_num = par_num;
     s.reset();
     s.kind = kind;
     s.permuted = true;
@@ -469,33 +491,50 @@ static int pick_chunk(const Ctx *c)
     return chunk;
 }
 
-// Source-partitioned balanced mode.  On high-degree graphs the aggregation is bound by L2-miss traffic (every config
-// runs at ~7.4 TB/s of it) and the 4 MB L2 of an XCD holds a sliver of X; the reference's locality schedule
-// (graph_schedule.h:156-243: per column range, per row, the sub-row of edges whose source falls in the range, cut every
-// NG edges) maps onto the 8 XCDs directly: with 16 ranges every XCD walks two source slices one after the other, so its
-// L2 only ever serves 1/16 of X -- reddit-shaped SAGE F=602: L2 hit rate 0.08 -> 0.41, fabric traffic 273 -> 198 GB,
-// 36.9 -> 30.2 ms; GAT 8x32: 13.4 -> 11.5 ms.  The price is one partial row per (row, range) and their ordered combine
-// (V * 16 scratch rows), which only pays when a row has many edges per range: products-shaped (avg degree 50) 7.8 -> 21 ms,
-// so it is chosen for avg degree >= 192 only (V = 400 k sweep, F = 128: degree 150 3.68 vs 3.50 ms chunked, 200 4.26 vs 4.61, 300 5.41 vs 6.70).  16 ranges (30.2 ms on the item kernels) against 8: 33.1, 24: 29.6, 32: 31.8,
-// 48: 38.6 ms -- shorter sub-rows and more partial rows eat the extra hits.  GNNAGG_PARTITIONS = 0 / N overrides.
+// Source-partitioned ("2-D blocked") balanced mode.  On high-degree graphs the aggregation is bound by L2-miss traffic: rows
+// gathered from the Infinity Cache or HBM arrive at 6.3-7.9 TB/s, rows gathered from an XCD's own 4 MB L2 at 24 TB/s
+// (256-byte segments; scripts/micro/gather_ceiling.hip, profiles/r02/gather_ceiling.txt).  The reference's locality
+// schedule (graph_schedule.h:156-243: per column range, per row, the sub-row of edges whose source falls in the range, cut
+// every NG edges) supplies the order; two things make the slice an L2 walks actually fit:
+//  * the features are processed one COLUMN TILE of tile_w floats at a time (tile-major block order), so the slice is
+//    (rows of a range) x (tile_w * 4 bytes), not (rows of a range) x (row pitch);
+//  * the number of ranges is chosen from the slice size, P = ceil(columns * tile_w * 4 / slice bytes), bounded so that a
+//    (row, range) sub-row keeps about a dozen edges on average (every (row, range, tile) costs one partial row).
+// Per-column summation order does not depend on the tiling: partials of a row are folded in ascending group order exactly
+// as the reference's arrays list them (restated by orc_locality_schedule + orc_gcn_grouped_seg with seg = 0).
+// Round 1 (16 ranges x full rows, 35 MB slices): reddit-shaped SAGE F=602 36.9 -> 28.8 ms, L2 hit 0.08 -> 0.41.
+// GNNAGG_PARTITIONS = 0 / N overrides; GNNAGG_TILE_W, GNNAGG_SLICE_KB tune the slice.
+static int parts_for_cols(const Ctx *c, long cols)
+{
+    const long slice = std::max(1L, (long)c->opt_slice_kb) * 1024;
+    long p = (cols * c->opt_tile_w * 4 + slice - 1) / slice;
+    p = std::min<long>(p, std::max(1, c->avg_deg() / 12));
+    return (int)std::max(1L, std::min(p, 1024L));
+}
+
+// 0: chunked plan; -1: source-partitioned with the range count taken from the column count; N > 0: N ranges
 static int auto_partitions(const Ctx *c)
 {
-    static const int env = getenv("GNNAGG_PARTITIONS") ? atoi(getenv("GNNAGG_PARTITIONS")) : -1;
     if (c->no_auto_partition) return 0;
-    if (env >= 0) return env;
-    return c->avg_deg() >= 192 ? 16 : 0;
+    if (c->opt_partitions >= 0) return c->opt_partitions;
+    return c->avg_deg() >= c->opt_part_min_deg ? -1 : 0;
 }
 
 static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind, bool keep_eid = false);
+
+static int build_spans(Ctx *c, Schedule &s);
 
 static int build_partitioned(Ctx *c, int parts)
 {
     c->plan.reset();
     c->plan_part.reset();
-    c->partitions = parts;
     Schedule &s = c->sched[1];
-    int rc = build_locality(c, s, parts, pick_chunk(c), -1, GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING, true);
+    // the segmented-stream kernel wants several groups per span: groups of at most 128 edges there
+    const bool spans = c->tiled && c->kind == Ctx::GCN && c->use_spans;
+    int rc = build_locality(c, s, parts, spans ? std::min(pick_chunk(c), 128) : pick_chunk(c), -1,
+                            GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING, true);
     if (rc) return rc;
+    c->partitions = s.par_num;
     // the same groups as 16-byte descriptors {beg, end, dest, row} for the plan kernels' short-row path (dest < 0: ~scratch
     // slot of a row with several groups), rows without edges behind them; the order and the XCD costs are the schedule's
     BalancedPlan &p = c->plan_part;
@@ -508,10 +547,65 @@ static int build_partitioned(Ctx *c, int parts)
     }
     for (int r : s.h_empty) t0.insert(t0.end(), {0, 0, r, r});
     p.n0 = (int)(t0.size() / 4);
-    p.chunk = pick_chunk(c);
+    p.chunk = spans ? std::min(pick_chunk(c), 128) : pick_chunk(c);
     p.t0_cost_prefix = s.cost_prefix;
     if ((rc = p.t0.upload(t0))) return rc;
     p.valid = true;
+    if (spans && (rc = build_spans(c, s))) return rc;
+    return GNNAGG_OK;
+}
+
+// Segmented-stream form of the partitioned order: spans of whole groups with about kSpanEdges edges each, the ids with
+// the group-end flags, and the row -> groups lists of the ordered combine.
+static constexpr int kSpanEdges = 512;
+
+static int build_spans(Ctx *c, Schedule &s)
+{
+    const int G = s.num_target, V = c->V;
+    if (G == 0) return GNNAGG_OK;
+    int mx = 0;
+    for (int v : s.h_idx_s) mx = std::max(mx, v);
+    if ((unsigned)mx > 0x3fffffffu) return GNNAGG_OK;  // the two flag bits are not free: stay on the descriptor kernels
+    static const int span_env = getenv("GNNAGG_SPAN_EDGES") ? atoi(getenv("GNNAGG_SPAN_EDGES")) : kSpanEdges;
+    const int span_edges = std::max(1, span_env);
+    std::vector<int> groups_of((size_t)V, 0);
+    for (int g = 0; g < G; ++g) groups_of[s.h_target[g]]++;
+    // flagged ids
+    std::vector<int> idx_f(s.h_idx_s);
+    for (int g = 0; g < G; ++g) {
+        const int last = s.h_ptr_s[g + 1] - 1;
+        unsigned w = (unsigned)idx_f[last] | 0x80000000u;
+        if (groups_of[s.h_target[g]] == 1) w |= 0x40000000u;
+        idx_f[last] = (int)w;
+    }
+    // spans
+    std::vector<int> span_g(1, 0);
+    s.span_cost_prefix.assign(1, 0);
+    for (int g = 0; g < G;) {
+        const int e0 = s.h_ptr_s[g];
+        int h = g + 1;
+        while (h < G && s.h_ptr_s[h] - e0 < span_edges) ++h;
+        span_g.push_back(h);
+        s.span_cost_prefix.push_back((long)s.h_ptr_s[h]);
+        g = h;
+    }
+    s.n_spans = (int)span_g.size() - 1;
+    // row -> groups (stable counting sort keeps the ascending group order), rows with several groups heaviest first
+    std::vector<int> rg_ptr((size_t)V + 1, 0), rg_idx((size_t)G);
+    for (int r = 0; r < V; ++r) rg_ptr[r + 1] = rg_ptr[r] + groups_of[r];
+    {
+        std::vector<int> cur(rg_ptr.begin(), rg_ptr.end() - 1);
+        for (int g = 0; g < G; ++g) rg_idx[cur[s.h_target[g]]++] = g;
+    }
+    std::vector<int> crows;
+    for (int r = 0; r < V; ++r)
+        if (groups_of[r] > 1) crows.push_back(r);
+    std::stable_sort(crows.begin(), crows.end(), [&](int a, int b) { return groups_of[a] > groups_of[b]; });
+    s.n_crows = (int)crows.size();
+    int rc;
+    if ((rc = s.idx_f.upload(idx_f)) || (rc = s.span_g.upload(span_g)) || (rc = s.crows.upload(crows)) ||
+        (rc = s.rg_ptr.upload(rg_ptr)) || (rc = s.rg_idx.upload(rg_idx)))
+        return rc;
     return GNNAGG_OK;
 }
 
@@ -528,35 +622,80 @@ static int refresh_partitioned_val(Ctx *c, Schedule *s)
 }
 
 static int get_sched(Ctx *c, int mode, Schedule **out);
-// The partitioned order keeps one partial row per (row, range) in scratch: num_v * 16 * feat floats (9 GB for the reddit-shaped
-// F = 602 case).  When that exceeds a quarter of the device memory the handle is moved to the chunked plan for good
-// (gnnagg_balanced_partitions reports 0 from then on).
-static int demote_if_scratch_too_large(Ctx *c, int mode, int feat, int heads, Schedule **s)
+
+// Moves a handle from the source-partitioned order to the chunked plan for good (its scratch does not fit):
+// gnnagg_balanced_partitions reports 0 from then on and sched[1] describes the chunked order again.
+static int demote_partitioned(Ctx *c)
 {
-    if (mode != GNNAGG_MODE_BALANCED || c->partitions == 0) return GNNAGG_OK;
-    const size_t need = (size_t)c->sched[1].n_slots * ((size_t)feat + (size_t)heads) * sizeof(float);
-    if (need <= (c->partial.n + c->partial_den.n) * sizeof(float)) return GNNAGG_OK;  // already allocated (no API call: capture-safe)
-    static size_t total_b = 0;
-    if (total_b == 0) {
-        size_t free_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { total_b = 0; return GNNAGG_OK; }
-    }
-    if (need <= total_b / 4) return GNNAGG_OK;
     c->partitions = 0;
     c->no_auto_partition = 1;
     c->sched[1].reset();
     c->plan_part.reset();
-    return get_sched(c, mode, s);
+    c->xt.release();
+    return build_balanced_plan(c, pick_chunk(c));
+}
+
+// Scratch of a run on the partitioned order: one partial row per (row with several groups, group) -- n_slots * padded
+// feature length floats (11 GB for the reddit-shaped F = 602 case) -- plus the tiled image of X.  Grown on demand; when the
+// growth would take more than half of the memory that is free right now, or the allocation fails, *demoted is set and the
+// caller re-dispatches on the chunked plan.
+static int reserve_partitioned_scratch(Ctx *c, size_t partial_floats, size_t den_floats, size_t xt_floats, bool *demoted)
+{
+    *demoted = false;
+    const size_t grow = (partial_floats > c->partial.n ? partial_floats : 0) + (den_floats > c->partial_den.n ? den_floats : 0) +
+                        (xt_floats > c->xt.n ? xt_floats : 0);
+    if (grow == 0) return GNNAGG_OK;  // no API call: capture-safe once warm
+    size_t free_b = 0, total_b = 0;
+    bool ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && grow * sizeof(float) <= free_b / 2 + (c->partial.n + c->partial_den.n + c->xt.n) * sizeof(float);
+    if (ok) {
+        ok = c->partial.reserve(partial_floats) == GNNAGG_OK && c->partial_den.reserve(den_floats) == GNNAGG_OK &&
+             c->xt.reserve(xt_floats) == GNNAGG_OK;
+        if (!ok) (void)hipGetLastError();  // out of memory is handled here, not reported
+    }
+    if (ok) return GNNAGG_OK;
+    *demoted = true;
+    return demote_partitioned(c);
+}
+
+// TileSpec of one run on the partitioned order: lane geometry, strides, and which image of X the kernel reads.
+struct TiledRun {
+    TileSpec spec;
+    int ntiles = 1;
+    bool retile = false;
+    size_t partial_floats = 0, xt_floats = 0;
+};
+
+static TiledRun plan_tiles(const Ctx *c, const Schedule &s, const float *x, const float *y, int feat, int lane_unit)
+{
+    TiledRun t;
+    t.partial_floats = (size_t)s.n_slots * feat;
+    if (!c->tiled || lane_unit % 4 != 0) return t;  // (GAT: a lane's 4 columns must belong to one head)
+    const int tw = c->opt_tile_w;
+    t.ntiles = (feat + tw - 1) / tw;
+    const bool direct_ok = ((size_t)feat * 4) % 128 == 0 && ((uintptr_t)x % 128) == 0;
+    t.retile = c->opt_retile != 0 || !direct_ok;
+    t.spec.on = 1;
+    t.spec.tile_w = tw;
+    t.spec.xpitch = t.retile ? tw : feat;
+    t.spec.x_tile_stride = t.retile ? (long)s.total_cols * tw : tw;
+    t.spec.ppitch = tw;
+    t.spec.p_tile_stride = (long)s.n_slots * tw;
+    t.spec.yvec = (feat % 4 == 0 && (uintptr_t)y % 16 == 0) ? 4 : (feat % 2 == 0 && (uintptr_t)y % 8 == 0) ? 2 : 1;
+    t.partial_floats = (size_t)s.n_slots * tw * t.ntiles;
+    t.xt_floats = t.retile ? (size_t)s.total_cols * tw * t.ntiles : 0;
+    return t;
 }
 
 static int get_sched(Ctx *c, int mode, Schedule **out)
 {
+    // "fast_rows": the reference drivers' run(vin, vout, B, 0) gets the balanced order (gnnagg_set_option)
+    if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
     if (mode == GNNAGG_MODE_SCHEDULED) {
         if (!c->sched[0].valid)
             return fail(GNNAGG_ERR_STATE, "scheduled run without schedule() (reference: assert aggr_gcn.h:392)");
         *out = &c->sched[0];
     } else if (mode == GNNAGG_MODE_BALANCED) {
-        if (c->partitions > 0 || (c->use_plan && !c->plan.valid && auto_partitions(c) > 0)) {
+        if (c->partitions > 0 || (c->use_plan && !c->plan.valid && auto_partitions(c) != 0)) {
             if (!c->sched[1].valid) {
                 int rc = build_partitioned(c, c->partitions > 0 ? c->partitions : auto_partitions(c));
                 if (rc) return rc;
@@ -597,7 +736,8 @@ struct NnRequest {  // run_with_nn: transformed[V, cols] = y . weight[feat, cols
     int cols;
 };
 
-static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0, const NnRequest *nn = nullptr)
+static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0, const NnRequest *nn = nullptr,
+                   int probe = 0)
 {
     if ((flags & GNNAGG_FLAG_ACCUMULATE) && (mode != GNNAGG_MODE_BALANCED || reduce != GNNAGG_REDUCE_SUM || !c->use_plan))
         return fail(GNNAGG_ERR_ARG, "GNNAGG_FLAG_ACCUMULATE needs GNNAGG_MODE_BALANCED and GNNAGG_REDUCE_SUM");
@@ -607,10 +747,10 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     if (!x || !y) return fail(GNNAGG_ERR_ARG, "null feature pointer");
     if (reduce < GNNAGG_REDUCE_SUM || reduce > GNNAGG_REDUCE_MAX) return fail(GNNAGG_ERR_ARG, "bad reduce");
     if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
+    if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
-    if ((rc = demote_if_scratch_too_large(c, mode, feat, 0, &s))) return rc;
     const bool acc_on_partitioned = (flags & GNNAGG_FLAG_ACCUMULATE) && c->partitions > 0;
     if (acc_on_partitioned && !c->plan.valid && (rc = build_balanced_plan_keep(c))) return rc;  // y += A.x needs the plan kernel
     if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && (c->partitions == 0 || acc_on_partitioned)) ||
@@ -639,25 +779,55 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             if ((rc = reserve_hub_counters(c, p.n_mrows, feat, &P.hub_count_stride))) return rc;
             P.slot_hub = p.slot_hub.p; P.hub_count = c->hub_count.p;
         }
+        P.probe = probe;
         return launch_gcn_plan(P, c->stream);
     }
     if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors) {
         // source-partitioned order on the plan kernel's short-row path: every group of sched[1] is a descriptor, rows with
-        // several groups meet in scratch and k_combine folds them in ascending group order
+        // several groups meet in scratch and k_combine folds them in ascending group order; tile-major on the tiled image
+        // of X (2-D blocked) unless GNNAGG_TILED=0
         BalancedPlan &p = c->plan_part;
+        TiledRun tr = plan_tiles(c, *s, x, y, feat, 4);
+        const bool span_run = tr.spec.on && s->n_spans > 0;
+        if (span_run) {  // every group owns a partial row (slot = group index): sequential flushes
+            tr.spec.p_tile_stride = (long)s->num_target * tr.spec.tile_w;
+            tr.partial_floats = (size_t)s->num_target * tr.spec.tile_w * tr.ntiles;
+        }
+        bool demoted = false;
+        if ((rc = reserve_partitioned_scratch(c, tr.partial_floats, 0, tr.xt_floats, &demoted))) return rc;
+        if (demoted) return gcn_run(c, x, y, feat, mode, reduce, flags, nn, probe);
         if ((rc = refresh_partitioned_val(c, s))) return rc;
+        if (span_run) {
+            SpanLaunch S;
+            S.span_g = s->span_g.p; S.n_spans = s->n_spans; S.span_cost_prefix = s->span_cost_prefix.data();
+            S.ptr_s = s->ptr_s.p; S.idx_f = s->idx_f.p; S.val_s = c->d_val ? s->val_s.p : nullptr; S.target = s->target.p;
+            S.n_groups = s->num_target; S.crows = s->crows.p; S.n_crows = s->n_crows; S.rg_ptr = s->rg_ptr.p; S.rg_idx = s->rg_idx.p;
+            S.empty_rows = s->empty_rows.p; S.n_empty = s->n_empty; S.row_ptr = c->d_ptr;
+            S.x = x; S.y = y; S.partial = c->partial.p; S.feat = feat; S.reduce = reduce; S.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
+            S.tile = tr.spec; S.probe = probe;
+            if (tr.retile) {
+                if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
+                S.x = c->xt.p;
+            }
+            if ((rc = launch_gcn_span(S, c->stream)) || !nn || probe) return rc;
+            return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
+        }
         GcnPlanLaunch P;
         P.t0 = p.t0.p; P.n0 = p.n0; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
         P.hubs = s->worklist();
         P.row_ptr = c->d_ptr; P.idx = s->idx_s.p; P.val = c->d_val ? s->val_s.p : nullptr; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
         P.xcd_remap = c->xcd_remap; P.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0; P.num_rows = c->V; P.t0_partials = 1;
-        if (s->n_slots > 0) {
-            if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
-            P.partial = c->partial.p;
+        P.partial = c->partial.p;
+        P.tile = tr.spec;
+        if (tr.retile) {
+            if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
+            P.x = c->xt.p;
         }
         if (nn) { P.nn_weight = nn->weight; P.nn_out = nn->out; P.nn_cols = nn->cols; }
+        P.probe = probe;
         return launch_gcn_plan(P, c->stream);
     }
+    if (probe) return fail(GNNAGG_ERR_ARG, "probe: balanced mode (or a neighbor-grouping schedule that runs on the plan kernel) only");
     if (mode == GNNAGG_MODE_ROWS && c->use_plan) {
         if (!c->rows_plan.valid && (rc = build_rows_plan(c))) return rc;
         RowsPlan &p = c->rows_plan;
@@ -708,11 +878,13 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             L.xcd_item_cost_prefix = c->row_cost_prefix.data();
         }
     } else {
-        if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && (rc = refresh_partitioned_val(c, s))) return rc;
+        // permuted orders read a permuted copy of the edge values; it follows the caller's array (updateval re-aliases it,
+        // aggr_gcn.h:540-544, and callers rewrite it in place), so it is re-gathered before every run
+        if (s->permuted && (rc = refresh_partitioned_val(c, s))) return rc;
         L.xcd_item_cost_prefix = s->cost_prefix.data();
         L.wl = s->worklist();
         L.idx = s->permuted ? s->idx_s.p : c->d_idx;
-        L.val = s->permuted ? ((mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && !c->d_val) ? nullptr : s->val_s.p) : c->d_val;
+        L.val = s->permuted ? (c->d_val ? s->val_s.p : nullptr) : c->d_val;
         if (s->n_slots > 0) {
             if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
             L.partial = c->partial.p;
@@ -729,10 +901,10 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     if (c->kind != Ctx::GAT) return fail(GNNAGG_ERR_ARG, "handle is not a GAT aggregator");
     if (!x || !y || !att) return fail(GNNAGG_ERR_ARG, "null feature/attention pointer");
     if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
+    if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
-    if ((rc = demote_if_scratch_too_large(c, mode, feat, heads, &s))) return rc;
     if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && c->partitions == 0) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
         BalancedPlan &p = mode == GNNAGG_MODE_BALANCED ? c->plan : c->plan_sched;
         GatPlanLaunch P;
@@ -759,16 +931,23 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     }
     if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors) {
         BalancedPlan &p = c->plan_part;  // source-partitioned order on the descriptor path, as in gcn_run
+        if (heads <= 0 || feat % heads != 0) return fail(GNNAGG_ERR_ARG, "GAT needs feat % heads == 0");
+        const TiledRun tr = plan_tiles(c, *s, x, y, feat, feat / heads);
+        bool demoted = false;
+        if ((rc = reserve_partitioned_scratch(c, tr.partial_floats, (size_t)s->n_slots * heads, tr.xt_floats, &demoted))) return rc;
+        if (demoted) return gat_run(c, x, att, y, feat, heads, slope, mode, newval);
         GatPlanLaunch P;
         P.t0 = p.t0.p; P.n0 = p.n0; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
         P.hubs = s->worklist();
         P.idx = s->idx_s.p; P.att = att; P.x = x; P.y = y; P.newval = newval; P.feat = feat; P.heads = heads; P.slope = slope;
+        P.eperm = s->eperm.p;  // newval[E,H] is defined in CSR edge order (gnnagg.h): scattered through the permutation
         P.xcd_remap = c->xcd_remap;
-        if (s->n_slots > 0) {
-            if ((rc = c->partial.reserve((size_t)s->n_slots * feat))) return rc;
-            if ((rc = c->partial_den.reserve((size_t)s->n_slots * heads))) return rc;
-            P.partial = c->partial.p;
-            P.partial_den = c->partial_den.p;
+        P.partial = c->partial.p;
+        P.partial_den = c->partial_den.p;
+        P.tile = tr.spec;
+        if (tr.retile) {
+            if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
+            P.x = c->xt.p;
         }
         return launch_gat_plan(P, c->stream);
     }
@@ -870,11 +1049,11 @@ static int do_schedule(Ctx *c, int kind, const int *param, int total_v)
         }
         case GNNAGG_SCHED_LOCALITY:
             c->plan_sched.reset();
-            return build_locality(c, c->sched[0], param[0], 0, total_v, kind);
+            return build_locality(c, c->sched[0], param[0], 0, total_v, kind, true);
         case GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING:
             if (param[1] <= 0) return fail(GNNAGG_ERR_ARG, "neighbor group size must be >= 1");
             c->plan_sched.reset();
-            return build_locality(c, c->sched[0], param[0], param[1], total_v, kind);
+            return build_locality(c, c->sched[0], param[0], param[1], total_v, kind, true);
         case GNNAGG_SCHED_NOP:
             c->plan_sched.reset();
             c->sched[0].reset();
@@ -926,6 +1105,14 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_SORT_WINDOW")) c->sort_window = atoi(e);
     if (const char *e = getenv("GNNAGG_INKERNEL_COMBINE")) c->inkernel_combine = atoi(e);
     if (const char *e = getenv("GNNAGG_PART_DESC")) c->part_descriptors = atoi(e);
+    if (const char *e = getenv("GNNAGG_TILED")) c->tiled = atoi(e);
+    if (const char *e = getenv("GNNAGG_PARTITIONS")) c->opt_partitions = atoi(e);
+    if (const char *e = getenv("GNNAGG_PART_MIN_DEG")) c->opt_part_min_deg = atoi(e);
+    if (const char *e = getenv("GNNAGG_TILE_W")) { const int w = atoi(e); if (w == 32 || w == 64 || w == 128 || w == 256) c->opt_tile_w = w; }
+    if (const char *e = getenv("GNNAGG_SLICE_KB")) c->opt_slice_kb = std::max(1, atoi(e));
+    if (const char *e = getenv("GNNAGG_RETILE")) c->opt_retile = atoi(e);
+    if (const char *e = getenv("GNNAGG_FAST_ROWS")) c->fast_rows = atoi(e);
+    if (const char *e = getenv("GNNAGG_SPANS")) c->use_spans = atoi(e);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);
@@ -973,11 +1160,36 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream)
     return GNNAGG_OK;
 }
 
+int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
+{
+    GET_CTX(h);
+    if (!name) return fail(GNNAGG_ERR_ARG, "null option name");
+    const std::string n(name);
+    bool replan = false;  // the library-chosen balanced order depends on it: rebuilt on the next use
+    if (n == "partitions") { if (value < -1) return fail(GNNAGG_ERR_ARG, "partitions: -1 (auto), 0 (never) or a count"); c->opt_partitions = value; c->no_auto_partition = 0; replan = true; }
+    else if (n == "partition_min_degree") { c->opt_part_min_deg = value; replan = true; }
+    else if (n == "tile_width") { if (value != 32 && value != 64 && value != 128 && value != 256) return fail(GNNAGG_ERR_ARG, "tile_width: 32, 64, 128 or 256"); c->opt_tile_w = value; replan = true; }
+    else if (n == "slice_kb") { if (value < 1) return fail(GNNAGG_ERR_ARG, "slice_kb must be >= 1"); c->opt_slice_kb = value; replan = true; }
+    else if (n == "retile") c->opt_retile = value;
+    else if (n == "tiled") c->tiled = value;
+    else if (n == "fast_rows") c->fast_rows = value;
+    else if (n == "spans") { c->use_spans = value; replan = true; }
+    else if (n == "inkernel_combine") c->inkernel_combine = value;
+    else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
+    if (replan) {
+        c->partitions = 0;
+        c->sched[1].reset();
+        c->plan_part.reset();
+        c->plan.reset();
+    }
+    return GNNAGG_OK;
+}
+
 int gnnagg_update_val(gnnagg_handle h, const float *d_val)
 {
     GET_CTX(h);
     if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
-    c->d_val = d_val;  // aliases, like aggr_gcn.h:540-544
+    c->d_val = d_val;  // aliases, like aggr_gcn.h:540-544; permuted schedules re-gather their copy before every run
     return GNNAGG_OK;
 }
 
@@ -994,7 +1206,7 @@ int gnnagg_schedule_balanced(gnnagg_handle h, int chunk)
     c->partitions = 0;
     c->sched[1].reset();
     c->plan_part.reset();
-    if (chunk == 0 && c->use_plan && auto_partitions(c) > 0) return build_partitioned(c, auto_partitions(c));
+    if (chunk == 0 && c->use_plan && auto_partitions(c) != 0) return build_partitioned(c, auto_partitions(c));
     if (c->use_plan) return build_balanced_plan(c, chunk > 0 ? chunk : pick_chunk(c));
     return build_grouping(c, c->sched[1], chunk > 0 ? chunk : pick_chunk(c), GNNAGG_SCHED_NEIGHBOR_GROUPING);
 }
@@ -1002,6 +1214,7 @@ int gnnagg_schedule_balanced(gnnagg_handle h, int chunk)
 int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks)
 {
     GET_CTX(h);
+    if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
     if (mode == GNNAGG_MODE_ROWS) {
         if (chunk) *chunk = 0x7fffffff;
         if (seg_chunks) *seg_chunks = 0;
@@ -1042,6 +1255,7 @@ int gnnagg_num_target(gnnagg_handle h, int mode, int *out)
 {
     GET_CTX(h);
     if (!out) return fail(GNNAGG_ERR_ARG, "null output");
+    if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
     if (mode == GNNAGG_MODE_ROWS) {
         *out = c->V;
         return GNNAGG_OK;
@@ -1110,6 +1324,7 @@ int gnnagg_gcn_run_clock(gnnagg_handle h, const float *d_x, float *d_y, int feat
     GcnLaunch L;
     L.row_ptr = c->d_ptr; L.x = d_x; L.y = d_y; L.feat = feat; L.reduce = GNNAGG_REDUCE_SUM; L.xcd_remap = 0;
     L.timer = d_timer; L.timer_blocks_out = num_blocks;
+    L.timer_capacity = d_timer ? *num_blocks : 0;  // in: workgroups d_timer has room for (the size query's answer)
     if (!s) {
         L.wl.ptr = c->d_ptr; L.wl.n_items = c->V; L.idx = c->d_idx; L.val = c->d_val;
     } else {
@@ -1137,6 +1352,14 @@ int gnnagg_gcn_run_ex(gnnagg_handle h, const float *d_x, float *d_y, int feat, i
 {
     GET_CTX(h);
     return gcn_run(c, d_x, d_y, feat, mode, reduce, flags);
+}
+
+int gnnagg_gcn_probe_gather(gnnagg_handle h, const float *d_x, int feat, int mode)
+{
+    GET_CTX(h);
+    // y is never written by the probe instantiation; a non-null pointer keeps the argument checks and the lane geometry
+    // (alignment class of y) those of a real run
+    return gcn_run(c, d_x, const_cast<float *>(d_x), feat, mode, GNNAGG_REDUCE_SUM, 0, nullptr, 1);
 }
 
 int gnnagg_check_csr(gnnagg_handle h, int num_cols, int *bad_rows, int *bad_indices)

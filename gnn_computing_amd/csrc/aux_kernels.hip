@@ -552,4 +552,45 @@ int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out
     return GNNAGG_OK;
 }
 
+// ------------------------------------------------------------------ column-tiled image of X (2-D blocked mode)
+// xt[t][r][0 .. tile_w) = x[r][t * tile_w ..], zero beyond feat.  Rows of x whose pitch is not a multiple of a 128-byte
+// line (F = 602: 2408 B) make every 256-byte tile segment of a gather straddle three lines -- 1.5x the L2 footprint and
+// traffic; the tiled image is line-aligned whatever the caller's pitch is, and costs one streaming pass over X.
+// One thread per (row, 4-column quad): reads are coalesced along the row, writes are 16-byte stores.
+__global__ __launch_bounds__(256) void k_tile_x(const float *__restrict__ x, float *__restrict__ xt, int rows, int feat, int tile_w,
+                                                int quads_per_row)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)rows * quads_per_row;
+    if (i >= total) return;
+    const int r = (int)(i / quads_per_row), q = (int)(i - (long)r * quads_per_row);
+    const int c = q * 4;
+    const float *src = x + (size_t)r * feat + c;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 3 < feat) {
+        if ((((uintptr_t)src) & 15) == 0) v = *reinterpret_cast<const float4 *>(src);
+        else if ((((uintptr_t)src) & 7) == 0) {
+            const float2 a = *reinterpret_cast<const float2 *>(src), b = *reinterpret_cast<const float2 *>(src + 2);
+            v = make_float4(a.x, a.y, b.x, b.y);
+        } else v = make_float4(src[0], src[1], src[2], src[3]);
+    } else {
+        if (c < feat) v.x = src[0];
+        if (c + 1 < feat) v.y = src[1];
+        if (c + 2 < feat) v.z = src[2];
+    }
+    const int t = c / tile_w, ct = c - t * tile_w;
+    *reinterpret_cast<float4 *>(xt + ((size_t)t * rows + r) * tile_w + ct) = v;
+}
+
+int launch_tile_x(const float *x, float *xt, int rows, int feat, int tile_w, void *stream_v)
+{
+    if (rows <= 0) return GNNAGG_OK;
+    const int ntiles = (feat + tile_w - 1) / tile_w;
+    const int quads = ntiles * tile_w / 4;
+    const long total = (long)rows * quads;
+    hipLaunchKernelGGL(k_tile_x, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, x, xt, rows, feat, tile_w, quads);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
 }  // namespace gnnagg

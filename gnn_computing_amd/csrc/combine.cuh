@@ -18,7 +18,17 @@ struct CombineArgs {
     const float *partial_den;  // GAT only
     float *y;
     int n_mrows, feat, ntiles, heads, dhead, mean;
+    // addressing of the partial scratch (floats): row-major (ppitch = feat, p_tile_stride = the lane group's column span) or
+    // the 2-D blocked mode's tile-major image; yvec = alignment class of the Y rows (below VEC: element-wise stores)
+    int ppitch, yvec;
+    long p_tile_stride;
 };
+
+static inline void combine_strides(CombineArgs &c, int feat, const Geometry &g, const TileSpec *tile)
+{
+    c.ppitch = feat; c.p_tile_stride = g.group * g.vec; c.yvec = g.vec;
+    if (tile && tile->on) { c.ppitch = tile->ppitch; c.p_tile_stride = tile->p_tile_stride; c.yvec = tile->yvec; }
+}
 
 // Adds the partial rows of every split row in ascending slot order (deterministic counterpart of
 // the reference's atomicAdd, aggr_gcn.h:112) and applies mean / softmax normalisation.
@@ -49,6 +59,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
         const int col0 = tile * GROUP * VEC;
         const int col = col0 + lane * VEC;
         constexpr int W = GROUP * VEC;                // columns of this tile
+        const float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride;
         const int c = (int)threadIdx.x;               // summing thread <-> column c of the tile
         const bool sum_ok = c < W && col0 + c < F;
         const int hc = IS_GAT ? (col0 + c) / a.dhead : 0;
@@ -59,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
                 Pack<VEC> p[kCombineBatch];
 #pragma unroll
                 for (int u = 0; u < kCombineBatch; ++u)
-                    if (p0 + u < nst && col < F) p[u] = load_pack<VEC>(a.partial + (size_t)(sb + p0 + u) * F + col);
+                    if (p0 + u < nst && col < F) p[u] = load_pack<VEC>(ptile + (size_t)(sb + p0 + u) * a.ppitch + lane * VEC);
 #pragma unroll
                 for (int u = 0; u < kCombineBatch; ++u)
                     if (p0 + u < nst && col < F) store_pack<VEC>(&stage[(p0 + u) * W + lane * VEC], p[u].v);
@@ -118,6 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
     }
     const bool active = here && col < a.feat;
     if (!nn && !active) return;
+    const float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride;
     const int row = here ? a.mrow_id[m] : 0;
     if (active) {
         float acc[VEC];
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
 #pragma unroll
             for (int u = 0; u < CU; ++u)
                 if (sb + u < s1) {
-                    p[u] = load_pack<VEC>(a.partial + (size_t)(sb + u) * F + col);
+                    p[u] = load_pack<VEC>(ptile + (size_t)(sb + u) * a.ppitch + lane * VEC);
                     if (IS_GAT) pd[u] = a.partial_den[(size_t)(sb + u) * a.heads + h];
                 }
 #pragma unroll
@@ -167,7 +179,8 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
             for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
         }
         if (!IS_GAT && a.relu) relu_pack<VEC>(acc);
-        store_pack<VEC>(a.y + (size_t)row * F + col, acc);
+        if (a.yvec < VEC || F - col < VEC) store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
+        else store_pack<VEC>(a.y + (size_t)row * F + col, acc);
         if (nn) store_pack<VEC>(&stage[grp * GROUP * VEC + col], acc);  // ntiles == 1: col = lane * VEC
     }
     if (!nn) return;

@@ -54,6 +54,17 @@ struct WorkList {
     int n_big = 0;
 };
 
+// Lane geometry of the 2-D blocked mode: 16-byte lanes on a tile of `tile_w` floats (re-tiled or line-aligned X).
+struct TileSpec {
+    int on = 0;            // 1: tile-major launch with the strides below
+    int tile_w = 64;       // floats per column tile (GROUP = tile_w / 4 lanes)
+    int xpitch = 0;        // floats between consecutive X rows as the kernel sees them
+    long x_tile_stride = 0;  // floats between the first columns of consecutive tiles of X
+    int ppitch = 0;        // floats between consecutive partial rows
+    long p_tile_stride = 0;  // floats between consecutive tiles of the partial scratch
+    int yvec = 1;          // alignment class of the caller's Y rows (4 / 2 / 1)
+};
+
 struct GcnLaunch {
     WorkList wl;
     const int *row_ptr = nullptr;  // original CSR ptr (degrees for mean)
@@ -69,6 +80,7 @@ struct GcnLaunch {
     int relu = 0;        // y = max(result, 0)
     void *timer = nullptr;          // run_clock: unsigned long long[3 * blocks]
     int *timer_blocks_out = nullptr;  // run_clock: receives the number of workgroups of the items kernel
+    int timer_capacity = 0;           // run_clock: workgroups the timer buffer has room for (checked against the grid)
     // host array [n_items + n_empty + 1]: prefix sums of the per-item cost, for xcd_remap == 2
     const long *xcd_item_cost_prefix = nullptr;
 };
@@ -101,7 +113,34 @@ struct GcnPlanLaunch {
     const float *nn_weight = nullptr;
     float *nn_out = nullptr;
     int nn_cols = 0;
+    TileSpec tile;  // 2-D blocked mode (short-row descriptors only: n1 == 0)
+    int probe = 0;  // 1: gather probe -- the same descriptors, id/value loads and feature gathers, no chain, no stores
 };
+
+// 2-D blocked order as a segmented stream (agg_span.hip): lane groups walk spans of whole groups of the permuted edge list.
+struct SpanLaunch {
+    const int *span_g = nullptr;              // [n_spans + 1] first group of every span
+    int n_spans = 0;
+    const long *span_cost_prefix = nullptr;   // host, n_spans + 1 entries: edges before every span
+    const int *ptr_s = nullptr;               // [n_groups + 1] edge offsets of the groups (permuted order)
+    const int *idx_f = nullptr;               // ids with the group-end flags in the top two bits
+    const float *val_s = nullptr;             // permuted values, nullptr => implicit 1
+    const int *target = nullptr;              // [n_groups] row of every group
+    int n_groups = 0;
+    const int *crows = nullptr;               // rows with >= 2 groups, most groups first
+    int n_crows = 0;
+    const int *rg_ptr = nullptr, *rg_idx = nullptr;  // row -> its groups (ascending)
+    const int *empty_rows = nullptr;          // rows without any group
+    int n_empty = 0;
+    const int *row_ptr = nullptr;             // CSR ptr (degrees for mean)
+    const float *x = nullptr;                 // the image of X named by `tile`
+    float *y = nullptr;
+    float *partial = nullptr;                 // [ntiles][n_groups][tile_w]
+    int feat = 0, reduce = GNNAGG_REDUCE_SUM, relu = 0;
+    TileSpec tile;
+    int probe = 0;
+};
+int launch_gcn_span(const SpanLaunch &a, void *stream);
 
 // Long rows of the rows mode (`scheduled = 0`, canonical CSR-order chains): k_gcn_rows_long.
 struct GcnRowsLongLaunch {
@@ -168,6 +207,8 @@ struct GatPlanLaunch {
     const int *slot_hub = nullptr;
     int *hub_count = nullptr;
     int hub_count_stride = 0;
+    TileSpec tile;              // 2-D blocked mode, as in GcnPlanLaunch
+    const int *eperm = nullptr; // permuted orders: original edge of every position (newval is written in CSR edge order)
 };
 int launch_gat_plan(const GatPlanLaunch &a, void *stream);
 // Backward of the single-head fused GAT aggregation (k_rowdot + k_gat_bwd_edges); wl = chunked edge work items.
@@ -200,5 +241,7 @@ int launch_dense_rows(const int *rows, int n_rows, const float *Y, const float *
 int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream);
 int launch_check_csr(const int *ptr, const int *idx, int V, int E, int num_cols, int *d_counts, void *stream);
 int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out, void *stream);
+// xt[t][r][0..tile_w) = x[r][t*tile_w ..] (zero beyond feat): the column-tiled image of X the 2-D blocked mode gathers from
+int launch_tile_x(const float *x, float *xt, int rows, int feat, int tile_w, void *stream);
 
 }  // namespace gnnagg

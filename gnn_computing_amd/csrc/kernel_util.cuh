@@ -98,6 +98,24 @@ __device__ __forceinline__ void store_pack(float *p, const float (&a)[VEC])
     }
 }
 
+// Store of a lane's VEC results when the destination's alignment class (`avec` = 4 / 2 / 1: 16-, 8- or 4-byte aligned
+// rows) or the number of valid columns (`nvalid`, the ragged last tile) is below VEC: the 2-D blocked mode computes on
+// 16-byte lanes (re-tiled X) whatever the caller's row pitch is.
+template <int VEC>
+__device__ __forceinline__ void store_pack_any(float *p, const float (&a)[VEC], int nvalid, int avec)
+{
+    if (nvalid >= VEC && avec >= VEC) {
+        store_pack<VEC>(p, a);
+    } else if (VEC == 4 && nvalid >= 4 && avec >= 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(a[0], a[1]);
+        *reinterpret_cast<float2 *>(p + 2) = make_float2(a[2], a[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            if (k < nvalid) p[k] = a[k];
+    }
+}
+
 // Output rows are written once and never re-read by this kernel: a write-through (sc1) store leaves the XCD's L2
 // to the gathered feature rows instead of parking 87 MB of results in it.  Buffer store so the cache bits can be
 // given (aux 16 = sc1); `yoff` is the element offset from `ybase` (callers guarantee the byte offset fits 31 bits).
@@ -167,6 +185,18 @@ __device__ __forceinline__ int logical_block(int b, int nblocks, int ntiles, int
     const int ib = k / ntiles;
     if (ib >= xr.count[xcd]) return -1;
     return (xr.first[xcd] + ib) * ntiles + (k - ib * ntiles);
+}
+
+// 2-D blocked mode (source range x column tile): the linear work index runs TILE-major, L = tile * item_blocks + ib, so a
+// contiguous XCD range walks ONE column tile of ONE source range after the other -- the slice of X its L2 has to hold is
+// (rows of a range) x (tile bytes).  xr.first / xr.count are cut over L.  Returns ib * ntiles + tile like logical_block.
+__device__ __forceinline__ int logical_block_tile_major(int b, int item_blocks, int ntiles, const XcdRanges &xr)
+{
+    const int xcd = b & 7, k = b >> 3;
+    if (k >= xr.count[xcd]) return -1;
+    const int L = xr.first[xcd] + k;
+    const int tile = L / item_blocks;
+    return (L - tile * item_blocks) * ntiles + tile;
 }
 
 struct GcnArgs {
@@ -341,6 +371,39 @@ static int fill_xcd_ranges(const long *cost_prefix, int n_items, int items_per_b
         xr.first[x] = start;
         xr.count[x] = stop - start;
         longest = std::max(longest, stop - start);
+        start = stop;
+    }
+    return longest;
+}
+
+// Tile-major variant: the work list is (tile 0: all item blocks)(tile 1: all item blocks)...; 8 contiguous ranges of about
+// equal cost over that list.  first/count are in linear (tile * item_blocks + ib) units; returns the longest range.
+static int fill_xcd_ranges_tile_major(const long *cost_prefix, int n_items, int items_per_block, int item_blocks, int ntiles,
+                                      XcdRanges &xr)
+{
+    const long per_tile = cost_prefix[n_items];
+    const long total = per_tile * ntiles;
+    long start = 0;
+    int longest = 0;
+    for (int x = 0; x < 8; ++x) {
+        long stop;
+        if (x == 7 || per_tile == 0) {
+            stop = x == 7 ? (long)item_blocks * ntiles : start;
+        } else {
+            const long want = total * (x + 1) / 8;
+            const long tile = std::min<long>(want / per_tile, ntiles - 1);
+            const long rem = want - tile * per_tile;
+            int lo = 0, hi = item_blocks;
+            while (lo < hi) {
+                const int mid = (lo + hi) / 2;
+                const long c = cost_prefix[std::min((long)mid * items_per_block, (long)n_items)];
+                if (c < rem) lo = mid + 1; else hi = mid;
+            }
+            stop = std::max(start, tile * item_blocks + lo);
+        }
+        xr.first[x] = (int)start;
+        xr.count[x] = (int)(stop - start);
+        longest = std::max(longest, (int)(stop - start));
         start = stop;
     }
     return longest;

@@ -95,6 +95,17 @@ int gnnagg_gat_create(const int *d_ptr, const int *d_idx, int num_v, int num_e, 
 int gnnagg_destroy(gnnagg_handle h);
 /* hipStream_t as void*; NULL = default stream.  Work of later calls is enqueued there. */
 int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
+/* Per-handle knobs (defaults come from the environment variables in brackets; DESIGN.md section 4 "A/B knobs"):
+ *   "partitions" [GNNAGG_PARTITIONS]      -1 the library decides, 0 never, N > 0: N source ranges for the balanced mode
+ *   "partition_min_degree" [GNNAGG_PART_MIN_DEG]  average degree from which the library partitions (192)
+ *   "tile_width" [GNNAGG_TILE_W]          floats per column tile of the 2-D blocked balanced mode: 32 / 64 / 128 / 256
+ *   "slice_kb" [GNNAGG_SLICE_KB]          target size of the X slice an XCD's L2 holds (4096)
+ *   "retile" [GNNAGG_RETILE], "tiled" [GNNAGG_TILED], "inkernel_combine" [GNNAGG_INKERNEL_COMBINE]   A/B switches
+ *   "fast_rows" [GNNAGG_FAST_ROWS]        1: GNNAGG_MODE_ROWS (`scheduled = 0`) runs the balanced order -- results within the
+ *                                         1e-5 bound instead of bit-exact CSR-order chains; 0 (default): canonical order
+ * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
+int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
+/* Aggregator_GCN::updateval, aggr_gcn.h:540-544: re-aliases the edge values (borrowed; read at run time). */
 int gnnagg_update_val(gnnagg_handle h, const float *d_val);
 
 /* Aggregator::schedule, aggregator.h:67-99 / Aggregator_GCN::schedule aggr_gcn.h:501-538.
@@ -140,10 +151,20 @@ int gnnagg_gcn_run(gnnagg_handle h, const float *d_x, float *d_y, int feat, int 
  * edges included. */
 #define GNNAGG_FLAG_RELU 2
 int gnnagg_gcn_run_ex(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, int reduce, int flags);
+/* Measurement aid (no reference counterpart): the gather ceiling of gnnagg_gcn_run(h, d_x, ., feat, mode, SUM).  Launches
+ * the same kernel over the same work items with the same descriptor / neighbor-id / edge-value loads and the same
+ * feature-row gathers (same addresses, same batching), but consumes the data with integer XORs instead of the
+ * dependent FMA chains and stores nothing.  Its duration is what the memory system needs to deliver this launch's
+ * gathers; bench.py reports roofline.frac = probe time / kernel time.  GNNAGG_MODE_BALANCED (or a neighbor-grouping
+ * schedule that runs on the plan kernel); asynchronous on the handle's stream. */
+int gnnagg_gcn_probe_gather(gnnagg_handle h, const float *d_x, int feat, int mode);
 /* Aggregator_GCN::run_clock, aggr_gcn.h:462-489 (Figure 8 load-balance study).  Runs the one-item-per-lane-group
  * kernel of mode rows (the reference's aggr_gcn_clock) or scheduled (aggr_gcn_target_clock) with per-workgroup
  * stamps: d_timer[3b] = start, [3b+1] = end (ticks of the constant wall clock, gnnagg_wall_clock_hz), [3b+2] = CU id.
- * Call with d_timer == NULL to get *num_blocks (the timer needs 3 * num_blocks entries). */
+ * Call with d_timer == NULL to get *num_blocks (the timer needs 3 * num_blocks entries; pass the run's d_x / d_y to the
+ * query when they may be less than 16-byte aligned -- the lane geometry, and with it the grid, follows their alignment).
+ * With d_timer != NULL, *num_blocks is in/out: in = the workgroups d_timer has room for (GNNAGG_ERR_ARG when the launch
+ * needs more), out = the workgroups launched. */
 int gnnagg_gcn_run_clock(gnnagg_handle h, const float *d_x, float *d_y, int feat, int mode, unsigned long long *d_timer,
                          int *num_blocks, int *waves_per_cu);
 long long gnnagg_wall_clock_hz(void);

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-kernel summary of scripts/prof_config.sh: average duration (kernel trace), fabric-side traffic (FETCH_SIZE x 2 per the
+gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, KB -> bytes) and L2 hit rate TCC_HIT / (TCC_HIT + TCC_MISS)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+out, cfg = sys.argv[1], sys.argv[2]
+dur = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob(os.path.join(out, "trace_" + cfg, "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        d = dur[r["Kernel_Name"]]
+        d[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+        d[1] += 1
+pmc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(os.path.join(out, "pmc_%s_*" % cfg, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        a = pmc[r["Kernel_Name"]][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+print("# config %s %s -- per-launch averages; traffic = FETCH_SIZE*2*1024 + WRITE_SIZE*1024 (fabric side, Infinity-Cache hits included)" % (cfg, sys.argv[3] if len(sys.argv) > 3 else ""))
+tot = 0.0
+for k, (s, n) in sorted(dur.items(), key=lambda t: -t[1][0]):
+    if "gnnagg" not in k:
+        continue
+    avg = s / n
+    c = {name: v[0] / v[1] for name, v in pmc.get(k, {}).items()}
+    traffic = (c.get("FETCH_SIZE", 0) * 2 + c.get("WRITE_SIZE", 0)) * 1024
+    hit = c.get("TCC_HIT_sum", 0) / max(c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0), 1)
+    print("%-70s n=%3d avg %10.1f us  traffic %8.2f GB (%6.2f TB/s)  fetch %8.2f GB write %8.2f GB  L2 hit %.3f  tcp->tcc rd %.3g  ea rd %.3g" % (
+        k[:70], n, avg, traffic / 1e9, traffic / avg / 1e6 if avg else 0, c.get("FETCH_SIZE", 0) * 2048 / 1e9, c.get("WRITE_SIZE", 0) * 1024 / 1e9, hit,
+        c.get("TCP_TCC_READ_REQ_sum", 0), c.get("TCC_EA0_RDREQ_sum", 0)))
+    tot += avg
+print("sum of per-launch averages: %.1f us" % tot)

@@ -1,0 +1,297 @@
+"""GPU parity of the round-2 additions around the balanced mode: the 2-D blocked (source range x column tile) order on the
+column-tiled image of X, handle options, the gather probe, permuted schedules following updateval, run_clock's capacity
+check.  Same bar as tests/test_gpu_parity.py: bit-exact wherever the kernel keeps the oracle's association."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import gnn_computing_amd as gnc
+from gnn_computing_amd import _lib
+from oracle import oracle as orc
+from test_gpu_parity import DEV, assert_within, dev, gat_scale, rand
+
+pytestmark = pytest.mark.gpu
+
+
+def hub_graph(V, E, seed, alpha=0.9):
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=seed, alpha=alpha)
+    return ptr_t.numpy(), idx_t.numpy()
+
+
+def blocked_reference(agg, ptr, idx, val):
+    """The order the library reports, restated with the oracle's scheduler: groups of localityNeighborGrouping
+    (graph_schedule.h:156-243) for (partitions, chunk, column count), folded flat in ascending group order."""
+    parts, cols = agg.balanced_partitions(), agg.balanced_partition_columns()
+    chunk, seg = agg.balanced_params()
+    assert parts >= 1 and seg == 0
+    return orc.locality_schedule(ptr, idx, parts, cols, ng=chunk, val=val)
+
+
+@pytest.mark.parametrize("F", [602, 100, 64, 30, 33, 256])
+@pytest.mark.parametrize("slice_kb,tile_w", [(16, 64), (64, 32), (4, 128)])
+def test_blocked_gcn_matches_the_restated_order(F, slice_kb, tile_w):
+    """Auto-chosen range count from (columns x tile bytes / slice), every column-tile geometry, Y rows that are 16-, 8- and
+    4-byte aligned (F = 602 is BASELINE's SAGE width: 8-byte rows, ragged last tile), sum / mean / max / fused ReLU."""
+    V, E = 900, 260000
+    ptr, idx = hub_graph(V, E, seed=5)
+    x, val = rand((V, F), 1), rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("slice_kb", slice_kb)
+    agg.set_option("tile_width", tile_w)
+    parts, cols = agg.balanced_partitions(), agg.balanced_partition_columns()
+    assert cols == int(idx.max()) + 1
+    expect = min(-(-cols * tile_w * 4 // (slice_kb * 1024)), max(1, (E // V) // 12))   # slice-sized, >= 12 edges per sub-row
+    assert parts == expect and parts > 1
+    ps, ix, tg, vs = blocked_reference(agg, ptr, idx, val)
+    got = agg.get_schedule("balanced", with_val=True)
+    assert all(np.array_equal(a, b) for a, b in zip(got, (ps, ix, tg, vs)))
+    ref = orc.gcn_grouped(ps, tg, ix, vs, x, V, seg=0)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), y, 128, "balanced")
+    assert np.array_equal(y.cpu().numpy(), ref)
+    agg.run(dev(x), y, 128, "balanced", relu=True)
+    assert np.array_equal(y.cpu().numpy(), np.maximum(ref, 0))
+    deg = np.diff(ptr)
+    agg.run(dev(x), y, 128, "balanced", reduce="mean")
+    assert np.array_equal(y.cpu().numpy()[deg > 0], (ref / np.maximum(deg, 1)[:, None].astype(np.float32))[deg > 0])
+    assert np.all(y.cpu().numpy()[deg == 0] == 0)
+    agg.run(dev(x), y, 128, "balanced", reduce="max")
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x))
+    # within the fp32 bound of the canonical CSR-order chain (north_star's 1e-5)
+    agg.run(dev(x), y, 128, "balanced")
+    assert_within(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x), "blocked vs CSR order")
+    # implicit unit weights and an x / y pair that is only 4-byte aligned
+    agg1 = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, F, F)
+    agg1.set_option("slice_kb", slice_kb)
+    agg1.set_option("tile_width", tile_w)
+    xb = torch.empty(V * F + 1, device=DEV)
+    yb = torch.full((V * F + 1,), 7.0, device=DEV)
+    xb[1:].copy_(dev(x).reshape(-1))
+    agg1.run_with_feat(xb[1:].view(V, F), yb[1:].view(V, F), 128, "balanced", F)
+    s1 = blocked_reference(agg1, ptr, idx, None)
+    assert np.array_equal(yb[1:].view(V, F).cpu().numpy(), orc.gcn_grouped(s1[0], s1[2], s1[1], None, x, V, seg=0))
+    assert float(yb[0]) == 7.0
+
+
+def test_blocked_mode_a_b_switches_give_identical_results():
+    """The segmented-stream kernel, one descriptor per lane group, tile-major on the tiled image or on the caller's X
+    (line-aligned rows), and the round-1 order without column tiles differ in schedule only: the same bits."""
+    V, E, F = 700, 220000, 256
+    ptr, idx = hub_graph(V, E, seed=6)
+    x, val = rand((V, F), 3), rand(E, 4)
+    for opts in ({}, {"retile": 0}, {"tiled": 0}, {"tile_width": 256}, {"spans": 0}, {"spans": 0, "retile": 0}, {"tile_width": 32}):
+        agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+        agg.set_option("partitions", 8)
+        for k, v in opts.items():
+            agg.set_option(k, v)
+        y = torch.full((V, F), 7.0, device=DEV)
+        agg.run(dev(x), y, 128, "balanced")
+        chunk = agg.balanced_params()[0]          # (spans cut groups at 128 edges, the descriptor kernels at pick_chunk)
+        ps, ix, tg, vs = orc.locality_schedule(ptr, idx, 8, int(idx.max()) + 1, ng=chunk, val=val)
+        assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, vs, x, V, seg=0)), str(opts)
+
+
+@pytest.mark.parametrize("F,H", [(256, 8), (64, 1), (96, 4), (30, 3)])
+def test_blocked_gat_and_newval_in_csr_edge_order(F, H):
+    """GAT on the blocked order (head width 3 is not a multiple of the 16-byte lanes: the library keeps the row-major
+    geometry there), and the un-normalised weights come back in CSR edge order although the kernel walks a permuted
+    edge list (round-1 advisor finding)."""
+    V, E = 800, 200000
+    ptr, idx = hub_graph(V, E, seed=7)
+    x, att = rand((V, F), 1), rand((V, H, 2), 2) * 0.4
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.set_option("slice_kb", 16)
+    parts = gat.balanced_partitions()
+    assert parts > 1
+    y = torch.full((V, F), 7.0, device=DEV)
+    newval = torch.full((E, H), 7.0, device=DEV)
+    gat.run(dev(x), dev(att), y, 128, "balanced", heads=H, newval=newval)
+    ps, ix, tg = gat.get_schedule("balanced")
+    ops, oix, otg, _ = orc.locality_schedule(ptr, idx, parts, gat.balanced_partition_columns(), ng=gat.balanced_params()[0])
+    assert np.array_equal(ps, ops) and np.array_equal(ix, oix) and np.array_equal(tg, otg)
+    ref, _, _ = orc.gat_grouped(ops, otg, oix, att, x, V, H, seg=0)
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "blocked gat")
+    assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0)
+    # newval: CSR edge order, the same weights the canonical rows mode writes
+    _, ref_newval, _ = orc.gat_grouped(*orc.neighbor_grouping(ptr, 1 << 30), idx, att, x, V, H, seg=0)
+    np.testing.assert_allclose(newval.cpu().numpy(), ref_newval, rtol=1e-6)
+    nv_rows = torch.full((E, H), 7.0, device=DEV)
+    gat.run(dev(x), dev(att), y, 128, "rows", heads=H, newval=nv_rows)
+    assert torch.equal(newval, nv_rows)
+
+
+def test_single_range_is_the_library_choice_for_small_graphs():
+    """600 columns x 256 B fit any L2: one range, tile-major order only; rows longer than the chunk still split."""
+    V, E, F = 600, 200000, 128
+    ptr, idx = hub_graph(V, E, seed=8)
+    x = rand((V, F), 1)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, F, F)
+    assert agg.balanced_partitions() == 1
+    y = torch.empty((V, F), device=DEV)
+    agg.run(dev(x), y, 128, "balanced")
+    ps, ix, tg, _ = blocked_reference(agg, ptr, idx, None)
+    assert np.array_equal(ix, idx) and int(np.diff(ps).max()) <= agg.balanced_params()[0] < int(np.diff(ptr).max())
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, None, x, V, seg=0))
+    agg.set_option("partitions", 0)      # never partition: the chunked plan with its 16-chunk segment fold
+    assert agg.balanced_partitions() == 0 and agg.balanced_params()[1] == 16
+    agg.run(dev(x), y, 128, "balanced")
+    chunk, seg = agg.balanced_params()
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(*orc.neighbor_grouping(ptr, chunk), idx, None, x, V, seg=seg))
+
+
+def test_fast_rows_option_gives_scheduled0_the_balanced_order():
+    """reference drivers call run(vin, vout, B, 0) (aggr_gcn.h:379-410); with the option that call runs the balanced order:
+    within 1e-5 of the canonical chain instead of bit-equal to it, and restatable."""
+    V, E, F = 5000, 150000, 128
+    ptr, idx = hub_graph(V, E, seed=9, alpha=1.0)
+    x, val = rand((V, F), 1), rand(E, 2)
+    seq = orc.gcn_seq(ptr, idx, val, x)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    y = torch.empty((V, F), device=DEV)
+    agg.run(dev(x), y, 512, 0)
+    assert np.array_equal(y.cpu().numpy(), seq)                      # default: canonical CSR-order chains
+    agg.set_option("fast_rows", 1)
+    agg.run(dev(x), y, 512, 0)
+    chunk, seg = agg.mode_params("rows")
+    assert (chunk, seg) == agg.balanced_params() and seg == 16
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(*orc.neighbor_grouping(ptr, chunk), idx, val, x, V, seg=seg))
+    assert_within(y.cpu().numpy(), seq, orc.gcn_abs_scale(ptr, idx, val, x), "fast rows vs CSR order")
+    agg.set_option("fast_rows", 0)
+    agg.run(dev(x), y, 512, 0)
+    assert np.array_equal(y.cpu().numpy(), seq)
+    # GAT
+    att = rand((V, 2), 3) * 0.4
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.set_option("fast_rows", 1)
+    gat.run(dev(x), dev(att), y, 128, 0)
+    ch, sg = gat.balanced_params()
+    ref, _, _ = orc.gat_grouped(*orc.neighbor_grouping(ptr, ch), idx, att, x, V, 1, seg=sg)
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "fast rows gat")
+
+
+@pytest.mark.parametrize("kind,param", [("locality", [3]), ("locality_neighbor_grouping", [4, 8])])
+def test_user_locality_schedule_follows_updateval(kind, param):
+    """A locality schedule permutes the edge values into its own copy (aggr_gcn.h:509-537); updateval (:540-544) and
+    in-place rewrites of the caller's array must reach it (round-1 advisor finding)."""
+    V, E, F = 200, 6000, 64
+    ptr, idx = gnc.graph.uniform_random_csr(V, E, seed=12)
+    x, v1, v2, v3 = rand((V, F), 1), rand(E, 2), rand(E, 3), rand(E, 4)
+    dv = dev(v1)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dv, F, F)
+    agg.schedule(gnc.Schedule[kind], param)
+    ng = param[1] if len(param) > 1 else 0
+    y = torch.empty((V, F), device=DEV)
+
+    def check(v):
+        agg.run(dev(x), y, 512, 1)
+        ps, ix, tg, vs = orc.locality_schedule(ptr, idx, param[0], V, ng, v)
+        assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, vs, x, V))
+        assert np.array_equal(agg.get_schedule("scheduled", with_val=True)[3], vs)
+
+    check(v1)
+    dv.copy_(dev(v2))          # rewritten in place
+    check(v2)
+    dv3 = dev(v3)
+    agg.updateval(dv3)         # re-aliased
+    check(v3)
+
+
+def test_run_clock_checks_the_timer_capacity():
+    """The size query without feature pointers assumes 16-byte lanes; a 4-byte-aligned x picks scalar lanes, more column
+    tiles and a larger grid -- the timed call must refuse a buffer sized from the wrong answer (round-1 advisor finding)."""
+    V, E, F = 2000, 30000, 128
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=21)
+    val = torch.ones(E, device=DEV)
+    agg = gnc.Aggregator_GCN(ptr_t.to(DEV), idx_t.to(DEV), val, F, F)
+    L = gnc.lib()
+    xb = torch.randn(V * F + 1, device=DEV)
+    x_odd = xb[1:].view(V, F)
+    y = torch.empty((V, F), device=DEV)
+    nb_aligned, nb_odd = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(L.gnnagg_gcn_run_clock(agg._h, None, None, F, _lib.MODE_ROWS, None, ctypes.byref(nb_aligned), None))
+    _lib.check(L.gnnagg_gcn_run_clock(agg._h, x_odd.data_ptr(), y.data_ptr(), F, _lib.MODE_ROWS, None, ctypes.byref(nb_odd), None))
+    assert nb_odd.value > nb_aligned.value
+    timer = torch.zeros((nb_odd.value, 3), dtype=torch.int64, device=DEV)
+    cap = ctypes.c_int(nb_aligned.value)
+    rc = L.gnnagg_gcn_run_clock(agg._h, x_odd.data_ptr(), y.data_ptr(), F, _lib.MODE_ROWS, timer.data_ptr(), ctypes.byref(cap), None)
+    assert rc == _lib.ERR_ARG and b"timer buffer too small" in L.gnnagg_last_error()
+    assert int(timer.abs().sum()) == 0                                # nothing was written
+    cap = ctypes.c_int(nb_odd.value)
+    _lib.check(L.gnnagg_gcn_run_clock(agg._h, x_odd.data_ptr(), y.data_ptr(), F, _lib.MODE_ROWS, timer.data_ptr(), ctypes.byref(cap), None))
+    torch.cuda.synchronize()
+    assert cap.value == nb_odd.value and int((timer[:, 1] != 0).sum()) > 0.9 * nb_odd.value
+
+
+@pytest.mark.parametrize("case", ["chunked", "blocked", "scheduled"])
+def test_gather_probe_runs_the_same_work_and_writes_nothing(case):
+    V, E, F = 4000, 300000, 128
+    ptr, idx = hub_graph(V, E, seed=13)
+    x = rand((V, F), 1)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), torch.ones(E, device=DEV), F, F)
+    mode = "balanced"
+    if case == "blocked":
+        agg.set_option("partitions", 4)
+    elif case == "chunked":
+        agg.set_option("partitions", 0)
+    else:
+        agg.schedule(gnc.Schedule.neighbor_grouping, [256])   # few rows split: the plan kernel runs this schedule
+        mode = "scheduled"
+        assert agg.mode_params("scheduled") == (256, 16)
+    dx = dev(x)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dx, y, 128, mode)
+    ref = y.clone()
+    agg.probe_gather(dx, mode)
+    torch.cuda.synchronize()
+    assert torch.equal(dx.cpu(), torch.from_numpy(x)) and torch.equal(y, ref)
+    with pytest.raises(gnc.GnnAggError):
+        agg.probe_gather(dx, "rows")
+
+
+def test_set_option_rejects_unknown_names_and_values():
+    ptr, idx = gnc.graph.uniform_random_csr(50, 400, seed=1)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, 32, 32)
+    for name, value in (("no_such_option", 1), ("tile_width", 48), ("slice_kb", 0), ("partitions", -2)):
+        with pytest.raises(gnc.GnnAggError):
+            agg.set_option(name, value)
+
+
+def test_hub_fold_stress_two_handles_two_streams():
+    """The in-kernel hub fold under load: segment workgroups of dozens of hubs publish their sums across XCDs (sc1 stores,
+    drained, one agent-scope atomic per workgroup) while a second handle does the same on another stream; hundreds of
+    launches alternating three inputs, every checked result bit-equal to the first launch's and to the oracle."""
+    V, E, F = 20000, 1500000, 128
+    ptr, idx = gnc.graph.powerlaw_csr(V, E, seed=3, alpha=1.1, device=DEV)
+    val = torch.randn(E, device=DEV)
+    aggs = [gnc.Aggregator_GCN(ptr, idx, val, F, F) for _ in range(2)]
+    for a in aggs:
+        a.set_option("partitions", 0)
+        a.schedule_balanced(16)      # 256-edge segments: dozens of hubs with tens to hundreds of segments
+    deg = (ptr[1:] - ptr[:-1])
+    assert int((deg > 4096).sum()) >= 10
+    xs = [torch.randn((V, F), device=DEV) for _ in range(3)]
+    refs = []
+    y = torch.empty((V, F), device=DEV)
+    for x in xs:
+        aggs[0].run(x, y, 128, "balanced")
+        refs.append(y.clone())
+    chunk, seg = aggs[0].balanced_params()
+    ps, tg = orc.neighbor_grouping(ptr.cpu().numpy(), chunk)
+    assert np.array_equal(refs[0].cpu().numpy(),
+                          orc.gcn_grouped(ps, tg, idx.cpu().numpy(), val.cpu().numpy(), xs[0].cpu().numpy(), V, seg=seg))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ys = [torch.empty((V, F), device=DEV) for _ in range(2)]
+    torch.cuda.synchronize()
+    bad, N = 0, 600
+    for it in range(N):
+        k = it % 3
+        for a, st, yy in zip(aggs, streams, ys):
+            with torch.cuda.stream(st):
+                a.run(xs[k], yy, 128, "balanced")
+        if it % 25 == 0 or it > N - 4:
+            torch.cuda.synchronize()
+            bad += sum(0 if torch.equal(yy, refs[k]) else 1 for yy in ys)
+    torch.cuda.synchronize()
+    assert bad == 0

@@ -54,7 +54,7 @@ def test_reddit_sage_mean_f602(reddit):
     xh = x.cpu().numpy()
     chunk, seg = agg.balanced_params()
     parts = agg.balanced_partitions()
-    assert parts == 16 and seg == 0   # avg degree 492: the library picks the source-partitioned order here
+    assert parts >= 8 and seg == 0   # avg degree 492: the library picks the source-partitioned (2-D blocked) order here
     ps, ix, tg, _ = orc.locality_schedule(sp, si, parts, agg.balanced_partition_columns(), ng=chunk)   # the same order restated on the sampled rows
     ref_sum = orc.gcn_grouped(ps, tg, ix, None, xh, len(rows), seg=0)
     deg = np.maximum(np.diff(sp), 1)[:, None].astype(np.float32)
@@ -85,18 +85,33 @@ def test_reddit_gat_8x32(reddit):
     gat.run(x, att, y, 128, "balanced", heads=H)
     rows = pick_rows(ptr, 40, 2)
     sp, si, _ = sample_rows(ptr, idx, rows)
-    # the sampled rows' destination terms must sit at the sampled positions: build a compact att for the oracle
     xh, atth = x.cpu().numpy(), att.cpu().numpy()
-    ref = np.empty((len(rows), F), np.float32)
-    att_k = atth.copy()
-    for k, r in enumerate(rows):
-        # one-row CSR: its row 0 is the destination, so row 0 of att temporarily carries att[r,:,0]
-        # (the source terms att[:,:,1] stay in place, including att[0,:,1])
-        one_ptr = np.array([0, sp[k + 1] - sp[k]], np.int32)
-        att_k[0, :, 0] = atth[r, :, 0]
-        ref[k] = orc.gat_fused(one_ptr, si[sp[k]:sp[k + 1]], att_k, xh, H)[0]
+    # The library's order restated on the sampled rows (as for SAGE above): the groups of the source-partitioned schedule,
+    # folded flat in ascending group order.  The oracle reads the centre term of compact row k at att[k,:,0] and the source
+    # terms at att[id,:,1] -- different slots, so one array can carry both.
+    chunk, seg = gat.balanced_params()
+    parts = gat.balanced_partitions()
+    assert parts >= 8 and seg == 0
+    att_mix = atth.copy()
+    att_mix[:len(rows), :, 0] = atth[rows, :, 0]
+    ps, ix, tg, _ = orc.locality_schedule(sp, si, parts, gat.balanced_partition_columns(), ng=chunk)
+    ref, _, _ = orc.gat_grouped(ps, tg, ix, att_mix, xh, len(rows), H, seg=0)
     got = y[torch.from_numpy(rows).to(DEV)].cpu().numpy()
-    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5)  # fused vs chunked association + expf ulps
+    # north_star's 1e-5, condition-aware: same association as the kernel, device expf vs libm is what is left
+    w = orc.gat_att(sp, si, att_mix, H)                       # normalised weights of the sampled rows' edges [E', H]
+    scale = np.zeros((len(rows), F))
+    for k in range(len(rows)):
+        e0, e1 = int(sp[k]), int(sp[k + 1])
+        if e1 > e0:
+            scale[k] = np.einsum("eh,ehd->hd", w[e0:e1].astype(np.float64),
+                                 np.abs(xh[si[e0:e1]]).reshape(e1 - e0, H, D)).reshape(F)
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    bound = 1e-5 * (scale + np.abs(ref)) + 1e-30
+    assert np.all(err <= bound), "GAT 8x32: worst ratio %.3g" % float((err / bound).max())
+    # and against the canonical CSR-order fused result (different association): same bound
+    ref_csr = orc.gat_fused(sp, si, att_mix, xh, H)
+    err = np.abs(got.astype(np.float64) - ref_csr.astype(np.float64))
+    assert np.all(err <= bound), "GAT 8x32 vs CSR order: worst ratio %.3g" % float((err / bound).max())
     assert not np.isnan(got).any()
     # size-independent: softmax weights sum to 1 -> aggregating a constant gives that constant (1e-5)
     const = torch.full((V, F), 2.0, device=DEV)
@@ -113,7 +128,10 @@ def test_reddit_gat_8x32(reddit):
     gat1.run_att(att1, w, 128)
     gcn = gnc.Aggregator_GCN(ptr, idx, w, D, D)
     gcn.run(x1, y2, 128, "balanced")
-    assert float((y1 - y2).abs().max()) < 1e-4
+    # two routes to the same value, each within 1e-5 * sum_e w_e |x_e| of it
+    scale = torch.empty((V, D), device=DEV)
+    gcn.run(x1.abs(), scale, 128, "balanced")
+    assert bool(torch.all((y1 - y2).abs() <= 2e-5 * scale + 1e-30))
 
 
 def test_products_gcn_f100():
