@@ -18,6 +18,8 @@
 // Summation order: exactly the groups of the reference's localityNeighborGrouping arrays (graph_schedule.h:156-243),
 // each an FMA chain from 0 in list order; a row's group sums are added in ascending group order by k_combine_groups.
 // Restated by orc_locality_schedule + orc_gcn_grouped_seg(seg = 0); bit-exact.
+#include <type_traits>
+
 #include "kernel_util.cuh"
 
 namespace gnnagg {
@@ -36,13 +38,16 @@ struct SpanArgs {
     float *y;
     float *partial;
     int n_spans, span_blocks, feat, ntiles, mean, relu, yvec, xpitch, ppitch;
+    int tile0;  // first column tile of this launch (the XCD ranges run over the launch's tiles)
     long x_tile_stride, p_tile_stride;
     unsigned ptile_bytes;
     unsigned *probe_sink;
     XcdRanges xr;
 };
 
-template <int GROUP, bool IS_MAX, bool HAS_VAL, bool PROBE>
+// FAST_ADDR: every byte offset inside one tile image of X fits 32 bits and ids fit 24 (host-checked): the gather address
+// is (uniform tile base) + a 32-bit lane offset -- one 24-bit multiply per gather instead of 64-bit address arithmetic.
+template <int GROUP, bool IS_MAX, bool HAS_VAL, bool PROBE, bool FAST_ADDR>
 __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
 {
     constexpr int VEC = 4, GPB = 256 / GROUP, U = kUnroll;
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
         const int L = a.xr.first[xcd] + k;
         tile = L / a.span_blocks;
         sb = L - tile * a.span_blocks;
+        tile += a.tile0;
     }
     const int s = sb * GPB + grp;
     if (s >= a.n_spans) return;
@@ -63,19 +69,80 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
     int g = a.span_g[s];
     const int g1 = a.span_g[s + 1];
     const int e0 = a.ptr_s[g], e_end = a.ptr_s[g1];
-    const float *__restrict__ xcol = a.x + (size_t)tile * a.x_tile_stride + lane * VEC;
+    const float *__restrict__ xtile = a.x + (size_t)tile * a.x_tile_stride;  // wave-uniform
+    const float *__restrict__ xcol = xtile + lane * VEC;
+    const unsigned lane_off = (unsigned)(lane * VEC), xpitch = (unsigned)a.xpitch;
     float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride;
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
     unsigned sig = 0;
-    int cnt = 0;  // edges of the current group so far (the degree of a single-group row: mean)
+    int gstart = e0;  // first edge of the current group (its length = the degree of a single-group row: mean)
     unsigned my_s = 0;
     float my_w = 1.0f;
     if (e0 + lane < e_end) {
         my_s = (unsigned)a.idx_f[e0 + lane];
         if (HAS_VAL) my_w = a.val_s[e0 + lane];
     }
+    // one batch of U edges of the window at cb: gathers issued together, then the chain in list order; FULL: no bound checks
+    auto batch = [&](auto full_tag, int cb, int j, int n) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        unsigned sr[U];
+        float w[U];
+        Pack<VEC> xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sr[u] = (unsigned)__shfl((int)my_s, j + u, GROUP);
+            if (HAS_VAL) w[u] = __shfl(my_w, j + u, GROUP);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (FULL || j + u < n) {
+                if constexpr (FAST_ADDR) xv[u] = load_pack<VEC>(xtile + (__umul24(sr[u] & kIdMask, xpitch) + lane_off));
+                else xv[u] = load_pack<VEC>(xcol + (size_t)(sr[u] & kIdMask) * a.xpitch);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (FULL || j + u < n) {
+                if constexpr (PROBE) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) sig ^= __float_as_uint(xv[u].v[k]);
+                    if (HAS_VAL) sig ^= __float_as_uint(w[u]);
+                    continue;
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (IS_MAX) {
+                        const float p = HAS_VAL ? xv[u].v[k] * w[u] : xv[u].v[k];
+                        acc[k] = p > acc[k] ? p : acc[k];
+                    } else {
+                        // implicit unit weights: fma(x, 1, acc) == acc + x exactly
+                        acc[k] = HAS_VAL ? __builtin_fmaf(xv[u].v[k], w[u], acc[k]) : acc[k] + xv[u].v[k];
+                    }
+                }
+                if (sr[u] & kLastFlag) {  // lane-group uniform: the group ends here
+                    const int e_next = cb + j + u + 1;
+                    if (sr[u] & kDirectFlag) {
+                        const int row = a.target[g];
+                        if (a.mean) {
+                            const float dg = (float)(e_next - gstart);
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
+                        }
+                        if (a.relu) relu_pack<VEC>(acc);
+                        if (col < F) store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
+                    } else if (a.ptile_bytes) {
+                        store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
+                    } else {
+                        store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
+                    }
+                    ++g;
+                    gstart = e_next;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+                }
+            }
+    };
     for (int cb = e0; cb < e_end; cb += GROUP) {
         unsigned nx_s = 0;
         float nx_w = 1.0f;
@@ -84,60 +151,12 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
             if (HAS_VAL) nx_w = a.val_s[cb + GROUP + lane];
         }
         const int n = e_end - cb < GROUP ? e_end - cb : GROUP;
+        if (n == GROUP) {
 #pragma unroll 1
-        for (int j = 0; j < n; j += U) {
-            unsigned sr[U];
-            float w[U];
-            Pack<VEC> xv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                sr[u] = (unsigned)__shfl((int)my_s, j + u, GROUP);
-                if (HAS_VAL) w[u] = __shfl(my_w, j + u, GROUP);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (j + u < n) xv[u] = load_pack<VEC>(xcol + (size_t)(sr[u] & kIdMask) * a.xpitch);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (j + u < n) {
-                    if constexpr (PROBE) {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) sig ^= __float_as_uint(xv[u].v[k]);
-                        if (HAS_VAL) sig ^= __float_as_uint(w[u]);
-                        continue;
-                    }
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        if (IS_MAX) {
-                            const float p = HAS_VAL ? xv[u].v[k] * w[u] : xv[u].v[k];
-                            acc[k] = p > acc[k] ? p : acc[k];
-                        } else {
-                            // implicit unit weights: fma(x, 1, acc) == acc + x exactly
-                            acc[k] = HAS_VAL ? __builtin_fmaf(xv[u].v[k], w[u], acc[k]) : acc[k] + xv[u].v[k];
-                        }
-                    }
-                    ++cnt;
-                    if (sr[u] & kLastFlag) {  // lane-group uniform: the group ends here
-                        if (sr[u] & kDirectFlag) {
-                            const int row = a.target[g];
-                            if (a.mean) {
-                                const float dg = (float)cnt;
-#pragma unroll
-                                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
-                            }
-                            if (a.relu) relu_pack<VEC>(acc);
-                            if (col < F) store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
-                        } else if (a.ptile_bytes) {
-                            store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
-                        } else {
-                            store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
-                        }
-                        ++g;
-                        cnt = 0;
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
-                    }
-                }
+            for (int j = 0; j < GROUP; j += U) batch(std::true_type{}, cb, j, n);
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < n; j += U) batch(std::false_type{}, cb, j, n);
         }
         my_s = nx_s;
         my_w = nx_w;
@@ -156,6 +175,7 @@ struct CombineGroupsArgs {
     const float *partial;
     float *y;
     int n_crows, feat, ntiles, mean, relu, yvec, ppitch;
+    int tile0;  // first column tile of this launch (ntiles = tiles of the launch)
     long p_tile_stride;
 };
 
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(256) void k_combine_groups(const CombineGroupsArgs 
 {
     constexpr int VEC = 4, GPB = 256 / GROUP, CU = 16;
     const int lane = threadIdx.x & (GROUP - 1);
-    const int tile = blockIdx.x % a.ntiles;
+    const int tile = a.tile0 + blockIdx.x % a.ntiles;
     const int i = (blockIdx.x / a.ntiles) * GPB + (int)threadIdx.x / GROUP;
     if (i >= a.n_crows) return;
     const int row = a.crows[i];
@@ -220,6 +240,252 @@ __global__ __launch_bounds__(256) void k_zero_rows(const int *__restrict__ rows,
     y[(size_t)rows[r] * F + (i - (long)r * F)] = 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------ GAT on the same stream
+// Fused edge softmax + weighted SpMM (reference aggr_gat / aggr_gat_fine, aggr_gat.h:116-205) over spans.  A column tile
+// covers HT = tile_w / dhead whole heads (or part of one head: HT = 1).  Per edge every lane gathers its head's source term
+// with the feature segment and exponentiates; the centre term changes with the GROUP, so the centre terms of the next 2 x
+// GROUP groups ride in two register windows (lane j: group gw0 + j, one register per head of the tile), refilled a whole
+// window ahead -- no dependent load at a group boundary.  Flush: numerator to the group's partial row, denominator to
+// partial_den[g, h] by the lane that holds the head's first column.
+struct GatSpanArgs {
+    SpanArgs s;
+    const float *att;     // [V, H, 2]
+    float *partial_den;   // [G, H]
+    float *newval;        // optional [E, H], CSR edge order
+    const int *eperm;     // permuted position -> CSR edge
+    int heads, dhead;
+    float slope;
+};
+
+template <int GROUP, int HT>
+__global__ __launch_bounds__(256) void k_gat_span(const GatSpanArgs A)
+{
+    const SpanArgs &a = A.s;
+    // a whole 16-edge window of gathers in flight: this kernel waits on memory latency (SQ_WAIT_ANY 82 % of the wave cycles,
+    // TA 63 % busy on the reddit-shaped 8 x 32 case), not on address processing -- 8 per batch: 13.0 ms, 16: 9.7 ms
+    constexpr int VEC = 4, GPB = 256 / GROUP, U = GROUP < 16 ? GROUP : 16;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int grp = (int)threadIdx.x / GROUP;
+    int tile, sb;
+    {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        if (k >= a.xr.count[xcd]) return;
+        const int L = a.xr.first[xcd] + k;
+        tile = L / a.span_blocks;
+        sb = L - tile * a.span_blocks;
+        tile += a.tile0;
+    }
+    const int s = sb * GPB + grp;
+    if (s >= a.n_spans) return;
+    const int F = a.feat, H = A.heads;
+    const int col = (tile * GROUP + lane) * VEC;
+    const bool col_ok = col < F;
+    const int h0 = (tile * GROUP * VEC) / A.dhead;            // first head of this tile
+    const int hl = (HT > 1 && col_ok) ? col / A.dhead - h0 : 0;  // this lane's head inside the tile
+    // which heads of the tile have their first column here (they write newval / partial_den): all of them when a tile
+    // holds whole heads; with a head wider than the tile, only the tile where that head starts
+    const bool tile_starts_head = HT > 1 || (h0 * A.dhead == tile * GROUP * VEC);
+    const bool head_leader = col_ok && (col % A.dhead) == 0;
+    int g = a.span_g[s];
+    const int g1 = a.span_g[s + 1];
+    const int e0 = a.ptr_s[g], e_end = a.ptr_s[g1];
+    const float *__restrict__ xcol = a.x + (size_t)tile * a.x_tile_stride + lane * VEC;
+    float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride;
+    const int lane_bit_base = ((int)threadIdx.x & 63) & ~(GROUP - 1);  // first lane of this group inside the wavefront
+    // centre-term windows: lane j holds the centre terms of group gw0 + j (cur) / gw0 + GROUP + j (next), one per tile head
+    int gw0 = g;
+    int tw_c, tw_n;
+    float aw_c[HT], aw_n[HT];
+    auto load_win = [&](int gbase, int &tw, float (&aw)[HT]) {
+        tw = gbase + lane < g1 ? a.target[gbase + lane] : 0;
+#pragma unroll
+        for (int k = 0; k < HT; ++k) {
+            const int hh = h0 + k < H ? h0 + k : H - 1;
+            aw[k] = A.att[((size_t)tw * H + hh) * 2];
+        }
+    };
+    load_win(gw0, tw_c, aw_c);
+    load_win(gw0 + GROUP, tw_n, aw_n);
+    // The weight of an edge is the same for every column of a head, so lane j computes the weights of edge cb + j ONCE per
+    // window -- one source-term gather and one exp per head of the tile -- and the group shares them with ds_bpermute like
+    // the edge values of the GCN chain (every lane gathering and exponentiating every edge made the kernel VALU-bound:
+    // reddit-shaped 8 x 32, 9.97 ms against 5 ms of gathers).  Source terms of window W + 1 are requested while window W
+    // is processed.
+    unsigned my_s = 0;
+    int my_e = 0;
+    float as_c[HT];
+#pragma unroll
+    for (int k = 0; k < HT; ++k) as_c[k] = 0.0f;
+    auto load_src_terms = [&](unsigned sw, bool valid, float (&as)[HT]) {
+        const size_t src = sw & kIdMask;
+#pragma unroll
+        for (int k = 0; k < HT; ++k) {
+            const int hh = h0 + k < H ? h0 + k : H - 1;
+#if defined(GAT_ABL) && GAT_ABL == 1
+            if (valid) as[k] = (float)(src & 7) * 0.01f;
+#else
+            if (valid) as[k] = A.att[(src * H + hh) * 2 + 1];
+#endif
+        }
+    };
+    if (e0 + lane < e_end) {
+        my_s = (unsigned)a.idx_f[e0 + lane];
+        if (A.newval) my_e = A.eperm[e0 + lane];
+    }
+    load_src_terms(my_s, e0 + lane < e_end, as_c);
+    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.0f;
+    for (int cb = e0; cb < e_end; cb += GROUP) {
+        unsigned nx_s = 0;
+        int nx_e = 0;
+        const bool nx_valid = cb + GROUP + lane < e_end;
+        if (nx_valid) {
+            nx_s = (unsigned)a.idx_f[cb + GROUP + lane];
+            if (A.newval) nx_e = A.eperm[cb + GROUP + lane];
+        }
+        const int n = e_end - cb < GROUP ? e_end - cb : GROUP;
+        // ---- this lane's edge (cb + lane): its group = current group + group ends before it in this window
+        float wk[HT];
+        {
+            const unsigned long long ends = __ballot((my_s & kLastFlag) != 0 && lane < n);
+            const unsigned mine = (unsigned)(ends >> lane_bit_base) & (GROUP >= 32 ? ~0u : ((1u << (GROUP & 31)) - 1u));
+            int gi;
+            if constexpr (GROUP == 64) gi = __popcll(ends & ((1ull << lane) - 1ull));
+            else gi = __popc(mine & ((1u << lane) - 1u));
+            gi += g - gw0;  // index into the two windows: < 2 * GROUP
+            const int gsel = gi < GROUP ? gi : gi - GROUP;
+#pragma unroll
+            for (int k = 0; k < HT; ++k) {
+                const float c0 = __shfl(aw_c[k], gsel, GROUP), c1 = __shfl(aw_n[k], gsel, GROUP);
+#if defined(GAT_ABL) && GAT_ABL == 2
+                wk[k] = lane < n ? (gi < GROUP ? c0 : c1) + as_c[k] : 0.0f;
+#else
+                wk[k] = lane < n ? edge_weight(gi < GROUP ? c0 : c1, as_c[k], A.slope) : 0.0f;
+#endif
+            }
+            if (A.newval && tile_starts_head && lane < n) {
+#pragma unroll
+                for (int k = 0; k < HT; ++k)
+                    if (h0 + k < H) A.newval[(size_t)my_e * H + h0 + k] = wk[k];
+            }
+        }
+#pragma unroll 1
+        for (int j = 0; j < n; j += U) {
+            unsigned sr[U];
+            Pack<VEC> xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) sr[u] = (unsigned)__shfl((int)my_s, j + u, GROUP);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (j + u < n) xv[u] = load_pack<VEC>(xcol + (size_t)(sr[u] & kIdMask) * a.xpitch);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (j + u < n) {
+                    float w = __shfl(wk[0], j + u, GROUP);
+#pragma unroll
+                    for (int k = 1; k < HT; ++k) {
+                        const float v = __shfl(wk[k], j + u, GROUP);
+                        w = hl == k ? v : w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
+                    den += w;
+                    if (sr[u] & kLastFlag) {  // lane-group uniform: the group ends here
+                        if (sr[u] & kDirectFlag) {
+                            const int row = __shfl(tw_c, g - gw0, GROUP);
+                            if (col_ok) {
+                                if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
+#pragma unroll
+                                    for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+                                }
+                                store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
+                            }
+                        } else {
+#if !defined(GAT_ABL) || GAT_ABL != 3
+                            if (a.ptile_bytes) store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
+                            else store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
+                            if (head_leader) A.partial_den[(size_t)g * H + col / A.dhead] = den;
+#else
+                            if (den == 123.456f) A.partial_den[0] = acc[0];
+#endif
+                        }
+                        ++g;
+                        den = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+                        if (g - gw0 == GROUP) {  // next window becomes current; the one after it is requested now
+                            gw0 = g;
+                            tw_c = tw_n;
+#pragma unroll
+                            for (int k = 0; k < HT; ++k) aw_c[k] = aw_n[k];
+                            load_win(gw0 + GROUP, tw_n, aw_n);
+                        }
+                    }
+                }
+        }
+        load_src_terms(nx_s, nx_valid, as_c);  // window W + 1's source terms: in flight across the loop back-edge
+        my_s = nx_s;
+        my_e = nx_e;
+    }
+}
+
+struct CombineGroupsGatArgs {
+    CombineGroupsArgs c;
+    const float *partial_den;
+    int heads, dhead;
+};
+
+template <int GROUP>
+__global__ __launch_bounds__(256) void k_combine_groups_gat(const CombineGroupsGatArgs A)
+{
+    const CombineGroupsArgs &a = A.c;
+    constexpr int VEC = 4, GPB = 256 / GROUP, CU = 16;
+    const int lane = threadIdx.x & (GROUP - 1);
+    const int tile = a.tile0 + blockIdx.x % a.ntiles;
+    const int i = (blockIdx.x / a.ntiles) * GPB + (int)threadIdx.x / GROUP;
+    if (i >= a.n_crows) return;
+    const int row = a.crows[i];
+    const int F = a.feat, H = A.heads;
+    const int col = (tile * GROUP + lane) * VEC;
+    const bool col_ok = col < F;
+    const int h = col_ok ? col / A.dhead : 0;
+    const int q0 = a.rg_ptr[row], q1 = a.rg_ptr[row + 1];
+    const float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride + lane * VEC;
+    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.0f;
+    int my_g = q0 + lane < q1 ? a.rg_idx[q0 + lane] : 0;
+    for (int qb = q0; qb < q1; qb += GROUP) {
+        const int nx_g = qb + GROUP + lane < q1 ? a.rg_idx[qb + GROUP + lane] : 0;
+        const int n = q1 - qb < GROUP ? q1 - qb : GROUP;
+        for (int j = 0; j < n; j += CU) {
+            Pack<VEC> p[CU];
+            float pd[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int gsel = __shfl(my_g, j + u, GROUP);
+                if (j + u < n) {
+                    p[u] = load_pack<VEC>(ptile + (size_t)gsel * a.ppitch);
+                    pd[u] = A.partial_den[(size_t)gsel * H + h];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u)
+                if (j + u < n) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += p[u].v[k];
+                    den += pd[u];
+                }
+        }
+        my_g = nx_g;
+    }
+    if (!col_ok) return;
+    if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+    }
+    store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
+}
+
 static unsigned *span_probe_sink()
 {
     static unsigned *p = nullptr;
@@ -227,67 +493,118 @@ static unsigned *span_probe_sink()
     return p;
 }
 
+// Launch plan shared by the GCN and GAT launchers: either ONE span launch over all tiles followed by one combine, or (with
+// an auxiliary stream) one span launch per tile on `stream`, each followed by its combine on the auxiliary stream.
+template <class SpanFn, class CombineFn>
+static int run_span_plan(const SpanLaunch &L, int ntiles, hipStream_t stream, SpanFn span, CombineFn combine)
+{
+    hipStream_t aux = (hipStream_t)L.aux_stream;
+    const bool overlap = aux != nullptr && ntiles > 1 && L.n_events >= ntiles && L.join_event != nullptr && L.n_crows > 0 && !L.probe;
+    if (!overlap) {
+        if (L.n_spans > 0) { const int rc = span(0, ntiles, stream); if (rc) return rc; }
+        if (!L.probe && L.n_crows > 0) { const int rc = combine(0, ntiles, stream); if (rc) return rc; }
+    } else {
+        for (int t = 0; t < ntiles; ++t) {
+            if (L.n_spans > 0) { const int rc = span(t, 1, stream); if (rc) return rc; }
+            hipEvent_t ev = (hipEvent_t)L.events[t];
+            HIP_TRY(hipEventRecord(ev, stream));
+            HIP_TRY(hipStreamWaitEvent(aux, ev, 0));
+            const int rc = combine(t, 1, aux);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipEventRecord((hipEvent_t)L.join_event, aux));
+        HIP_TRY(hipStreamWaitEvent(stream, (hipEvent_t)L.join_event, 0));
+    }
+    if (!L.probe && L.n_empty > 0) {
+        const long total = (long)L.n_empty * L.feat;
+        hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, L.empty_rows, L.n_empty, L.y, L.feat);
+        HIP_TRY(hipGetLastError());
+    }
+    return GNNAGG_OK;
+}
+
+static void fill_span_args(SpanArgs &a, const SpanLaunch &L, int ntiles_total, int group)
+{
+    static const int wt_env = getenv("GNNAGG_PARTIAL_WT") ? atoi(getenv("GNNAGG_PARTIAL_WT")) : 1;
+    a.span_g = L.span_g; a.ptr_s = L.ptr_s; a.idx_f = L.idx_f; a.val_s = L.val_s; a.target = L.target;
+    a.x = L.x; a.y = L.y; a.partial = L.partial;
+    a.n_spans = L.n_spans; a.feat = L.feat; a.ntiles = ntiles_total; a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.relu = L.relu;
+    a.yvec = L.tile.yvec; a.xpitch = L.tile.xpitch; a.ppitch = L.tile.ppitch;
+    a.x_tile_stride = L.tile.x_tile_stride; a.p_tile_stride = L.tile.p_tile_stride;
+    const size_t tb = (size_t)L.n_groups * L.tile.ppitch * sizeof(float);
+    a.ptile_bytes = (wt_env && tb < 0x7fffffffULL) ? (unsigned)tb : 0u;
+    a.probe_sink = nullptr;
+    a.tile0 = 0;
+    a.span_blocks = ceil_div(L.n_spans, 256 / group);
+}
+
+static void fill_combine_args(CombineGroupsArgs &c, const SpanLaunch &L)
+{
+    c.crows = L.crows; c.rg_ptr = L.rg_ptr; c.rg_idx = L.rg_idx; c.row_ptr = L.row_ptr; c.partial = L.partial; c.y = L.y;
+    c.n_crows = L.n_crows; c.feat = L.feat; c.mean = L.reduce == GNNAGG_REDUCE_MEAN; c.relu = L.relu;
+    c.yvec = L.tile.yvec; c.ppitch = L.tile.ppitch; c.p_tile_stride = L.tile.p_tile_stride;
+    c.tile0 = 0; c.ntiles = 1;
+}
+
 int launch_gcn_span(const SpanLaunch &L, void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
     if (L.feat <= 0 || !L.tile.on) return fail(GNNAGG_ERR_STATE, "internal: span launch without a tile spec");
     const int tw = L.tile.tile_w, group = tw / 4;
+    if (group != 8 && group != 16 && group != 32 && group != 64) return fail(GNNAGG_ERR_ARG, "unsupported tile width");
     const int ntiles = (L.feat + tw - 1) / tw;
     const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
-    static const int wt_env = getenv("GNNAGG_PARTIAL_WT") ? atoi(getenv("GNNAGG_PARTIAL_WT")) : 1;
-    if (L.n_spans > 0) {
-        SpanArgs a;
-        a.span_g = L.span_g; a.ptr_s = L.ptr_s; a.idx_f = L.idx_f; a.val_s = L.val_s; a.target = L.target;
-        a.x = L.x; a.y = L.y; a.partial = L.partial;
-        a.n_spans = L.n_spans; a.feat = L.feat; a.ntiles = ntiles; a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.relu = L.relu;
-        a.yvec = L.tile.yvec; a.xpitch = L.tile.xpitch; a.ppitch = L.tile.ppitch;
-        a.x_tile_stride = L.tile.x_tile_stride; a.p_tile_stride = L.tile.p_tile_stride;
-        const size_t tb = (size_t)L.n_groups * L.tile.ppitch * sizeof(float);
-        a.ptile_bytes = (wt_env && tb < 0x7fffffffULL) ? (unsigned)tb : 0u;
-        a.probe_sink = nullptr;
+    const bool has_val = L.val_s != nullptr;
+    if (L.probe && is_max) return fail(GNNAGG_ERR_ARG, "probe: sum/mean only");
+    // 32-bit lane offsets inside a tile image / 24-bit ids (FAST_ADDR)
+    const bool fast = L.x_rows > 0 && L.x_rows < (1 << 24) && L.tile.xpitch < (1 << 24) &&
+                      (size_t)L.x_rows * L.tile.xpitch * sizeof(float) < 0xffffffffULL;
+    SpanArgs a0;
+    fill_span_args(a0, L, ntiles, group);
+    if (L.probe) {
+        a0.probe_sink = span_probe_sink();
+        if (!a0.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
+    }
+    auto span = [&](int tile0, int nt, hipStream_t st) -> int {
+        SpanArgs a = a0;
+        a.tile0 = tile0;
         const int gpb = 256 / group;
-        a.span_blocks = ceil_div(L.n_spans, gpb);
-        const int grid = 8 * fill_xcd_ranges_tile_major(L.span_cost_prefix, L.n_spans, gpb, a.span_blocks, ntiles, a.xr);
-        const bool has_val = L.val_s != nullptr;
-        if (L.probe) {
-            if (is_max) return fail(GNNAGG_ERR_ARG, "probe: sum/mean only");
-            a.probe_sink = span_probe_sink();
-            if (!a.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
+        const int grid = 8 * fill_xcd_ranges_tile_major(L.span_cost_prefix, L.n_spans, gpb, a.span_blocks, nt, a.xr);
+#define SPAN_K(G, MAXF, VALF, PROBEF)                                                                                 \
+        {                                                                                                               \
+            if (fast) hipLaunchKernelGGL((k_gcn_span<G, MAXF, VALF, PROBEF, true>), dim3(grid), dim3(256), 0, st, a);    \
+            else      hipLaunchKernelGGL((k_gcn_span<G, MAXF, VALF, PROBEF, false>), dim3(grid), dim3(256), 0, st, a);   \
         }
-#define SPAN_CALL(G)                                                                                                        \
-        {                                                                                                                   \
-            if (L.probe) {                                                                                                  \
-                if (has_val) hipLaunchKernelGGL((k_gcn_span<G, false, true, true>), dim3(grid), dim3(256), 0, stream, a);    \
-                else         hipLaunchKernelGGL((k_gcn_span<G, false, false, true>), dim3(grid), dim3(256), 0, stream, a);   \
-            } else if (is_max) {                                                                                            \
-                if (has_val) hipLaunchKernelGGL((k_gcn_span<G, true, true, false>), dim3(grid), dim3(256), 0, stream, a);    \
-                else         hipLaunchKernelGGL((k_gcn_span<G, true, false, false>), dim3(grid), dim3(256), 0, stream, a);   \
-            } else {                                                                                                        \
-                if (has_val) hipLaunchKernelGGL((k_gcn_span<G, false, true, false>), dim3(grid), dim3(256), 0, stream, a);   \
-                else         hipLaunchKernelGGL((k_gcn_span<G, false, false, false>), dim3(grid), dim3(256), 0, stream, a);  \
-            }                                                                                                               \
+#define SPAN_CALL(G)                                                                                                    \
+        {                                                                                                               \
+            if (L.probe) {                                                                                              \
+                if (has_val) SPAN_K(G, false, true, true) else SPAN_K(G, false, false, true)                            \
+            } else if (is_max) {                                                                                        \
+                if (has_val) SPAN_K(G, true, true, false) else SPAN_K(G, true, false, false)                            \
+            } else {                                                                                                    \
+                if (has_val) SPAN_K(G, false, true, false) else SPAN_K(G, false, false, false)                          \
+            }                                                                                                           \
         }
         switch (group) {
             case 8: SPAN_CALL(8) break;
             case 16: SPAN_CALL(16) break;
             case 32: SPAN_CALL(32) break;
-            case 64: SPAN_CALL(64) break;
-            default: return fail(GNNAGG_ERR_ARG, "unsupported tile width");
+            default: SPAN_CALL(64) break;
         }
+#undef SPAN_K
 #undef SPAN_CALL
         HIP_TRY(hipGetLastError());
-    }
-    if (L.probe) return GNNAGG_OK;
-    if (L.n_crows > 0) {
+        return GNNAGG_OK;
+    };
+    auto combine = [&](int tile0, int nt, hipStream_t st) -> int {
         CombineGroupsArgs c;
-        c.crows = L.crows; c.rg_ptr = L.rg_ptr; c.rg_idx = L.rg_idx; c.row_ptr = L.row_ptr; c.partial = L.partial; c.y = L.y;
-        c.n_crows = L.n_crows; c.feat = L.feat; c.ntiles = ntiles; c.mean = L.reduce == GNNAGG_REDUCE_MEAN; c.relu = L.relu;
-        c.yvec = L.tile.yvec; c.ppitch = L.tile.ppitch; c.p_tile_stride = L.tile.p_tile_stride;
-        const int grid = ceil_div(L.n_crows, 256 / group) * ntiles;
-#define COMB_CALL(G)                                                                                              \
-        {                                                                                                         \
-            if (is_max) hipLaunchKernelGGL((k_combine_groups<G, true>), dim3(grid), dim3(256), 0, stream, c);      \
-            else        hipLaunchKernelGGL((k_combine_groups<G, false>), dim3(grid), dim3(256), 0, stream, c);     \
+        fill_combine_args(c, L);
+        c.tile0 = tile0; c.ntiles = nt;
+        const int grid = ceil_div(L.n_crows, 256 / group) * nt;
+#define COMB_CALL(G)                                                                                          \
+        {                                                                                                     \
+            if (is_max) hipLaunchKernelGGL((k_combine_groups<G, true>), dim3(grid), dim3(256), 0, st, c);      \
+            else        hipLaunchKernelGGL((k_combine_groups<G, false>), dim3(grid), dim3(256), 0, st, c);     \
         }
         switch (group) {
             case 8: COMB_CALL(8) break;
@@ -297,13 +614,67 @@ int launch_gcn_span(const SpanLaunch &L, void *stream_v)
         }
 #undef COMB_CALL
         HIP_TRY(hipGetLastError());
-    }
-    if (L.n_empty > 0) {
-        const long total = (long)L.n_empty * L.feat;
-        hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, L.empty_rows, L.n_empty, L.y, L.feat);
+        return GNNAGG_OK;
+    };
+    return run_span_plan(L, ntiles, stream, span, combine);
+}
+
+int launch_gat_span(const GatSpanLaunch &G, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    const SpanLaunch &L = G.s;
+    if (L.feat <= 0 || !L.tile.on || G.heads <= 0 || L.feat % G.heads != 0)
+        return fail(GNNAGG_ERR_STATE, "internal: GAT span launch without a tile spec");
+    const int tw = L.tile.tile_w, group = tw / 4, dhead = L.feat / G.heads;
+    if (group != 8 && group != 16 && group != 32 && group != 64) return fail(GNNAGG_ERR_ARG, "unsupported tile width");
+    const int ht = tw >= dhead ? tw / dhead : 1;
+    if (!gat_span_tiles(L.feat, G.heads, tw)) return fail(GNNAGG_ERR_STATE, "internal: head width does not tile");
+    const int ntiles = (L.feat + tw - 1) / tw;
+    GatSpanArgs A0;
+    fill_span_args(A0.s, L, ntiles, group);
+    A0.s.val_s = nullptr; A0.s.mean = 0; A0.s.relu = 0;
+    A0.att = G.att; A0.partial_den = G.partial_den; A0.newval = G.newval; A0.eperm = G.eperm; A0.heads = G.heads; A0.dhead = dhead;
+    A0.slope = G.slope;
+    auto span = [&](int tile0, int nt, hipStream_t st) -> int {
+        GatSpanArgs A = A0;
+        A.s.tile0 = tile0;
+        const int gpb = 256 / group;
+        const int grid = 8 * fill_xcd_ranges_tile_major(L.span_cost_prefix, L.n_spans, gpb, A.s.span_blocks, nt, A.s.xr);
+#define GAT_SPAN_HT(G_, HT_) hipLaunchKernelGGL((k_gat_span<G_, HT_>), dim3(grid), dim3(256), 0, st, A)
+#define GAT_SPAN_CALL(G_)                                                      \
+        switch (ht) {                                                          \
+            case 1: GAT_SPAN_HT(G_, 1); break;                                 \
+            case 2: GAT_SPAN_HT(G_, 2); break;                                 \
+            case 4: GAT_SPAN_HT(G_, 4); break;                                 \
+            default: GAT_SPAN_HT(G_, 8); break;                                \
+        }
+        switch (group) {
+            case 8: GAT_SPAN_CALL(8) break;
+            case 16: GAT_SPAN_CALL(16) break;
+            case 32: GAT_SPAN_CALL(32) break;
+            default: GAT_SPAN_CALL(64) break;
+        }
+#undef GAT_SPAN_CALL
+#undef GAT_SPAN_HT
         HIP_TRY(hipGetLastError());
-    }
-    return GNNAGG_OK;
+        return GNNAGG_OK;
+    };
+    auto combine = [&](int tile0, int nt, hipStream_t st) -> int {
+        CombineGroupsGatArgs C;
+        fill_combine_args(C.c, L);
+        C.c.mean = 0; C.c.relu = 0; C.c.tile0 = tile0; C.c.ntiles = nt;
+        C.partial_den = G.partial_den; C.heads = G.heads; C.dhead = dhead;
+        const int grid = ceil_div(L.n_crows, 256 / group) * nt;
+        switch (group) {
+            case 8: hipLaunchKernelGGL((k_combine_groups_gat<8>), dim3(grid), dim3(256), 0, st, C); break;
+            case 16: hipLaunchKernelGGL((k_combine_groups_gat<16>), dim3(grid), dim3(256), 0, st, C); break;
+            case 32: hipLaunchKernelGGL((k_combine_groups_gat<32>), dim3(grid), dim3(256), 0, st, C); break;
+            default: hipLaunchKernelGGL((k_combine_groups_gat<64>), dim3(grid), dim3(256), 0, st, C); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return GNNAGG_OK;
+    };
+    return run_span_plan(L, ntiles, stream, span, combine);
 }
 
 }  // namespace gnnagg

@@ -154,6 +154,8 @@ struct Ctx {
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> tile_events;  // blocked mode: tile t's span kernel done (its combine waits on the aux stream)
+    int overlap_combine = 0;              // blocked mode, A/B: per-tile launches with tile t's combine on the aux stream beside tile t + 1 (measured slower: reddit-shaped F=602 15.4 -> 16.9 ms, GAT 8x32 9.8 -> 10.7 ms)
     Schedule sched_edges;    // chunked work items of the edge kernels (run_att, u_add_v, add_to_center, div_each)
     DevBuf<float> den;       // [V,heads] row sums of run_att
     DevBuf<float> partial, partial_den;
@@ -524,13 +526,34 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
 
 static int build_spans(Ctx *c, Schedule &s);
 
+// aux stream + events of the per-tile overlap (created on first use: never inside a capture of a warm handle)
+static int span_overlap(Ctx *c, int ntiles, SpanLaunch &S)
+{
+    if (!c->overlap_combine || ntiles < 2) return GNNAGG_OK;
+    if (!c->aux_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    while ((int)c->tile_events.size() < ntiles) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->tile_events.push_back(e);
+    }
+    S.aux_stream = c->aux_stream;
+    S.events = reinterpret_cast<void **>(c->tile_events.data());
+    S.n_events = (int)c->tile_events.size();
+    S.join_event = c->ev_join;
+    return GNNAGG_OK;
+}
+
 static int build_partitioned(Ctx *c, int parts)
 {
     c->plan.reset();
     c->plan_part.reset();
     Schedule &s = c->sched[1];
     // the segmented-stream kernel wants several groups per span: groups of at most 128 edges there
-    const bool spans = c->tiled && c->kind == Ctx::GCN && c->use_spans;
+    const bool spans = c->tiled && c->use_spans;
     int rc = build_locality(c, s, parts, spans ? std::min(pick_chunk(c), 128) : pick_chunk(c), -1,
                             GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING, true);
     if (rc) return rc;
@@ -803,8 +826,9 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             S.ptr_s = s->ptr_s.p; S.idx_f = s->idx_f.p; S.val_s = c->d_val ? s->val_s.p : nullptr; S.target = s->target.p;
             S.n_groups = s->num_target; S.crows = s->crows.p; S.n_crows = s->n_crows; S.rg_ptr = s->rg_ptr.p; S.rg_idx = s->rg_idx.p;
             S.empty_rows = s->empty_rows.p; S.n_empty = s->n_empty; S.row_ptr = c->d_ptr;
-            S.x = x; S.y = y; S.partial = c->partial.p; S.feat = feat; S.reduce = reduce; S.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
+            S.x = x; S.x_rows = s->total_cols; S.y = y; S.partial = c->partial.p; S.feat = feat; S.reduce = reduce; S.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
             S.tile = tr.spec; S.probe = probe;
+            if ((rc = span_overlap(c, tr.ntiles, S))) return rc;
             if (tr.retile) {
                 if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
                 S.x = c->xt.p;
@@ -932,10 +956,33 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors) {
         BalancedPlan &p = c->plan_part;  // source-partitioned order on the descriptor path, as in gcn_run
         if (heads <= 0 || feat % heads != 0) return fail(GNNAGG_ERR_ARG, "GAT needs feat % heads == 0");
-        const TiledRun tr = plan_tiles(c, *s, x, y, feat, feat / heads);
+        TiledRun tr = plan_tiles(c, *s, x, y, feat, feat / heads);
+        const bool span_run = tr.spec.on && s->n_spans > 0 && gat_span_tiles(feat, heads, tr.spec.tile_w);
+        size_t den_floats = (size_t)s->n_slots * heads;
+        if (span_run) {
+            tr.spec.p_tile_stride = (long)s->num_target * tr.spec.tile_w;
+            tr.partial_floats = (size_t)s->num_target * tr.spec.tile_w * tr.ntiles;
+            den_floats = (size_t)s->num_target * heads;
+        }
         bool demoted = false;
-        if ((rc = reserve_partitioned_scratch(c, tr.partial_floats, (size_t)s->n_slots * heads, tr.xt_floats, &demoted))) return rc;
+        if ((rc = reserve_partitioned_scratch(c, tr.partial_floats, den_floats, tr.xt_floats, &demoted))) return rc;
         if (demoted) return gat_run(c, x, att, y, feat, heads, slope, mode, newval);
+        if (span_run) {
+            GatSpanLaunch G;
+            SpanLaunch &S = G.s;
+            S.span_g = s->span_g.p; S.n_spans = s->n_spans; S.span_cost_prefix = s->span_cost_prefix.data();
+            S.ptr_s = s->ptr_s.p; S.idx_f = s->idx_f.p; S.target = s->target.p;
+            S.n_groups = s->num_target; S.crows = s->crows.p; S.n_crows = s->n_crows; S.rg_ptr = s->rg_ptr.p; S.rg_idx = s->rg_idx.p;
+            S.empty_rows = s->empty_rows.p; S.n_empty = s->n_empty; S.row_ptr = c->d_ptr;
+            S.x = x; S.x_rows = s->total_cols; S.y = y; S.partial = c->partial.p; S.feat = feat; S.tile = tr.spec;
+            G.att = att; G.partial_den = c->partial_den.p; G.newval = newval; G.eperm = s->eperm.p; G.heads = heads; G.slope = slope;
+            if ((rc = span_overlap(c, tr.ntiles, S))) return rc;
+            if (tr.retile) {
+                if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
+                S.x = c->xt.p;
+            }
+            return launch_gat_span(G, c->stream);
+        }
         GatPlanLaunch P;
         P.t0 = p.t0.p; P.n0 = p.n0; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
         P.hubs = s->worklist();
@@ -1113,6 +1160,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_RETILE")) c->opt_retile = atoi(e);
     if (const char *e = getenv("GNNAGG_FAST_ROWS")) c->fast_rows = atoi(e);
     if (const char *e = getenv("GNNAGG_SPANS")) c->use_spans = atoi(e);
+    if (const char *e = getenv("GNNAGG_OVERLAP_COMBINE")) c->overlap_combine = atoi(e);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);
@@ -1148,6 +1196,7 @@ int gnnagg_destroy(gnnagg_handle h)
         (void)hipStreamDestroy(c->aux_stream);
         (void)hipEventDestroy(c->ev_fork);
         (void)hipEventDestroy(c->ev_join);
+        for (hipEvent_t e : c->tile_events) (void)hipEventDestroy(e);
     }
     delete c;
     return GNNAGG_OK;
@@ -1174,6 +1223,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "tiled") c->tiled = value;
     else if (n == "fast_rows") c->fast_rows = value;
     else if (n == "spans") { c->use_spans = value; replan = true; }
+    else if (n == "overlap_combine") c->overlap_combine = value;
     else if (n == "inkernel_combine") c->inkernel_combine = value;
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
     if (replan) {

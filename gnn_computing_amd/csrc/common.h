@@ -134,13 +134,40 @@ struct SpanLaunch {
     int n_empty = 0;
     const int *row_ptr = nullptr;             // CSR ptr (degrees for mean)
     const float *x = nullptr;                 // the image of X named by `tile`
+    int x_rows = 0;                           // rows of that image (ids are < x_rows)
     float *y = nullptr;
     float *partial = nullptr;                 // [ntiles][n_groups][tile_w]
     int feat = 0, reduce = GNNAGG_REDUCE_SUM, relu = 0;
     TileSpec tile;
     int probe = 0;
+    // Overlap of the ordered combine with the aggregation: one launch per column tile, tile t's combine (HBM-bound: it
+    // streams the partial rows) runs on aux_stream beside tile t + 1's span kernel (bound by L1 / address processing).
+    // events: ntiles hipEvent_t (tile t's span kernel done), join_event: the last combine done.  All null: one launch.
+    void *aux_stream = nullptr;
+    void **events = nullptr;
+    int n_events = 0;
+    void *join_event = nullptr;
 };
 int launch_gcn_span(const SpanLaunch &a, void *stream);
+struct GatSpanLaunch {
+    SpanLaunch s;                   // val_s unused
+    const float *att = nullptr;     // [V, H, 2]
+    float *partial_den = nullptr;   // [n_groups, H]
+    float *newval = nullptr;        // optional [E, H], CSR edge order (scattered through eperm)
+    const int *eperm = nullptr;
+    int heads = 1;
+    float slope = 0.2f;
+};
+int launch_gat_span(const GatSpanLaunch &a, void *stream);
+// whether the GAT span kernel covers (feat, heads) at this tile width
+static inline bool gat_span_tiles(int feat, int heads, int tile_w)
+{
+    if (heads <= 0 || feat % heads != 0) return false;
+    const int dhead = feat / heads;
+    if (dhead % 4 != 0) return false;
+    if (tile_w >= dhead) { const int ht = tile_w / dhead; return tile_w % dhead == 0 && (ht == 1 || ht == 2 || ht == 4 || ht == 8); }
+    return dhead % tile_w == 0;
+}
 
 // Long rows of the rows mode (`scheduled = 0`, canonical CSR-order chains): k_gcn_rows_long.
 struct GcnRowsLongLaunch {

@@ -32,5 +32,8 @@ for k, (s, n) in sorted(dur.items(), key=lambda t: -t[1][0]):
     print("%-70s n=%3d avg %10.1f us  traffic %8.2f GB (%6.2f TB/s)  fetch %8.2f GB write %8.2f GB  L2 hit %.3f  tcp->tcc rd %.3g  ea rd %.3g" % (
         k[:70], n, avg, traffic / 1e9, traffic / avg / 1e6 if avg else 0, c.get("FETCH_SIZE", 0) * 2048 / 1e9, c.get("WRITE_SIZE", 0) * 1024 / 1e9, hit,
         c.get("TCP_TCC_READ_REQ_sum", 0), c.get("TCC_EA0_RDREQ_sum", 0)))
+    extra = {n: v for n, v in c.items() if n.startswith(("SQ_", "TA_", "GRBM", "TCP_TOTAL"))}
+    if extra:
+        print("      " + "  ".join("%s=%.4g" % (n, v) for n, v in sorted(extra.items())))
     tot += avg
 print("sum of per-launch averages: %.1f us" % tot)

@@ -81,7 +81,7 @@ def test_blocked_mode_a_b_switches_give_identical_results():
     V, E, F = 700, 220000, 256
     ptr, idx = hub_graph(V, E, seed=6)
     x, val = rand((V, F), 3), rand(E, 4)
-    for opts in ({}, {"retile": 0}, {"tiled": 0}, {"tile_width": 256}, {"spans": 0}, {"spans": 0, "retile": 0}, {"tile_width": 32}):
+    for opts in ({}, {"retile": 0}, {"tiled": 0}, {"tile_width": 256}, {"spans": 0}, {"spans": 0, "retile": 0}, {"tile_width": 32}, {"overlap_combine": 0}):
         agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
         agg.set_option("partitions", 8)
         for k, v in opts.items():
