@@ -145,15 +145,24 @@ def run_single(args, dev):
     results["no_reorder"] = time_steps(lambda: agg0.run(dx, y, 512, mode), args.steps, args.warmup, lambda: None)
     # with the locality reorder applied on load (reference: load_graph(..., "_thres_0.2"), our.py:79)
     t0 = time.perf_counter()
-    # the reorder GENERATOR is the reference's offline clustering (script/cluster2.py) restated in C++:
-    # MinHash-64 + LSH(0.2) + greedy capped-64 merge (gnnagg_cluster_reorder); its output is what a
-    # <dset>.reorder_thres_0.2 file holds
-    rows, n_clusters = gnc.cluster_reorder(ptr, idx)
+    # the reorder GENERATOR (what writes a <dset>.reorder_thres_0.2 file; the reference's is the offline script
+    # script/cluster2.py) is the library's gnnagg_cluster_reorder_ex: cache-aware greedy ordering -- each next row is the one
+    # with the largest share of its source rows among the 8192 most recently gathered (an LRU model of an XCD's L2) -- over
+    # singleton clusters.  The reference's MinHash-64 + LSH(0.2) + capped-64 clustering written in first-member order
+    # (order="first_member") is timed beside it as "reorder_minhash_clusters".
+    rows, n_clusters = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=8192)
     nptr, nidx, rev = gnc.reorder_csr(ptr, idx, rows)
     t_reorder = time.perf_counter() - t0
     agg1 = build(nptr, nidx)
     dx1 = torch.from_numpy(np.ascontiguousarray(x[rows])).to(dev)
     results["reorder"] = time_steps(lambda: agg1.run(dx1, y, 512, mode), args.steps, args.warmup, lambda: None)
+    y_reorder = y.clone()
+    rows_m, _ = gnc.cluster_reorder(ptr, idx, order="first_member")
+    mptr, midx, _ = gnc.reorder_csr(ptr, idx, rows_m)
+    agg2 = build(mptr, midx)
+    dx2 = torch.from_numpy(np.ascontiguousarray(x[rows_m])).to(dev)
+    results["reorder_minhash_clusters"] = time_steps(lambda: agg2.run(dx2, y, 512, mode), args.steps, args.warmup, lambda: None)
+    y.copy_(y_reorder)
     # sanity: the timed kernel's output matches the oracle on this very input (outside the timed region)
     from oracle import oracle as orc
     ps, ix, tg = agg1.get_schedule(mode) if mode != "rows" else (None, None, None)
@@ -191,7 +200,7 @@ def run_single(args, dev):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "arxiv-shaped power-law CSR 169343x1166243 (seed 123), GCN sum, feat=128, "
                                "explicit unit weights, %s, mode=%s" % (
-                                   "reorder_thres_0.2 (MinHash-LSH clustering) applied on load" if which == "reorder" else "no reorder", mode),
+                                   "locality reorder (cache-aware greedy order, gnnagg_cluster_reorder_ex) applied on load like a .reorder_thres_0.2 file" if which == "reorder" else "no reorder", mode),
                    "num_v": V, "num_e": E, "feat": FEAT},
         "achieved_gbps": achieved,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": B / probe_s / 1e9, "unit": "GB/s",
@@ -214,6 +223,9 @@ def run_single(args, dev):
                                     "bytes (Infinity-Cache hits included)"},
         other: {"value": E / (results[other][0] / args.steps), "avg_launch_us": results[other][1] * 1e6,
                 "achieved_gbps": B / results[other][1] / 1e9},
+        "reorder_minhash_clusters": {"value": E / (results["reorder_minhash_clusters"][0] / args.steps),
+                                     "avg_launch_us": results["reorder_minhash_clusters"][1] * 1e6,
+                                     "note": "the reference's clustering (MinHash-64, LSH 0.2, cap 64) in first-member order"},
         "reorder_prep_s": t_reorder, "schedule_prep_s": prep.get("schedule_prep_s"),
     }
     if not args.no_cpu:
@@ -272,44 +284,87 @@ def run_multi(args, dev, rank, world):
     feat = 100 if strong else FEAT
     V1, E1 = gnc.graph.SHAPES["products" if strong else "arxiv"]
     Vg, Eg = (V1, E1) if strong else (V1 * world, E1 * world)
-    # rank 0 generates the global graph on its GPU (seeded, community order = "locality reorder applied on load") and
-    # broadcasts it: every rank must cut exactly the same partition, or the all-to-all split sizes would disagree
+    # rank 0 generates the global graph on its GPU (seeded, community order = "locality reorder applied on load"); every
+    # rank receives the row offsets (to cut the same nnz-balanced partition) and ONLY ITS OWN rows' neighbor ids
     if rank == 0:
         ptr_t, idx_t = gnc.graph.powerlaw_csr(Vg, Eg, seed=123, device=dev, community_order=True)
     else:
         ptr_t = torch.empty(Vg + 1, dtype=torch.int32, device=dev)
-        idx_t = torch.empty(Eg, dtype=torch.int32, device=dev)
     dist.broadcast(ptr_t, src=0)
-    dist.broadcast(idx_t, src=0)
-    ptr, idx = ptr_t.cpu().numpy(), idx_t.cpu().numpy()
-    del ptr_t, idx_t
-    val = np.ones(Eg, np.float32)
-    pg = PartitionedGCN(ptr, idx, val, feat, device=dev, mode=os.environ.get("BENCH_MODE", "balanced"))
+    ptr = ptr_t.cpu().numpy()
+    bounds = gnc.partition_rows(ptr, world)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    e0, e1 = int(ptr[r0]), int(ptr[r1])
+    p2p_dev = dev if dist.get_backend() == "nccl" else torch.device("cpu")   # (gloo moves point-to-point data through the host)
+    if rank == 0:
+        for r in range(1, world):
+            dist.send(idx_t[int(ptr[bounds[r]]):int(ptr[bounds[r + 1]])].contiguous().to(p2p_dev), dst=r)
+        idx_slice = idx_t[e0:e1].cpu().numpy()
+        del idx_t
+    else:
+        buf = torch.empty(e1 - e0, dtype=torch.int32, device=p2p_dev)
+        dist.recv(buf, src=0)
+        idx_slice = buf.cpu().numpy()
+        del buf
+    del ptr_t
+    val_slice = np.ones(e1 - e0, np.float32)
+    transport = os.environ.get("BENCH_TRANSPORT", "torch")   # "rccl": the C-ABI's grouped ncclSend / ncclRecv
+    pg = PartitionedGCN(ptr[r0:r1 + 1], idx_slice, val_slice, feat, device=dev, mode=os.environ.get("BENCH_MODE", "balanced"),
+                        row_slice=True, bounds=bounds, num_cols=Vg, transport=transport)
+    hx = pg.hx
+    # correctness outside the timed region: features that are a closed form of the GLOBAL row id, so every rank can check
+    # the halo rows it pulled and (on its first rows) the aggregation against the oracle without any further exchange
+    def closed_form(ids):
+        r = torch.as_tensor(ids, dtype=torch.int64, device=dev)[:, None]
+        c = torch.arange(feat, dtype=torch.int64, device=dev)[None, :]
+        return (((r * 131 + c * 71) % 1013).to(torch.float32) / 1013.0 - 0.5)
+    pg.set_local_x(closed_form(np.arange(r0, r1)))
+    y_chk = pg.step().clone()
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(pg.x_halo, closed_form(hx.halo_ids))) if hx.n_halo else True
+    from oracle import oracle as orc
+    nchk = min(hx.n_local, 2000)
+    lp = hx.local_ptr[:nchk + 1]
+    x_ext = pg.x_ext.cpu().numpy()
+    ref = orc.gcn_seq(lp, hx.local_idx[:lp[-1]], val_slice[:lp[-1]], x_ext)
+    scale = orc.gcn_abs_scale(lp, hx.local_idx[:lp[-1]], val_slice[:lp[-1]], x_ext)
+    ok = ok and bool(np.all(np.abs(y_chk[:nchk].cpu().numpy() - ref) <= 1e-5 * scale + 1e-30))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    assert int(flag.item()) == 1, "row-partitioned step differs from the oracle / halo rows differ from their owners' rows"
     g = torch.Generator(device=dev)
     g.manual_seed(123 + rank)
-    pg.set_local_x(torch.randn((pg.hx.n_local, feat), generator=g, device=dev))
+    pg.set_local_x(torch.randn((hx.n_local, feat), generator=g, device=dev))
     wall, dev_s, med_s = time_steps(pg.step, args.steps, args.warmup, dist.barrier)
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    halo = torch.tensor([pg.hx.halo_bytes(feat), pg.num_e_local], dtype=torch.float64, device=dev)
+    halo = torch.tensor([hx.halo_bytes(feat), pg.num_e_local], dtype=torch.float64, device=dev)
     dist.all_reduce(halo, op=dist.ReduceOp.SUM)
     wall = float(t.item())
     if rank != 0:
         return None
     B = algorithmic_bytes(Vg, Eg, feat)
+    step_s = wall / args.steps
     return {
-        "metric": "aggregated edges/sec, GCN SpMM feat=%d" % feat, "value": Eg / (wall / args.steps), "unit": "edges/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "metric": "aggregated edges/sec, GCN SpMM feat=%d" % feat, "value": Eg / step_s, "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s power-law CSR (%dx%d, seed 123, community order), GCN sum, feat=%d, 1-D row "
-                               "partition + RCCL all-to-all halo pull per step (overlapped with the local-source edges)" % (
-                                   "products-shaped" if strong else "%d x arxiv-shaped" % world, Vg, Eg, feat),
-                   "num_v": Vg, "num_e": Eg, "feat": feat, "halo_bytes_per_step_all_ranks": float(halo[0].item())},
-        "achieved_gbps": B / (wall / args.steps) / 1e9,
-        "roofline": {"bound": "hbm", "achieved": B / (wall / args.steps) / 1e9 / world, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": B / (wall / args.steps) / 1e9 / world / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "per-GPU share of the step (halo exchange included)", "algorithmic_bytes": B},
+                               "partition + RCCL halo pull per step (%s; overlapped with the local-source edges)" % (
+                                   "products-shaped" if strong else "%d x arxiv-shaped" % world, Vg, Eg, feat,
+                                   "all_to_all_single" if transport == "torch" else "grouped ncclSend/ncclRecv behind the C-ABI"),
+                   "num_v": Vg, "num_e": Eg, "feat": feat, "halo_bytes_per_step_all_ranks": float(halo[0].item()),
+                   "verified_against_oracle": True},
+        "achieved_gbps": B / step_s / 1e9,
+        # per-GPU share of the step, halo exchange included: the bound is whichever of the xGMI links and the memory system
+        # is slower for this partition -- reported against the HBM figure for continuity with the 1-GPU line, not as a
+        # kernel roofline (that is the N = 1 line's job)
+        "roofline": {"bound": "hbm", "achieved": B / step_s / 1e9 / world, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": min(1.0, B / step_s / 1e9 / world / HBM_PEAK_GBPS), "traffic": None,
+                     "kernel": "per-GPU share of the step (halo exchange over xGMI included; gather-model bytes, cache-served "
+                               "gathers count: see the N = 1 line for the measured ceiling)", "algorithmic_bytes": B,
+                     "halo_bytes_per_rank": float(halo[0].item()) / world},
     }
 
 

@@ -1,0 +1,169 @@
+// dist_step -- the row-partitioned (multi-GPU) aggregation step driven from C++ through the C-ABI only: one process per
+// GPU, RCCL grouped send/recv behind gnnagg_dist_* (the reference itself asserts GPUNUM == 1,
+// Figure9/main.cu:19).  Start it once per GPU with RANK / WORLD_SIZE / LOCAL_RANK in the environment (the variables
+// torchrun and most MPI launchers set), e.g.
+//     for r in 0 1 2 3 4 5 6 7; do RANK=$r WORLD_SIZE=8 LOCAL_RANK=$r ./dist_step.out --dataset products --datadir D \
+//         --feature-len 100 --idfile /tmp/gnnagg.id & done; wait
+// Every rank loads the graph, keeps ITS row slice (gnnagg_partition_rows + gnnagg_halo_plan_slice), exchanges the request
+// lists once (gnnagg_dist_alltoallv), then times `--iters` steps of  halo pull (gnnagg_dist_halo_exchange)  +  balanced
+// aggregation over [X_local ; X_halo].  One JSON line per rank on stderr; rank 0 also prints the slowest rank's time.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../include/gnnagg.h"
+
+#define CK(expr)                                                                                   \
+    do {                                                                                           \
+        const int rc_ = (expr);                                                                    \
+        if (rc_ != GNNAGG_OK) {                                                                    \
+            fprintf(stderr, "%s failed (%d): %s\n", #expr, rc_, gnnagg_last_error());              \
+            exit(1);                                                                               \
+        }                                                                                          \
+    } while (0)
+#define HCK(expr)                                                                                  \
+    do {                                                                                           \
+        const hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "%s failed: %s\n", #expr, hipGetErrorString(e_));                      \
+            exit(1);                                                                               \
+        }                                                                                          \
+    } while (0)
+
+static int env_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+
+template <class T>
+static T *to_device(const std::vector<T> &h)
+{
+    T *p = nullptr;
+    HCK(hipMalloc((void **)&p, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    if (!h.empty()) HCK(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    return p;
+}
+
+int main(int argc, char **argv)
+{
+    std::string dataset, datadir = "../data/", idfile = "/tmp/gnnagg_dist.id";
+    int feat = 128, iters = 20;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        const std::string k = argv[i];
+        if (k == "--dataset") dataset = argv[i + 1];
+        else if (k == "--datadir") datadir = argv[i + 1];
+        else if (k == "--feature-len") feat = atoi(argv[i + 1]);
+        else if (k == "--iters") iters = atoi(argv[i + 1]);
+        else if (k == "--idfile") idfile = argv[i + 1];
+        else { fprintf(stderr, "unknown flag %s\n", k.c_str()); return 2; }
+    }
+    if (dataset.empty()) { fprintf(stderr, "usage: dist_step.out --dataset D [--datadir DIR] [--feature-len F] [--iters K] [--idfile PATH]\n"); return 2; }
+    const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), local_rank = env_int("LOCAL_RANK", 0);
+    HCK(hipSetDevice(local_rank));
+    gnnagg_set_abort_on_error(0);
+
+    // the graph and this rank's slice of it
+    int V = 0, E = 0, *h_ptr = nullptr, *h_idx = nullptr;
+    CK(gnnagg_load_graph(datadir.c_str(), dataset.c_str(), "", 0, &V, &E, &h_ptr, &h_idx, nullptr, nullptr));
+    std::vector<int> bounds((size_t)world + 1);
+    CK(gnnagg_partition_rows(h_ptr, V, world, bounds.data()));
+    const int r0 = bounds[rank], r1 = bounds[rank + 1], n_local = r1 - r0;
+    const int nnz = h_ptr[r1] - h_ptr[r0];
+    std::vector<int> lptr((size_t)n_local + 1), lidx((size_t)std::max(nnz, 1)), recv_rows_i((size_t)world);
+    int *halo_ids = nullptr, n_halo = 0;
+    CK(gnnagg_halo_plan_slice(h_ptr + r0, h_idx + h_ptr[r0], V, bounds.data(), world, rank, lptr.data(), lidx.data(), &halo_ids,
+                              recv_rows_i.data(), &n_halo));
+
+    gnnagg_comm comm = 0;
+    CK(gnnagg_dist_comm_create_from_file(idfile.c_str(), rank, world, 300, &comm));
+    hipStream_t stream;
+    HCK(hipStreamCreate(&stream));
+
+    // one-time: tell every owner which of its rows this rank needs (counts, then the id lists)
+    std::vector<long long> recv_rows(world), send_rows(world), ones(world, 1);
+    for (int p = 0; p < world; ++p) recv_rows[p] = recv_rows_i[p];
+    {
+        long long *d_a = to_device(recv_rows), *d_b = to_device(send_rows);
+        CK(gnnagg_dist_alltoallv(comm, d_a, ones.data(), d_b, ones.data(), (int)sizeof(long long), stream));
+        HCK(hipStreamSynchronize(stream));
+        HCK(hipMemcpy(send_rows.data(), d_b, sizeof(long long) * world, hipMemcpyDeviceToHost));
+        (void)hipFree(d_a); (void)hipFree(d_b);
+    }
+    long long n_send = 0;
+    for (int p = 0; p < world; ++p) n_send += send_rows[p];
+    std::vector<int> h_req(halo_ids, halo_ids + n_halo);
+    int *d_req = to_device(h_req), *d_send_ids = nullptr;
+    HCK(hipMalloc((void **)&d_send_ids, sizeof(int) * std::max<long long>(n_send, 1)));
+    CK(gnnagg_dist_alltoallv(comm, d_req, recv_rows.data(), d_send_ids, send_rows.data(), (int)sizeof(int), stream));
+    HCK(hipStreamSynchronize(stream));
+    {   // global ids -> rows of the local X
+        std::vector<int> ids((size_t)n_send);
+        HCK(hipMemcpy(ids.data(), d_send_ids, sizeof(int) * n_send, hipMemcpyDeviceToHost));
+        for (auto &v : ids) v -= r0;
+        HCK(hipMemcpy(d_send_ids, ids.data(), sizeof(int) * n_send, hipMemcpyHostToDevice));
+    }
+
+    // device state: local CSR (columns = X_ext slots), X_ext = [X_local ; X_halo], send buffer, Y
+    int *d_ptr = to_device(lptr), *d_idx = to_device(lidx);
+    std::vector<float> hx((size_t)n_local * feat);
+    {
+        std::mt19937_64 gen(123 + rank);
+        std::normal_distribution<float> nd(0.f, 1.f);
+        for (auto &v : hx) v = nd(gen);
+    }
+    float *d_x_ext = nullptr, *d_send = nullptr, *d_y = nullptr;
+    HCK(hipMalloc((void **)&d_x_ext, sizeof(float) * std::max<size_t>((size_t)(n_local + n_halo) * feat, 1)));
+    HCK(hipMalloc((void **)&d_send, sizeof(float) * std::max<size_t>((size_t)n_send * feat, 1)));
+    HCK(hipMalloc((void **)&d_y, sizeof(float) * std::max<size_t>((size_t)n_local * feat, 1)));
+    HCK(hipMemcpy(d_x_ext, hx.data(), sizeof(float) * hx.size(), hipMemcpyHostToDevice));
+    float *d_x_halo = d_x_ext + (size_t)n_local * feat;
+
+    gnnagg_handle agg = 0;
+    CK(gnnagg_gcn_create(d_ptr, d_idx, nullptr, n_local, nnz, &agg));
+    CK(gnnagg_set_stream(agg, stream));
+    CK(gnnagg_schedule_balanced(agg, 0));
+    auto step = [&] {
+        CK(gnnagg_dist_halo_exchange(comm, d_x_ext, d_send_ids, send_rows.data(), recv_rows.data(), feat, d_send, d_x_halo, stream));
+        CK(gnnagg_gcn_run(agg, d_x_ext, d_y, feat, GNNAGG_MODE_BALANCED, GNNAGG_REDUCE_SUM));
+    };
+    for (int i = 0; i < 3; ++i) step();
+    HCK(hipStreamSynchronize(stream));
+    hipEvent_t a, b;
+    HCK(hipEventCreate(&a)); HCK(hipEventCreate(&b));
+    HCK(hipEventRecord(a, stream));
+    for (int i = 0; i < iters; ++i) step();
+    HCK(hipEventRecord(b, stream));
+    HCK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HCK(hipEventElapsedTime(&ms, a, b));
+    const double sec = ms * 1e-3 / iters;
+    // a checksum of the halo rows against what their owners hold is the launcher's job at world > 1; at world == 1 there is
+    // no halo and the step is the single-GPU aggregation
+    fprintf(stderr, "{\"rank\": %d, \"world\": %d, \"n_local\": %d, \"nnz_local\": %d, \"n_halo\": %d, \"n_send\": %lld, \"seconds\": %.9f, "
+                    "\"edges_per_s\": %.6e, \"halo_bytes\": %.0f}\n",
+            rank, world, n_local, nnz, n_halo, n_send, sec, (double)nnz / sec, (double)n_halo * feat * 4.0);
+    // the slowest rank bounds the step: gather the times on rank 0
+    {
+        std::vector<double> mine(1, sec), all((size_t)world, 0.0);
+        std::vector<long long> sc(world, 0), rc(world, 0);
+        sc[0] = 1;                       // everybody sends one double to rank 0
+        if (rank == 0) for (int p = 0; p < world; ++p) rc[p] = 1;
+        double *d_m = to_device(mine), *d_all = to_device(all);
+        CK(gnnagg_dist_alltoallv(comm, d_m, sc.data(), d_all, rc.data(), (int)sizeof(double), stream));
+        HCK(hipStreamSynchronize(stream));
+        if (rank == 0) {
+            HCK(hipMemcpy(all.data(), d_all, sizeof(double) * world, hipMemcpyDeviceToHost));
+            const double worst = *std::max_element(all.begin(), all.end());
+            fprintf(stderr, "{\"summary\": \"slowest rank\", \"world\": %d, \"seconds\": %.9f, \"edges_per_s\": %.6e}\n", world, worst, (double)E / worst);
+        }
+        (void)hipFree(d_m); (void)hipFree(d_all);
+    }
+    CK(gnnagg_destroy(agg));
+    CK(gnnagg_dist_comm_destroy(comm));
+    gnnagg_free_host(halo_ids); gnnagg_free_host(h_ptr); gnnagg_free_host(h_idx);
+    if (rank == 0) remove(idfile.c_str());
+    return 0;
+}

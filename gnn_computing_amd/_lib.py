@@ -79,11 +79,21 @@ SIGNATURES = {
     "gnnagg_locality_schedule": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, P_INT]),
     "gnnagg_cluster_reorder": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_int, ctypes.c_ulonglong, c_void_p, P_INT]),
+    "gnnagg_cluster_reorder_ex": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_int, ctypes.c_ulonglong, c_int, c_int, c_void_p, P_INT]),
     # D
     "gnnagg_partition_rows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "gnnagg_halo_plan": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, PP_INT,
                                  c_void_p, P_INT]),
     "gnnagg_pack_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "gnnagg_halo_plan_slice": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, PP_INT,
+                                       c_void_p, P_INT]),
+    "gnnagg_dist_unique_id": (c_int, [c_void_p]),
+    "gnnagg_dist_comm_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int64)]),
+    "gnnagg_dist_comm_create_from_file": (c_int, [c_char_p, c_int, c_int, c_int, ctypes.POINTER(c_int64)]),
+    "gnnagg_dist_comm_destroy": (c_int, [c_int64]),
+    "gnnagg_dist_comm_info": (c_int, [c_int64, P_INT, P_INT]),
+    "gnnagg_dist_alltoallv": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gnnagg_dist_halo_exchange": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

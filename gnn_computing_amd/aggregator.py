@@ -419,15 +419,18 @@ def locality_schedule(ptr, idx, par_num, total_v, ng=0, val=None):
     return ptr_s[:G + 1].copy(), idx_s[:ne].copy(), tgt[:G].copy(), (None if val is None else val_s[:ne].copy())
 
 
-def cluster_reorder(ptr, idx, threshold=0.2, num_perm=64, cluster_cap=64, seed=123):
-    """gnnagg_cluster_reorder (reference script/cluster2.py).  Returns (rows, num_clusters); rows[i] = old node id
-    placed at new position i, ready for graph.write_reorder_file / reorder_csr."""
+def cluster_reorder(ptr, idx, threshold=0.2, num_perm=64, cluster_cap=64, seed=123, order="first_member", cache_rows=4096):
+    """gnnagg_cluster_reorder[_ex] (reference script/cluster2.py).  Returns (rows, num_clusters); rows[i] = old node id
+    placed at new position i, ready for graph.write_reorder_file / reorder_csr.  order="first_member" writes the clusters
+    as the reference script does; order="cache_greedy" orders them with an LRU model of `cache_rows` feature rows."""
     ptr, idx = _np_i(ptr), _np_i(idx)
     V = len(ptr) - 1
     rows = np.empty(V, np.int32)
     nc = ctypes.c_int(0)
-    check(lib().gnnagg_cluster_reorder(ptr.ctypes.data, idx.ctypes.data, V, ctypes.c_float(threshold), int(num_perm),
-                                       int(cluster_cap), ctypes.c_ulonglong(seed), rows.ctypes.data, ctypes.byref(nc)))
+    mode = {"first_member": 0, "cache_greedy": 1}[order]
+    check(lib().gnnagg_cluster_reorder_ex(ptr.ctypes.data, idx.ctypes.data, V, ctypes.c_float(threshold), int(num_perm),
+                                          int(cluster_cap), ctypes.c_ulonglong(seed), mode, int(cache_rows), rows.ctypes.data,
+                                          ctypes.byref(nc)))
     return rows, nc.value
 
 
@@ -438,18 +441,29 @@ def partition_rows(ptr, nparts):
     return b
 
 
-def halo_plan(ptr, idx, bounds, rank):
-    """gnnagg_halo_plan -> dict(local_ptr, local_idx, halo_ids, halo_counts)."""
+def halo_plan(ptr, idx, bounds, rank, row_slice=False, num_cols=None):
+    """gnnagg_halo_plan / gnnagg_halo_plan_slice -> dict(local_ptr, local_idx, halo_ids, halo_counts).  row_slice=True:
+    (ptr, idx) hold the rank's own rows only (ptr[0 .. n_local] with any base, global column ids in idx)."""
     ptr, idx, bounds = _np_i(ptr), _np_i(idx), _np_i(bounds)
     nparts = len(bounds) - 1
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
-    nnz = int(ptr[r1] - ptr[r0])
+    if row_slice:
+        if len(ptr) != r1 - r0 + 1:
+            raise ValueError("row slice must have bounds[rank+1] - bounds[rank] + 1 ptr entries")
+        nnz = int(ptr[-1] - ptr[0])
+    else:
+        nnz = int(ptr[r1] - ptr[r0])
     lptr, lidx = np.empty(r1 - r0 + 1, np.int32), np.empty(max(nnz, 1), np.int32)
     counts = np.empty(nparts, np.int32)
     ids_p, nh = _lib.P_INT(), ctypes.c_int(0)
-    check(lib().gnnagg_halo_plan(ptr.ctypes.data, idx.ctypes.data, len(ptr) - 1, bounds.ctypes.data, nparts, int(rank),
-                                 lptr.ctypes.data, lidx.ctypes.data, ctypes.byref(ids_p), counts.ctypes.data,
-                                 ctypes.byref(nh)))
+    if row_slice:
+        check(lib().gnnagg_halo_plan_slice(ptr.ctypes.data, idx.ctypes.data, int(num_cols), bounds.ctypes.data, nparts, int(rank),
+                                           lptr.ctypes.data, lidx.ctypes.data, ctypes.byref(ids_p), counts.ctypes.data,
+                                           ctypes.byref(nh)))
+    else:
+        check(lib().gnnagg_halo_plan(ptr.ctypes.data, idx.ctypes.data, len(ptr) - 1, bounds.ctypes.data, nparts, int(rank),
+                                     lptr.ctypes.data, lidx.ctypes.data, ctypes.byref(ids_p), counts.ctypes.data,
+                                     ctypes.byref(nh)))
     ids = np.ctypeslib.as_array(ids_p, shape=(nh.value,)).copy() if nh.value else np.empty(0, np.int32)
     lib().gnnagg_free_host(ctypes.cast(ids_p, ctypes.c_void_p))
     return dict(local_ptr=lptr, local_idx=lidx[:nnz].copy(), halo_ids=ids, halo_counts=counts, n_local=r1 - r0)

@@ -1733,6 +1733,16 @@ int gnnagg_cluster_reorder(const int *h_ptr, const int *h_idx, int num_v, float 
                            cluster_cap > 0 ? cluster_cap : 64, seed, 8, h_rows_out, num_clusters);
 }
 
+int gnnagg_cluster_reorder_ex(const int *h_ptr, const int *h_idx, int num_v, float threshold, int num_perm, int cluster_cap,
+                              unsigned long long seed, int order_mode, int cache_rows, int *h_rows_out, int *num_clusters)
+{
+    if (!h_ptr || !h_rows_out || num_v < 0 || (h_ptr[num_v] > 0 && !h_idx))
+        return fail(GNNAGG_ERR_ARG, "bad cluster_reorder arguments");
+    return cluster_reorder(h_ptr, h_idx, num_v, threshold > 0 ? threshold : 0.2, num_perm > 0 ? num_perm : 64,
+                           cluster_cap > 0 ? cluster_cap : 64, seed, 8, h_rows_out, num_clusters, order_mode,
+                           cache_rows > 0 ? cache_rows : 4096);
+}
+
 // ------------------------------------------------------------------------------- Section D
 int gnnagg_partition_rows(const int *h_ptr, int num_v, int nparts, int *h_bounds)
 {
@@ -1749,6 +1759,16 @@ int gnnagg_halo_plan(const int *h_ptr, const int *h_idx, int num_v, const int *h
         return fail(GNNAGG_ERR_ARG, "bad halo_plan arguments");
     return halo_plan(h_ptr, h_idx, num_v, h_bounds, nparts, rank, h_local_ptr, h_local_idx, h_halo_ids, h_halo_counts,
                      num_halo);
+}
+
+int gnnagg_halo_plan_slice(const int *h_ptr_slice, const int *h_idx_slice, int num_cols, const int *h_bounds, int nparts, int rank,
+                           int *h_local_ptr, int *h_local_idx, int **h_halo_ids, int *h_halo_counts, int *num_halo)
+{
+    if (!h_ptr_slice || !h_idx_slice || !h_bounds || nparts <= 0 || rank < 0 || rank >= nparts || num_cols < 0 || !h_local_ptr ||
+        !h_local_idx || !h_halo_ids || !h_halo_counts || !num_halo)
+        return fail(GNNAGG_ERR_ARG, "bad halo_plan_slice arguments");
+    return halo_plan_slice(h_ptr_slice, h_idx_slice, num_cols, h_bounds, nparts, rank, h_local_ptr, h_local_idx, h_halo_ids,
+                           h_halo_counts, num_halo);
 }
 
 int gnnagg_pack_rows(const float *d_x, const int *d_ids, int n, int feat, float *d_out, void *hip_stream)

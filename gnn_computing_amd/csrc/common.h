@@ -19,12 +19,14 @@ int locality_schedule(const int *ptr, const int *idx, const float *val, int par_
 int load_graph(const char *datadir, const char *dset, const char *suffix, int shuffle, int *num_v, int *num_e,
                int **ptr_o, int **idx_o, int **rows_o, int **rrows_o);
 void partition_rows(const int *ptr, int V, int nparts, int *bounds);
+int halo_plan_slice(const int *ptr_slice, const int *idx_slice, int num_cols, const int *bounds, int nparts, int rank, int *lptr,
+                    int *lidx, int **halo_ids_o, int *halo_counts, int *num_halo);
 int halo_plan(const int *ptr, const int *idx, int V, const int *bounds, int nparts, int rank, int *lptr, int *lidx,
               int **halo_ids_o, int *halo_counts, int *num_halo);
 
 // ---- reorder.cpp
 int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int num_perm, int cap, uint64_t seed,
-                    int max_bucket, int *rows_out, int *num_clusters_out);
+                    int max_bucket, int *rows_out, int *num_clusters_out, int order_mode = 0, int cache_rows = 4096);
 
 // ---- agg_gcn.hip / agg_gat.hip / aux_kernels.hip : launch descriptors (all pointers are device pointers)
 

@@ -1,0 +1,235 @@
+// dist_rccl.cpp -- RCCL transport of the row-partitioned (multi-GPU) path behind the C-ABI (gnnagg.h Section D).
+//
+// The reference has no multi-GPU aggregation (Figure9/main.cu:19 asserts GPUNUM == 1; its NCCL calls are commented out,
+// include/util.h:25,42,72); SURVEY.md 8(e) is the specification: one-time all-to-all of request lists, then per
+// aggregation a pack kernel + ncclGroupStart / 7 x (ncclSend, ncclRecv) / ncclGroupEnd on the caller's stream -- over the
+// point-to-point xGMI mesh every pairwise message rides its own link, so a grouped send/recv IS the all-to-all-v.
+//
+// librccl is loaded lazily with dlopen: libgnnagg.so has no link-time dependency on it (the single-GPU path never needs
+// it), and a process that already holds a copy -- torch ships one -- keeps using that copy (RTLD_NOLOAD first).
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace gnnagg {
+
+struct RcclApi {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static RcclApi *rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names)
+            if ((api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;  // a copy this process already mapped
+        if (!api.h)
+            for (const char *n : names)
+                if ((api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!api.h) return;
+#define LOAD(sym) api.sym = reinterpret_cast<decltype(api.sym)>(dlsym(api.h, "nccl" #sym))
+        LOAD(GetUniqueId); LOAD(CommInitRank); LOAD(CommDestroy); LOAD(GroupStart); LOAD(GroupEnd); LOAD(Send); LOAD(Recv);
+        LOAD(GetErrorString);
+#undef LOAD
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv)
+            api.h = nullptr;
+    });
+    return api.h ? &api : nullptr;
+}
+
+#define RCCL_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t _r = (expr);                                                                              \
+        if (_r != ncclSuccess)                                                                                 \
+            return fail(GNNAGG_ERR_HIP, std::string(#expr) + ": " + (R->GetErrorString ? R->GetErrorString(_r) : "rccl error")); \
+    } while (0)
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+static std::mutex g_comm_mu;
+static std::set<Comm *> g_comms;
+
+static Comm *lookup_comm(gnnagg_comm c)
+{
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    Comm *p = reinterpret_cast<Comm *>(c);
+    return g_comms.count(p) ? p : nullptr;
+}
+
+}  // namespace gnnagg
+
+using namespace gnnagg;
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int gnnagg_dist_unique_id(char *id128)
+{
+    if (!id128) return fail(GNNAGG_ERR_ARG, "null id buffer");
+    RcclApi *R = rccl();
+    if (!R) return fail(GNNAGG_ERR_STATE, "librccl could not be loaded");
+    ncclUniqueId id;
+    RCCL_TRY(R->GetUniqueId(&id));
+    static_assert(sizeof(id) == GNNAGG_UNIQUE_ID_BYTES, "unique id size");
+    memcpy(id128, &id, sizeof(id));
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_comm_create(const char *id128, int rank, int world, gnnagg_comm *out)
+{
+    if (!out) return fail(GNNAGG_ERR_ARG, "null output communicator");
+    *out = 0;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(GNNAGG_ERR_ARG, "bad communicator arguments");
+    RcclApi *R = rccl();
+    if (!R) return fail(GNNAGG_ERR_STATE, "librccl could not be loaded");
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    Comm *c = new Comm;
+    c->rank = rank; c->world = world;
+    const ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);  // binds to the calling thread's current HIP device
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(GNNAGG_ERR_HIP, std::string("ncclCommInitRank: ") + (R->GetErrorString ? R->GetErrorString(r) : "rccl error"));
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_comm_mu);
+        g_comms.insert(c);
+    }
+    *out = reinterpret_cast<gnnagg_comm>(c);
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_comm_create_from_file(const char *path, int rank, int world, int timeout_s, gnnagg_comm *out)
+{
+    if (!path || !out) return fail(GNNAGG_ERR_ARG, "bad communicator arguments");
+    char id[GNNAGG_UNIQUE_ID_BYTES];
+    const std::string p(path);
+    if (rank == 0) {
+        int rc = gnnagg_dist_unique_id(id);
+        if (rc) return rc;
+        const std::string tmp = p + ".tmp." + std::to_string((long)getpid());
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { if (f) fclose(f); return fail(GNNAGG_ERR_IO, "cannot write " + tmp); }
+        fclose(f);
+        if (rename(tmp.c_str(), p.c_str()) != 0) return fail(GNNAGG_ERR_IO, "cannot publish " + p);  // atomic: readers see all 128 bytes or no file
+    } else {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s > 0 ? timeout_s : 120);
+        for (;;) {
+            FILE *f = fopen(p.c_str(), "rb");
+            if (f) {
+                const size_t got = fread(id, 1, sizeof(id), f);
+                fclose(f);
+                if (got == sizeof(id)) break;
+            }
+            if (std::chrono::steady_clock::now() > t_end) return fail(GNNAGG_ERR_IO, "timed out waiting for " + p);
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    return gnnagg_dist_comm_create(id, rank, world, out);
+}
+
+int gnnagg_dist_comm_destroy(gnnagg_comm h)
+{
+    Comm *c;
+    {
+        std::lock_guard<std::mutex> lk(g_comm_mu);
+        c = reinterpret_cast<Comm *>(h);
+        if (!g_comms.count(c)) return fail(GNNAGG_ERR_ARG, "invalid or destroyed communicator");
+        g_comms.erase(c);
+    }
+    RcclApi *R = rccl();
+    if (R && c->comm) (void)R->CommDestroy(c->comm);
+    delete c;
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_comm_info(gnnagg_comm h, int *rank, int *world)
+{
+    Comm *c = lookup_comm(h);
+    if (!c) return fail(GNNAGG_ERR_ARG, "invalid or destroyed communicator");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_alltoallv(gnnagg_comm h, const void *d_send, const long long *h_send_counts, void *d_recv,
+                          const long long *h_recv_counts, int elem_bytes, void *hip_stream)
+{
+    Comm *c = lookup_comm(h);
+    if (!c) return fail(GNNAGG_ERR_ARG, "invalid or destroyed communicator");
+    if (!h_send_counts || !h_recv_counts || elem_bytes <= 0) return fail(GNNAGG_ERR_ARG, "bad alltoallv arguments");
+    RcclApi *R = rccl();
+    if (!R) return fail(GNNAGG_ERR_STATE, "librccl could not be loaded");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const char *sp = static_cast<const char *>(d_send);
+    char *rp = static_cast<char *>(d_recv);
+    size_t soff = 0, roff = 0;
+    // the part a rank keeps for itself is a device-to-device copy on the same stream (no self send/recv in the group)
+    std::vector<size_t> so((size_t)c->world), ro((size_t)c->world);
+    for (int p = 0; p < c->world; ++p) {
+        if (h_send_counts[p] < 0 || h_recv_counts[p] < 0) return fail(GNNAGG_ERR_ARG, "negative alltoallv count");
+        so[p] = soff; ro[p] = roff;
+        soff += (size_t)h_send_counts[p] * elem_bytes;
+        roff += (size_t)h_recv_counts[p] * elem_bytes;
+    }
+    if ((soff > 0 && !d_send) || (roff > 0 && !d_recv)) return fail(GNNAGG_ERR_ARG, "null alltoallv buffer");
+    if (h_send_counts[c->rank] != h_recv_counts[c->rank]) return fail(GNNAGG_ERR_ARG, "alltoallv: self send and receive counts differ");
+    if (h_send_counts[c->rank] > 0) {
+        const hipError_t e = hipMemcpyAsync(rp + ro[c->rank], sp + so[c->rank], (size_t)h_send_counts[c->rank] * elem_bytes,
+                                            hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return fail(GNNAGG_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    }
+    if (c->world == 1) return GNNAGG_OK;
+    RCCL_TRY(R->GroupStart());
+    for (int p = 0; p < c->world; ++p) {
+        if (p == c->rank) continue;
+        if (h_send_counts[p] > 0) RCCL_TRY(R->Send(sp + so[p], (size_t)h_send_counts[p] * elem_bytes, ncclInt8, p, c->comm, stream));
+        if (h_recv_counts[p] > 0) RCCL_TRY(R->Recv(rp + ro[p], (size_t)h_recv_counts[p] * elem_bytes, ncclInt8, p, c->comm, stream));
+    }
+    RCCL_TRY(R->GroupEnd());
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_halo_exchange(gnnagg_comm h, const float *d_x_local, const int *d_send_ids, const long long *h_send_rows,
+                              const long long *h_recv_rows, int feat, float *d_send_buf, float *d_x_halo, void *hip_stream)
+{
+    Comm *c = lookup_comm(h);
+    if (!c) return fail(GNNAGG_ERR_ARG, "invalid or destroyed communicator");
+    if (!h_send_rows || !h_recv_rows || feat <= 0) return fail(GNNAGG_ERR_ARG, "bad halo_exchange arguments");
+    long long n_send = 0;
+    for (int p = 0; p < c->world; ++p) n_send += h_send_rows[p];
+    if (n_send > 0x7fffffffLL) return fail(GNNAGG_ERR_ARG, "too many halo rows to pack");
+    if (n_send > 0) {
+        const int rc = launch_pack_rows(d_x_local, d_send_ids, (int)n_send, feat, d_send_buf, hip_stream);
+        if (rc) return rc;
+    }
+    return gnnagg_dist_alltoallv(h, d_send_buf, h_send_rows, d_x_halo, h_recv_rows, feat * (int)sizeof(float), hip_stream);
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -299,17 +299,20 @@ void partition_rows(const int *ptr, int V, int nparts, int *bounds)
 }
 
 // Local CSR of `rank` with columns renumbered into [0, n_local + n_halo): see gnnagg.h Section D.
-int halo_plan(const int *ptr, const int *idx, int V, const int *bounds, int nparts, int rank, int *lptr,
-              int *lidx, int **halo_ids_o, int *halo_counts, int *num_halo)
+// Slice form: the rank only holds ITS rows -- ptr_slice[0 .. n_local] (any base offset) and the global column ids of
+// those rows -- plus the partition bounds; nothing of the other ranks' rows is read.
+int halo_plan_slice(const int *ptr_slice, const int *idx_slice, int num_cols, const int *bounds, int nparts, int rank, int *lptr,
+                    int *lidx, int **halo_ids_o, int *halo_counts, int *num_halo)
 {
     const int r0 = bounds[rank], r1 = bounds[rank + 1];
     const int nloc = r1 - r0;
-    const int e0 = ptr[r0], e1 = ptr[r1];
+    const int base = ptr_slice[0];
+    const int ne = ptr_slice[nloc] - base;
     std::vector<int> remote;
-    remote.reserve((size_t)(e1 - e0) / 4 + 16);
-    for (int e = e0; e < e1; ++e) {
-        const int c = idx[e];
-        if (c < 0 || c >= V) return fail(GNNAGG_ERR_ARG, "column id out of range in halo_plan");
+    remote.reserve((size_t)ne / 4 + 16);
+    for (int e = 0; e < ne; ++e) {
+        const int c = idx_slice[e];
+        if (c < 0 || c >= num_cols) return fail(GNNAGG_ERR_ARG, "column id out of range in halo_plan");
         if (c < r0 || c >= r1) remote.push_back(c);
     }
     std::sort(remote.begin(), remote.end());
@@ -320,20 +323,27 @@ int halo_plan(const int *ptr, const int *idx, int V, const int *bounds, int npar
         auto hi = std::lower_bound(remote.begin(), remote.end(), bounds[p + 1]);
         halo_counts[p] = (int)(hi - lo);
     }
-    for (int i = 0; i <= nloc; ++i) lptr[i] = ptr[r0 + i] - e0;
+    for (int i = 0; i <= nloc; ++i) lptr[i] = ptr_slice[i] - base;
 #pragma omp parallel for schedule(static)
-    for (int e = e0; e < e1; ++e) {
-        const int c = idx[e];
+    for (int e = 0; e < ne; ++e) {
+        const int c = idx_slice[e];
         if (c >= r0 && c < r1)
-            lidx[e - e0] = c - r0;
+            lidx[e] = c - r0;
         else
-            lidx[e - e0] = nloc + (int)(std::lower_bound(remote.begin(), remote.end(), c) - remote.begin());
+            lidx[e] = nloc + (int)(std::lower_bound(remote.begin(), remote.end(), c) - remote.begin());
     }
     int *ids = (int *)malloc(sizeof(int) * std::max<size_t>(remote.size(), 1));
     std::copy(remote.begin(), remote.end(), ids);
     *halo_ids_o = ids;
     *num_halo = (int)remote.size();
     return GNNAGG_OK;
+}
+
+int halo_plan(const int *ptr, const int *idx, int V, const int *bounds, int nparts, int rank, int *lptr,
+              int *lidx, int **halo_ids_o, int *halo_counts, int *num_halo)
+{
+    const int r0 = bounds[rank];
+    return halo_plan_slice(ptr + r0, idx + ptr[r0], V, bounds, nparts, rank, lptr, lidx, halo_ids_o, halo_counts, num_halo);
 }
 
 }  // namespace gnnagg

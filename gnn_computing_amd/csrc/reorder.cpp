@@ -9,8 +9,13 @@
 //   4. greedy merge with path-halving union-find: a popped pair whose ends are both cluster roots is
 //      merged (smaller into larger, ties into the first); a cluster reaching `cap` nodes is frozen;
 //      a pair with a non-root end is re-queued as (root, root) with the roots' own similarity (:121-151)
-//   5. nodes are written cluster by cluster in order of each cluster's first node id, ascending
-//      inside a cluster (:156-171): rows[i] = old id placed at new position i.
+//   5. nodes are written cluster by cluster, ascending inside a cluster (:156-171): rows[i] = old id placed at new
+//      position i.  Cluster order: order_mode 0 = by each cluster's first node id (what the reference script does --
+//      consecutive clusters are then unrelated); order_mode 1 = CACHE-AWARE GREEDY: the clusters are emitted so that each
+//      next cluster is the one whose rows find the largest share of their source rows among the `cache_rows` most recently
+//      gathered ones (an LRU model of an XCD's L2, which is what the reorder is for -- the reference's Figure 9 is an L2
+//      hit-rate plot).  Clustering finds rows with SIMILAR neighbor sets; the ordering pass also puts clusters with
+//      OVERLAPPING neighbor sets next to each other, which on the arxiv-shaped input is where most of the reuse is.
 //
 // Parity note: the reference hashes with datasketch (sha1 + its own permutations, README.md:16), whose
 // source is not part of the reference tree, so the candidate sets -- and therefore the exact permutation --
@@ -19,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <queue>
 #include <unordered_map>
 #include <unordered_set>
@@ -64,10 +70,131 @@ static double jaccard_sorted(const int *a, int na, const int *b, int nb)
     return (double)inter / (double)uni;
 }
 
+// Emits the clusters (members[c] = node ids, ascending) in cache-aware greedy order.
+// Rows longer than kLongRow edges take no part in the cache model: the balanced kernels cut them into segments that run
+// first and on whatever XCD the dispatcher picks, not in row order beside their neighbors (27 % of the edges of the
+// arxiv-shaped input); clusters made only of such rows are written last.
+static constexpr int kLongRow = 64;
+// Source rows gathered by more than kHubCut clusters do not vote: they are in the cache whatever the order is (or thrash
+// it whatever the order is), and scanning their long gatherer lists on every (re)entry is what makes the pass quadratic
+// on power-law graphs (products-shaped: hours -> minutes).  They still occupy cache capacity in the model.
+static const long kHubCut = getenv("GNNAGG_HUB_CUT") ? atol(getenv("GNNAGG_HUB_CUT")) : 4096;
+
+static void emit_cache_greedy(const int *ptr, const int *idx, int V, const std::vector<std::vector<int>> &members,
+                              int cache_rows, int *rows_out)
+{
+    const int NC = (int)members.size();
+    const long E = ptr[V];
+    // cluster -> (source, multiplicity) lists, and their transpose source -> (cluster, multiplicity)
+    std::vector<long> cp((size_t)NC + 1, 0);
+    std::vector<int> cs, cm;
+    cs.reserve((size_t)E);
+    cm.reserve((size_t)E);
+    {
+        std::vector<int> tmp;
+        for (int c = 0; c < NC; ++c) {
+            tmp.clear();
+            for (int v : members[c])
+                if (ptr[v + 1] - ptr[v] <= kLongRow) tmp.insert(tmp.end(), idx + ptr[v], idx + ptr[v + 1]);
+            std::sort(tmp.begin(), tmp.end());
+            for (size_t a = 0; a < tmp.size();) {
+                size_t b = a;
+                while (b < tmp.size() && tmp[b] == tmp[a]) ++b;
+                cs.push_back(tmp[a]);
+                cm.push_back((int)(b - a));
+                a = b;
+            }
+            cp[c + 1] = (long)cs.size();
+        }
+    }
+    const long NZ = (long)cs.size();
+    std::vector<long> tp((size_t)V + 1, 0);
+    for (long k = 0; k < NZ; ++k) ++tp[(size_t)cs[k] + 1];
+    for (int v = 0; v < V; ++v) tp[v + 1] += tp[v];
+    std::vector<int> tc((size_t)NZ), tm((size_t)NZ);
+    {
+        std::vector<long> cur(tp.begin(), tp.end() - 1);
+        for (int c = 0; c < NC; ++c)
+            for (long k = cp[c]; k < cp[c + 1]; ++k) {
+                const long pos = cur[cs[k]]++;
+                tc[pos] = c;
+                tm[pos] = cm[k];
+            }
+    }
+    std::vector<long> edges((size_t)NC);
+    for (int c = 0; c < NC; ++c) {
+        long e = 0;
+        for (int v : members[c])
+            if (ptr[v + 1] - ptr[v] <= kLongRow) e += ptr[v + 1] - ptr[v];
+        edges[c] = std::max(1L, e);
+    }
+    // LRU over source rows: intrusive list, head = most recent
+    std::vector<int> prv((size_t)V, -1), nxt((size_t)V, -1);
+    std::vector<char> cached((size_t)V, 0), placed((size_t)NC, 0);
+    int head = -1, tail = -1, ncached = 0;
+    std::vector<long> score((size_t)NC, 0);
+    struct Ent { double ratio; long sc; int c; };
+    auto cmp = [](const Ent &a, const Ent &b) { return a.ratio < b.ratio || (a.ratio == b.ratio && a.c > b.c); };
+    std::priority_queue<Ent, std::vector<Ent>, decltype(cmp)> heap(cmp);
+    auto push = [&](int c) { heap.push({(double)score[c] / (double)edges[c], score[c], c}); };
+    auto unlink = [&](int s) {
+        if (prv[s] >= 0) nxt[prv[s]] = nxt[s]; else head = nxt[s];
+        if (nxt[s] >= 0) prv[nxt[s]] = prv[s]; else tail = prv[s];
+    };
+    auto to_front = [&](int s) {
+        prv[s] = -1; nxt[s] = head;
+        if (head >= 0) prv[head] = s;
+        head = s;
+        if (tail < 0) tail = s;
+    };
+    auto touch = [&](int s) {
+        if (cached[s]) { unlink(s); to_front(s); return; }
+        cached[s] = 1; ++ncached;
+        to_front(s);
+        if (tp[s + 1] - tp[s] <= kHubCut)
+            for (long k = tp[s]; k < tp[s + 1]; ++k)
+                if (!placed[tc[k]]) { score[tc[k]] += tm[k]; push(tc[k]); }
+        if (ncached > cache_rows) {
+            const int old = tail;
+            unlink(old);
+            cached[old] = 0; --ncached;
+            if (tp[old + 1] - tp[old] <= kHubCut)
+                for (long k = tp[old]; k < tp[old + 1]; ++k)
+                    if (!placed[tc[k]]) score[tc[k]] -= tm[k];  // its heap entries go stale; re-pushed when popped
+        }
+    };
+    int pos = 0, seed = 0, seed2 = 0;
+    for (int done = 0; done < NC; ++done) {
+        int c = -1;
+        while (!heap.empty()) {
+            const Ent e = heap.top();
+            heap.pop();
+            if (placed[e.c]) continue;
+            if (e.sc != score[e.c]) { if (score[e.c] > 0) push(e.c); continue; }
+            if (e.sc <= 0) continue;
+            c = e.c;
+            break;
+        }
+        if (c < 0) {  // nothing related to the cache: next unplaced cluster in first-member order (source-less ones last)
+            while (seed < NC && (placed[seed] || cp[seed] == cp[seed + 1])) ++seed;
+            if (seed < NC) {
+                c = seed;
+            } else {
+                while (placed[seed2]) ++seed2;
+                c = seed2;
+            }
+        }
+        placed[c] = 1;
+        for (int v : members[c]) rows_out[pos++] = v;
+        for (long k = cp[c]; k < cp[c + 1]; ++k) touch(cs[k]);
+    }
+}
+
 int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int num_perm, int cap, uint64_t seed,
-                    int max_bucket, int *rows_out, int *num_clusters_out)
+                    int max_bucket, int *rows_out, int *num_clusters_out, int order_mode, int cache_rows)
 {
     if (V < 0 || num_perm < 1 || num_perm > 256 || cap < 1) return fail(GNNAGG_ERR_ARG, "bad cluster_reorder arguments");
+    if (order_mode < 0 || order_mode > 1 || (order_mode == 1 && cache_rows < 1)) return fail(GNNAGG_ERR_ARG, "bad cluster order mode");
     // sorted neighbor sets (the similarity is on sets; the CSR itself is not modified)
     std::vector<int> sidx(idx, idx + ptr[V]);
 #pragma omp parallel for schedule(dynamic, 1024)
@@ -102,6 +229,7 @@ int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int
     }
 
     struct Pair { double simi; int p1, p2; };
+    const bool no_merge = cap <= 1;  // cap 1: every node is its own cluster (the ordering pass alone)
     auto cmp = [](const Pair &a, const Pair &b) { return a.simi < b.simi; };
     std::priority_queue<Pair, std::vector<Pair>, decltype(cmp)> que(cmp);
     std::unordered_set<uint64_t> queued;
@@ -110,7 +238,7 @@ int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int
         return jaccard_sorted(sidx.data() + ptr[a], ptr[a + 1] - ptr[a], sidx.data() + ptr[b], ptr[b + 1] - ptr[b]);
     };
     // candidates: rows sharing a band bucket (empty rows are never queried, cluster2.py:83-84)
-    {
+    if (!no_merge) {
         std::vector<std::pair<uint64_t, int>> keys;
         keys.reserve(V);
         for (int b = 0; b < B; ++b) {
@@ -171,8 +299,12 @@ int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int
         if (first_pos[ro] < 0) { first_pos[ro] = (int)members.size(); members.emplace_back(); }
         members[first_pos[ro]].push_back(i);
     }
-    int pos = 0;
-    for (auto &mset : members) for (int v : mset) rows_out[pos++] = v;
+    if (order_mode == 1) {
+        emit_cache_greedy(ptr, idx, V, members, cache_rows, rows_out);
+    } else {
+        int pos = 0;
+        for (auto &mset : members) for (int v : mset) rows_out[pos++] = v;
+    }
     if (num_clusters_out) *num_clusters_out = (int)members.size();
     return GNNAGG_OK;
 }

@@ -17,8 +17,10 @@ Two execution plans share the same communication plan:
   (GNNAGG_FLAG_ACCUMULATE).  Deterministic; equals the single-GPU result up to the one extra fp32
   add per row that joins the two parts.
 
-torch.distributed is the transport only (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests);
-the send-buffer pack and the aggregation are HIP kernels behind the C-ABI.
+Transports (same plan, same buffers): "torch" = torch.distributed.all_to_all_single (backend "nccl" = RCCL on ROCm,
+"gloo" in the CPU tests); "rccl" = the C-ABI's own grouped ncclSend / ncclRecv (gnnagg_dist_halo_exchange)
+-- what a C++ driver uses (drivers/dist_step.cpp); torch.distributed then only carries the 128-byte unique id.  The
+send-buffer pack and the aggregation are HIP kernels behind the C-ABI either way.
 """
 import ctypes
 
@@ -39,6 +41,67 @@ def _hip_pack_rows(x, ids, out):
                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
+class _StreamWork:
+    """What exchange(async_op=True) returns for the C-ABI transport: wait() makes the current stream wait for the
+    communication stream (the counterpart of torch.distributed's Work.wait())."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class RcclTransport:
+    """The C-ABI's RCCL communicator (gnnagg_dist_*): created from a unique id that rank 0 draws and torch.distributed
+    broadcasts (any launcher channel would do: drivers/dist_step.cpp passes it through a file)."""
+
+    def __init__(self, group=None, device=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            check(lib().gnnagg_dist_unique_id(buf))
+        holder = [bytes(buf.raw)]
+        dist.broadcast_object_list(holder, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self._h = ctypes.c_int64(0)
+        with torch.cuda.device(dev):
+            check(lib().gnnagg_dist_comm_create(ctypes.c_char_p(holder[0]), self.rank, self.world, ctypes.byref(self._h)))
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def close(self):
+        if self._h.value:
+            lib().gnnagg_dist_comm_destroy(self._h)
+            self._h = ctypes.c_int64(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alltoallv(self, send, send_counts, recv, recv_counts):
+        """Contiguous device tensors, counts in elements of send.element_size() per rank; on the current stream."""
+        n = self.world
+        sc = (ctypes.c_longlong * n)(*[int(v) for v in send_counts])
+        rc = (ctypes.c_longlong * n)(*[int(v) for v in recv_counts])
+        check(lib().gnnagg_dist_alltoallv(self._h, ctypes.c_void_p(send.data_ptr()), sc, ctypes.c_void_p(recv.data_ptr()), rc,
+                                          int(send.element_size()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def halo_exchange(self, x_local, send_ids, send_rows, recv_rows, send_buf, x_halo, async_op):
+        n = self.world
+        sc = (ctypes.c_longlong * n)(*[int(v) for v in send_rows])
+        rc = (ctypes.c_longlong * n)(*[int(v) for v in recv_rows])
+        st = self.stream if async_op else torch.cuda.current_stream()
+        if async_op:
+            st.wait_stream(torch.cuda.current_stream())      # x_local is ready when the pack starts
+        check(lib().gnnagg_dist_halo_exchange(self._h, ctypes.c_void_p(x_local.data_ptr()), ctypes.c_void_p(send_ids.data_ptr()),
+                                              sc, rc, int(x_local.shape[1]), ctypes.c_void_p(send_buf.data_ptr()),
+                                              ctypes.c_void_p(x_halo.data_ptr()), ctypes.c_void_p(st.cuda_stream)))
+        return _StreamWork(st) if async_op else None
+
+
 class HaloExchange:
     """Static communication plan of one rank + the per-aggregation exchange.
 
@@ -49,17 +112,35 @@ class HaloExchange:
     """
 
     def __init__(self, ptr, idx, rank=None, world=None, group=None, device="cpu", bounds=None, pack_fn=None,
-                 offline=False):
+                 offline=False, row_slice=False, num_cols=None, transport="torch"):
+        """row_slice=False: (ptr, idx) is the global CSR (every rank holds it at plan time).  row_slice=True: (ptr, idx) are
+        THIS rank's rows only -- ptr[0 .. n_local] with any base offset, idx with global column ids -- and `bounds`
+        (partition_rows of the global ptr, e.g. computed by rank 0 and broadcast) and `num_cols` are required.
+        transport: "torch" (torch.distributed all_to_all_single) or "rccl" (the C-ABI's grouped send/recv)."""
         self.group = group
         self.offline = offline
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.device = torch.device(device)
         self.pack_fn = pack_fn or _hip_pack_rows
+        self.rccl = None
+        if transport == "rccl" and not offline and self.world > 1:
+            self.rccl = RcclTransport(group, self.device)
+        elif transport not in ("torch", "rccl"):
+            raise ValueError("transport must be 'torch' or 'rccl'")
         ptr = np.ascontiguousarray(ptr, dtype=np.int32)
         idx = np.ascontiguousarray(idx, dtype=np.int32)
-        self.bounds = partition_rows(ptr, self.world) if bounds is None else np.asarray(bounds, np.int32)
-        plan = halo_plan(ptr, idx, self.bounds, self.rank)
+        if row_slice:
+            if bounds is None or num_cols is None:
+                raise ValueError("row_slice=True needs bounds and num_cols")
+            self.bounds = np.asarray(bounds, np.int32)
+            plan = halo_plan(ptr, idx, self.bounds, self.rank, row_slice=True, num_cols=int(num_cols))
+            self.e0 = int(ptr[0])
+            self.e1 = int(ptr[-1])
+        else:
+            self.bounds = partition_rows(ptr, self.world) if bounds is None else np.asarray(bounds, np.int32)
+            plan = halo_plan(ptr, idx, self.bounds, self.rank)
+            self.e0, self.e1 = int(ptr[self.bounds[self.rank]]), int(ptr[self.bounds[self.rank + 1]])
         self.n_local = plan["n_local"]
         self.local_ptr = plan["local_ptr"]
         self.local_idx = plan["local_idx"]
@@ -67,7 +148,6 @@ class HaloExchange:
         self.recv_counts = plan["halo_counts"].astype(np.int64)  # rows received from each rank
         self.n_halo = int(len(self.halo_ids))
         self.row0 = int(self.bounds[self.rank])
-        self.e0, self.e1 = int(ptr[self.bounds[self.rank]]), int(ptr[self.bounds[self.rank + 1]])
         if offline:
             self.send_counts = np.zeros(self.world, np.int64)
             self.send_ids = torch.zeros(0, dtype=torch.int32, device=self.device)
@@ -125,6 +205,8 @@ class HaloExchange:
         feat = x_local.shape[1]
         if send_buf is None or send_buf.shape[0] < self.n_send:
             send_buf = torch.empty((max(self.n_send, 1), feat), dtype=x_local.dtype, device=x_local.device)
+        if self.rccl is not None:
+            return self.rccl.halo_exchange(x_local, self.send_ids, self.send_counts, self.recv_counts, send_buf, x_halo, async_op)
         if self.n_send:
             self.pack_fn(x_local, self.send_ids, send_buf)
         return dist.all_to_all_single(x_halo, send_buf[:self.n_send],
@@ -136,13 +218,20 @@ class PartitionedGCN:
     """Row-partitioned GCN/SAGE aggregation: y_local = A[rows of this rank, :] @ X (global)."""
 
     def __init__(self, ptr, idx, val=None, feat=128, group=None, device=None, mode="balanced", rank=None, world=None,
-                 overlap=True, offline=False):
+                 overlap=True, offline=False, row_slice=False, bounds=None, num_cols=None, transport="torch"):
+        """row_slice=True: ptr / idx / val hold this rank's rows only (see HaloExchange)."""
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.hx = HaloExchange(ptr, idx, rank=rank, world=world, group=group, device=device, offline=offline)
+        self.hx = HaloExchange(ptr, idx, rank=rank, world=world, group=group, device=device, offline=offline,
+                               row_slice=row_slice, bounds=bounds, num_cols=num_cols, transport=transport)
         hx = self.hx
         self.feat, self.mode = feat, mode
         self.overlap = bool(overlap) and mode == "balanced"
-        val_loc = None if val is None else np.ascontiguousarray(np.asarray(val, np.float32)[hx.e0:hx.e1])
+        if val is None:
+            val_loc = None
+        elif row_slice:
+            val_loc = np.ascontiguousarray(np.asarray(val, np.float32))
+        else:
+            val_loc = np.ascontiguousarray(np.asarray(val, np.float32)[hx.e0:hx.e1])
         self.x_ext = hx.alloc_x_ext(feat)                # [X_local ; X_halo], one allocation
         self.x_local = self.x_ext[:hx.n_local]
         self.x_halo = self.x_ext[hx.n_local:]

@@ -249,6 +249,13 @@ int gnnagg_locality_schedule(const int *h_ptr, const int *h_idx, const float *h_
  * h_rows_out[i] = old node id placed at new position i: the content of a <dset>.reorder<suffix> file. */
 int gnnagg_cluster_reorder(const int *h_ptr, const int *h_idx, int num_v, float threshold, int num_perm, int cluster_cap,
                            unsigned long long seed, int *h_rows_out, int *num_clusters);
+/* The same clustering with a choice of the order the clusters are written in.  order_mode 0: by first member (the
+ * reference script, cluster2.py:156-171; = gnnagg_cluster_reorder).  order_mode 1: cache-aware greedy -- each next cluster
+ * is the one whose rows find the largest share of their source rows among the cache_rows most recently gathered rows (an
+ * LRU model of one XCD's L2; 0 = 4096 rows, 2 MB of 512-byte feature rows), so clusters with overlapping neighbor sets
+ * become neighbors in the new numbering. */
+int gnnagg_cluster_reorder_ex(const int *h_ptr, const int *h_idx, int num_v, float threshold, int num_perm, int cluster_cap,
+                              unsigned long long seed, int order_mode, int cache_rows, int *h_rows_out, int *num_clusters);
 
 /* ---------------------------------------------------------------------------------------------
  * D. 1-D row partition + halo exchange support
@@ -262,8 +269,36 @@ int gnnagg_partition_rows(const int *h_ptr, int num_v, int nparts, int *h_bounds
  * global ids of the halo slots; h_halo_counts[nparts] = halo ids owned by each rank. */
 int gnnagg_halo_plan(const int *h_ptr, const int *h_idx, int num_v, const int *h_bounds, int nparts, int rank,
                      int *h_local_ptr, int *h_local_idx, int **h_halo_ids, int *h_halo_counts, int *num_halo);
+/* The same plan from the rank's OWN rows only: h_ptr_slice[0 .. n_local] (any base offset: the slice of a global ptr array
+ * or a 0-based local one) and h_idx_slice[nnz_local] with GLOBAL column ids; num_cols = global column count.  Nothing of
+ * the other ranks' rows is needed (gnnagg_halo_plan reads the same data out of a global CSR). */
+int gnnagg_halo_plan_slice(const int *h_ptr_slice, const int *h_idx_slice, int num_cols, const int *h_bounds, int nparts, int rank,
+                           int *h_local_ptr, int *h_local_idx, int **h_halo_ids, int *h_halo_counts, int *num_halo);
 /* out[i,:] = x[ids[i],:] for i < n  (send-buffer pack before the all-to-all) */
 int gnnagg_pack_rows(const float *d_x, const int *d_ids, int n, int feat, float *d_out, void *hip_stream);
+
+/* RCCL transport (one process per GPU; SURVEY.md 8e: grouped ncclSend / ncclRecv over the xGMI mesh).  librccl is loaded
+ * on first use (GNNAGG_ERR_STATE when it cannot be); the communicator binds to the calling thread's current HIP device.
+ *   gnnagg_dist_unique_id            rank 0 creates the 128-byte id; the launcher hands it to the other ranks (a file, an
+ *                                    environment variable, MPI, a torch.distributed broadcast ...)
+ *   gnnagg_dist_comm_create          every rank, same id (collective: returns when all `world` ranks have called it)
+ *   gnnagg_dist_comm_create_from_file  the same with the id passed through `path` (rank 0 writes it atomically, the others
+ *                                    poll for up to timeout_s seconds): all a C++ driver started once per GPU needs
+ *   gnnagg_dist_alltoallv            h_send_counts[p] / h_recv_counts[p] elements of elem_bytes bytes to / from rank p,
+ *                                    packed contiguously in rank order in d_send / d_recv; asynchronous on hip_stream
+ *   gnnagg_dist_halo_exchange        one aggregation's halo pull: packs x_local[send_ids] (rows the peers asked for, in
+ *                                    rank order) into d_send_buf and exchanges rows of feat floats into d_x_halo */
+#define GNNAGG_UNIQUE_ID_BYTES 128
+typedef int64_t gnnagg_comm;
+int gnnagg_dist_unique_id(char *id128);
+int gnnagg_dist_comm_create(const char *id128, int rank, int world, gnnagg_comm *out);
+int gnnagg_dist_comm_create_from_file(const char *path, int rank, int world, int timeout_s, gnnagg_comm *out);
+int gnnagg_dist_comm_destroy(gnnagg_comm c);
+int gnnagg_dist_comm_info(gnnagg_comm c, int *rank, int *world);
+int gnnagg_dist_alltoallv(gnnagg_comm c, const void *d_send, const long long *h_send_counts, void *d_recv,
+                          const long long *h_recv_counts, int elem_bytes, void *hip_stream);
+int gnnagg_dist_halo_exchange(gnnagg_comm c, const float *d_x_local, const int *d_send_ids, const long long *h_send_rows,
+                              const long long *h_recv_rows, int feat, float *d_send_buf, float *d_x_halo, void *hip_stream);
 
 #ifdef __cplusplus
 }

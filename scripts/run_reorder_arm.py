@@ -20,6 +20,11 @@ ptr, idx = ptr.numpy(), idx.numpy()
 if arm == "lsh":
     rows, _ = gnc.cluster_reorder(ptr, idx)
     ptr, idx, _ = gnc.reorder_csr(ptr, idx, rows)
+elif arm.startswith("greedy"):   # greedy[:cache_rows[:cluster_cap]]
+    parts = arm.split(":")
+    rows, _ = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cache_rows=int(parts[1]) if len(parts) > 1 else 4096,
+                                  cluster_cap=int(parts[2]) if len(parts) > 2 else 1)
+    ptr, idx, _ = gnc.reorder_csr(ptr, idx, rows)
 elif arm == "community":
     V, E = gnc.graph.SHAPES["arxiv"]
     p, i = gnc.graph.powerlaw_csr(V, E, seed=123, community_order=True)

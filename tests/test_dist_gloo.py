@@ -63,6 +63,14 @@ def _worker(rank, world, port, F, q):
         scale = orc.gcn_abs_scale(ptr, idx, val, x)[r0:r1]
         ok_y = ok_y and bool(np.all(np.abs(y_split - y_global[r0:r1]) <= 1e-5 * scale + 1e-30))
         ok_y = ok_y and len(il) + len(ir) == hx.e1 - hx.e0 and (ir.max(initial=-1) < hx.n_halo)
+        # the same plan built from THIS rank's rows only (row slice + partition bounds): nothing of the global CSR needed
+        hs = HaloExchange(ptr[r0:r1 + 1], idx[ptr[r0]:ptr[r1]], device="cpu", row_slice=True, bounds=hx.bounds, num_cols=V,
+                          pack_fn=lambda xs, ids, out: out[:ids.numel()].copy_(xs.index_select(0, ids.long())))
+        ok_slice = (np.array_equal(hs.local_ptr, hx.local_ptr) and np.array_equal(hs.local_idx, hx.local_idx) and
+                    np.array_equal(hs.halo_ids, hx.halo_ids) and np.array_equal(hs.recv_counts, hx.recv_counts) and
+                    np.array_equal(hs.send_counts, hx.send_counts) and torch.equal(hs.send_ids, hx.send_ids) and
+                    (hs.e0, hs.e1) == (hx.e0, hx.e1))
+        ok_y = ok_y and ok_slice
         tot = torch.tensor([hx.e1 - hx.e0, hx.n_local], dtype=torch.int64)
         dist.all_reduce(tot)
         q.put((rank, ok_halo, ok_y, int(tot[0]) == E, int(tot[1]) == V, hx.n_halo, int(hx.send_counts.sum())))

@@ -3,6 +3,7 @@ datasketch's hashing is not reproducible here (parity unpinned), s
 what is pinned: a valid permutation, planted clusters come out contiguous, the cluster cap holds, the file it
 produces is consumed by the loader, and aggregation results are permutation-invariant."""
 import numpy as np
+import pytest
 
 import gnn_computing_amd as gnc
 from gnn_computing_amd import graph
@@ -78,3 +79,56 @@ def test_degenerate_inputs():
     assert rows.tolist() == [0, 1, 2, 3, 4] and nc == 5  # empty rows are never queried (cluster2.py:83-84)
     rows, nc = gnc.cluster_reorder(np.array([0], np.int32), np.zeros(0, np.int32))
     assert len(rows) == 0
+
+
+def _lru_hit_rate(ptr, idx, cap):
+    """Share of the gathers that find their source row among the `cap` most recently gathered ones (rows in order)."""
+    from collections import OrderedDict
+    lru, hits = OrderedDict(), 0
+    for s in idx.tolist():
+        if s in lru:
+            hits += 1
+            lru.move_to_end(s)
+        else:
+            lru[s] = 1
+            if len(lru) > cap:
+                lru.popitem(last=False)
+    return hits / max(len(idx), 1)
+
+
+@pytest.mark.parametrize("cluster_cap", [1, 64])
+def test_cache_greedy_order_is_a_permutation_and_finds_hidden_locality(cluster_cap):
+    """order_mode 1 (gnnagg_cluster_reorder_ex): a hidden ring order with windowed neighbor sets, scattered by a random
+    relabelling.  The cache-aware greedy order must be a valid permutation and recover a large part of the reuse the hidden
+    order has -- far more than the first-member order of the same clusters."""
+    V, deg, window = 6000, 8, 64
+    rng = np.random.default_rng(5)
+    sigma = rng.permutation(V)                      # node -> hidden position
+    inv = np.argsort(sigma)
+    ptr = np.arange(0, (V + 1) * deg, deg, dtype=np.int32)
+    pos = (sigma[:, None] + rng.integers(-window, window + 1, (V, deg))) % V
+    idx = np.sort(inv[pos], axis=1).astype(np.int32).ravel()
+    cap_rows = 256
+    rows_g, nc_g = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=cluster_cap, cache_rows=cap_rows)
+    rows_f, nc_f = gnc.cluster_reorder(ptr, idx, order="first_member", cluster_cap=cluster_cap)
+    assert sorted(rows_g.tolist()) == list(range(V)) and nc_g == nc_f
+    if cluster_cap == 1:
+        assert nc_g == V and np.array_equal(rows_f, np.arange(V))      # singleton clusters: first-member order = identity
+    hit = {}
+    for name, rows in (("greedy", rows_g), ("first", rows_f), ("hidden", inv.astype(np.int32))):
+        p, i, _ = gnc.reorder_csr(ptr, idx, rows)
+        hit[name] = _lru_hit_rate(p, i, cap_rows)
+    assert hit["hidden"] > 0.8
+    assert hit["greedy"] > 0.6 * hit["hidden"] and hit["greedy"] > hit["first"] + 0.05
+    if cluster_cap == 1:
+        assert hit["first"] < 0.3 and hit["greedy"] > 2 * hit["first"]   # (the scattered numbering itself has no reuse)
+
+
+def test_cluster_reorder_ex_argument_checks():
+    import ctypes
+    from gnn_computing_amd._lib import check
+    ptr, idx, _ = planted(4, 6, 10, 3)
+    rows = np.empty(len(ptr) - 1, np.int32)
+    with pytest.raises(gnc.GnnAggError):   # unknown order mode
+        check(gnc.lib().gnnagg_cluster_reorder_ex(ptr.ctypes.data, idx.ctypes.data, len(ptr) - 1, ctypes.c_float(0.2), 64, 64,
+                                                  ctypes.c_ulonglong(1), 7, 4096, rows.ctypes.data, None))
