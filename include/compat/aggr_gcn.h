@@ -63,7 +63,7 @@ public:
         int nb = 0;
         checkGnnagg(gnnagg_gcn_run_clock(handle, nullptr, nullptr, feat_in, scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS,
                                          nullptr, &nb, nullptr));
-        clock_capacity = nb;
+        clock_capacity[scheduled ? 1 : 0] = nb;
         return nb;
     }
     double run_clock(float *vin, float *vout, clocktype *timer, int BLOCK_SIZE, bool scheduled)
@@ -71,7 +71,7 @@ public:
         (void)BLOCK_SIZE;
         // in: the workgroups `timer` has room for -- what clock_blocks() answered; a caller that sized the buffer itself
         // (as the reference's drivers do) is trusted like the reference trusts it
-        int nb = clock_capacity > 0 ? clock_capacity : 0x7fffffff;
+        int nb = clock_capacity[scheduled ? 1 : 0] > 0 ? clock_capacity[scheduled ? 1 : 0] : 0x7fffffff;
         checkHipErrors(hipDeviceSynchronize());
         timestamp(t0);
         checkGnnagg(gnnagg_gcn_run_clock(handle, vin, vout, feat_in, scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS, timer,
@@ -101,6 +101,6 @@ public:
 
 private:
     float *d_val = nullptr;
-    int clock_capacity = 0;  // last answer of clock_blocks()
+    int clock_capacity[2] = {0, 0};  // last answer of clock_blocks(scheduled = 0 / 1)
 };
 #endif
