@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 FEAT = 128
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+L2_GATHER_PEAK_GBPS = 24500.0  # measured: 256-byte row gathers from an XCD's own L2 (profiles/r02/gather_ceiling.txt)
 
 
 def algorithmic_bytes(V, E, F, explicit_val=True):
@@ -240,13 +241,14 @@ def run_other_config(args, dev):
     name = {"R": "reddit", "G": "reddit", "P1": "products"}[args.config]
     ptr, idx = gnc.graph.dataset(name, device=dev)
     V, E = ptr.numel() - 1, idx.numel()
+    H = 1
     if args.config == "R":
         F, what = 602, "reddit-shaped CSR %dx%d, GraphSAGE mean, feat=602, implicit weights, mode=balanced" % (V, E)
         agg = gnc.Aggregator_GCN(ptr, idx, None, F, F)
         x, y = torch.randn((V, F), device=dev), torch.empty((V, F), device=dev)
         step = lambda: agg.run(x, y, 512, "balanced", reduce="mean")  # noqa: E731
         B = E * (4 * F + 4) + V * 4 * F + 4 * (V + 1)
-        kernel = "k_gcn_plan"
+        kernel = "k_gcn_span (+ k_tile_x, k_combine_groups)"
     elif args.config == "G":
         H, F = 8, 256
         what = "reddit-shaped CSR %dx%d, GAT 8 heads x 32 fused edge-softmax + SpMM, mode=balanced" % (V, E)
@@ -255,7 +257,7 @@ def run_other_config(args, dev):
         att = torch.randn((V, H, 2), device=dev)
         step = lambda: agg.run(x, att, y, 128, "balanced", heads=H)  # noqa: E731
         B = E * (4 * F + 4 + 4 * H) + V * (4 * F + 4 * H) + 4 * (V + 1)
-        kernel = "k_gat_plan"
+        kernel = "k_gat_span (+ k_tile_x, k_combine_groups_gat)"
     else:
         F, what = 100, "products-shaped CSR %dx%d, GCN sum, feat=100, explicit unit weights, mode=balanced, 1 GPU" % (V, E)
         agg = gnc.Aggregator_GCN(ptr, idx, torch.ones(E, device=dev), F, F)
@@ -266,14 +268,33 @@ def run_other_config(args, dev):
     steps, warm = min(args.steps, 20), min(args.warmup, 3)
     wall, dev_s, med_s = time_steps(step, steps, warm, lambda: None)
     achieved = B / dev_s / 1e9
+    # ceiling: the gather probe of the same launch sequence (GCN configs); the fused GAT has no probe instantiation -- its
+    # ceiling is the measured L2-resident 256-byte row-gather rate of scripts/micro/gather_ceiling.hip (24.5 TB/s)
+    probe_s = None
+    if args.config != "G":
+        _, probe_s, _ = time_steps(lambda: agg.probe_gather(x, "balanced"), steps, warm, lambda: None)
+    peak = B / probe_s / 1e9 if probe_s else L2_GATHER_PEAK_GBPS
+    traffic, traffic_label = pmc_traffic(args.config)
+    explicit = args.config == "P1"
+    C = (2 * V * 4 * F + E * (4 + (4 if explicit else 0)) + (V + 1) * 4) + (V * 8 * H * 2 if args.config == "G" else 0)
     return {"metric": "aggregated edges/sec, config %s" % args.config, "value": E / (wall / steps), "unit": "edges/s",
             "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": wall / steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": what, "num_v": V, "num_e": E, "feat": F},
+            "config": {"workload": what, "num_v": V, "num_e": E, "feat": F, "source_partitions": agg.balanced_partitions()},
             "achieved_gbps": achieved,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel, "algorithmic_bytes": B,
-                         "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6}}
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": min(1.0, achieved / peak),
+                         "frac_is": ("probe time / step time (same launch sequence, no FMA chains, no stores)" if probe_s else
+                                     "gather-model bytes per second over the measured L2-resident 256-B row-gather ceiling "
+                                     "(profiles/r02/gather_ceiling.txt)"),
+                         "traffic": traffic, "traffic_source": traffic_label, "kernel": kernel, "algorithmic_bytes": B,
+                         "compulsory_bytes": C, "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
+                         "ceiling_probe_us": probe_s * 1e6 if probe_s else None,
+                         "hbm_peak_gbps": HBM_PEAK_GBPS, "gather_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
+                         "traffic_frac_of_hbm_peak": (traffic / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "compulsory_frac_of_hbm_peak": C / dev_s / 1e9 / HBM_PEAK_GBPS,
+                         "note": "the step is several launches (column-tiling of X, aggregation, ordered combine): times are of the "
+                                 "whole step, traffic of the dominant kernel; gather bytes are served by the L2 in the 2-D blocked "
+                                 "order, so gather_frac_of_hbm_peak is not an HBM utilisation"}}
 
 
 def run_multi(args, dev, rank, world):

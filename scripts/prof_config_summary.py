@@ -20,6 +20,13 @@ for f in glob.glob(os.path.join(out, "pmc_%s_*" % cfg, "**", "*counter_collectio
         a = pmc[r["Kernel_Name"]][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"])
         a[1] += 1
+import json
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    commit = os.environ.get("GNNAGG_BUILD_LABEL", "unknown")
+kernels = []
 print("# config %s %s -- per-launch averages; traffic = FETCH_SIZE*2*1024 + WRITE_SIZE*1024 (fabric side, Infinity-Cache hits included)" % (cfg, sys.argv[3] if len(sys.argv) > 3 else ""))
 tot = 0.0
 for k, (s, n) in sorted(dur.items(), key=lambda t: -t[1][0]):
@@ -32,8 +39,14 @@ for k, (s, n) in sorted(dur.items(), key=lambda t: -t[1][0]):
     print("%-70s n=%3d avg %10.1f us  traffic %8.2f GB (%6.2f TB/s)  fetch %8.2f GB write %8.2f GB  L2 hit %.3f  tcp->tcc rd %.3g  ea rd %.3g" % (
         k[:70], n, avg, traffic / 1e9, traffic / avg / 1e6 if avg else 0, c.get("FETCH_SIZE", 0) * 2048 / 1e9, c.get("WRITE_SIZE", 0) * 1024 / 1e9, hit,
         c.get("TCP_TCC_READ_REQ_sum", 0), c.get("TCC_EA0_RDREQ_sum", 0)))
+    kernels.append({"kernel": k, "launches": n, "avg_us": avg, "traffic_bytes": traffic, "fetch_bytes": c.get("FETCH_SIZE", 0) * 2048,
+                    "write_bytes": c.get("WRITE_SIZE", 0) * 1024, "l2_hit": hit})
     extra = {n: v for n, v in c.items() if n.startswith(("SQ_", "TA_", "GRBM", "TCP_TOTAL"))}
     if extra:
         print("      " + "  ".join("%s=%.4g" % (n, v) for n, v in sorted(extra.items())))
     tot += avg
 print("sum of per-launch averages: %.1f us" % tot)
+json.dump({"config": cfg, "options": sys.argv[3] if len(sys.argv) > 3 else "", "build": os.environ.get("GNNAGG_BUILD_LABEL", commit),
+           "_correction": "FETCH_SIZE (KB) x 2 x 1024 (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE "
+                          "(KB) x 1024; fabric-side counters, Infinity-Cache hits included; separate --pmc passes",
+           "kernels": kernels}, open(os.path.join(out, "summary_%s.json" % cfg), "w"), indent=1)

@@ -16,13 +16,13 @@ F = sys.argv[1] if len(sys.argv) > 1 else "128"
 d = tempfile.mkdtemp() + "/"
 ptr, idx = gnc.graph.dataset("arxiv")
 gnc.graph.write_graph_files(d, "arxiv", ptr.numpy(), idx.numpy(), text=False, dumps=True)
-rows, _ = gnc.cluster_reorder(ptr.numpy(), idx.numpy())
+rows, _ = gnc.cluster_reorder(ptr.numpy(), idx.numpy(), order="cache_greedy", cluster_cap=1, cache_rows=8192)
 gnc.graph.write_reorder_file(d, "arxiv", np.asarray(rows, np.int32))
 for exe, extra in (("fig8.out", ["--nei", "16"]), ("fig9.out", ["--nei", "32"]), ("fig9.out", ["--nei", "32", "--reorder", "_thres_0.2"]),
                    ("fig10a.out", ["--nei", "32"]), ("fig10b.out", ["--nei", "64", "--outfea", "32"])):
     r = subprocess.run([os.path.join(ROOT, "drivers", exe), "--dataset", "arxiv", "--datadir", d, "--feature-len", F] + extra,
                        capture_output=True, text=True, timeout=600)
-    print("==", exe, " ".join(extra), "rc", r.returncode)
+    print("==", exe, " ".join(extra), "rc", r.returncode, "GNNAGG_FAST_ROWS=" + os.environ.get("GNNAGG_FAST_ROWS", "0"))
     for line in r.stderr.splitlines():
         if line.startswith("{"):
             print("  ", line[:260])
