@@ -133,10 +133,34 @@ static void emit_cache_greedy(const int *ptr, const int *idx, int V, const std::
     std::vector<char> cached((size_t)V, 0), placed((size_t)NC, 0);
     int head = -1, tail = -1, ncached = 0;
     std::vector<long> score((size_t)NC, 0);
-    struct Ent { double ratio; long sc; int c; };
-    auto cmp = [](const Ent &a, const Ent &b) { return a.ratio < b.ratio || (a.ratio == b.ratio && a.c > b.c); };
-    std::priority_queue<Ent, std::vector<Ent>, decltype(cmp)> heap(cmp);
-    auto push = [&](int c) { heap.push({(double)score[c] / (double)edges[c], score[c], c}); };
+    // Candidates in a bucket queue keyed by the cached share score / edges (kBuckets levels; O(1) per score change, O(NC)
+    // memory: a binary heap with lazy deletion grew to tens of GB on the products-shaped graph).  Inside a bucket the most
+    // recently touched cluster goes first.
+    constexpr int kBuckets = 128;
+    std::vector<int> bprev((size_t)NC, -1), bnext((size_t)NC, -1), inb((size_t)NC, -1), bhead(kBuckets + 1, -1);
+    int top = -1;
+    auto bucket_of = [&](int c) -> int {
+        if (score[c] <= 0) return -1;
+        const long b = score[c] * kBuckets / edges[c];
+        return (int)std::min<long>(b, kBuckets);
+    };
+    auto b_unlink = [&](int c) {
+        const int b = inb[c];
+        if (b < 0) return;
+        if (bprev[c] >= 0) bnext[bprev[c]] = bnext[c]; else bhead[b] = bnext[c];
+        if (bnext[c] >= 0) bprev[bnext[c]] = bprev[c];
+        inb[c] = -1;
+    };
+    auto b_update = [&](int c) {  // after a score change: move c to the front of its (new) bucket
+        const int b = bucket_of(c);
+        b_unlink(c);
+        if (b < 0) return;
+        bprev[c] = -1; bnext[c] = bhead[b];
+        if (bhead[b] >= 0) bprev[bhead[b]] = c;
+        bhead[b] = c;
+        inb[c] = b;
+        if (b > top) top = b;
+    };
     auto unlink = [&](int s) {
         if (prv[s] >= 0) nxt[prv[s]] = nxt[s]; else head = nxt[s];
         if (nxt[s] >= 0) prv[nxt[s]] = prv[s]; else tail = prv[s];
@@ -153,28 +177,21 @@ static void emit_cache_greedy(const int *ptr, const int *idx, int V, const std::
         to_front(s);
         if (tp[s + 1] - tp[s] <= kHubCut)
             for (long k = tp[s]; k < tp[s + 1]; ++k)
-                if (!placed[tc[k]]) { score[tc[k]] += tm[k]; push(tc[k]); }
+                if (!placed[tc[k]]) { score[tc[k]] += tm[k]; b_update(tc[k]); }
         if (ncached > cache_rows) {
             const int old = tail;
             unlink(old);
             cached[old] = 0; --ncached;
             if (tp[old + 1] - tp[old] <= kHubCut)
                 for (long k = tp[old]; k < tp[old + 1]; ++k)
-                    if (!placed[tc[k]]) score[tc[k]] -= tm[k];  // its heap entries go stale; re-pushed when popped
+                    if (!placed[tc[k]]) { score[tc[k]] -= tm[k]; b_update(tc[k]); }
         }
     };
     int pos = 0, seed = 0, seed2 = 0;
     for (int done = 0; done < NC; ++done) {
         int c = -1;
-        while (!heap.empty()) {
-            const Ent e = heap.top();
-            heap.pop();
-            if (placed[e.c]) continue;
-            if (e.sc != score[e.c]) { if (score[e.c] > 0) push(e.c); continue; }
-            if (e.sc <= 0) continue;
-            c = e.c;
-            break;
-        }
+        while (top >= 0 && bhead[top] < 0) --top;
+        if (top >= 0) c = bhead[top];
         if (c < 0) {  // nothing related to the cache: next unplaced cluster in first-member order (source-less ones last)
             while (seed < NC && (placed[seed] || cp[seed] == cp[seed + 1])) ++seed;
             if (seed < NC) {
@@ -184,6 +201,7 @@ static void emit_cache_greedy(const int *ptr, const int *idx, int V, const std::
                 c = seed2;
             }
         }
+        b_unlink(c);
         placed[c] = 1;
         for (int v : members[c]) rows_out[pos++] = v;
         for (long k = cp[c]; k < cp[c + 1]; ++k) touch(cs[k]);
