@@ -59,23 +59,32 @@ def log(*a):
 
 def time_steps(step_fn, steps, warmup, barrier):
     """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides.
-    Returns (wall seconds for K steps, avg device seconds per step from HIP events on the launch stream)."""
+    Returns (wall seconds for the K steps, avg device seconds per step from ONE pair of HIP events around the K launches on
+    the launch stream, median device seconds per step).  Nothing but the K steps is enqueued inside the timed region: an
+    event record between launches is a barrier packet that drains the queue (it cost ~3 us per 80 us step); the per-step
+    median comes from a separate pass with one event pair per launch, after the timed region."""
     for _ in range(warmup):
         step_fn()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step_fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev = ev0.elapsed_time(ev1) * 1e-3 / steps
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     evs[0].record()
     for i in range(steps):
         step_fn()
         evs[i + 1].record()
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev = evs[0].elapsed_time(evs[steps]) * 1e-3 / steps
     per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e-3 for i in range(steps))
     return wall, dev, per[len(per) // 2]
 

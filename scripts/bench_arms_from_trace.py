@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-arm averages of the aggregation kernel from the rocprofv3 kernel trace of `bench.py --steps K --warmup W`: the bench
 launches the same kernel for several inputs one after the other (no reorder, locality reorder = the headline arm, MinHash
-clusters, uniform-random ids), each W warm-up + K timed launches; the probe launches are a different template
-instantiation.  usage: bench_arms_from_trace.py <kernel_trace.csv> K W"""
+clusters, uniform-random ids), each W warm-up + K timed launches + K launches with one event pair each (the median); the
+probe launches are a different template instantiation.  usage: bench_arms_from_trace.py <kernel_trace.csv> K W"""
 import csv
 import sys
 
@@ -15,7 +15,7 @@ probe = [r for r in rows if "false, true>" in r["Kernel_Name"]]
 def arms(rs, names):
     out = []
     for i, name in enumerate(names):
-        g = rs[i * (K + W) + W:(i + 1) * (K + W)]
+        g = rs[i * (2 * K + W) + W:i * (2 * K + W) + W + K]   # per arm: W warm-up, K timed, K more for the per-launch median
         if len(g) == K:
             us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in g]
             out.append("%-52s n=%d avg %.2f us  median %.2f us  (%s)" % (name, K, sum(us) / K, sorted(us)[K // 2], g[0]["Kernel_Name"][:60]))
