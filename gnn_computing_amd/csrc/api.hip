@@ -163,7 +163,7 @@ struct Ctx {
     int tiled = 1;         // source-partitioned balanced mode runs tile-major on the tiled image (GNNAGG_TILED=0: r01 order)
     // gnnagg_set_option knobs (defaults from the environment, see create())
     int opt_partitions = -1;   // -1: library decides (avg degree >= opt_part_min_deg), 0: never partition, N: N source ranges
-    int opt_part_min_deg = 192;
+    int opt_part_min_deg = 96;   // measured crossover of the blocked order against the chunked plan (profiles/r02/partition_threshold.txt)
     int opt_tile_w = 64;       // floats per column tile of the 2-D blocked mode
     int opt_slice_kb = 4096;   // target size of the X slice one XCD's L2 holds (measured optimum 4-6 MB on the reddit-shaped F=602 case)
     int opt_retile = 1;        // 0: gather from the caller's X when its rows are 128-byte aligned
@@ -553,8 +553,9 @@ static int build_partitioned(Ctx *c, int parts)
     c->plan_part.reset();
     Schedule &s = c->sched[1];
     // the segmented-stream kernel wants several groups per span: groups of at most 128 edges there
+    static const int span_chunk = getenv("GNNAGG_SPAN_CHUNK") ? std::max(1, atoi(getenv("GNNAGG_SPAN_CHUNK"))) : 128;
     const bool spans = c->tiled && c->use_spans;
-    int rc = build_locality(c, s, parts, spans ? std::min(pick_chunk(c), 128) : pick_chunk(c), -1,
+    int rc = build_locality(c, s, parts, spans ? std::min(pick_chunk(c), span_chunk) : pick_chunk(c), -1,
                             GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING, true);
     if (rc) return rc;
     c->partitions = s.par_num;
@@ -570,7 +571,7 @@ static int build_partitioned(Ctx *c, int parts)
     }
     for (int r : s.h_empty) t0.insert(t0.end(), {0, 0, r, r});
     p.n0 = (int)(t0.size() / 4);
-    p.chunk = spans ? std::min(pick_chunk(c), 128) : pick_chunk(c);
+    p.chunk = spans ? std::min(pick_chunk(c), span_chunk) : pick_chunk(c);
     p.t0_cost_prefix = s.cost_prefix;
     if ((rc = p.t0.upload(t0))) return rc;
     p.valid = true;

@@ -97,7 +97,7 @@ int gnnagg_destroy(gnnagg_handle h);
 int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
 /* Per-handle knobs (defaults come from the environment variables in brackets; DESIGN.md section 4 "A/B knobs"):
  *   "partitions" [GNNAGG_PARTITIONS]      -1 the library decides, 0 never, N > 0: N source ranges for the balanced mode
- *   "partition_min_degree" [GNNAGG_PART_MIN_DEG]  average degree from which the library partitions (192)
+ *   "partition_min_degree" [GNNAGG_PART_MIN_DEG]  average degree from which the library partitions (96)
  *   "tile_width" [GNNAGG_TILE_W]          floats per column tile of the 2-D blocked balanced mode: 32 / 64 / 128 / 256
  *   "slice_kb" [GNNAGG_SLICE_KB]          target size of the X slice an XCD's L2 holds (4096)
  *   "retile" [GNNAGG_RETILE], "tiled" [GNNAGG_TILED], "inkernel_combine" [GNNAGG_INKERNEL_COMBINE]   A/B switches
@@ -127,7 +127,7 @@ int gnnagg_balanced_params(gnnagg_handle h, int *chunk, int *seg_chunks);
  * GNNAGG_MODE_ROWS: one chain per row (*chunk = INT_MAX, *seg_chunks = 0). */
 int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks);
 /* Source partitions of the balanced mode: 0 for the chunked order reported by gnnagg_balanced_params; P > 0 when the library
- * chose the source-partitioned order for a high-degree graph (avg degree >= 192): the groups are those of
+ * chose the source-partitioned (2-D blocked) order for a high-degree graph (avg degree >= 96): the groups are those of
  * gnnagg_locality_schedule(par_num = P, neighbor_num = chunk, total = *total_cols) -- partition-major, row-minor, CSR order
  * inside a sub-row -- folded flat in ascending group order per row; gnnagg_get_schedule(h, GNNAGG_MODE_BALANCED, ...) returns
  * them.  *total_cols (may be NULL) = largest neighbor id + 1: the column count the ranges are cut from (the CSR need not be

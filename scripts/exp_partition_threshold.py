@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where the source-partitioned balanced mode starts to pay: V = 400 k rows, average degree swept, chunked plan vs 16 ranges.
-Run twice: GNNAGG_PARTITIONS=0 and GNNAGG_PARTITIONS=16 (the knob is read once per process)."""
+"""Where the 2-D blocked balanced mode starts to pay: V rows (argv[1], default 400 k), average degree swept, chunked plan
+("partitions" = 0) against the blocked order with the library's range count (forced on: "partition_min_degree" = 1)."""
 import os
 import sys
 
@@ -25,14 +25,20 @@ def t(fn, it=5):
     return a.elapsed_time(b) / it
 
 
-V = 400000
-for deg in (64, 100, 150, 200, 300):
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
+for deg in (32, 64, 100, 150, 200, 300):
     for F in (128, 256):
         ptr, idx = gnc.graph.powerlaw_csr(V, V * deg, seed=123, device=dev)
         x = torch.randn((V, F), device=dev)
         y = torch.empty((V, F), device=dev)
-        agg = gnc.Aggregator_GCN(ptr, idx, None, F, F)
-        agg.schedule_balanced(0)
-        ms = t(lambda: agg.run(x, y, 128, "balanced"))
-        print("deg %d F=%d partitions=%d: %.2f ms" % (deg, F, agg.balanced_partitions(), ms), flush=True)
-        del agg, x, y, ptr, idx
+        res = []
+        for opts in ({"partitions": 0}, {"partition_min_degree": 1}):
+            agg = gnc.Aggregator_GCN(ptr, idx, None, F, F)
+            for k, v in opts.items():
+                agg.set_option(k, v)
+            agg.schedule_balanced(0)
+            ms = t(lambda: agg.run(x, y, 128, "balanced"))
+            res.append("P=%d %.2f ms" % (agg.balanced_partitions(), ms))
+            del agg
+        print("V %d deg %d F=%d: chunked %s | blocked %s" % (V, deg, F, res[0], res[1]), flush=True)
+        del x, y, ptr, idx

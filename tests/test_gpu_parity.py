@@ -816,7 +816,7 @@ def test_gat_run_bwd(F):
 
 
 def test_balanced_mode_source_partitioned_on_high_degree_graph():
-    """avg degree >= 192: the balanced mode picks the source-partitioned order (16 column ranges, the reference's
+    """High average degree: the balanced mode picks the source-partitioned order (here forced to 16 column ranges, the reference's
     localityNeighborGrouping arrays, graph_schedule.h:156-243) -- GCN sum/mean/max, fused ReLU, accumulate (falls back to
     the chunked plan), run_with_nn and GAT, all against the oracle on the schedule the library reports."""
     V, E, F, H = 600, 200000, 64, 2
