@@ -258,7 +258,7 @@ struct GatSpanArgs {
 };
 
 template <int GROUP, int HT>
-__global__ __launch_bounds__(256) void k_gat_span(const GatSpanArgs A)
+__global__ __launch_bounds__(256, 4) void k_gat_span(const GatSpanArgs A)
 {
     const SpanArgs &a = A.s;
     // a whole 16-edge window of gathers in flight: this kernel waits on memory latency (SQ_WAIT_ANY 82 % of the wave cycles,
@@ -371,16 +371,18 @@ __global__ __launch_bounds__(256) void k_gat_span(const GatSpanArgs A)
         }
 #pragma unroll 1
         for (int j = 0; j < n; j += U) {
-            unsigned sr[U];
             Pack<VEC> xv[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) sr[u] = (unsigned)__shfl((int)my_s, j + u, GROUP);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (j + u < n) xv[u] = load_pack<VEC>(xcol + (size_t)(sr[u] & kIdMask) * a.xpitch);
+            for (int u = 0; u < U; ++u) {
+                const unsigned sid = (unsigned)__shfl((int)my_s, j + u, GROUP);
+                if (j + u < n) xv[u] = load_pack<VEC>(xcol + (size_t)(sid & kIdMask) * a.xpitch);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (j + u < n) {
+                    // (the id word is fetched from its lane again instead of being kept: 16 registers fewer per lane, and
+                    // registers -- 3 vs 4 waves per SIMD -- are what limits the gathers in flight here)
+                    const unsigned sru = (unsigned)__shfl((int)my_s, j + u, GROUP);
                     float w = __shfl(wk[0], j + u, GROUP);
 #pragma unroll
                     for (int k = 1; k < HT; ++k) {
@@ -390,8 +392,8 @@ __global__ __launch_bounds__(256) void k_gat_span(const GatSpanArgs A)
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
                     den += w;
-                    if (sr[u] & kLastFlag) {  // lane-group uniform: the group ends here
-                        if (sr[u] & kDirectFlag) {
+                    if (sru & kLastFlag) {  // lane-group uniform: the group ends here
+                        if (sru & kDirectFlag) {
                             const int row = __shfl(tw_c, g - gw0, GROUP);
                             if (col_ok) {
                                 if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
