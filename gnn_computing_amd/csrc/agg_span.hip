@@ -257,8 +257,10 @@ struct GatSpanArgs {
     float slope;
 };
 
+// (4 waves per SIMD asked for at 1-2 heads per tile: 128 registers, 7 of them spilled off the hot path -- 9.72 -> 9.47 ms on
+// the reddit-shaped 8 x 32 case; wider head counts keep their registers)
 template <int GROUP, int HT>
-__global__ __launch_bounds__(256, 4) void k_gat_span(const GatSpanArgs A)
+__global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSpanArgs A)
 {
     const SpanArgs &a = A.s;
     // a whole 16-edge window of gathers in flight: this kernel waits on memory latency (SQ_WAIT_ANY 82 % of the wave cycles,
