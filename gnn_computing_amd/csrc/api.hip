@@ -694,7 +694,8 @@ static TiledRun plan_tiles(const Ctx *c, const Schedule &s, const float *x, cons
     TiledRun t;
     t.partial_floats = (size_t)s.n_slots * feat;
     if (!c->tiled || lane_unit % 4 != 0) return t;  // (GAT: a lane's 4 columns must belong to one head)
-    const int tw = c->opt_tile_w;
+    int tw = c->opt_tile_w;
+    while (tw > 32 && tw / 2 >= feat) tw /= 2;  // narrow features: no lanes on columns that do not exist (F <= 32: 8-lane groups)
     t.ntiles = (feat + tw - 1) / tw;
     const bool direct_ok = ((size_t)feat * 4) % 128 == 0 && ((uintptr_t)x % 128) == 0;
     t.retile = c->opt_retile != 0 || !direct_ok;

@@ -29,7 +29,7 @@ def blocked_reference(agg, ptr, idx, val):
     return orc.locality_schedule(ptr, idx, parts, cols, ng=chunk, val=val)
 
 
-@pytest.mark.parametrize("F", [602, 100, 64, 30, 33, 256])
+@pytest.mark.parametrize("F", [602, 100, 64, 30, 33, 256, 8])
 @pytest.mark.parametrize("slice_kb,tile_w", [(16, 64), (64, 32), (4, 128)])
 def test_blocked_gcn_matches_the_restated_order(F, slice_kb, tile_w):
     """Auto-chosen range count from (columns x tile bytes / slice), every column-tile geometry, Y rows that are 16-, 8- and
@@ -93,7 +93,7 @@ def test_blocked_mode_a_b_switches_give_identical_results():
         assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, vs, x, V, seg=0)), str(opts)
 
 
-@pytest.mark.parametrize("F,H", [(256, 8), (64, 1), (96, 4), (30, 3)])
+@pytest.mark.parametrize("F,H", [(256, 8), (64, 1), (96, 4), (30, 3), (32, 1), (16, 2)])
 def test_blocked_gat_and_newval_in_csr_edge_order(F, H):
     """GAT on the blocked order (head width 3 is not a multiple of the 16-byte lanes: the library keeps the row-major
     geometry there), and the un-normalised weights come back in CSR edge order although the kernel walks a permuted
