@@ -167,6 +167,7 @@ struct Ctx {
     int opt_tile_w = 64;       // floats per column tile of the 2-D blocked mode
     int opt_slice_kb = 4096;   // target size of the X slice one XCD's L2 holds (measured optimum 4-6 MB on the reddit-shaped F=602 case)
     int opt_retile = 1;        // 0: gather from the caller's X when its rows are 128-byte aligned
+    int opt_scratch_limit_mb = 0;  // > 0: the blocked order may not take more scratch than this (else: half of the free memory)
     int use_spans = 1;         // GCN, tiled: the segmented-stream kernel (agg_span.hip); 0: one descriptor per lane group
     int fast_rows = 0;         // 1: `scheduled = 0` runs the balanced order (within 1e-5) instead of CSR-order chains
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
@@ -671,6 +672,7 @@ static int reserve_partitioned_scratch(Ctx *c, size_t partial_floats, size_t den
     if (grow == 0) return GNNAGG_OK;  // no API call: capture-safe once warm
     size_t free_b = 0, total_b = 0;
     bool ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && grow * sizeof(float) <= free_b / 2 + (c->partial.n + c->partial_den.n + c->xt.n) * sizeof(float);
+    if (c->opt_scratch_limit_mb > 0 && (partial_floats + den_floats + xt_floats) * sizeof(float) > (size_t)c->opt_scratch_limit_mb << 20) ok = false;
     if (ok) {
         ok = c->partial.reserve(partial_floats) == GNNAGG_OK && c->partial_den.reserve(den_floats) == GNNAGG_OK &&
              c->xt.reserve(xt_floats) == GNNAGG_OK;
@@ -1222,6 +1224,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "tile_width") { if (value != 32 && value != 64 && value != 128 && value != 256) return fail(GNNAGG_ERR_ARG, "tile_width: 32, 64, 128 or 256"); c->opt_tile_w = value; replan = true; }
     else if (n == "slice_kb") { if (value < 1) return fail(GNNAGG_ERR_ARG, "slice_kb must be >= 1"); c->opt_slice_kb = value; replan = true; }
     else if (n == "retile") c->opt_retile = value;
+    else if (n == "scratch_limit_mb") c->opt_scratch_limit_mb = value;
     else if (n == "tiled") c->tiled = value;
     else if (n == "fast_rows") c->fast_rows = value;
     else if (n == "spans") { c->use_spans = value; replan = true; }

@@ -100,7 +100,10 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *   "partition_min_degree" [GNNAGG_PART_MIN_DEG]  average degree from which the library partitions (96)
  *   "tile_width" [GNNAGG_TILE_W]          floats per column tile of the 2-D blocked balanced mode: 32 / 64 / 128 / 256
  *   "slice_kb" [GNNAGG_SLICE_KB]          target size of the X slice an XCD's L2 holds (4096)
- *   "retile" [GNNAGG_RETILE], "tiled" [GNNAGG_TILED], "inkernel_combine" [GNNAGG_INKERNEL_COMBINE]   A/B switches
+ *   "scratch_limit_mb"                    > 0: cap on the scratch (partial rows + tiled image of X) the blocked order may take;
+ *                                         a handle that would need more -- or more than half of the free device memory, or
+ *                                         whose allocation fails -- moves to the chunked plan for good
+ *   "retile" [GNNAGG_RETILE], "tiled" [GNNAGG_TILED], "spans" [GNNAGG_SPANS], "overlap_combine", "inkernel_combine"   A/B switches
  *   "fast_rows" [GNNAGG_FAST_ROWS]        1: GNNAGG_MODE_ROWS (`scheduled = 0`) runs the balanced order -- results within the
  *                                         1e-5 bound instead of bit-exact CSR-order chains; 0 (default): canonical order
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */

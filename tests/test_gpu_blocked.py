@@ -295,3 +295,37 @@ def test_hub_fold_stress_two_handles_two_streams():
             bad += sum(0 if torch.equal(yy, refs[k]) else 1 for yy in ys)
     torch.cuda.synchronize()
     assert bad == 0
+
+
+def test_blocked_order_demotes_to_the_chunked_plan_when_its_scratch_does_not_fit():
+    """The blocked order needs one partial row per group and a tiled image of X; a handle whose scratch would not fit (here:
+    a 1 MB cap) moves to the chunked plan for good, reports that order from then on, and stays correct (round-1 advisor
+    finding: the description of the order has to follow the demotion)."""
+    V, E, F = 900, 260000, 128
+    ptr, idx = hub_graph(V, E, seed=5)
+    x, val = rand((V, F), 1), rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("slice_kb", 16)
+    assert agg.balanced_partitions() > 1
+    agg.set_option("scratch_limit_mb", 1)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), y, 128, "balanced")
+    assert agg.balanced_partitions() == 0
+    chunk, seg = agg.balanced_params()
+    assert seg == 16
+    ps, tg = orc.neighbor_grouping(ptr, chunk)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=seg))
+    got = agg.get_schedule("balanced")
+    assert np.array_equal(got[0], ps) and np.array_equal(got[2], tg)
+    agg.run(dev(x), y, 128, "balanced", reduce="mean")       # and it stays there
+    assert agg.balanced_partitions() == 0
+    # GAT handles demote the same way
+    att = rand((V, 2), 3) * 0.4
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.set_option("slice_kb", 16)
+    gat.set_option("scratch_limit_mb", 1)
+    gat.run(dev(x), dev(att), y, 128, "balanced")
+    assert gat.balanced_partitions() == 0
+    ch, sg = gat.balanced_params()
+    ref, _, _ = orc.gat_grouped(*orc.neighbor_grouping(ptr, ch), idx, att, x, V, 1, seg=sg)
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "demoted gat")
