@@ -66,6 +66,9 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
     if (s >= a.n_spans) return;
     const int F = a.feat;
     const int col = (tile * GROUP + lane) * VEC;
+    // lanes beyond the last feature column (F = 602: 9 of the 16 lanes of tile 9) neither gather nor store: the address
+    // path is what bounds this kernel, and it works per active lane / touched line
+    const bool col_ok = col < F;
     int g = a.span_g[s];
     const int g1 = a.span_g[s + 1];
     const int e0 = a.ptr_s[g], e_end = a.ptr_s[g1];
@@ -84,20 +87,31 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
         my_s = (unsigned)a.idx_f[e0 + lane];
         if (HAS_VAL) my_w = a.val_s[e0 + lane];
     }
-    // one batch of U edges of the window at cb: gathers issued together, then the chain in list order; FULL: no bound checks
-    auto batch = [&](auto full_tag, int cb, int j, int n) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    // one batch of U edges of the window at cb: gathers issued together, then the chain in list order.  JC >= 0: a full window,
+    // batch offset known at compile time (no bound checks; the id / value of edge JC + u comes by group_bcast: a DPP move for
+    // 16-lane groups); JC == -2: a full window, runtime offset; JC == -1: the last, partial window.
+    auto batch = [&](auto jc_tag, int cb, int j, int n) {
+        constexpr int JC = decltype(jc_tag)::value;
+        constexpr bool FULL = JC != -1;  // -2: a full window with a runtime batch offset (wider lane groups: no DPP form)
         unsigned sr[U];
         float w[U];
         Pack<VEC> xv[U];
+        if constexpr (JC >= 0) {
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                sr[u] = (unsigned)group_bcast<GROUP, JC + u>((int)my_s);
+                if (HAS_VAL) w[u] = group_bcast<GROUP, JC + u>(my_w);
+            });
+        } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            sr[u] = (unsigned)__shfl((int)my_s, j + u, GROUP);
-            if (HAS_VAL) w[u] = __shfl(my_w, j + u, GROUP);
+            for (int u = 0; u < U; ++u) {
+                sr[u] = (unsigned)__shfl((int)my_s, j + u, GROUP);
+                if (HAS_VAL) w[u] = __shfl(my_w, j + u, GROUP);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (FULL || j + u < n) {
+            if ((FULL || j + u < n) && col_ok) {
                 if constexpr (FAST_ADDR) xv[u] = load_pack<VEC>(xtile + (__umul24(sr[u] & kIdMask, xpitch) + lane_off));
                 else xv[u] = load_pack<VEC>(xcol + (size_t)(sr[u] & kIdMask) * a.xpitch);
             }
@@ -105,19 +119,23 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
         for (int u = 0; u < U; ++u)
             if (FULL || j + u < n) {
                 if constexpr (PROBE) {
+                    if (col_ok) {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) sig ^= __float_as_uint(xv[u].v[k]);
+                        for (int k = 0; k < VEC; ++k) sig ^= __float_as_uint(xv[u].v[k]);
+                    }
                     if (HAS_VAL) sig ^= __float_as_uint(w[u]);
                     continue;
                 }
+                if (col_ok) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if (IS_MAX) {
-                        const float p = HAS_VAL ? xv[u].v[k] * w[u] : xv[u].v[k];
-                        acc[k] = p > acc[k] ? p : acc[k];
-                    } else {
-                        // implicit unit weights: fma(x, 1, acc) == acc + x exactly
-                        acc[k] = HAS_VAL ? __builtin_fmaf(xv[u].v[k], w[u], acc[k]) : acc[k] + xv[u].v[k];
+                    for (int k = 0; k < VEC; ++k) {
+                        if (IS_MAX) {
+                            const float p = HAS_VAL ? xv[u].v[k] * w[u] : xv[u].v[k];
+                            acc[k] = p > acc[k] ? p : acc[k];
+                        } else {
+                            // implicit unit weights: fma(x, 1, acc) == acc + x exactly
+                            acc[k] = HAS_VAL ? __builtin_fmaf(xv[u].v[k], w[u], acc[k]) : acc[k] + xv[u].v[k];
+                        }
                     }
                 }
                 if (sr[u] & kLastFlag) {  // lane-group uniform: the group ends here
@@ -130,11 +148,10 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
                             for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
                         }
                         if (a.relu) relu_pack<VEC>(acc);
-                        if (col < F) store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
-                    } else if (a.ptile_bytes) {
-                        store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
-                    } else {
-                        store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
+                        if (col_ok) store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
+                    } else if (col_ok) {
+                        if (a.ptile_bytes) store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
+                        else store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
                     }
                     ++g;
                     gstart = e_next;
@@ -152,11 +169,18 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
         }
         const int n = e_end - cb < GROUP ? e_end - cb : GROUP;
         if (n == GROUP) {
+            if constexpr (GROUP == 16 && GNNAGG_DPP_SPAN_GCN) {
+                static_for<GROUP / U>([&](auto bc) {
+                    constexpr int J = decltype(bc)::value * U;
+                    batch(std::integral_constant<int, J>{}, cb, J, n);
+                });
+            } else {
 #pragma unroll 1
-            for (int j = 0; j < GROUP; j += U) batch(std::true_type{}, cb, j, n);
+                for (int j = 0; j < GROUP; j += U) batch(std::integral_constant<int, -2>{}, cb, j, n);
+            }
         } else {
 #pragma unroll 1
-            for (int j = 0; j < n; j += U) batch(std::false_type{}, cb, j, n);
+            for (int j = 0; j < n; j += U) batch(std::integral_constant<int, -1>{}, cb, j, n);
         }
         my_s = nx_s;
         my_w = nx_w;
@@ -193,6 +217,7 @@ __global__ __launch_bounds__(256) void k_combine_groups(const CombineGroupsArgs 
     const int row = a.crows[i];
     const int F = a.feat;
     const int col = (tile * GROUP + lane) * VEC;
+    const bool col_ok = col < F;  // lanes beyond the last column read nothing (their partial columns were never written)
     const int q0 = a.rg_ptr[row], q1 = a.rg_ptr[row + 1];
     const float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride + lane * VEC;
     float acc[VEC];
@@ -207,11 +232,11 @@ __global__ __launch_bounds__(256) void k_combine_groups(const CombineGroupsArgs 
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
                 const int gsel = __shfl(my_g, j + u, GROUP);
-                if (j + u < n) p[u] = load_pack<VEC>(ptile + (size_t)gsel * a.ppitch);
+                if (j + u < n && col_ok) p[u] = load_pack<VEC>(ptile + (size_t)gsel * a.ppitch);
             }
 #pragma unroll
             for (int u = 0; u < CU; ++u)
-                if (j + u < n) {
+                if (j + u < n && col_ok) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
                         if (IS_MAX) acc[k] = p[u].v[k] > acc[k] ? p[u].v[k] : acc[k];
@@ -221,7 +246,7 @@ __global__ __launch_bounds__(256) void k_combine_groups(const CombineGroupsArgs 
         }
         my_g = nx_g;
     }
-    if (col >= F) return;
+    if (!col_ok) return;
     if (a.mean) {
         const float d = (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
 #pragma unroll
@@ -249,13 +274,29 @@ __global__ __launch_bounds__(256) void k_zero_rows(const int *__restrict__ rows,
 // partial_den[g, h] by the lane that holds the head's first column.
 struct GatSpanArgs {
     SpanArgs s;
-    const float *att;     // [V, H, 2]
+    const float *as_t;    // compact source terms [head group][att_rows][HT] (k_tile_att)
+    const float *ac_t;    // compact centre terms, same layout
     float *partial_den;   // [G, H]
     float *newval;        // optional [E, H], CSR edge order
     const int *eperm;     // permuted position -> CSR edge
-    int heads, dhead;
+    int heads, dhead, att_rows;
     float slope;
 };
+
+// HT consecutive floats with one load
+template <int HT>
+__device__ __forceinline__ void load_terms(const float *__restrict__ p, float (&o)[HT])
+{
+    if constexpr (HT == 1) o[0] = p[0];
+    else if constexpr (HT == 2) { const float2 v = *reinterpret_cast<const float2 *>(p); o[0] = v.x; o[1] = v.y; }
+    else {
+#pragma unroll
+        for (int q = 0; q < HT / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
+            o[4 * q] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+        }
+    }
+}
 
 // (4 waves per SIMD asked for at 1-2 heads per tile: 128 registers, 7 of them spilled off the hot path -- 9.72 -> 9.47 ms on
 // the reddit-shaped 8 x 32 case; wider head counts keep their registers)
@@ -294,17 +335,16 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
     const float *__restrict__ xcol = a.x + (size_t)tile * a.x_tile_stride + lane * VEC;
     float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride;
     const int lane_bit_base = ((int)threadIdx.x & 63) & ~(GROUP - 1);  // first lane of this group inside the wavefront
+    // compact attention terms of this tile's head group (k_tile_att): [att_rows][HT]
+    const float *__restrict__ as_hg = A.as_t + (size_t)(h0 / HT) * A.att_rows * HT;
+    const float *__restrict__ ac_hg = A.ac_t + (size_t)(h0 / HT) * A.att_rows * HT;
     // centre-term windows: lane j holds the centre terms of group gw0 + j (cur) / gw0 + GROUP + j (next), one per tile head
     int gw0 = g;
     int tw_c, tw_n;
     float aw_c[HT], aw_n[HT];
     auto load_win = [&](int gbase, int &tw, float (&aw)[HT]) {
         tw = gbase + lane < g1 ? a.target[gbase + lane] : 0;
-#pragma unroll
-        for (int k = 0; k < HT; ++k) {
-            const int hh = h0 + k < H ? h0 + k : H - 1;
-            aw[k] = A.att[((size_t)tw * H + hh) * 2];
-        }
+        load_terms<HT>(ac_hg + (size_t)tw * HT, aw);
     };
     load_win(gw0, tw_c, aw_c);
     load_win(gw0 + GROUP, tw_n, aw_n);
@@ -319,16 +359,7 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
 #pragma unroll
     for (int k = 0; k < HT; ++k) as_c[k] = 0.0f;
     auto load_src_terms = [&](unsigned sw, bool valid, float (&as)[HT]) {
-        const size_t src = sw & kIdMask;
-#pragma unroll
-        for (int k = 0; k < HT; ++k) {
-            const int hh = h0 + k < H ? h0 + k : H - 1;
-#if defined(GAT_ABL) && GAT_ABL == 1
-            if (valid) as[k] = (float)(src & 7) * 0.01f;
-#else
-            if (valid) as[k] = A.att[(src * H + hh) * 2 + 1];
-#endif
-        }
+        if (valid) load_terms<HT>(as_hg + (size_t)(sw & kIdMask) * HT, as);
     };
     if (e0 + lane < e_end) {
         my_s = (unsigned)a.idx_f[e0 + lane];
@@ -359,11 +390,7 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
 #pragma unroll
             for (int k = 0; k < HT; ++k) {
                 const float c0 = __shfl(aw_c[k], gsel, GROUP), c1 = __shfl(aw_n[k], gsel, GROUP);
-#if defined(GAT_ABL) && GAT_ABL == 2
-                wk[k] = lane < n ? (gi < GROUP ? c0 : c1) + as_c[k] : 0.0f;
-#else
                 wk[k] = lane < n ? edge_weight(gi < GROUP ? c0 : c1, as_c[k], A.slope) : 0.0f;
-#endif
             }
             if (A.newval && tile_starts_head && lane < n) {
 #pragma unroll
@@ -371,25 +398,47 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
                     if (h0 + k < H) A.newval[(size_t)my_e * H + h0 + k] = wk[k];
             }
         }
-#pragma unroll 1
-        for (int j = 0; j < n; j += U) {
+        // one batch of U edges: gathers issued together, then the weighted chain.  JC >= 0: full window, compile-time offset
+        // (ids, flags and weights of edge JC + u by group_bcast: DPP moves for 16-lane groups); JC == -1: runtime offset j
+        auto batch = [&](auto jc_tag, int j) {
+            constexpr int JC = decltype(jc_tag)::value;
             Pack<VEC> xv[U];
+            if constexpr (JC >= 0) {
+                static_for<U>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    const unsigned sid = (unsigned)group_bcast<GROUP, JC + u>((int)my_s);
+                    xv[u] = load_pack<VEC>(xcol + (size_t)(sid & kIdMask) * a.xpitch);
+                });
+            } else {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const unsigned sid = (unsigned)__shfl((int)my_s, j + u, GROUP);
-                if (j + u < n) xv[u] = load_pack<VEC>(xcol + (size_t)(sid & kIdMask) * a.xpitch);
+                for (int u = 0; u < U; ++u) {
+                    const unsigned sid = (unsigned)__shfl((int)my_s, j + u, GROUP);
+                    if (j + u < n) xv[u] = load_pack<VEC>(xcol + (size_t)(sid & kIdMask) * a.xpitch);
+                }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (j + u < n) {
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if (JC >= 0 || j + u < n) {
                     // (the id word is fetched from its lane again instead of being kept: 16 registers fewer per lane, and
                     // registers -- 3 vs 4 waves per SIMD -- are what limits the gathers in flight here)
-                    const unsigned sru = (unsigned)__shfl((int)my_s, j + u, GROUP);
-                    float w = __shfl(wk[0], j + u, GROUP);
+                    unsigned sru;
+                    float w;
+                    if constexpr (JC >= 0) {
+                        sru = (unsigned)group_bcast<GROUP, JC + u>((int)my_s);
+                        w = group_bcast<GROUP, JC + u>(wk[0]);
+                        static_for<HT - 1>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value + 1;
+                            const float v = group_bcast<GROUP, JC + u>(wk[k]);
+                            w = hl == k ? v : w;
+                        });
+                    } else {
+                        sru = (unsigned)__shfl((int)my_s, j + u, GROUP);
+                        w = __shfl(wk[0], j + u, GROUP);
 #pragma unroll
-                    for (int k = 1; k < HT; ++k) {
-                        const float v = __shfl(wk[k], j + u, GROUP);
-                        w = hl == k ? v : w;
+                        for (int k = 1; k < HT; ++k) {
+                            const float v = __shfl(wk[k], j + u, GROUP);
+                            w = hl == k ? v : w;
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
@@ -405,13 +454,9 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
                                 store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
                             }
                         } else {
-#if !defined(GAT_ABL) || GAT_ABL != 3
                             if (a.ptile_bytes) store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
                             else store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
                             if (head_leader) A.partial_den[(size_t)g * H + col / A.dhead] = den;
-#else
-                            if (den == 123.456f) A.partial_den[0] = acc[0];
-#endif
                         }
                         ++g;
                         den = 0.0f;
@@ -426,6 +471,16 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
                         }
                     }
                 }
+            });
+        };
+        if (n == GROUP && GROUP == 16 && GNNAGG_DPP_SPAN_GAT) {
+            static_for<GROUP / U>([&](auto bc) {
+                constexpr int J = decltype(bc)::value * U;
+                batch(std::integral_constant<int, J>{}, J);
+            });
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < n; j += U) batch(std::integral_constant<int, -1>{}, j);
         }
         load_src_terms(nx_s, nx_valid, as_c);  // window W + 1's source terms: in flight across the loop back-edge
         my_s = nx_s;
@@ -637,7 +692,8 @@ int launch_gat_span(const GatSpanLaunch &G, void *stream_v)
     GatSpanArgs A0;
     fill_span_args(A0.s, L, ntiles, group);
     A0.s.val_s = nullptr; A0.s.mean = 0; A0.s.relu = 0;
-    A0.att = G.att; A0.partial_den = G.partial_den; A0.newval = G.newval; A0.eperm = G.eperm; A0.heads = G.heads; A0.dhead = dhead;
+    if (!G.as_t || !G.ac_t || G.att_rows <= 0) return fail(GNNAGG_ERR_STATE, "internal: GAT span launch without the compact attention image");
+    A0.as_t = G.as_t; A0.ac_t = G.ac_t; A0.att_rows = G.att_rows; A0.partial_den = G.partial_den; A0.newval = G.newval; A0.eperm = G.eperm; A0.heads = G.heads; A0.dhead = dhead;
     A0.slope = G.slope;
     auto span = [&](int tile0, int nt, hipStream_t st) -> int {
         GatSpanArgs A = A0;

@@ -160,6 +160,7 @@ struct Ctx {
     DevBuf<float> den;       // [V,heads] row sums of run_att
     DevBuf<float> partial, partial_den;
     DevBuf<float> xt;      // 2-D blocked mode: column-tiled image of X, rebuilt by every run (k_tile_x)
+    DevBuf<float> att_t;   // 2-D blocked GAT: compact source / centre attention terms per head group, rebuilt by every run (k_tile_att)
     int tiled = 1;         // source-partitioned balanced mode runs tile-major on the tiled image (GNNAGG_TILED=0: r01 order)
     // gnnagg_set_option knobs (defaults from the environment, see create())
     int opt_partitions = -1;   // -1: library decides (avg degree >= opt_part_min_deg), 0: never partition, N: N source ranges
@@ -984,6 +985,14 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
             if (tr.retile) {
                 if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
                 S.x = c->xt.p;
+            }
+            {   // compact attention terms: one HT-float load per edge instead of HT strided ones (k_tile_att)
+                const int dhead = feat / heads, ht = tr.spec.tile_w >= dhead ? tr.spec.tile_w / dhead : 1;
+                const int n_hg = (heads + ht - 1) / ht, arows = c->V > s->total_cols ? c->V : s->total_cols;
+                const size_t half = (size_t)n_hg * arows * ht;
+                if ((rc = c->att_t.reserve(2 * half))) return rc;
+                if ((rc = launch_tile_att(att, c->att_t.p, c->att_t.p + half, arows, heads, ht, c->stream))) return rc;
+                G.as_t = c->att_t.p; G.ac_t = c->att_t.p + half; G.att_rows = arows;
             }
             return launch_gat_span(G, c->stream);
         }

@@ -593,4 +593,36 @@ int launch_tile_x(const float *x, float *xt, int rows, int feat, int tile_w, voi
     return GNNAGG_OK;
 }
 
+// ------------------------------------------------------------------ compact attention terms (2-D blocked GAT)
+// att is [V, H, 2] (centre term, source term interleaved per head): a tile of the span kernel needs the source terms of its
+// HT heads per EDGE -- HT four-byte loads that each touch a different 64-byte att row per lane.  The compact image keeps
+// them per head group hg = first head / HT as as_t[hg][v][0 .. HT) (and the centre terms as ac_t likewise): one HT * 4-byte
+// load per edge, rows 16x denser in the L2 / L1 than att's.  Heads beyond H replicate head H - 1 (never stored).
+__global__ __launch_bounds__(256) void k_tile_att(const float *__restrict__ att, float *__restrict__ as_t, float *__restrict__ ac_t,
+                                                  int rows, int heads, int ht, int n_hg)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_hg = (long)rows * ht;
+    if (i >= per_hg * n_hg) return;
+    const int hg = (int)(i / per_hg);
+    const long rem = i - (long)hg * per_hg;
+    const int v = (int)(rem / ht), k = (int)(rem - (long)v * ht);
+    int h = hg * ht + k;
+    h = h < heads ? h : heads - 1;
+    const float2 cs = *reinterpret_cast<const float2 *>(att + ((size_t)v * heads + h) * 2);
+    ac_t[i] = cs.x;
+    as_t[i] = cs.y;
+}
+
+int launch_tile_att(const float *att, float *as_t, float *ac_t, int rows, int heads, int ht, void *stream_v)
+{
+    if (rows <= 0) return GNNAGG_OK;
+    const int n_hg = (heads + ht - 1) / ht;
+    const long total = (long)rows * ht * n_hg;
+    hipLaunchKernelGGL(k_tile_att, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, att, as_t, ac_t, rows, heads,
+                       ht, n_hg);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
 }  // namespace gnnagg

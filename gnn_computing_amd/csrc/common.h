@@ -154,6 +154,9 @@ int launch_gcn_span(const SpanLaunch &a, void *stream);
 struct GatSpanLaunch {
     SpanLaunch s;                   // val_s unused
     const float *att = nullptr;     // [V, H, 2]
+    const float *as_t = nullptr;    // compact source terms  [ceil(H / HT)][att_rows][HT] (k_tile_att), HT = heads per tile
+    const float *ac_t = nullptr;    // compact centre terms, same layout
+    int att_rows = 0;
     float *partial_den = nullptr;   // [n_groups, H]
     float *newval = nullptr;        // optional [E, H], CSR edge order (scattered through eperm)
     const int *eperm = nullptr;
@@ -272,5 +275,6 @@ int launch_check_csr(const int *ptr, const int *idx, int V, int E, int num_cols,
 int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out, void *stream);
 // xt[t][r][0..tile_w) = x[r][t*tile_w ..] (zero beyond feat): the column-tiled image of X the 2-D blocked mode gathers from
 int launch_tile_x(const float *x, float *xt, int rows, int feat, int tile_w, void *stream);
+int launch_tile_att(const float *att, float *as_t, float *ac_t, int rows, int heads, int ht, void *stream);
 
 }  // namespace gnnagg

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -199,6 +200,43 @@ __device__ __forceinline__ int logical_block_tile_major(int b, int item_blocks, 
     return (L - tile * item_blocks) * ntiles + tile;
 }
 
+// A/B switches for the DPP forms of the id / value broadcast (measured: DESIGN.md section 4).
+#ifndef GNNAGG_DPP_CHAIN
+#define GNNAGG_DPP_CHAIN 0
+#endif
+#ifndef GNNAGG_DPP_SPAN_GCN
+#define GNNAGG_DPP_SPAN_GCN 0
+#endif
+#ifndef GNNAGG_DPP_SPAN_GAT
+#define GNNAGG_DPP_SPAN_GAT 1
+#endif
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn &&f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// Value of lane SRC (a compile-time index) of every lane group, in all lanes of the group.  16-lane groups are exactly the
+// DPP rows: row_newbcast is a full-rate VALU move with no LDS round trip -- ds_bpermute, what __shfl compiles to, goes
+// through the LDS pipe and puts ~100 cycles into the id -> address -> gather chain.  (Checked on gfx950:
+// scripts/micro/dpp_test.)
+template <int GROUP, int SRC>
+__device__ __forceinline__ int group_bcast(int v)
+{
+    if constexpr (GROUP == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xf, 0xf, false);
+    else return __shfl(v, SRC, GROUP);
+}
+template <int GROUP, int SRC>
+__device__ __forceinline__ float group_bcast(float v)
+{
+    return __int_as_float(group_bcast<GROUP, SRC>(__float_as_int(v)));
+}
+
 struct GcnArgs {
     const int *ptr, *target, *slot, *empty_rows;
     const int *row_ptr;
@@ -223,6 +261,60 @@ __device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end,
                                             const int *__restrict__ idx, const float *__restrict__ val,
                                             const float *__restrict__ xcol, int F)
 {
+    if constexpr (GROUP >= 16 && GNNAGG_DPP_CHAIN) {
+        // Windows of 16 edges, one copy per 16-lane DPP row of the group (lanes l and l + 16 load the same id: one request):
+        // the (id, value) of edge cb + u then reaches every lane of the group by row_newbcast -- a VALU move instead of the
+        // ds_bpermute round trip through the LDS pipe (arxiv-shaped headline: see DESIGN.md section 4).  Same edge order,
+        // same bits.
+        const int l16 = lane & 15;
+        int my_s = 0;
+        float my_w = 1.0f;
+        if (beg + l16 < end) {
+            my_s = idx[beg + l16];
+            if (val) my_w = val[beg + l16];
+        }
+        for (int cb = beg; cb < end; cb += 16) {
+            int nx_s = 0;
+            float nx_w = 1.0f;
+            if (cb + 16 + l16 < end) {
+                nx_s = idx[cb + 16 + l16];
+                if (val) nx_w = val[cb + 16 + l16];
+            }
+            const int n = end - cb < 16 ? end - cb : 16;
+            static_for<16 / kUnroll>([&](auto bc) {
+                constexpr int J = decltype(bc)::value * kUnroll;
+                if (J < n) {
+                    int s[kUnroll];
+                    float w[kUnroll];
+                    Pack<VEC> xv[kUnroll];
+                    static_for<kUnroll>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value;
+                        s[u] = group_bcast<16, J + u>(my_s);
+                        w[u] = group_bcast<16, J + u>(my_w);
+                    });
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u)
+                        if (J + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u)
+                        if (J + u < n && col_ok) {
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) {
+                                if (IS_MAX) {
+                                    const float p = xv[u].v[k] * w[u];
+                                    acc[k] = p > acc[k] ? p : acc[k];
+                                } else {
+                                    acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
+                                }
+                            }
+                        }
+                }
+            });
+            my_s = nx_s;
+            my_w = nx_w;
+        }
+        return;
+    }
     int my_s = 0;
     float my_w = 1.0f;
     if (beg + lane < end) {
