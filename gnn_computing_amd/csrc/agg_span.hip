@@ -39,6 +39,7 @@ struct SpanArgs {
     float *partial;
     int n_spans, span_blocks, feat, ntiles, mean, relu, yvec, xpitch, ppitch;
     int tile0;  // first column tile of this launch (the XCD ranges run over the launch's tiles)
+    int xshift_bytes;  // log2 of the X row pitch in bytes when it is a power of two and 32-bit offsets cover a tile image, else -1
     long x_tile_stride, p_tile_stride;
     unsigned ptile_bytes;
     unsigned *probe_sink;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
         const int L = a.xr.first[xcd] + k;
         tile = L / a.span_blocks;
         sb = L - tile * a.span_blocks;
-        tile += a.tile0;
+        tile = __builtin_amdgcn_readfirstlane(tile + a.tile0);  // workgroup-uniform: tile bases and buffer resources in SGPRs
     }
     const int s = sb * GPB + grp;
     if (s >= a.n_spans) return;
@@ -298,15 +299,27 @@ __device__ __forceinline__ void load_terms(const float *__restrict__ p, float (&
     }
 }
 
-// (4 waves per SIMD asked for at 1-2 heads per tile: 128 registers, 7 of them spilled off the hot path -- 9.72 -> 9.47 ms on
-// the reddit-shaped 8 x 32 case; wider head counts keep their registers)
-template <int GROUP, int HT>
+// Value of lane SRC of every 16-lane DPP row, written only to the lanes of the DPP banks (4 lanes each) in BANKS; the other
+// lanes keep `old`.  Head selection without a compare + select: the lanes of head k of a tile are whole banks.
+template <int SRC, int BANKS>
+__device__ __forceinline__ float row_bcast_banks(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x150 + SRC, 0xf, BANKS, false));
+}
+
+// (4 waves per SIMD asked for at 1-2 heads per tile: 128 registers -- 9.72 -> 9.47 ms on the reddit-shaped 8 x 32 case; wider
+// head counts keep their registers.)  The kernel is bound by VALU issue as much as by the gathers (rocprofv3, reddit-shaped
+// 8 x 32: 25 VALU instructions per gathered segment before the round-2 rewrite), so the per-edge path is kept to: one DPP
+// row broadcast for the id, one shift-or for the gather offset (SHIFT: line-aligned power-of-two row pitch, 32-bit offsets
+// from a wave-uniform tile base), one broadcast per head of the tile for the weight (bank-masked: no select), the FMAs, the
+// denominator add and the group-end test.  Everything that happens once per window or once per group stays out of it.
+template <int GROUP, int HT, bool SHIFT>
 __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSpanArgs A)
 {
     const SpanArgs &a = A.s;
-    // a whole 16-edge window of gathers in flight: this kernel waits on memory latency (SQ_WAIT_ANY 82 % of the wave cycles,
-    // TA 63 % busy on the reddit-shaped 8 x 32 case), not on address processing -- 8 per batch: 13.0 ms, 16: 9.7 ms
+    // a whole 16-edge window of gathers in flight (8 per batch: 13.0 ms, 16: 9.7 ms on the reddit-shaped 8 x 32 case)
     constexpr int VEC = 4, GPB = 256 / GROUP, U = GROUP < 16 ? GROUP : 16;
+    constexpr bool BANKED = GROUP == 16 && (HT == 2 || HT == 4);  // a head's lanes = whole DPP banks
     const int lane = threadIdx.x & (GROUP - 1);
     const int grp = (int)threadIdx.x / GROUP;
     int tile, sb;
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
         const int L = a.xr.first[xcd] + k;
         tile = L / a.span_blocks;
         sb = L - tile * a.span_blocks;
-        tile += a.tile0;
+        tile = __builtin_amdgcn_readfirstlane(tile + a.tile0);  // workgroup-uniform: tile bases and buffer resources in SGPRs
     }
     const int s = sb * GPB + grp;
     if (s >= a.n_spans) return;
@@ -332,13 +345,17 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
     int g = a.span_g[s];
     const int g1 = a.span_g[s + 1];
     const int e0 = a.ptr_s[g], e_end = a.ptr_s[g1];
-    const float *__restrict__ xcol = a.x + (size_t)tile * a.x_tile_stride + lane * VEC;
+    const float *__restrict__ xtile = a.x + (size_t)tile * a.x_tile_stride;  // wave-uniform
+    const float *__restrict__ xcol = xtile + lane * VEC;
+    const unsigned lane_boff = (unsigned)(lane * VEC * sizeof(float)), xshift = (unsigned)a.xshift_bytes;
     float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride;
     const int lane_bit_base = ((int)threadIdx.x & 63) & ~(GROUP - 1);  // first lane of this group inside the wavefront
     // compact attention terms of this tile's head group (k_tile_att): [att_rows][HT]
     const float *__restrict__ as_hg = A.as_t + (size_t)(h0 / HT) * A.att_rows * HT;
     const float *__restrict__ ac_hg = A.ac_t + (size_t)(h0 / HT) * A.att_rows * HT;
-    // centre-term windows: lane j holds the centre terms of group gw0 + j (cur) / gw0 + GROUP + j (next), one per tile head
+    // centre-term windows: lane j holds the centre terms of group gw0 + j (cur) / gw0 + GROUP + j (next), one per tile head.
+    // A window of GROUP edges ends at most GROUP groups, so shifting the windows between edge windows keeps every group
+    // of the current edge window inside the two (g - gw0 < GROUP at its start).
     int gw0 = g;
     int tw_c, tw_n;
     float aw_c[HT], aw_n[HT];
@@ -349,10 +366,9 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
     load_win(gw0, tw_c, aw_c);
     load_win(gw0 + GROUP, tw_n, aw_n);
     // The weight of an edge is the same for every column of a head, so lane j computes the weights of edge cb + j ONCE per
-    // window -- one source-term gather and one exp per head of the tile -- and the group shares them with ds_bpermute like
-    // the edge values of the GCN chain (every lane gathering and exponentiating every edge made the kernel VALU-bound:
-    // reddit-shaped 8 x 32, 9.97 ms against 5 ms of gathers).  Source terms of window W + 1 are requested while window W
-    // is processed.
+    // window -- one source-term load and one exp per head of the tile -- and the group shares them like the edge values of
+    // the GCN chain (every lane gathering and exponentiating every edge made the kernel VALU-bound: reddit-shaped 8 x 32,
+    // 9.97 ms against 5 ms of gathers).  Source terms of window W + 1 are requested while window W is processed.
     unsigned my_s = 0;
     int my_e = 0;
     float as_c[HT];
@@ -377,10 +393,23 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
             if (A.newval) nx_e = A.eperm[cb + GROUP + lane];
         }
         const int n = e_end - cb < GROUP ? e_end - cb : GROUP;
+        if (n < GROUP) {
+            // the span's last window: the lanes beyond it repeat its last edge's source with weight 0 and no flags, so the
+            // one unrolled path below serves every window
+            const unsigned last = (unsigned)__shfl((int)my_s, n - 1, GROUP) & kIdMask;
+            if (lane >= n) my_s = last;
+        }
+        if (g - gw0 >= GROUP) {  // next centre-term window becomes current; the one after it is requested
+            gw0 += GROUP;
+            tw_c = tw_n;
+#pragma unroll
+            for (int k = 0; k < HT; ++k) aw_c[k] = aw_n[k];
+            load_win(gw0 + GROUP, tw_n, aw_n);
+        }
         // ---- this lane's edge (cb + lane): its group = current group + group ends before it in this window
         float wk[HT];
         {
-            const unsigned long long ends = __ballot((my_s & kLastFlag) != 0 && lane < n);
+            const unsigned long long ends = __ballot((my_s & kLastFlag) != 0);
             const unsigned mine = (unsigned)(ends >> lane_bit_base) & (GROUP >= 32 ? ~0u : ((1u << (GROUP & 31)) - 1u));
             int gi;
             if constexpr (GROUP == 64) gi = __popcll(ends & ((1ull << lane) - 1ull));
@@ -398,90 +427,64 @@ __global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSp
                     if (h0 + k < H) A.newval[(size_t)my_e * H + h0 + k] = wk[k];
             }
         }
-        // one batch of U edges: gathers issued together, then the weighted chain.  JC >= 0: full window, compile-time offset
-        // (ids, flags and weights of edge JC + u by group_bcast: DPP moves for 16-lane groups); JC == -1: runtime offset j
-        auto batch = [&](auto jc_tag, int j) {
-            constexpr int JC = decltype(jc_tag)::value;
+        // one batch of U edges at compile-time offsets: gathers issued together, then the weighted chain
+        static_for<GROUP / U>([&](auto bc) {
+            constexpr int J = decltype(bc)::value * U;
             Pack<VEC> xv[U];
-            if constexpr (JC >= 0) {
-                static_for<U>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    const unsigned sid = (unsigned)group_bcast<GROUP, JC + u>((int)my_s);
-                    xv[u] = load_pack<VEC>(xcol + (size_t)(sid & kIdMask) * a.xpitch);
-                });
-            } else {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const unsigned sid = (unsigned)__shfl((int)my_s, j + u, GROUP);
-                    if (j + u < n) xv[u] = load_pack<VEC>(xcol + (size_t)(sid & kIdMask) * a.xpitch);
-                }
-            }
             static_for<U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                if (JC >= 0 || j + u < n) {
-                    // (the id word is fetched from its lane again instead of being kept: 16 registers fewer per lane, and
-                    // registers -- 3 vs 4 waves per SIMD -- are what limits the gathers in flight here)
-                    unsigned sru;
-                    float w;
-                    if constexpr (JC >= 0) {
-                        sru = (unsigned)group_bcast<GROUP, JC + u>((int)my_s);
-                        w = group_bcast<GROUP, JC + u>(wk[0]);
-                        static_for<HT - 1>([&](auto kc) {
-                            constexpr int k = decltype(kc)::value + 1;
-                            const float v = group_bcast<GROUP, JC + u>(wk[k]);
-                            w = hl == k ? v : w;
-                        });
-                    } else {
-                        sru = (unsigned)__shfl((int)my_s, j + u, GROUP);
-                        w = __shfl(wk[0], j + u, GROUP);
+                const unsigned sid = (unsigned)group_bcast<GROUP, J + u>((int)my_s);
+                if constexpr (SHIFT)  // the shift drops the flag bits (ids < 2^24, host-checked)
+                    xv[u] = load_pack<VEC>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(xtile) + ((sid << xshift) | lane_boff)));
+                else
+                    xv[u] = load_pack<VEC>(xcol + (size_t)(sid & kIdMask) * a.xpitch);
+            });
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                // (the id word is fetched from its lane again instead of being kept: 16 registers fewer per lane, and
+                // registers -- 3 vs 4 waves per SIMD -- are what limits the gathers in flight here)
+                const unsigned sru = (unsigned)group_bcast<GROUP, J + u>((int)my_s);
+                float w = group_bcast<GROUP, J + u>(wk[0]);
+                if constexpr (BANKED) {
+                    static_for<HT - 1>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value + 1;
+                        constexpr int banks = HT == 2 ? 0xC : (1 << k);
+                        w = row_bcast_banks<J + u, banks>(w, wk[k]);
+                    });
+                } else {
+                    static_for<HT - 1>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value + 1;
+                        const float v = group_bcast<GROUP, J + u>(wk[k]);
+                        w = hl == k ? v : w;
+                    });
+                }
 #pragma unroll
-                        for (int k = 1; k < HT; ++k) {
-                            const float v = __shfl(wk[k], j + u, GROUP);
-                            w = hl == k ? v : w;
-                        }
-                    }
+                for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
+                den += w;
+                if (sru & kLastFlag) {  // lane-group uniform: the group ends here
+                    if (sru & kDirectFlag) {
+                        const int gi = g - gw0;  // < 2 * GROUP
+                        const int r0 = __shfl(tw_c, gi & (GROUP - 1), GROUP), r1 = __shfl(tw_n, gi & (GROUP - 1), GROUP);
+                        const int row = gi < GROUP ? r0 : r1;
+                        if (col_ok) {
+                            if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
-                    den += w;
-                    if (sru & kLastFlag) {  // lane-group uniform: the group ends here
-                        if (sru & kDirectFlag) {
-                            const int row = __shfl(tw_c, g - gw0, GROUP);
-                            if (col_ok) {
-                                if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
-#pragma unroll
-                                    for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
-                                }
-                                store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
+                                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
                             }
-                        } else {
-                            if (a.ptile_bytes) store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
-                            else store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
-                            if (head_leader) A.partial_den[(size_t)g * H + col / A.dhead] = den;
+                            store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
                         }
-                        ++g;
-                        den = 0.0f;
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-                        if (g - gw0 == GROUP) {  // next window becomes current; the one after it is requested now
-                            gw0 = g;
-                            tw_c = tw_n;
-#pragma unroll
-                            for (int k = 0; k < HT; ++k) aw_c[k] = aw_n[k];
-                            load_win(gw0 + GROUP, tw_n, aw_n);
-                        }
+                    } else {
+                        if (a.ptile_bytes) store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
+                        else store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
+                        if (head_leader) A.partial_den[(size_t)g * H + col / A.dhead] = den;
                     }
+                    ++g;
+                    den = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
                 }
             });
-        };
-        if (n == GROUP && GROUP == 16 && GNNAGG_DPP_SPAN_GAT) {
-            static_for<GROUP / U>([&](auto bc) {
-                constexpr int J = decltype(bc)::value * U;
-                batch(std::integral_constant<int, J>{}, J);
-            });
-        } else {
-#pragma unroll 1
-            for (int j = 0; j < n; j += U) batch(std::integral_constant<int, -1>{}, j);
-        }
+        });
         load_src_terms(nx_s, nx_valid, as_c);  // window W + 1's source terms: in flight across the loop back-edge
         my_s = nx_s;
         my_e = nx_e;
@@ -595,6 +598,13 @@ static void fill_span_args(SpanArgs &a, const SpanLaunch &L, int ntiles_total, i
     a.probe_sink = nullptr;
     a.tile0 = 0;
     a.span_blocks = ceil_div(L.n_spans, 256 / group);
+    a.xshift_bytes = -1;
+    const size_t pitch_b = (size_t)L.tile.xpitch * sizeof(float);
+    if (L.x_rows > 0 && L.x_rows < (1 << 24) && (pitch_b & (pitch_b - 1)) == 0 && pitch_b >= 16 && (size_t)L.x_rows * pitch_b < 0xffffffffULL) {
+        int sh = 0;
+        while (((size_t)1 << sh) < pitch_b) ++sh;
+        a.xshift_bytes = sh;
+    }
 }
 
 static void fill_combine_args(CombineGroupsArgs &c, const SpanLaunch &L)
@@ -700,7 +710,11 @@ int launch_gat_span(const GatSpanLaunch &G, void *stream_v)
         A.s.tile0 = tile0;
         const int gpb = 256 / group;
         const int grid = 8 * fill_xcd_ranges_tile_major(L.span_cost_prefix, L.n_spans, gpb, A.s.span_blocks, nt, A.s.xr);
-#define GAT_SPAN_HT(G_, HT_) hipLaunchKernelGGL((k_gat_span<G_, HT_>), dim3(grid), dim3(256), 0, st, A)
+#define GAT_SPAN_HT(G_, HT_)                                                                                                   \
+        {                                                                                                                      \
+            if (A.s.xshift_bytes >= 0) hipLaunchKernelGGL((k_gat_span<G_, HT_, true>), dim3(grid), dim3(256), 0, st, A);       \
+            else                       hipLaunchKernelGGL((k_gat_span<G_, HT_, false>), dim3(grid), dim3(256), 0, st, A);      \
+        }
 #define GAT_SPAN_CALL(G_)                                                      \
         switch (ht) {                                                          \
             case 1: GAT_SPAN_HT(G_, 1); break;                                 \

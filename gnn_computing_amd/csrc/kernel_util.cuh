@@ -207,9 +207,6 @@ __device__ __forceinline__ int logical_block_tile_major(int b, int item_blocks, 
 #ifndef GNNAGG_DPP_SPAN_GCN
 #define GNNAGG_DPP_SPAN_GCN 0
 #endif
-#ifndef GNNAGG_DPP_SPAN_GAT
-#define GNNAGG_DPP_SPAN_GAT 1
-#endif
 
 // Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
 template <int N, class Fn>
@@ -223,12 +220,13 @@ __device__ __forceinline__ void static_for(Fn &&f)
 
 // Value of lane SRC (a compile-time index) of every lane group, in all lanes of the group.  16-lane groups are exactly the
 // DPP rows: row_newbcast is a full-rate VALU move with no LDS round trip -- ds_bpermute, what __shfl compiles to, goes
-// through the LDS pipe and puts ~100 cycles into the id -> address -> gather chain.  (Checked on gfx950:
-// scripts/micro/dpp_test.)
+// through the LDS pipe and puts ~100 cycles into the id -> address -> gather chain.  Used by the GAT span kernel (10.2 ->
+// 8.7 ms on the reddit-shaped 8 x 32 case); on the GCN kernels the unrolled form costs registers and measured slower
+// (arxiv-shaped headline 77 -> 103 us, reddit-shaped F = 602 15.9 -> 16.1 ms): GNNAGG_DPP_CHAIN / GNNAGG_DPP_SPAN_GCN stay 0.
 template <int GROUP, int SRC>
 __device__ __forceinline__ int group_bcast(int v)
 {
-    if constexpr (GROUP == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xf, 0xf, false);
+    if constexpr (GROUP == 16) return __builtin_amdgcn_mov_dpp(v, 0x150 + SRC, 0xf, 0xf, true);  // every lane is written
     else return __shfl(v, SRC, GROUP);
 }
 template <int GROUP, int SRC>
