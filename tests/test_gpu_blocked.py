@@ -122,6 +122,33 @@ def test_blocked_gat_and_newval_in_csr_edge_order(F, H):
     assert torch.equal(newval, nv_rows)
 
 
+@pytest.mark.parametrize("F,H,opts", [(96, 3, {"retile": 0}), (96, 3, {}), (256, 8, {"retile": 0}), (256, 8, {"tile_width": 128}),
+                                      (256, 8, {"tile_width": 256}), (128, 4, {"tile_width": 32}), (64, 1, {"tile_width": 32}),
+                                      (256, 2, {"tile_width": 64})])
+def test_blocked_gat_span_kernel_variants(F, H, opts):
+    """k_gat_span's instantiations: heads per tile 1 / 2 / 4 / 8 (the compact attention image replicates the last head where a
+    tile reaches beyond it: 3 heads of 32 on 64-float tiles), a head wider than the tile, gathers from the caller's X with a
+    row pitch that is not a power of two (96 floats: the 64-bit address path) and from the tiled image (shift-or offsets)."""
+    V, E = 900, 260000
+    ptr, idx = hub_graph(V, E, seed=11)
+    x, att = rand((V, F), 5), rand((V, H, 2), 6) * 0.4
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.set_option("slice_kb", 16)
+    for k, v in opts.items():
+        gat.set_option(k, v)
+    parts = gat.balanced_partitions()
+    assert parts > 1
+    y = torch.full((V, F), 7.0, device=DEV)
+    newval = torch.full((E, H), 7.0, device=DEV)
+    gat.run(dev(x), dev(att), y, 128, "balanced", heads=H, newval=newval)
+    ops, oix, otg, _ = orc.locality_schedule(ptr, idx, parts, gat.balanced_partition_columns(), ng=gat.balanced_params()[0])
+    ref, _, _ = orc.gat_grouped(ops, otg, oix, att, x, V, H, seg=0)
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "blocked gat %s" % opts)
+    assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0)
+    _, ref_newval, _ = orc.gat_grouped(*orc.neighbor_grouping(ptr, 1 << 30), idx, att, x, V, H, seg=0)
+    np.testing.assert_allclose(newval.cpu().numpy(), ref_newval, rtol=1e-6)
+
+
 def test_single_range_is_the_library_choice_for_small_graphs():
     """600 columns x 256 B fit any L2: one range, tile-major order only; rows longer than the chunk still split."""
     V, E, F = 600, 200000, 128
