@@ -609,9 +609,9 @@ __global__ __launch_bounds__(256) void k_tile_att(const float *__restrict__ att,
     const int v = (int)(rem / ht), k = (int)(rem - (long)v * ht);
     int h = hg * ht + k;
     h = h < heads ? h : heads - 1;
-    const float2 cs = *reinterpret_cast<const float2 *>(att + ((size_t)v * heads + h) * 2);
-    ac_t[i] = cs.x;
-    as_t[i] = cs.y;
+    const float *cs = att + ((size_t)v * heads + h) * 2;  // (scalar loads: the caller's att may be 4-byte aligned only)
+    ac_t[i] = cs[0];
+    as_t[i] = cs[1];
 }
 
 int launch_tile_att(const float *att, float *as_t, float *ac_t, int rows, int heads, int ht, void *stream_v)

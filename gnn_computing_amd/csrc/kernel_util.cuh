@@ -120,6 +120,9 @@ __device__ __forceinline__ void store_pack_any(float *p, const float (&a)[VEC], 
 // Output rows are written once and never re-read by this kernel: a write-through (sc1) store leaves the XCD's L2
 // to the gathered feature rows instead of parking 87 MB of results in it.  Buffer store so the cache bits can be
 // given (aux 16 = sc1); `yoff` is the element offset from `ybase` (callers guarantee the byte offset fits 31 bits).
+#ifndef GNNAGG_WT_AUX
+#define GNNAGG_WT_AUX 16
+#endif
 template <int VEC>
 __device__ __forceinline__ void store_pack_wt(float *ybase, unsigned nbytes, size_t yoff, const float (&a)[VEC])
 {
@@ -129,12 +132,12 @@ __device__ __forceinline__ void store_pack_wt(float *ybase, unsigned nbytes, siz
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     if constexpr (VEC == 4) {
         u4 v = {__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, GNNAGG_WT_AUX);
     } else if constexpr (VEC == 2) {
         u2 v = {__float_as_uint(a[0]), __float_as_uint(a[1])};
-        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, 0, GNNAGG_WT_AUX);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[0]), rsrc, voff, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[0]), rsrc, voff, 0, GNNAGG_WT_AUX);
     }
 }
 
