@@ -277,10 +277,11 @@ def run_other_config(args, dev):
     steps, warm = min(args.steps, 20), min(args.warmup, 3)
     wall, dev_s, med_s = time_steps(step, steps, warm, lambda: None)
     achieved = B / dev_s / 1e9
-    # ceiling: the gather probe of the same launch sequence (GCN configs); the fused GAT has no probe instantiation -- its
-    # ceiling is the measured L2-resident 256-byte row-gather rate of scripts/micro/gather_ceiling.hip (24.5 TB/s)
-    probe_s = None
-    if args.config != "G":
+    # ceiling: the gather probe of the same launch sequence (same id / value / attention-term loads and row gathers, no
+    # chains, no stores)
+    if args.config == "G":
+        _, probe_s, _ = time_steps(lambda: agg.probe_gather(x, att, "balanced", heads=H), steps, warm, lambda: None)
+    else:
         _, probe_s, _ = time_steps(lambda: agg.probe_gather(x, "balanced"), steps, warm, lambda: None)
     peak = B / probe_s / 1e9 if probe_s else L2_GATHER_PEAK_GBPS
     traffic, traffic_label = pmc_traffic(args.config)

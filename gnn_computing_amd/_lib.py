@@ -54,6 +54,7 @@ SIGNATURES = {
     "gnnagg_gcn_run": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int]),
     "gnnagg_gcn_run_ex": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "gnnagg_gcn_probe_gather": (c_int, [c_int64, c_void_p, c_int, c_int]),
+    "gnnagg_gat_probe_gather": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int]),
     "gnnagg_gcn_run_clock": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, P_INT, P_INT]),
     "gnnagg_wall_clock_hz": (ctypes.c_longlong, []),
     "gnnagg_gcn_run_edgewise": (c_int, [c_int64, c_void_p, c_void_p, c_int]),

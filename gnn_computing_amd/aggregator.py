@@ -247,6 +247,13 @@ class Aggregator_GAT(Aggregator):
                                    ctypes.c_float(slope), _mode(scheduled), _dev_ptr(newval, torch.float32, "newval")))
         return 0.0
 
+    def probe_gather(self, vin, vatt, scheduled="balanced", heads=1):
+        """Measurement aid (gnnagg_gat_probe_gather): the loads of run(vin, vatt, ., ., scheduled, heads) on the 2-D blocked
+        order without exp, chains or stores -- the gather ceiling of that launch."""
+        self._use_current_stream()
+        check(lib().gnnagg_gat_probe_gather(self._h, _dev_ptr(vin, torch.float32, "vin"), _dev_ptr(vatt, torch.float32, "vatt"),
+                                            int(vin.shape[1]), int(heads), _mode(scheduled)))
+
     def run_att(self, in_att, out_val, BLOCK_SIZE=128, heads=1, slope=0.2):
         """aggr_gat.h:395-401"""
         self._use_current_stream()

@@ -925,7 +925,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
 }
 
 static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat, int heads, float slope, int mode,
-                   float *newval)
+                   float *newval, int probe = 0)
 {
     if (c->kind != Ctx::GAT) return fail(GNNAGG_ERR_ARG, "handle is not a GAT aggregator");
     if (!x || !y || !att) return fail(GNNAGG_ERR_ARG, "null feature/attention pointer");
@@ -934,6 +934,8 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
+    if (probe && !(mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors))
+        return fail(GNNAGG_ERR_ARG, "GAT probe: only the 2-D blocked balanced order has a probe instantiation");
     if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && c->partitions == 0) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
         BalancedPlan &p = mode == GNNAGG_MODE_BALANCED ? c->plan : c->plan_sched;
         GatPlanLaunch P;
@@ -971,10 +973,12 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
         }
         bool demoted = false;
         if ((rc = reserve_partitioned_scratch(c, tr.partial_floats, den_floats, tr.xt_floats, &demoted))) return rc;
-        if (demoted) return gat_run(c, x, att, y, feat, heads, slope, mode, newval);
+        if (demoted) return gat_run(c, x, att, y, feat, heads, slope, mode, newval, probe);
+        if (probe && !span_run) return fail(GNNAGG_ERR_ARG, "GAT probe: the segmented-stream kernel does not cover this width / head count");
         if (span_run) {
             GatSpanLaunch G;
             SpanLaunch &S = G.s;
+            S.probe = probe;
             S.span_g = s->span_g.p; S.n_spans = s->n_spans; S.span_cost_prefix = s->span_cost_prefix.data();
             S.ptr_s = s->ptr_s.p; S.idx_f = s->idx_f.p; S.target = s->target.p;
             S.n_groups = s->num_target; S.crows = s->crows.p; S.n_crows = s->n_crows; S.rg_ptr = s->rg_ptr.p; S.rg_idx = s->rg_idx.p;
@@ -1468,6 +1472,13 @@ int gnnagg_gat_run(gnnagg_handle h, const float *d_x, const float *d_att, float 
 {
     GET_CTX(h);
     return gat_run(c, d_x, d_att, d_y, feat, heads, slope, mode, d_newval);
+}
+
+int gnnagg_gat_probe_gather(gnnagg_handle h, const float *d_x, const float *d_att, int feat, int heads, int mode)
+{
+    GET_CTX(h);
+    // y is never written by the probe instantiation (see gnnagg_gcn_probe_gather)
+    return gat_run(c, d_x, d_att, const_cast<float *>(d_x), feat, heads, 0.2f, mode, nullptr, 1);
 }
 
 int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, int heads, float slope)

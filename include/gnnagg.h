@@ -161,6 +161,9 @@ int gnnagg_gcn_run_ex(gnnagg_handle h, const float *d_x, float *d_y, int feat, i
  * gathers; bench.py reports roofline.frac = probe time / kernel time.  GNNAGG_MODE_BALANCED (or a neighbor-grouping
  * schedule that runs on the plan kernel); asynchronous on the handle's stream. */
 int gnnagg_gcn_probe_gather(gnnagg_handle h, const float *d_x, int feat, int mode);
+/* The same for gnnagg_gat_run on the 2-D blocked balanced order (k_gat_span): neighbor ids, compact attention terms and
+ * tile-row gathers as in the real run, no exp, no chain, no store.  GNNAGG_ERR_ARG on the other GAT paths. */
+int gnnagg_gat_probe_gather(gnnagg_handle h, const float *d_x, const float *d_att, int feat, int heads, int mode);
 /* Aggregator_GCN::run_clock, aggr_gcn.h:462-489 (Figure 8 load-balance study).  Runs the one-item-per-lane-group
  * kernel of mode rows (the reference's aggr_gcn_clock) or scheduled (aggr_gcn_target_clock) with per-workgroup
  * stamps: d_timer[3b] = start, [3b+1] = end (ticks of the constant wall clock, gnnagg_wall_clock_hz), [3b+2] = CU id.

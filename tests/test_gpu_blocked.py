@@ -277,6 +277,30 @@ def test_gather_probe_runs_the_same_work_and_writes_nothing(case):
         agg.probe_gather(dx, "rows")
 
 
+def test_gat_probe_runs_on_the_blocked_order_only_and_writes_nothing():
+    V, E, F, H = 800, 200000, 128, 4
+    ptr, idx = hub_graph(V, E, seed=9)
+    x, att = dev(rand((V, F), 1)), dev(rand((V, H, 2), 2) * 0.4)
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.set_option("slice_kb", 16)
+    assert gat.balanced_partitions() > 1
+    x0, att0 = x.clone(), att.clone()
+    y = torch.full((V, F), 7.0, device=DEV)
+    gat.run(x, att, y, 128, "balanced", heads=H)
+    y0 = y.clone()
+    gat.probe_gather(x, att, "balanced", heads=H)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x0) and torch.equal(att, att0)
+    gat.run(x, att, y, 128, "balanced", heads=H)   # scratch untouched by the probe: same bits again
+    assert torch.equal(y, y0)
+    with pytest.raises(Exception):
+        gat.probe_gather(x, att, "rows", heads=H)
+    chunked = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    chunked.set_option("partitions", 0)   # the chunked plan has no probe instantiation
+    with pytest.raises(Exception):
+        chunked.probe_gather(x, att, "balanced", heads=H)
+
+
 def test_set_option_rejects_unknown_names_and_values():
     ptr, idx = gnc.graph.uniform_random_csr(50, 400, seed=1)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, 32, 32)
