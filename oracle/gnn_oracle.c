@@ -10,13 +10,21 @@
  * evaluates it: fp32, one fused multiply-add per edge, accumulation in CSR order
  * (nvcc --use_fast_math contracts `rs += a * b` into an FMA, CMakeLists.txt:40).
  *
- * PARITY PINNING: the reference ships no tests, golden vectors or CPU compute path
- * (SURVEY.md section 4), and its host sources cannot be compiled in this image without
- * stand-in CUDA headers (util.h:4-8 pulls cusparse/cublas/curand), which the build rules
- * forbid.  The integer stages are pinned against the vectors SURVEY.md section 8c records
- * from the reference's own host code (tests/golden/survey_8c.json) plus hand-derived
- * known-answer graphs; the fp32 stages are pinned by hand-computed known answers only
- * => fp32 parity is "unpinned against a reference run".
+ * PARITY PINNING: the reference ships no tests, golden vectors or CPU compute path (SURVEY.md
+ * section 4).  This oracle is pinned against the REFERENCE ITSELF: oracle/ref_build.sh translates
+ * the reference's sources where they lie with ROCm's hipify-perl and compiles them for gfx950
+ * (oracle/_ref/libref_gnn.so, git-ignored; oracle/ref_shim.hip are the C entry points).
+ *   - integer stages (neighbor grouping, both locality schedules, reorderCSR, load_graph and its
+ *     cache files): the reference's host code runs in the CPU container -- exact equality,
+ *     tests/test_reference_host.py, recorded in tests/golden/reference_host.json;
+ *   - fp32 stages: the reference's kernels run on the MI355X -- orc_gcn_seq is BIT-EQUAL to
+ *     aggr_gcn; the grouped / GAT restatements agree with aggr_gcn_target, aggr_gat and
+ *     aggr_gat_fine + scaleArray within 1e-5 * sum_e |w_e x_e| (atomicAdd order, __expf) --
+ *     tests/test_gpu_reference.py, recorded in tests/golden/reference_device.npz.
+ * Not anchored: attGat / u_add_v / add_to_center / each_div and the backward kernel reduce with
+ * default-width warp shuffles (32 lanes on the reference's hardware, 64 here), so their results
+ * on this GPU would not be the reference's; those restatements rest on known answers and on the
+ * identity adapter == fused (tests/test_oracle_golden.py, tests/test_gpu_parity.py).
  *
  * Build: make -C oracle   (gcc -O3 -fopenmp -shared)
  */

@@ -1,0 +1,161 @@
+"""ctypes front-end of oracle/_ref/libref_gnn.so -- the REFERENCE's own code (hipify-perl translation of /root/reference,
+built by oracle/ref_build.sh), used to PIN the CPU oracle and the product:
+
+* host-only entry points (the reference's schedulers, reorderCSR, load_graph) run anywhere the library loads;
+* device entry points (Aggregator_GCN::run, Aggregator_GAT::run, csr2edgelist) need a GPU.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/ and by tests/golden/make_reference_vectors.py.  The product package never
+imports this module.  `available()` is False when the library was not built (no reference tree at build time).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_ref", "libref_gnn.so")
+_lib = None
+
+_I = ctypes.POINTER(ctypes.c_int)
+_F = ctypes.POINTER(ctypes.c_float)
+
+
+def build():
+    """Runs the committed recipe (needs /root/reference and hipify-perl; a no-op message otherwise)."""
+    subprocess.check_call(["bash", os.path.join(_HERE, "ref_build.sh")])
+    return os.path.exists(_SO)
+
+
+def available():
+    return os.path.exists(_SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libref_gnn.so is not built (oracle/ref_build.sh needs the reference tree)")
+        _lib = ctypes.CDLL(_SO)
+        for name in ("ref_device_count", "ref_neighbor_grouping", "ref_locality_schedule", "ref_locality_neighbor_grouping",
+                     "ref_reorder_csr", "ref_load_graph", "ref_gcn_run", "ref_csr2edgelist", "ref_gat_run"):
+            getattr(_lib, name).restype = ctypes.c_int
+    return _lib
+
+
+def _i(a):
+    return a.ctypes.data_as(_I)
+
+
+def _f(a):
+    return a.ctypes.data_as(_F)
+
+
+def _ci(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _cf(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count():
+    return int(lib().ref_device_count())
+
+
+def _groups(call, num_e, cap):
+    ptr_s, idx_s, target = np.zeros(cap + 1, np.int32), np.zeros(max(num_e, 1), np.int32), np.zeros(max(cap, 1), np.int32)
+    g = call(_i(ptr_s), _i(idx_s), _i(target), cap)
+    if g < 0:
+        raise RuntimeError("group capacity too small")
+    return ptr_s[:g + 1].copy(), idx_s[:num_e].copy(), target[:g].copy()
+
+
+def neighbor_grouping(ptr, idx, ng):
+    """graph_schedule.h:91-126 -> (ptr_s[G+1], idx_s[E], target[G])"""
+    ptr, idx = _ci(ptr), _ci(idx)
+    V, E = len(ptr) - 1, len(idx)
+    cap = V + E // max(ng, 1) + 8
+    return _groups(lambda p, i, t, c: lib().ref_neighbor_grouping(_i(ptr), _i(idx), int(ng), V, E, p, i, t, c), E, cap)
+
+
+def locality_schedule(ptr, idx, par_num, total_cols, ng=0):
+    """graph_schedule.h:17-89 (ng == 0) / localityNeighborGrouping :156-243 -> (ptr_s, idx_s, target)"""
+    ptr, idx = _ci(ptr), _ci(idx)
+    V, E = len(ptr) - 1, len(idx)
+    cap = V * par_num + (E // ng if ng else 0) + 8
+    if ng:
+        return _groups(lambda p, i, t, c: lib().ref_locality_neighbor_grouping(_i(ptr), _i(idx), int(par_num), int(ng), V, int(total_cols),
+                                                                                p, i, t, c, E), E, cap)
+    return _groups(lambda p, i, t, c: lib().ref_locality_schedule(_i(ptr), _i(idx), int(par_num), V, int(total_cols), p, i, t, c, E), E, cap)
+
+
+def reorder_csr(ptr, idx, rows):
+    """src/data.cu:4-29 with map = rows (old id placed at new position i) and its inverse"""
+    ptr, idx, rows = _ci(ptr), _ci(idx), _ci(rows)
+    V, E = len(ptr) - 1, len(idx)
+    rev = np.empty(V, np.int32)
+    rev[rows] = np.arange(V, dtype=np.int32)
+    newptr, newidx = np.zeros(V + 1, np.int32), np.zeros(max(E, 1), np.int32)
+    lib().ref_reorder_csr(_i(ptr), _i(idx), _i(rows), _i(rev), V, E, _i(newptr), _i(newidx))
+    return newptr, newidx[:E].copy()
+
+
+def load_graph(datadir, dset, shuffle=True, reorder_suffix="", cap_v=1 << 22, cap_e=1 << 26):
+    """src/data.cu:31-139.  `datadir` must be a directory NAMED data (the reference reads "../data/<dset>.*"); returns
+    (ptr, idx, rows or None, reverse_rows or None)."""
+    datadir = os.path.abspath(datadir)
+    assert os.path.basename(datadir) == "data", "the reference hard-codes ../data/"
+    work = os.path.join(os.path.dirname(datadir), "run")
+    os.makedirs(work, exist_ok=True)
+    with open(os.path.join(datadir, dset + ".config")) as f:
+        V, E = [int(t) for t in f.read().split()[:2]]
+    cap_v, cap_e = max(V, 1), max(E, 1)
+    nv, ne = ctypes.c_int(0), ctypes.c_int(0)
+    ptr, idx = np.zeros(cap_v + 1, np.int32), np.zeros(cap_e, np.int32)
+    rows, rev = np.zeros(cap_v, np.int32), np.zeros(cap_v, np.int32)
+    rc = lib().ref_load_graph(work.encode(), dset.encode(), 1 if shuffle else 0, reorder_suffix.encode(), ctypes.byref(nv), ctypes.byref(ne),
+                              _i(ptr), cap_v, _i(idx), cap_e, _i(rows), _i(rev))
+    if rc < 0:
+        raise RuntimeError("ref_load_graph failed (%d)" % rc)
+    V, E = nv.value, ne.value
+    return ptr[:V + 1].copy(), idx[:E].copy(), (rows[:V].copy() if rc == 1 else None), (rev[:V].copy() if rc == 1 else None)
+
+
+def gcn_run(ptr, idx, val, x, block=512, scheduled=False, ng=16, want_schedule=False):
+    """Aggregator_GCN::run (aggr_gcn.h:379-410): aggr_gcn, or schedule(neighbor_grouping, ng) + aggr_gcn_target.  feat must be a
+    multiple of 32 with block % feat == 0 (the reference's launch geometry).  Needs a GPU."""
+    ptr, idx, val, x = _ci(ptr), _ci(idx), _cf(val), _cf(x)
+    V, E, F = len(ptr) - 1, len(idx), x.shape[1]
+    assert F % 32 == 0 and block % F == 0 and block <= 1024
+    y = np.zeros((V, F), np.float32)
+    cap = V + E // max(ng, 1) + 8
+    sp, st = np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+    g = lib().ref_gcn_run(_i(ptr), _i(idx), _f(val), V, E, _f(x), _f(y), F, int(block), 1 if scheduled else 0, int(ng), _i(sp), _i(st), cap)
+    if g < 0:
+        raise RuntimeError("ref_gcn_run failed (%d)" % g)
+    if want_schedule:
+        return y, sp[:g + 1].copy(), st[:g].copy()
+    return y
+
+
+def csr2edgelist(ptr, idx):
+    ptr, idx = _ci(ptr), _ci(idx)
+    V, E = len(ptr) - 1, len(idx)
+    out = np.zeros(2 * max(E, 1), np.int32)
+    if lib().ref_csr2edgelist(_i(ptr), _i(idx), V, E, _i(out)) < 0:
+        raise RuntimeError("ref_csr2edgelist failed")
+    return out[:2 * E].reshape(E, 2).copy()
+
+
+def gat_run(ptr, idx, att, x, block=128, scheduled=False, ng=32):
+    """Aggregator_GAT::run (aggr_gat.h:317-354): aggr_gat, or schedule(neighbor_grouping, ng) + aggr_gat_fine + scaleArray.
+    att is [V, 2].  Needs a GPU."""
+    ptr, idx, att, x = _ci(ptr), _ci(idx), _cf(att), _cf(x)
+    V, E, F = len(ptr) - 1, len(idx), x.shape[1]
+    assert F % 32 == 0 and block % F == 0 and att.shape == (V, 2)
+    y = np.zeros((V, F), np.float32)
+    g = lib().ref_gat_run(_i(ptr), _i(idx), V, E, _f(x), _f(att), _f(y), F, int(block), 1 if scheduled else 0, int(ng))
+    if g < 0:
+        raise RuntimeError("ref_gat_run failed (%d)" % g)
+    return y

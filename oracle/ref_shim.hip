@@ -1,0 +1,232 @@
+// oracle/ref_shim.hip -- C entry points over the REFERENCE's own aggregation path, for oracle/_ref/libref_gnn.so.
+//
+// TEST INFRASTRUCTURE ONLY (tests/ pin the CPU oracle and the product against it; nothing under gnn_computing_amd/ loads it).
+//
+// This file is this repo's code; everything it calls is the reference's: oracle/ref_build.sh translates the reference's
+// sources WHERE THEY LIE (/root/reference/include/*.h, src/data.cu, src/util.cu) with ROCm's hipify-perl into a scratch
+// directory outside the repo, compiles this shim against them with hipcc for gfx950 and deletes the scratch directory.
+// No reference source is copied into the repo; only the built library lands in oracle/_ref/ (git-ignored).
+//
+// What runs unchanged on a 64-wide wavefront and is therefore exposed here:
+//   Aggregator_GCN::run  -> aggr_gcn        (include/aggr_gcn.h:5-36,  `__shfl(x, j, 32)`: explicit 32-lane width)
+//                        -> aggr_gcn_target (include/aggr_gcn.h:78-114, shared memory per 32-lane group + atomicAdd)
+//   Aggregator_GAT::run  -> aggr_gat        (include/aggr_gat.h:116-164), aggr_gat_fine + scaleArray (:167-213)
+//   Aggregator::schedule -> neighbor_grouping_schedule / locality_schedule / localityNeighborGrouping (graph_schedule.h:17-243)
+//   Aggregator::csr2edgelist (aggregator.h:11-23,115-122), load_graph / reorderCSR (src/data.cu:4-139)
+// NOT exposed: attGat / u_add_v / add_to_center / each_div / the backward kernel (aggr_gat.h:5-92,222-296) reduce with
+// `__shfl_down_sync(mask, v, i)` at the DEFAULT width, i.e. over the hardware warp: 64 lanes here, two rows per wavefront
+// -- their results on this hardware would not be the reference's.
+// (the library headers first: aggregator.h:5-6 turns __shfl / __shfl_down into macros, which must not be in force when
+// HIP's own headers declare functions of those names)
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hipsparse.h>
+#include <hipblas.h>
+#include <hiprand.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "aggr_gcn.h"
+#include "aggr_gat.h"
+
+// src/data.cu:4 (not declared in data.h with this signature)
+void reorderCSR(const int *ptr, const int *idx, const int *map, const int *reverse_map, int num_v, int num_e, int *&newptr, int *&newidx);
+
+namespace {
+
+template <class T>
+T *to_dev(const T *h, size_t n)
+{
+    T *d = nullptr;
+    if (hipMalloc((void **)&d, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    if (n && hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+}
+
+int copy_vec(const std::vector<int> &v, int *out, int cap)
+{
+    if ((int)v.size() > cap) return -1;
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(int));
+    return (int)v.size();
+}
+
+// exposes the protected schedule arrays of the reference's base class (aggregator.h:130-133)
+struct GcnProbe : Aggregator_GCN {
+    using Aggregator_GCN::Aggregator_GCN;
+    int *sched_ptr() { return d_ptr_scheduled; }
+    int *sched_target() { return d_target_scheduled; }
+    int *edgelist() { return d_edgelist; }
+};
+struct GatProbe : Aggregator_GAT {
+    using Aggregator_GAT::Aggregator_GAT;
+};
+
+}  // namespace
+
+extern "C" {
+
+#define REF_API __attribute__((visibility("default")))
+
+REF_API int ref_device_count()
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+// ---- host-only: the reference's schedulers (graph_schedule.h).  Return the number of groups, -1 when `cap` is too small.
+REF_API int ref_neighbor_grouping(const int *ptr, const int *idx, int ng, int num_v, int num_e, int *ptr_s, int *idx_s, int *target, int cap)
+{
+    std::vector<int> p, i, t;
+    neighbor_grouping_schedule(const_cast<int *>(ptr), const_cast<int *>(idx), ng, num_v, num_e, &p, &i, &t);
+    if (copy_vec(p, ptr_s, cap + 1) < 0 || copy_vec(i, idx_s, num_e) < 0 || copy_vec(t, target, cap) < 0) return -1;
+    return (int)t.size();
+}
+
+REF_API int ref_locality_schedule(const int *ptr, const int *idx, int par_num, int num_v, int total_num_v, int *ptr_s, int *idx_s, int *target,
+                                  int cap, int num_e)
+{
+    std::vector<int> p, i, t;
+    locality_schedule(const_cast<int *>(ptr), const_cast<int *>(idx), par_num, num_v, &p, &i, &t, total_num_v);
+    if (copy_vec(p, ptr_s, cap + 1) < 0 || copy_vec(i, idx_s, num_e) < 0 || copy_vec(t, target, cap) < 0) return -1;
+    return (int)t.size();
+}
+
+REF_API int ref_locality_neighbor_grouping(const int *ptr, const int *idx, int par_num, int ng, int num_v, int total_num_v, int *ptr_s,
+                                           int *idx_s, int *target, int cap, int num_e)
+{
+    std::vector<int> p, i, t;
+    localityNeighborGrouping(const_cast<int *>(ptr), const_cast<int *>(idx), par_num, ng, num_v, &p, &i, &t, total_num_v);
+    if (copy_vec(p, ptr_s, cap + 1) < 0 || copy_vec(i, idx_s, num_e) < 0 || copy_vec(t, target, cap) < 0) return -1;
+    return (int)t.size();
+}
+
+// ---- host-only: src/data.cu
+REF_API int ref_reorder_csr(const int *ptr, const int *idx, const int *map, const int *reverse_map, int num_v, int num_e, int *newptr, int *newidx)
+{
+    int *np = newptr, *ni = newidx;  // non-null: reorderCSR fills the caller's buffers
+    reorderCSR(ptr, idx, map, reverse_map, num_v, num_e, np, ni);
+    return 0;
+}
+
+// load_graph reads "../data/<dset>.*" relative to the working directory: `workdir` is a directory next to that data/.
+// With `shuffle` and an existing "<dset>.reorder<suffix>" the graph comes back reordered and rows / reverse_rows are filled.
+REF_API int ref_load_graph(const char *workdir, const char *dset, int shuffle, const char *reorder_suffix, int *num_v, int *num_e, int *ptr_out,
+                           int cap_v, int *idx_out, int cap_e, int *rows_out, int *reverse_rows_out)
+{
+    char cwd[4096];
+    if (!getcwd(cwd, sizeof(cwd)) || chdir(workdir) != 0) return -2;
+    rows = nullptr;
+    reverse_rows = nullptr;
+    reorderfile = "";
+    int v = 0, e = 0, *p = nullptr, *i = nullptr;
+    load_graph(std::string(dset), v, e, p, i, shuffle != 0, std::string(reorder_suffix ? reorder_suffix : ""));
+    (void)!chdir(cwd);
+    *num_v = v;
+    *num_e = e;
+    if (v > cap_v || e > cap_e) return -1;
+    memcpy(ptr_out, p, (size_t)(v + 1) * sizeof(int));
+    memcpy(idx_out, i, (size_t)e * sizeof(int));
+    int reordered = 0;
+    if (rows && reverse_rows) {
+        reordered = 1;
+        if (rows_out) memcpy(rows_out, rows, (size_t)v * sizeof(int));
+        if (reverse_rows_out) memcpy(reverse_rows_out, reverse_rows, (size_t)v * sizeof(int));
+    }
+    delete[] p;
+    delete[] i;
+    return reordered;
+}
+
+// ---- device: Aggregator_GCN (aggr_gcn.h:362-444).  Host arrays in / out; `scheduled` != 0 runs schedule(neighbor_grouping,
+// {ng}) first (aggr_gcn.h:379-410).  sched_* (optional, capacity `cap` groups) receive the reference's scheduled arrays.
+// Returns num_target (>= 0), or a negative error.
+REF_API int ref_gcn_run(const int *ptr, const int *idx, const float *val, int num_v, int num_e, const float *x, float *y, int feat, int block,
+                        int scheduled, int ng, int *sched_ptr, int *sched_target, int cap)
+{
+    n = num_v;
+    m = num_e;
+    feature_len = feat;
+    int *d_ptr = to_dev(ptr, (size_t)num_v + 1), *d_idx = to_dev(idx, num_e);
+    float *d_val = to_dev(val, num_e), *d_x = to_dev(x, (size_t)num_v * feat), *d_y = nullptr;
+    if (!d_ptr || !d_idx || !d_val || !d_x || hipMalloc((void **)&d_y, (size_t)num_v * feat * sizeof(float)) != hipSuccess) return -2;
+    if (hipMemset(d_y, 0xff, (size_t)num_v * feat * sizeof(float)) != hipSuccess) return -2;  // NaN pattern: run() must overwrite it
+    int rc = 0;
+    {
+        GcnProbe agg(nullptr, nullptr, d_ptr, d_idx, num_v, num_e, feat, feat, d_val);  // owns d_ptr / d_idx / d_val (aggregator.h:58-66)
+        if (scheduled) {
+            int param[2] = {ng, 0};
+            agg.schedule(neighbor_grouping, param);
+        }
+        agg.run(d_x, d_y, block, scheduled != 0);
+        if (hipDeviceSynchronize() != hipSuccess) rc = -3;
+        rc = rc ? rc : agg.num_target;
+        if (!rc || rc > 0) {
+            if (scheduled && sched_ptr && sched_target) {
+                if (agg.num_target > cap) rc = -1;
+                else {
+                    (void)hipMemcpy(sched_ptr, agg.sched_ptr(), (size_t)(agg.num_target + 1) * sizeof(int), hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(sched_target, agg.sched_target(), (size_t)agg.num_target * sizeof(int), hipMemcpyDeviceToHost);
+                }
+            }
+            if (hipMemcpy(y, d_y, (size_t)num_v * feat * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+        }
+    }
+    (void)hipFree(d_x);
+    (void)hipFree(d_y);
+    return rc;
+}
+
+// Aggregator::csr2edgelist (aggregator.h:115-122): edgelist[2e] = source, [2e + 1] = row
+REF_API int ref_csr2edgelist(const int *ptr, const int *idx, int num_v, int num_e, int *edgelist)
+{
+    n = num_v;
+    m = num_e;
+    int *d_ptr = to_dev(ptr, (size_t)num_v + 1), *d_idx = to_dev(idx, num_e);
+    std::vector<float> ones((size_t)num_e, 1.0f);
+    float *d_val = to_dev(ones.data(), num_e);
+    if (!d_ptr || !d_idx || !d_val) return -2;
+    int rc = 0;
+    {
+        GcnProbe agg(nullptr, nullptr, d_ptr, d_idx, num_v, num_e, 32, 32, d_val);
+        agg.csr2edgelist();
+        if (hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(edgelist, agg.edgelist(), (size_t)2 * num_e * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = -3;
+    }
+    return rc;
+}
+
+// ---- device: Aggregator_GAT::run (aggr_gat.h:317-354): att is [V, 2] (centre term, source term); slope 0.2 (:347).
+// The scheduled path never zeroes vout / scalar (aggr_gat.h:305,333): a fresh object and a zeroed vout per call here.
+REF_API int ref_gat_run(const int *ptr, const int *idx, int num_v, int num_e, const float *x, const float *att, float *y, int feat, int block,
+                        int scheduled, int ng)
+{
+    n = num_v;
+    m = num_e;
+    feature_len = feat;
+    int *d_ptr = to_dev(ptr, (size_t)num_v + 1), *d_idx = to_dev(idx, num_e);
+    float *d_x = to_dev(x, (size_t)num_v * feat), *d_att = to_dev(att, (size_t)num_v * 2), *d_y = nullptr;
+    if (!d_ptr || !d_idx || !d_x || !d_att || hipMalloc((void **)&d_y, (size_t)num_v * feat * sizeof(float)) != hipSuccess) return -2;
+    if (hipMemset(d_y, scheduled ? 0 : 0xff, (size_t)num_v * feat * sizeof(float)) != hipSuccess) return -2;
+    int rc = 0;
+    {
+        GatProbe agg(nullptr, nullptr, d_ptr, d_idx, num_v, num_e, feat, feat);
+        if (scheduled) {
+            int param[2] = {ng, 0};
+            agg.schedule(neighbor_grouping, param);
+        }
+        agg.run(d_x, d_att, d_y, block, scheduled != 0);
+        if (hipDeviceSynchronize() != hipSuccess) rc = -3;
+        rc = rc ? rc : agg.num_target;
+        if (hipMemcpy(y, d_y, (size_t)num_v * feat * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+    }
+    (void)hipFree(d_x);
+    (void)hipFree(d_att);
+    (void)hipFree(d_y);
+    return rc;
+}
+
+}  // extern "C"
