@@ -21,10 +21,11 @@
  *     aggr_gcn; the grouped / GAT restatements agree with aggr_gcn_target, aggr_gat and
  *     aggr_gat_fine + scaleArray within 1e-5 * sum_e |w_e x_e| (atomicAdd order, __expf) --
  *     tests/test_gpu_reference.py, recorded in tests/golden/reference_device.npz.
- * Not anchored: attGat / u_add_v / add_to_center / each_div and the backward kernel reduce with
- * default-width warp shuffles (32 lanes on the reference's hardware, 64 here), so their results
- * on this GPU would not be the reference's; those restatements rest on known answers and on the
- * identity adapter == fused (tests/test_oracle_golden.py, tests/test_gpu_parity.py).
+ *   - edge-softmax stages (attGat, u_add_v, add_to_center, each_div) through the reference's
+ *     methods with BLOCK_SIZE = 32 (one of its 32-lane warps per 64-lane wavefront): u_add_v and
+ *     each_div exact, attGat within 1e-5 relative, row sums within 1e-5 * sum|v|.
+ * Not anchored: the backward kernel (the product implements the mathematics of its comments, not
+ * the code), the naive spmm / validators, the dense GEMM, and the extensions (multi-head, mean / max).
  *
  * Build: make -C oracle   (gcc -O3 -fopenmp -shared)
  */

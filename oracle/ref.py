@@ -38,7 +38,7 @@ def lib():
             raise RuntimeError("oracle/_ref/libref_gnn.so is not built (oracle/ref_build.sh needs the reference tree)")
         _lib = ctypes.CDLL(_SO)
         for name in ("ref_device_count", "ref_neighbor_grouping", "ref_locality_schedule", "ref_locality_neighbor_grouping",
-                     "ref_reorder_csr", "ref_load_graph", "ref_gcn_run", "ref_csr2edgelist", "ref_gat_run"):
+                     "ref_reorder_csr", "ref_load_graph", "ref_gcn_run", "ref_csr2edgelist", "ref_gat_run", "ref_gat_edge_stage"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -159,3 +159,34 @@ def gat_run(ptr, idx, att, x, block=128, scheduled=False, ng=32):
     if g < 0:
         raise RuntimeError("ref_gat_run failed (%d)" % g)
     return y
+
+
+def _edge_stage(what, ptr, idx, vec, val):
+    ptr, idx = _ci(ptr), _ci(idx)
+    V, E = len(ptr) - 1, len(idx)
+    vec, val = np.array(vec, dtype=np.float32, order="C"), np.array(val, dtype=np.float32, order="C")
+    if val.size == 0:
+        val = np.zeros(1, np.float32)
+    if lib().ref_gat_edge_stage(int(what), _i(ptr), _i(idx), V, E, _f(vec), _f(val)) < 0:
+        raise RuntimeError("ref_gat_edge_stage(%d) failed" % what)
+    return vec, val[:E]
+
+
+def gat_att(ptr, idx, att):
+    """Aggregator_GAT::run_att -> attGat (aggr_gat.h:5-31,395-401), BLOCK_SIZE 32: normalised edge weights [E]."""
+    return _edge_stage(0, ptr, idx, att, np.zeros(len(idx), np.float32))[1]
+
+
+def gat_u_add_v(ptr, idx, att):
+    """run_u_add_v -> u_add_v (aggr_gat.h:33-48): att[row, 0] + att[src, 1] per edge."""
+    return _edge_stage(1, ptr, idx, att, np.zeros(len(idx), np.float32))[1]
+
+
+def gat_add_to_center(ptr, idx, val):
+    """run_add_to_center -> add_to_center (aggr_gat.h:50-74): row sums of val[E] -> [V]."""
+    return _edge_stage(2, ptr, idx, np.zeros(len(ptr) - 1, np.float32), val)[0]
+
+
+def gat_div_each(ptr, idx, vec, val):
+    """run_div_each -> each_div (aggr_gat.h:76-92): val[e] / vec[row]."""
+    return _edge_stage(3, ptr, idx, vec, val)[1]

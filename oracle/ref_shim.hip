@@ -13,9 +13,15 @@
 //   Aggregator_GAT::run  -> aggr_gat        (include/aggr_gat.h:116-164), aggr_gat_fine + scaleArray (:167-213)
 //   Aggregator::schedule -> neighbor_grouping_schedule / locality_schedule / localityNeighborGrouping (graph_schedule.h:17-243)
 //   Aggregator::csr2edgelist (aggregator.h:11-23,115-122), load_graph / reorderCSR (src/data.cu:4-139)
-// NOT exposed: attGat / u_add_v / add_to_center / each_div / the backward kernel (aggr_gat.h:5-92,222-296) reduce with
-// `__shfl_down_sync(mask, v, i)` at the DEFAULT width, i.e. over the hardware warp: 64 lanes here, two rows per wavefront
-// -- their results on this hardware would not be the reference's.
+//   Aggregator_GAT::run_att / run_u_add_v / run_add_to_center / run_div_each -> attGat, u_add_v, add_to_center, each_div
+//       (aggr_gat.h:5-92,395-425).  attGat and add_to_center reduce with `__shfl_down_sync(mask, v, i)` at the DEFAULT width,
+//       i.e. over the hardware warp -- 64 lanes here.  They are therefore called with BLOCK_SIZE = 32 (a parameter of the
+//       reference's own methods: one 32-lane warp per workgroup, so every wavefront carries exactly one of the reference's
+//       warps in its lower half): lane 0 then receives v[0] + v[16], + v[8] + v[24], ... -- the reference's tree, none of the
+//       inactive upper lanes on its path -- and the broadcast from lane 0 is the warp's lane 0.  With the drivers' BLOCK_SIZE
+//       (128: two rows per wavefront) the reductions would mix neighbouring rows on this hardware.
+// NOT exposed: the backward kernel (aggr_gat.h:222-296, "Experiment", no caller): the product implements the mathematics its
+// comments describe, not the code, so there is nothing to compare.
 // (the library headers first: aggregator.h:5-6 turns __shfl / __shfl_down into macros, which must not be in force when
 // HIP's own headers declare functions of those names)
 #include <hip/hip_runtime.h>
@@ -226,6 +232,35 @@ REF_API int ref_gat_run(const int *ptr, const int *idx, int num_v, int num_e, co
     (void)hipFree(d_x);
     (void)hipFree(d_att);
     (void)hipFree(d_y);
+    return rc;
+}
+
+// ---- device: the edge-softmax stages (aggr_gat.h:395-425), each through the reference's own method with BLOCK_SIZE = 32
+// (see the header).  what: 0 run_att (att[V,2] -> val[E] normalised), 1 run_u_add_v (att[V,2] -> val[E]),
+// 2 run_add_to_center (val[E] -> vec[V] row sums), 3 run_div_each (vec[V], val[E] in/out).
+REF_API int ref_gat_edge_stage(int what, const int *ptr, const int *idx, int num_v, int num_e, float *att_or_vec, float *val)
+{
+    n = num_v;
+    m = num_e;
+    int *d_ptr = to_dev(ptr, (size_t)num_v + 1), *d_idx = to_dev(idx, num_e);
+    const size_t nv = (what == 0 || what == 1) ? (size_t)num_v * 2 : (size_t)num_v;
+    float *d_v = to_dev(att_or_vec, nv), *d_e = to_dev(val, num_e);
+    if (!d_ptr || !d_idx || !d_v || !d_e) return -2;
+    int rc = 0;
+    {
+        GatProbe agg(nullptr, nullptr, d_ptr, d_idx, num_v, num_e, 32, 32);
+        switch (what) {
+            case 0: agg.run_att(d_v, d_e, 32); break;
+            case 1: agg.run_u_add_v(d_v, d_e, 32); break;
+            case 2: agg.run_add_to_center(d_e, d_v, 32); break;
+            default: agg.run_div_each(d_v, d_e, 32); break;
+        }
+        if (hipDeviceSynchronize() != hipSuccess) rc = -3;
+        if (what == 2) { if (hipMemcpy(att_or_vec, d_v, (size_t)num_v * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -3; }
+        else if (hipMemcpy(val, d_e, (size_t)num_e * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+    }
+    (void)hipFree(d_v);
+    (void)hipFree(d_e);
     return rc;
 }
 
