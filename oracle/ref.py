@@ -38,7 +38,7 @@ def lib():
             raise RuntimeError("oracle/_ref/libref_gnn.so is not built (oracle/ref_build.sh needs the reference tree)")
         _lib = ctypes.CDLL(_SO)
         for name in ("ref_device_count", "ref_neighbor_grouping", "ref_locality_schedule", "ref_locality_neighbor_grouping",
-                     "ref_reorder_csr", "ref_load_graph", "ref_gcn_run", "ref_csr2edgelist", "ref_gat_run", "ref_gat_edge_stage"):
+                     "ref_reorder_csr", "ref_load_graph", "ref_gcn_run", "ref_csr2edgelist", "ref_gat_run", "ref_gat_edge_stage", "ref_time_run"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -190,3 +190,17 @@ def gat_add_to_center(ptr, idx, val):
 def gat_div_each(ptr, idx, vec, val):
     """run_div_each -> each_div (aggr_gat.h:76-92): val[e] / vec[row]."""
     return _edge_stage(3, ptr, idx, vec, val)[1]
+
+
+def time_run(kind, ptr, idx, aux, x, block, scheduled=False, ng=16, warm=10, iters=10):
+    """Microseconds per Aggregator_GCN::run (kind "gcn", aux = val[E]) / Aggregator_GAT::run ("gat", aux = att[V,2]) on this GPU
+    (the reference's protocol: 10 warm-up + 10 timed calls, Figure10/main_a.cu:73-92)."""
+    ptr, idx, aux, x = _ci(ptr), _ci(idx), _cf(aux), _cf(x)
+    V, E, F = len(ptr) - 1, len(idx), x.shape[1]
+    assert F % 32 == 0 and block % F == 0 and block <= 1024
+    us = ctypes.c_double(0.0)
+    rc = lib().ref_time_run(0 if kind == "gcn" else 1, _i(ptr), _i(idx), _f(aux), V, E, _f(x), F, int(block), 1 if scheduled else 0, int(ng),
+                            int(warm), int(iters), ctypes.byref(us))
+    if rc < 0:
+        raise RuntimeError("ref_time_run failed (%d)" % rc)
+    return us.value

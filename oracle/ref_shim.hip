@@ -235,6 +235,53 @@ REF_API int ref_gat_run(const int *ptr, const int *idx, int num_v, int num_e, co
     return rc;
 }
 
+// ---- device: time the reference's run() on this GPU (hipEvents around `iters` calls after `warm` untimed ones; the
+// scheduled path includes its cudaMemset of vout, aggr_gcn.h:393, as the reference's own drivers time it).  kind 0: GCN, 1: GAT
+// (att = first 2 V floats of `aux`; GCN: aux = val[E]).  Returns microseconds per call in *us, num_target as the result.
+REF_API int ref_time_run(int kind, const int *ptr, const int *idx, const float *aux, int num_v, int num_e, const float *x, int feat, int block,
+                         int scheduled, int ng, int warm, int iters, double *us)
+{
+    n = num_v;
+    m = num_e;
+    feature_len = feat;
+    int *d_ptr = to_dev(ptr, (size_t)num_v + 1), *d_idx = to_dev(idx, num_e);
+    float *d_aux = to_dev(aux, kind == 0 ? (size_t)num_e : (size_t)num_v * 2), *d_x = to_dev(x, (size_t)num_v * feat), *d_y = nullptr;
+    if (!d_ptr || !d_idx || !d_aux || !d_x || hipMalloc((void **)&d_y, (size_t)num_v * feat * sizeof(float)) != hipSuccess) return -2;
+    (void)hipMemset(d_y, 0, (size_t)num_v * feat * sizeof(float));
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -2;
+    int rc = 0;
+    auto loop = [&](auto &agg, auto call) {
+        if (scheduled) {
+            int param[2] = {ng, 0};
+            agg.schedule(neighbor_grouping, param);
+        }
+        for (int i = 0; i < warm; ++i) call();
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < iters; ++i) call();
+        (void)hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = -3; return; }
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *us = (double)ms * 1e3 / (iters > 0 ? iters : 1);
+        rc = agg.num_target;
+    };
+    if (kind == 0) {
+        GcnProbe agg(nullptr, nullptr, d_ptr, d_idx, num_v, num_e, feat, feat, d_aux);
+        loop(agg, [&] { agg.run(d_x, d_y, block, scheduled != 0); });
+    } else {
+        GatProbe agg(nullptr, nullptr, d_ptr, d_idx, num_v, num_e, feat, feat);
+        loop(agg, [&] { agg.run(d_x, d_aux, d_y, block, scheduled != 0); });
+        (void)hipFree(d_aux);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d_x);
+    (void)hipFree(d_y);
+    return rc;
+}
+
 // ---- device: the edge-softmax stages (aggr_gat.h:395-425), each through the reference's own method with BLOCK_SIZE = 32
 // (see the header).  what: 0 run_att (att[V,2] -> val[E] normalised), 1 run_u_add_v (att[V,2] -> val[E]),
 // 2 run_add_to_center (val[E] -> vec[V] row sums), 3 run_div_each (vec[V], val[E] in/out).

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""The reference's OWN kernels (oracle/_ref/libref_gnn.so: /root/reference translated by hipify-perl, see oracle/ref_build.sh)
+timed on this MI355X beside this library, on the headline workload and the reference drivers' default shapes.  Context for
+DESIGN.md -- not a bench line: the reference was written for 32-lane warps (two of them share a wavefront here)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gnn_computing_amd as gnc  # noqa: E402
+from oracle import ref  # noqa: E402
+
+dev = torch.device("cuda", 0)
+
+
+def ours(fn, warm=10, iters=50):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters
+
+
+def main():
+    ptr_t, idx_t = gnc.graph.dataset("arxiv")
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    rows, _ = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=8192)
+    rptr, ridx, _ = gnc.reorder_csr(ptr, idx, rows)
+    V, E = len(ptr) - 1, len(idx)
+    rng = np.random.default_rng(123)
+    val = np.ones(E, np.float32)
+    att = (rng.standard_normal((V, 2)) * 0.3).astype(np.float32)
+    for name, (p, i) in (("no reorder", (ptr, idx)), ("locality reorder on load", (rptr, ridx))):
+        dp, di = torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev)
+        for F, block in ((128, 512), (32, 512)):
+            x = rng.standard_normal((V, F), dtype=np.float32)
+            dx, dy = torch.from_numpy(x).to(dev), torch.empty((V, F), device=dev)
+            agg = gnc.Aggregator_GCN(dp, di, torch.from_numpy(val).to(dev), F, F)
+            agg.schedule(gnc.Schedule.neighbor_grouping, [16])
+            out = dict(workload="arxiv-shaped %dx%d GCN sum F=%d, %s" % (V, E, F, name),
+                       reference_aggr_gcn_us=ref.time_run("gcn", p, i, val, x, block, False),
+                       reference_neighbor_grouping16_us=ref.time_run("gcn", p, i, val, x, block, True, 16),
+                       reference_neighbor_grouping32_us=ref.time_run("gcn", p, i, val, x, block, True, 32),
+                       ours_rows_us=ours(lambda: agg.run(dx, dy, 512, 0)),
+                       ours_neighbor_grouping16_us=ours(lambda: agg.run(dx, dy, 512, 1)),
+                       ours_balanced_us=ours(lambda: agg.run(dx, dy, 512, "balanced")))
+            print(json.dumps(out), flush=True)
+        F = 128
+        x = rng.standard_normal((V, F), dtype=np.float32)
+        dx, dy, datt = torch.from_numpy(x).to(dev), torch.empty((V, F), device=dev), torch.from_numpy(att).to(dev)
+        gat = gnc.Aggregator_GAT(dp, di, F, F)
+        gat.schedule(gnc.Schedule.neighbor_grouping, [32])
+        out = dict(workload="arxiv-shaped GAT (1 head) F=128, %s" % name,
+                   reference_aggr_gat_us=ref.time_run("gat", p, i, att, x, 128, False),
+                   reference_neighbor_grouping32_us=ref.time_run("gat", p, i, att, x, 128, True, 32),
+                   ours_rows_us=ours(lambda: gat.run(dx, datt, dy, 128, 0)),
+                   ours_neighbor_grouping32_us=ours(lambda: gat.run(dx, datt, dy, 128, 1)),
+                   ours_balanced_us=ours(lambda: gat.run(dx, datt, dy, 128, "balanced")))
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
