@@ -38,7 +38,7 @@ def lib():
             raise RuntimeError("oracle/_ref/libref_gnn.so is not built (oracle/ref_build.sh needs the reference tree)")
         _lib = ctypes.CDLL(_SO)
         for name in ("ref_device_count", "ref_neighbor_grouping", "ref_locality_schedule", "ref_locality_neighbor_grouping",
-                     "ref_reorder_csr", "ref_load_graph", "ref_gcn_run", "ref_csr2edgelist", "ref_gat_run", "ref_gat_edge_stage", "ref_time_run"):
+                     "ref_reorder_csr", "ref_load_graph", "ref_gcn_run", "ref_csr2edgelist", "ref_gat_run", "ref_gat_edge_stage", "ref_time_run", "ref_spmm_naive", "ref_valid", "ref_gcn_variant"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -204,3 +204,47 @@ def time_run(kind, ptr, idx, aux, x, block, scheduled=False, ng=16, warm=10, ite
     if rc < 0:
         raise RuntimeError("ref_time_run failed (%d)" % rc)
     return us.value
+
+
+def spmm_naive(ptr, idx, val, x, y0):
+    """spmm<L> (spmm.h:223-265), L = feat in {32, 64, 128}; rows without edges keep y0."""
+    ptr, idx, val, x = _ci(ptr), _ci(idx), _cf(val), _cf(x)
+    y = np.array(y0, dtype=np.float32, order="C")
+    rc = lib().ref_spmm_naive(_i(ptr), _i(idx), _f(val), len(ptr) - 1, len(idx), _f(x), _f(y), x.shape[1])
+    if rc < 0:
+        raise RuntimeError("ref_spmm_naive failed (%d)" % rc)
+    return y
+
+
+def valid(ref_y, ans, rows=None):
+    """valid (spmm.h:35-71) or, with the loader's rows[] map, validReordered (:73-91): the mismatch count."""
+    ref_y, ans = _cf(ref_y), _cf(ans)
+    rows = None if rows is None else _ci(rows)
+    V, F = ref_y.shape
+    n = lib().ref_valid(_f(ref_y), _f(ans), None if rows is None else _i(rows), V, F)
+    if n < 0:
+        raise RuntimeError("ref_valid failed (%d)" % n)
+    return n
+
+
+def gcn_edgewise(ptr, idx, val, x, block=512):
+    """Aggregator_GCN::runEdgeWise (aggr_gcn.h:446-460): 32 columns; E must be a multiple of block / 32."""
+    ptr, idx, val, x = _ci(ptr), _ci(idx), _cf(val), _cf(x)
+    V, E, F = len(ptr) - 1, len(idx), x.shape[1]
+    assert F == 32 and E % (block // 32) == 0
+    y = np.zeros((V, F), np.float32)
+    if lib().ref_gcn_variant(0, _i(ptr), _i(idx), _f(val), V, E, _f(x), _f(y), F, int(block), 0, None, None, 0) < 0:
+        raise RuntimeError("ref_gcn_variant(edgewise) failed")
+    return y
+
+
+def gcn_run_with_nn(ptr, idx, val, x, weight, block=128, ng=64):
+    """schedule(neighbor_grouping, ng) + Aggregator_GCN::run_with_nn (aggr_gcn.h:491-499) -> (vout [V, F], transformed [V, out])."""
+    ptr, idx, val, x, weight = _ci(ptr), _ci(idx), _cf(val), _cf(x), _cf(weight)
+    V, E, F = len(ptr) - 1, len(idx), x.shape[1]
+    out = weight.shape[1]
+    assert F % 32 == 0 and block % F == 0 and weight.shape[0] == F and out <= 32
+    y, tr = np.zeros((V, F), np.float32), np.zeros((V, out), np.float32)
+    if lib().ref_gcn_variant(1, _i(ptr), _i(idx), _f(val), V, E, _f(x), _f(y), F, int(block), int(ng), _f(weight), _f(tr), out) < 0:
+        raise RuntimeError("ref_gcn_variant(run_with_nn) failed")
+    return y, tr

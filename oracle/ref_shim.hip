@@ -20,6 +20,7 @@
 //       warps in its lower half): lane 0 then receives v[0] + v[16], + v[8] + v[24], ... -- the reference's tree, none of the
 //       inactive upper lanes on its path -- and the broadcast from lane 0 is the warp's lane 0.  With the drivers' BLOCK_SIZE
 //       (128: two rows per wavefront) the reductions would mix neighbouring rows on this hardware.
+//   Aggregator_GCN::runEdgeWise / run_with_nn (aggr_gcn.h:291-359,446-499), spmm<L> / valid / validReordered (spmm.h:11-91,223-265)
 // NOT exposed: the backward kernel (aggr_gat.h:222-296, "Experiment", no caller): the product implements the mathematics its
 // comments describe, not the code, so there is nothing to compare.
 // (the library headers first: aggregator.h:5-6 turns __shfl / __shfl_down into macros, which must not be in force when
@@ -37,6 +38,7 @@
 
 #include "aggr_gcn.h"
 #include "aggr_gat.h"
+#include "spmm.h"
 
 // src/data.cu:4 (not declared in data.h with this signature)
 void reorderCSR(const int *ptr, const int *idx, const int *map, const int *reverse_map, int num_v, int num_e, int *&newptr, int *&newidx);
@@ -280,6 +282,76 @@ REF_API int ref_time_run(int kind, const int *ptr, const int *idx, const float *
     (void)hipFree(d_x);
     (void)hipFree(d_y);
     return rc;
+}
+
+// ---- device: Aggregator_GCN::runEdgeWise (aggr_gcn.h:446-460 -> aggr_gcn_edgewise :291-302; 32 columns, one 32-lane warp per
+// edge, atomicAdd) and run_with_nn (:491-499 -> aggr_gcn_nn :304-359: neighbor-grouped aggregation whose group partials are
+// multiplied by `weight` [feat, out] and added into `transformed` with atomics; vout / transformed zeroed here as its caller
+// Figure10/main_b.cu does).  what 0: edge-wise (feat must be 32, num_e a multiple of block / 32: the kernel's bound check is
+// `row > num_e`), 1: run_with_nn (out <= 32).
+REF_API int ref_gcn_variant(int what, const int *ptr, const int *idx, const float *val, int num_v, int num_e, const float *x, float *y, int feat,
+                            int block, int ng, const float *weight, float *transformed, int out)
+{
+    n = num_v;
+    m = num_e;
+    feature_len = feat;
+    int *d_ptr = to_dev(ptr, (size_t)num_v + 1), *d_idx = to_dev(idx, num_e);
+    float *d_val = to_dev(val, num_e), *d_x = to_dev(x, (size_t)num_v * feat), *d_y = nullptr, *d_w = nullptr, *d_t = nullptr;
+    if (!d_ptr || !d_idx || !d_val || !d_x || hipMalloc((void **)&d_y, (size_t)num_v * feat * sizeof(float)) != hipSuccess) return -2;
+    (void)hipMemset(d_y, 0, (size_t)num_v * feat * sizeof(float));
+    if (what == 1) {
+        d_w = to_dev(weight, (size_t)feat * out);
+        if (!d_w || hipMalloc((void **)&d_t, (size_t)num_v * out * sizeof(float)) != hipSuccess) return -2;
+        (void)hipMemset(d_t, 0, (size_t)num_v * out * sizeof(float));
+    }
+    int rc = 0;
+    {
+        GcnProbe agg(nullptr, nullptr, d_ptr, d_idx, num_v, num_e, feat, what == 1 ? out : feat, d_val);
+        if (what == 0) {
+            agg.runEdgeWise(d_x, d_y, block, false);
+        } else {
+            int param[2] = {ng, 0};
+            agg.schedule(neighbor_grouping, param);
+            agg.run_with_nn(d_x, d_y, d_w, d_t, block);
+        }
+        if (hipDeviceSynchronize() != hipSuccess) rc = -3;
+        if (hipMemcpy(y, d_y, (size_t)num_v * feat * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+        if (what == 1 && hipMemcpy(transformed, d_t, (size_t)num_v * out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+    }
+    (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_w); (void)hipFree(d_t);
+    return rc;
+}
+
+// ---- device: the naive SpMM and the validators (spmm.h:11-91,223-265).  spmm<L>: one thread per row, y rows of empty rows
+// are left untouched (the caller's y comes back for them).  L in {32, 64, 128}.
+REF_API int ref_spmm_naive(const int *ptr, const int *idx, const float *val, int num_v, int num_e, const float *x, float *y, int feat)
+{
+    int *d_ptr = to_dev(ptr, (size_t)num_v + 1), *d_idx = to_dev(idx, num_e);
+    float *d_val = to_dev(val, num_e), *d_x = to_dev(x, (size_t)num_v * feat), *d_y = to_dev(y, (size_t)num_v * feat);
+    if (!d_ptr || !d_idx || !d_val || !d_x || !d_y) return -2;
+    const int grid = (num_v + TB - 1) / TB;
+    switch (feat) {
+        case 32: spmm<32><<<grid, TB>>>(num_v, d_ptr, d_idx, d_val, d_x, d_y); break;
+        case 64: spmm<64><<<grid, TB>>>(num_v, d_ptr, d_idx, d_val, d_x, d_y); break;
+        case 128: spmm<128><<<grid, TB>>>(num_v, d_ptr, d_idx, d_val, d_x, d_y); break;
+        default: return -1;
+    }
+    int rc = hipDeviceSynchronize() == hipSuccess && hipMemcpy(y, d_y, (size_t)num_v * feat * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+    (void)hipFree(d_ptr); (void)hipFree(d_idx); (void)hipFree(d_val); (void)hipFree(d_x); (void)hipFree(d_y);
+    return rc;
+}
+
+// valid (spmm.h:35-71) / validReordered (:73-91; `map` = the global rows[] of the loader, NULL: plain valid)
+REF_API int ref_valid(const float *ref_y, const float *ans, const int *map, int num_v, int feat)
+{
+    float *d_r = to_dev(ref_y, (size_t)num_v * feat), *d_a = to_dev(ans, (size_t)num_v * feat);
+    if (!d_r || !d_a) return -2;
+    int *saved = rows;
+    rows = const_cast<int *>(map);
+    const int bad = map ? validReordered(d_r, d_a, num_v, feat) : valid(d_r, d_a, num_v * feat);
+    rows = saved;
+    (void)hipFree(d_r); (void)hipFree(d_a);
+    return bad;
 }
 
 // ---- device: the edge-softmax stages (aggr_gat.h:395-425), each through the reference's own method with BLOCK_SIZE = 32
