@@ -122,16 +122,17 @@ def load_graph(datadir, dset, shuffle=True, reorder_suffix="", cap_v=1 << 22, ca
     return ptr[:V + 1].copy(), idx[:E].copy(), (rows[:V].copy() if rc == 1 else None), (rev[:V].copy() if rc == 1 else None)
 
 
-def gcn_run(ptr, idx, val, x, block=512, scheduled=False, ng=16, want_schedule=False):
+def gcn_run(ptr, idx, val, x, block=512, scheduled=False, ng=16, want_schedule=False, par=0):
     """Aggregator_GCN::run (aggr_gcn.h:379-410): aggr_gcn, or schedule(neighbor_grouping, ng) + aggr_gcn_target.  feat must be a
     multiple of 32 with block % feat == 0 (the reference's launch geometry).  Needs a GPU."""
     ptr, idx, val, x = _ci(ptr), _ci(idx), _cf(val), _cf(x)
     V, E, F = len(ptr) - 1, len(idx), x.shape[1]
     assert F % 32 == 0 and block % F == 0 and block <= 1024
     y = np.zeros((V, F), np.float32)
-    cap = V + E // max(ng, 1) + 8
+    cap = V * max(par, 1) + E // max(ng, 1) + 8
     sp, st = np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
-    g = lib().ref_gcn_run(_i(ptr), _i(idx), _f(val), V, E, _f(x), _f(y), F, int(block), 1 if scheduled else 0, int(ng), _i(sp), _i(st), cap)
+    kind = 0 if not scheduled else (2 if par > 0 else 1)   # par > 0: schedule(locality_neighbor_grouping, {par, ng})
+    g = lib().ref_gcn_run(_i(ptr), _i(idx), _f(val), V, E, _f(x), _f(y), F, int(block), kind, int(ng), _i(sp), _i(st), cap, int(par))
     if g < 0:
         raise RuntimeError("ref_gcn_run failed (%d)" % g)
     if want_schedule:

@@ -148,11 +148,11 @@ REF_API int ref_load_graph(const char *workdir, const char *dset, int shuffle, c
     return reordered;
 }
 
-// ---- device: Aggregator_GCN (aggr_gcn.h:362-444).  Host arrays in / out; `scheduled` != 0 runs schedule(neighbor_grouping,
-// {ng}) first (aggr_gcn.h:379-410).  sched_* (optional, capacity `cap` groups) receive the reference's scheduled arrays.
+// ---- device: Aggregator_GCN (aggr_gcn.h:362-444).  Host arrays in / out; `scheduled` 1 runs schedule(neighbor_grouping,
+// {ng}) first (aggr_gcn.h:379-410), 2 schedule(locality_neighbor_grouping, {par, ng}) (:500-537).  sched_* (optional, capacity `cap` groups) receive the reference's scheduled arrays.
 // Returns num_target (>= 0), or a negative error.
 REF_API int ref_gcn_run(const int *ptr, const int *idx, const float *val, int num_v, int num_e, const float *x, float *y, int feat, int block,
-                        int scheduled, int ng, int *sched_ptr, int *sched_target, int cap)
+                        int scheduled, int ng, int *sched_ptr, int *sched_target, int cap, int par)
 {
     n = num_v;
     m = num_e;
@@ -164,7 +164,10 @@ REF_API int ref_gcn_run(const int *ptr, const int *idx, const float *val, int nu
     int rc = 0;
     {
         GcnProbe agg(nullptr, nullptr, d_ptr, d_idx, num_v, num_e, feat, feat, d_val);  // owns d_ptr / d_idx / d_val (aggregator.h:58-66)
-        if (scheduled) {
+        if (scheduled == 2) {  // Aggregator_GCN::schedule override (aggr_gcn.h:500-537): permuted idx AND val
+            int param[2] = {par, ng};
+            agg.schedule(locality_neighbor_grouping, param);
+        } else if (scheduled) {
             int param[2] = {ng, 0};
             agg.schedule(neighbor_grouping, param);
         }
