@@ -209,4 +209,26 @@ inline void argParse(int argc, char **argv, int *p_limit = nullptr, int *p_limit
     inputgraph = dset;  // reference util.cu:133: later passed to load_graph as the dataset name
 }
 
+// ---- The reference's OWN helper names, spelled as its drivers spell them (reference util.h:29,82-104,144-151, util.cu:157-175).
+// With these, a reference driver (Figure8/9/10 main*.cu) needs nothing but the mechanical cuda* -> hip* rename of ROCm's
+// hipify-perl to build against this directory and libgnnagg.so -- no hand edits: drivers/build_reference_drivers.sh.
+#if __has_include(<hiprand.h>)
+#include <hiprand.h>
+#endif
+#if __has_include(<hipblas.h>)
+#include <hipblas.h>
+inline hipblasHandle_t cublasH = nullptr;
+inline hipblasHandle_t *cublasHs = new hipblasHandle_t[1]();
+#endif
+#define checkCudaErrors(status)                                                        \
+    do {                                                                               \
+        if ((int)(status) != 0) {                                                      \
+            std::stringstream _error;                                                  \
+            _error << "Cuda failure: " << (int)(status);                               \
+            FatalError(_error.str());                                                  \
+        }                                                                              \
+    } while (0)
+inline hipError_t cudaMalloc2(void **a, size_t s) { return hipMalloc2(a, s); }
+using namespace std;  // reference util.h:29 (its drivers write vector<...>, string, cout unqualified)
+
 #endif
