@@ -13,6 +13,11 @@ REF=${REF:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
 ROCM=${ROCM_PATH:-/opt/rocm}
 if [ ! -d "$REF/Figure9" ] || [ ! -x "$ROCM/bin/hipify-perl" ]; then echo "drivers/_ref: no reference tree: not built"; exit 0; fi
+if [ -f "$HERE/_ref/fig10b_ref.out" ] && [ -z "$FORCE" ]; then   # up to date?
+  newer=$(find "$REF/Figure9/main.cu" "$REF/Figure10/main_a.cu" "$REF/Figure10/main_b.cu" "$HERE/../include/compat" "$HERE/../include/gnnagg.h" \
+               "$HERE/build_reference_drivers.sh" -newer "$HERE/_ref/fig10b_ref.out" -type f 2>/dev/null | head -1)
+  if [ -z "$newer" ]; then echo "drivers/_ref is up to date"; exit 0; fi
+fi
 GEN=$(mktemp -d "${TMPDIR:-/tmp}/gnnrefdrv.XXXXXX")
 trap 'rm -rf "$GEN"' EXIT
 mkdir -p "$HERE/_ref"
