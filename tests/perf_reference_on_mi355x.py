@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reference's OWN kernels (oracle/_ref/libref_gnn.so: /root/reference translated by hipify-perl, see oracle/ref_build.sh)
 timed on this MI355X beside this library, on the headline workload and the reference drivers' default shapes.  Context for
-DESIGN.md -- not a bench line: the reference was written for 32-lane warps (two of them share a wavefront here)."""
+DESIGN.md -- not a bench line and not a pytest (it lives under tests/ because only tests/ may load oracle/): the reference was written for 32-lane warps (two of them share a wavefront here)."""
 import json
 import os
 import sys
@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import gnn_computing_amd as gnc  # noqa: E402
 from oracle import ref  # noqa: E402
 
