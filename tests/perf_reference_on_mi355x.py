@@ -67,5 +67,32 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def big():
+    """The high-degree / large shapes at a width the reference's launch geometry accepts (feat % 32 == 0): reddit-shaped and
+    products-shaped CSR, F = 128, implicit unit weights (the reference always streams a value array)."""
+    for name in ("reddit", "products"):
+        ptr_t, idx_t = gnc.graph.dataset(name, device=dev)
+        p, i = ptr_t.cpu().numpy(), idx_t.cpu().numpy()
+        V, E, F = len(p) - 1, len(i), 128
+        rng = np.random.default_rng(123)
+        x = rng.standard_normal((V, F), dtype=np.float32)
+        val = np.ones(E, np.float32)
+        dx, dy = torch.from_numpy(x).to(dev), torch.empty((V, F), device=dev)
+        agg = gnc.Aggregator_GCN(ptr_t, idx_t, torch.from_numpy(val).to(dev), F, F)
+        agg.schedule(gnc.Schedule.neighbor_grouping, [32])
+        out = dict(workload="%s-shaped %dx%d GCN sum F=%d" % (name, V, E, F),
+                   reference_aggr_gcn_us=ref.time_run("gcn", p, i, val, x, 512, False, warm=1, iters=3),
+                   reference_neighbor_grouping32_us=ref.time_run("gcn", p, i, val, x, 512, True, 32, warm=2, iters=5),
+                   ours_rows_us=ours(lambda: agg.run(dx, dy, 512, 0), 2, 5),
+                   ours_neighbor_grouping32_us=ours(lambda: agg.run(dx, dy, 512, 1), 2, 5),
+                   ours_balanced_us=ours(lambda: agg.run(dx, dy, 512, "balanced"), 2, 5))
+        print(json.dumps(out), flush=True)
+        del agg, dx, dy, ptr_t, idx_t
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        big()
+    else:
+        main()
