@@ -237,8 +237,13 @@ __device__ __forceinline__ bool hub_arrive_and_fold(const PlanArgs &a, const int
     return true;
 }
 
+#ifdef GNNAGG_PLAN_WAVES  // A/B: ask the register allocator for this many waves per SIMD (default: what 76 VGPRs give, 6)
+#define PLAN_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(GNNAGG_PLAN_WAVES, GNNAGG_PLAN_WAVES)))
+#else
+#define PLAN_WAVES_ATTR
+#endif
 template <int VEC, int GROUP, bool IS_MAX, bool PROBE = false>
-__global__ __launch_bounds__(block_of<GROUP>()) void k_gcn_plan(const PlanArgs a)
+__global__ __launch_bounds__(block_of<GROUP>()) PLAN_WAVES_ATTR void k_gcn_plan(const PlanArgs a)
 {
     constexpr int GPB = block_of<GROUP>() / GROUP;
     const int F = a.feat;
