@@ -3,7 +3,7 @@
 binding (/root/reference/Figure7/kernel.cpp: pybind wrappers over ten flat functions + new_load), translated where it lies by
 ROCm's hipify-perl (no hand edits) into a scratch directory whose ../include is THIS repo's include/compat, compiled with
 torch.utils.cpp_extension together with drivers/flat_cxx_linkage.cpp and linked with libgnnagg.so.  Output:
-drivers/_ref/gnncompile.so (git-ignored; tests/test_gpu_reference.py imports it and runs the reference's Python-level call
+oracle/_ref/drivers/gnncompile.so (git-ignored; tests/test_gpu_reference.py imports it and runs the reference's Python-level call
 sequence, Figure7/our.py:171-188).  Skips quietly when the reference tree or hipify-perl is missing."""
 import glob
 import os
@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = os.environ.get("REF", "/root/reference")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
-OUT = os.path.join(HERE, "_ref", "gnncompile.so")
+OUT = os.path.join(ROOT, "oracle", "_ref", "drivers", "gnncompile.so")
 
 
 def up_to_date():
@@ -31,10 +31,10 @@ def main():
     hipify = os.path.join(ROCM, "bin", "hipify-perl")
     src = os.path.join(REF, "Figure7", "kernel.cpp")
     if not os.path.exists(src) or not os.path.exists(hipify):
-        print("drivers/_ref/gnncompile.so: no reference tree: not built")
+        print("oracle/_ref/drivers/gnncompile.so: no reference tree: not built")
         return
     if up_to_date():
-        print("drivers/_ref/gnncompile.so is up to date")
+        print("oracle/_ref/drivers/gnncompile.so is up to date")
         return
     from torch.utils.cpp_extension import load
     gen = tempfile.mkdtemp(prefix="gnnreftorch.")
@@ -52,7 +52,7 @@ def main():
              build_directory=gen, verbose=False, is_python_module=False)
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         shutil.copy(os.path.join(gen, "gnncompile.so"), OUT)
-        print("drivers/_ref/gnncompile.so: the reference's Figure7/kernel.cpp built against include/compat + libgnnagg.so")
+        print("oracle/_ref/drivers/gnncompile.so: the reference's Figure7/kernel.cpp built against include/compat + libgnnagg.so")
     finally:
         shutil.rmtree(gen, ignore_errors=True)
 
