@@ -171,6 +171,7 @@ struct Ctx {
     int opt_scratch_limit_mb = 0;  // > 0: the blocked order may not take more scratch than this (else: half of the free memory)
     int use_spans = 1;         // GCN, tiled: the segmented-stream kernel (agg_span.hip); 0: one descriptor per lane group
     int fast_rows = 0;         // 1: `scheduled = 0` runs the balanced order (within 1e-5) instead of CSR-order chains
+    int fast_scheduled = 0;    // 1: `scheduled = 1` runs the balanced order too (the user's groups keep describing num_target / get_schedule)
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
     int xcd_remap = 2;         // 0 identity, 1 equal-count XCD ranges, 2 work-balanced XCD ranges
     DevBuf<int> hub_count;  // arrival counters of the in-kernel hub fold (zero between launches)
@@ -776,6 +777,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     if (reduce < GNNAGG_REDUCE_SUM || reduce > GNNAGG_REDUCE_MAX) return fail(GNNAGG_ERR_ARG, "bad reduce");
     if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
     if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
+    if (mode == GNNAGG_MODE_SCHEDULED && c->fast_scheduled && c->sched[0].valid) mode = GNNAGG_MODE_BALANCED;
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
@@ -931,6 +933,7 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     if (!x || !y || !att) return fail(GNNAGG_ERR_ARG, "null feature/attention pointer");
     if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
     if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
+    if (mode == GNNAGG_MODE_SCHEDULED && c->fast_scheduled && c->sched[0].valid && !newval) mode = GNNAGG_MODE_BALANCED;
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
@@ -1176,6 +1179,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_SLICE_KB")) c->opt_slice_kb = std::max(1, atoi(e));
     if (const char *e = getenv("GNNAGG_RETILE")) c->opt_retile = atoi(e);
     if (const char *e = getenv("GNNAGG_FAST_ROWS")) c->fast_rows = atoi(e);
+    if (const char *e = getenv("GNNAGG_FAST_SCHEDULED")) c->fast_scheduled = atoi(e);
     if (const char *e = getenv("GNNAGG_SPANS")) c->use_spans = atoi(e);
     if (const char *e = getenv("GNNAGG_OVERLAP_COMBINE")) c->overlap_combine = atoi(e);
     {
@@ -1240,6 +1244,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "scratch_limit_mb") c->opt_scratch_limit_mb = value;
     else if (n == "tiled") c->tiled = value;
     else if (n == "fast_rows") c->fast_rows = value;
+    else if (n == "fast_scheduled") c->fast_scheduled = value;
     else if (n == "spans") { c->use_spans = value; replan = true; }
     else if (n == "overlap_combine") c->overlap_combine = value;
     else if (n == "inkernel_combine") c->inkernel_combine = value;

@@ -106,6 +106,9 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *   "retile" [GNNAGG_RETILE], "tiled" [GNNAGG_TILED], "spans" [GNNAGG_SPANS], "overlap_combine", "inkernel_combine"   A/B switches
  *   "fast_rows" [GNNAGG_FAST_ROWS]        1: GNNAGG_MODE_ROWS (`scheduled = 0`) runs the balanced order -- results within the
  *                                         1e-5 bound instead of bit-exact CSR-order chains; 0 (default): canonical order
+ *   "fast_scheduled" [GNNAGG_FAST_SCHEDULED]  1: GNNAGG_MODE_SCHEDULED (`scheduled = 1`) runs the balanced order as well (a schedule
+ *                                         must still have been made; num_target / get_schedule keep describing the user's groups;
+ *                                         GAT calls that ask for newval keep the scheduled order); 0 (default): the user's groups
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
 int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
 /* Aggregator_GCN::updateval, aggr_gcn.h:540-544: re-aliases the edge values (borrowed; read at run time). */

@@ -198,6 +198,38 @@ def test_fast_rows_option_gives_scheduled0_the_balanced_order():
     assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "fast rows gat")
 
 
+def test_fast_scheduled_option_gives_scheduled1_the_balanced_order():
+    """reference drivers call schedule(neighbor_grouping, {NG}) + run(vin, vout, B, 1); with the option that call runs the
+    balanced order too (same bits as mode "balanced"), the user's groups keep describing num_target / get_schedule, and a
+    scheduled run without a schedule still fails."""
+    V, E, F = 5000, 150000, 128
+    ptr, idx = hub_graph(V, E, seed=9, alpha=1.0)
+    x, val = rand((V, F), 1), rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("fast_scheduled", 1)
+    y = torch.empty((V, F), device=DEV)
+    with pytest.raises(Exception):
+        agg.run(dev(x), y, 512, 1)
+    agg.schedule(gnc.Schedule.neighbor_grouping, [32])
+    ps, tg = orc.neighbor_grouping(ptr, 32)
+    agg.run(dev(x), y, 512, 1)
+    yb = torch.empty((V, F), device=DEV)
+    agg.run(dev(x), yb, 512, "balanced")
+    assert torch.equal(y, yb)
+    assert agg.num_target == len(tg) and np.array_equal(agg.get_schedule("scheduled")[0], ps)
+    assert_within(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x), "fast scheduled vs CSR order")
+    agg.set_option("fast_scheduled", 0)
+    agg.run(dev(x), y, 512, 1)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=agg.mode_params("scheduled")[1]))
+    att = rand((V, 2), 3) * 0.4
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.set_option("fast_scheduled", 1)
+    gat.schedule(gnc.Schedule.neighbor_grouping, [32])
+    gat.run(dev(x), dev(att), y, 128, 1)
+    gat.run(dev(x), dev(att), yb, 128, "balanced")
+    assert torch.equal(y, yb)
+
+
 @pytest.mark.parametrize("kind,param", [("locality", [3]), ("locality_neighbor_grouping", [4, 8])])
 def test_user_locality_schedule_follows_updateval(kind, param):
     """A locality schedule permutes the edge values into its own copy (aggr_gcn.h:509-537); updateval (:540-544) and
