@@ -116,7 +116,7 @@ struct PlanArgs {
 
 // Gather probe (bench.py's measured ceiling): everything chain_edges loads -- ids, values, feature segments, same
 // addresses, same batching -- consumed with integer XORs instead of the dependent FMA chain.
-template <int VEC, int GROUP>
+template <int VEC, int GROUP, int UNROLL = kUnroll>
 __device__ __forceinline__ unsigned probe_edges(int beg, int end, int lane, bool col_ok, const int *__restrict__ idx,
                                                 const float *__restrict__ val, const float *__restrict__ xcol, int F)
 {
@@ -135,19 +135,19 @@ __device__ __forceinline__ unsigned probe_edges(int beg, int end, int lane, bool
             if (val) nx_w = val[cb + GROUP + lane];
         }
         const int n = end - cb < GROUP ? end - cb : GROUP;
-        for (int j = 0; j < n; j += kUnroll) {
-            int s[kUnroll];
-            Pack<VEC> xv[kUnroll];
+        for (int j = 0; j < n; j += UNROLL) {
+            int s[UNROLL];
+            Pack<VEC> xv[UNROLL];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < UNROLL; ++u) {
                 s[u] = __shfl(my_s, j + u, GROUP);
                 sig ^= __float_as_uint(__shfl(my_w, j + u, GROUP));
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < UNROLL; ++u)
                 if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < UNROLL; ++u)
                 if (j + u < n && col_ok) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) sig ^= __float_as_uint(xv[u].v[k]);
@@ -242,7 +242,11 @@ __device__ __forceinline__ bool hub_arrive_and_fold(const PlanArgs &a, const int
 #else
 #define PLAN_WAVES_ATTR
 #endif
-template <int VEC, int GROUP, bool IS_MAX, bool PROBE = false>
+// UNROLL: row gathers issued per batch before the first FMA.  8 by default; 4 for the 32-lane geometry (64 < F <= 128) of
+// the balanced / scheduled orders: 59 instead of 76 VGPRs, 8 instead of 6 waves per SIMD -- the arxiv-shaped headline
+// with the locality reorder 77.9 -> 74.0 us (without reorder, and at F = 100: unchanged); the canonical rows mode keeps 8
+// (its chains are long: 182 -> 209 us with 4), and so do the narrow geometries (F = 32 balanced: 28.6 -> 36.3 us with 4).
+template <int VEC, int GROUP, bool IS_MAX, bool PROBE = false, int UNROLL = kUnroll>
 __global__ __launch_bounds__(block_of<GROUP>()) PLAN_WAVES_ATTR void k_gcn_plan(const PlanArgs a)
 {
     constexpr int GPB = block_of<GROUP>() / GROUP;
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) PLAN_WAVES_ATTR void k_gcn_plan(
         for (int c = grp; c < nch; c += GPB) {
             const int cb = d.x + c * a.chunk;
             const int ce = cb + a.chunk < d.y ? cb + a.chunk : d.y;
-            sig ^= probe_edges<VEC, GROUP>(cb, ce, lane, col < F, a.idx, a.val, a.x + col, F);
+            sig ^= probe_edges<VEC, GROUP, UNROLL>(cb, ce, lane, col < F, a.idx, a.val, a.x + col, F);
         }
         if (sig == 0x9e3779b9u) a.probe_sink[0] = sig;  // practically never: keeps the loads alive
         return;
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) PLAN_WAVES_ATTR void k_gcn_plan(
             for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
             const int cb = d.x + c * a.chunk;
             const int ce = cb + a.chunk < d.y ? cb + a.chunk : d.y;
-            chain_edges<VEC, GROUP, IS_MAX>(acc, cb, ce, lane, col_ok, a.idx, a.val, a.x + col, F);
+            chain_edges<VEC, GROUP, IS_MAX, UNROLL>(acc, cb, ce, lane, col_ok, a.idx, a.val, a.x + col, F);
             store_pack<VEC>(&stage[(c * GROUP + lane) * VEC], acc);
         }
         __syncthreads();
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) PLAN_WAVES_ATTR void k_gcn_plan(
     const int4 d = a.t0[item];
     const float *__restrict__ xcol = a.x + (size_t)tile * a.x_tile_stride + lane * VEC;
     if constexpr (PROBE) {
-        const unsigned sig = probe_edges<VEC, GROUP>(d.x, d.y, lane, col_ok, a.idx, a.val, xcol, a.xpitch);
+        const unsigned sig = probe_edges<VEC, GROUP, UNROLL>(d.x, d.y, lane, col_ok, a.idx, a.val, xcol, a.xpitch);
         if (sig == 0x9e3779b9u) a.probe_sink[0] = sig;
         return;
     }
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) PLAN_WAVES_ATTR void k_gcn_plan(
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
-    chain_edges<VEC, GROUP, IS_MAX>(acc, d.x, d.y, lane, col_ok, a.idx, a.val, xcol, a.xpitch);
+    chain_edges<VEC, GROUP, IS_MAX, UNROLL>(acc, d.x, d.y, lane, col_ok, a.idx, a.val, xcol, a.xpitch);
     if (!col_ok) return;
     if (d.z < 0) {  // one of several groups of its row (source-partitioned order): raw partial to its scratch slot
         // write-through when a descriptor can cover the tile: the partials are read back by k_combine only, and must not
@@ -874,6 +878,9 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     const bool want_nn = L.nn_weight != nullptr;
     // (8-lane groups, F <= 32: the GEMM is ~11 us on the arxiv-shaped input and the epilogue costs as much -- not fused)
     const bool fuse_nn = want_nn && !L.tile.on && !L.probe && g.ntiles == 1 && g.group >= 16 && !L.accumulate && !L.relu && !L.t0_partials && nn_fusion_enabled();
+    // 4 gathers per batch on the 32-lane float4 geometry when the caller asks for it (see k_gcn_plan)
+    static const int u4_env = getenv("GNNAGG_PLAN_UNROLL4") ? atoi(getenv("GNNAGG_PLAN_UNROLL4")) : 1;
+    const bool u4 = u4_env && L.unroll == 4 && g.vec == 4 && g.group == 32 && !L.tile.on && !fuse_nn;
     const int blk = block_for(g.group);
     const int gpb = fuse_nn ? std::max(kNnRows, blk / g.group) : blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
@@ -895,7 +902,8 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
         if (!a.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
         if (grid > 0) {
 #define CALL_PROBE hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, false, true>), dim3(grid), dim3(blk), 0, stream, a);
-            DISPATCH_GEOM(g, CALL_PROBE)
+            if (u4) hipLaunchKernelGGL((k_gcn_plan<4, 32, false, true, 4>), dim3(grid), dim3(blk), 0, stream, a);
+            else DISPATCH_GEOM(g, CALL_PROBE)
 #undef CALL_PROBE
             HIP_TRY(hipGetLastError());
         }
@@ -921,7 +929,10 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
 #define CALL_PLAN                                                                                            \
         if (is_max) hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, true>), dim3(grid), dim3(blk), 0, stream, a);        \
         else        hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, false>), dim3(grid), dim3(blk), 0, stream, a);
-        DISPATCH_GEOM(g, CALL_PLAN)
+        if (u4) {
+            if (is_max) hipLaunchKernelGGL((k_gcn_plan<4, 32, true, false, 4>), dim3(grid), dim3(blk), 0, stream, a);
+            else        hipLaunchKernelGGL((k_gcn_plan<4, 32, false, false, 4>), dim3(grid), dim3(blk), 0, stream, a);
+        } else DISPATCH_GEOM(g, CALL_PLAN)
 #undef CALL_PLAN
         HIP_TRY(hipGetLastError());
     }

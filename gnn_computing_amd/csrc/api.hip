@@ -810,6 +810,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             P.slot_hub = p.slot_hub.p; P.hub_count = c->hub_count.p;
         }
         P.probe = probe;
+        P.unroll = 4;
         return launch_gcn_plan(P, c->stream);
     }
     if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors) {

@@ -117,6 +117,7 @@ struct GcnPlanLaunch {
     int nn_cols = 0;
     TileSpec tile;  // 2-D blocked mode (short-row descriptors only: n1 == 0)
     int probe = 0;  // 1: gather probe -- the same descriptors, id/value loads and feature gathers, no chain, no stores
+    int unroll = 0; // 4: four gathers per batch where the geometry has that instantiation (balanced / scheduled orders); 0: default (8)
 };
 
 // 2-D blocked order as a segmented stream (agg_span.hip): lane groups walk spans of whole groups of the permuted edge list.

@@ -257,7 +257,7 @@ struct GcnArgs {
 // this once-streamed metadata were measured 1-5 % SLOWER, and nontemporal feature gathers 30 % slower at an
 // unchanged L2 hit rate -- `nt` does not bypass L2 allocation here; neither is used), kUnroll feature
 // gathers are issued before the first FMA.  Lanes with col_ok == false still carry metadata.
-template <int VEC, int GROUP, bool IS_MAX>
+template <int VEC, int GROUP, bool IS_MAX, int UNROLL = kUnroll>
 __device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end, int lane, bool col_ok,
                                             const int *__restrict__ idx, const float *__restrict__ val,
                                             const float *__restrict__ xcol, int F)
@@ -282,22 +282,22 @@ __device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end,
                 if (val) nx_w = val[cb + 16 + l16];
             }
             const int n = end - cb < 16 ? end - cb : 16;
-            static_for<16 / kUnroll>([&](auto bc) {
-                constexpr int J = decltype(bc)::value * kUnroll;
+            static_for<16 / UNROLL>([&](auto bc) {
+                constexpr int J = decltype(bc)::value * UNROLL;
                 if (J < n) {
-                    int s[kUnroll];
-                    float w[kUnroll];
-                    Pack<VEC> xv[kUnroll];
-                    static_for<kUnroll>([&](auto uc) {
+                    int s[UNROLL];
+                    float w[UNROLL];
+                    Pack<VEC> xv[UNROLL];
+                    static_for<UNROLL>([&](auto uc) {
                         constexpr int u = decltype(uc)::value;
                         s[u] = group_bcast<16, J + u>(my_s);
                         w[u] = group_bcast<16, J + u>(my_w);
                     });
 #pragma unroll
-                    for (int u = 0; u < kUnroll; ++u)
+                    for (int u = 0; u < UNROLL; ++u)
                         if (J + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
 #pragma unroll
-                    for (int u = 0; u < kUnroll; ++u)
+                    for (int u = 0; u < UNROLL; ++u)
                         if (J + u < n && col_ok) {
 #pragma unroll
                             for (int k = 0; k < VEC; ++k) {
@@ -330,20 +330,20 @@ __device__ __forceinline__ void chain_edges(float (&acc)[VEC], int beg, int end,
             if (val) nx_w = val[cb + GROUP + lane];
         }
         const int n = end - cb < GROUP ? end - cb : GROUP;
-        for (int j = 0; j < n; j += kUnroll) {
-            int s[kUnroll];
-            float w[kUnroll];
-            Pack<VEC> xv[kUnroll];
+        for (int j = 0; j < n; j += UNROLL) {
+            int s[UNROLL];
+            float w[UNROLL];
+            Pack<VEC> xv[UNROLL];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < UNROLL; ++u) {
                 s[u] = __shfl(my_s, j + u, GROUP);
                 w[u] = __shfl(my_w, j + u, GROUP);
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < UNROLL; ++u)
                 if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < UNROLL; ++u)
                 if (j + u < n && col_ok) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
