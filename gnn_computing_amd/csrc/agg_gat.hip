@@ -88,7 +88,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_items(const GatArgs a
 // The fused edge-softmax + weighted SpMM (reference aggr_gat / aggr_gat_fine, aggr_gat.h:116-205) on the same
 // plan as k_gcn_plan: short rows one lane group each, long rows one workgroup per <= 16-chunk segment with the
 // numerator AND denominator partials folded in ascending chunk order in LDS, hubs through scratch + k_combine.
-template <int VEC, int GROUP>
+template <int VEC, int GROUP, int UNROLL = kUnroll>
 __device__ __forceinline__ void chain_edges_gat(float (&acc)[VEC], float &den, int beg, int end, int lane, bool col_ok,
                                                 const int *__restrict__ idx, const float *__restrict__ att_src, int H,
                                                 float a_dst, float slope, const float *__restrict__ xcol, int F,
@@ -100,20 +100,20 @@ __device__ __forceinline__ void chain_edges_gat(float (&acc)[VEC], float &den, i
         int nx_s = 0;
         if (cb + GROUP + lane < end) nx_s = idx[cb + GROUP + lane];
         const int n = end - cb < GROUP ? end - cb : GROUP;
-        for (int j = 0; j < n; j += kUnroll) {
-            int s[kUnroll];
-            float as[kUnroll];
-            Pack<VEC> xv[kUnroll];
+        for (int j = 0; j < n; j += UNROLL) {
+            int s[UNROLL];
+            float as[UNROLL];
+            Pack<VEC> xv[UNROLL];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) s[u] = __shfl(my_s, j + u, GROUP);
+            for (int u = 0; u < UNROLL; ++u) s[u] = __shfl(my_s, j + u, GROUP);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < UNROLL; ++u)
                 if (j + u < n && col_ok) {
                     as[u] = att_src[(size_t)s[u] * H * 2];
                     xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
                 }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < UNROLL; ++u)
                 if (j + u < n && col_ok) {
                     const float w = edge_weight(a_dst, as[u], slope);
                     if (newval && head_leader) newval[(size_t)(eperm ? eperm[cb + j + u] : cb + j + u) * H + h] = w;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void chain_edges_gat(float (&acc)[VEC], float &den, i
 // every edge.  Ids are fetched two windows ahead and source terms one window ahead, so nothing dependent sits on the path;
 // the first feature gathers of a window are issued before its weights are needed.  Same values, same order as
 // chain_edges_gat (bit-identical results).
-template <int VEC, int GROUP>
+template <int VEC, int GROUP, int UNROLL = kUnroll>
 __device__ __forceinline__ void chain_edges_gat1(float (&acc)[VEC], float &den, int beg, int end, int lane, bool col_ok,
                                                  const int *__restrict__ idx, const float *__restrict__ att_src, float a_dst,
                                                  float slope, const float *__restrict__ xcol, int F, float *newval,
@@ -149,23 +149,23 @@ __device__ __forceinline__ void chain_edges_gat1(float (&acc)[VEC], float &den, 
         if (cb + GROUP + lane < end) a1 = att_src[(size_t)s1 * 2];
         const int n = end - cb < GROUP ? end - cb : GROUP;
         float my_w = 0.0f;
-        for (int j = 0; j < n; j += kUnroll) {
-            int s[kUnroll];
-            float w[kUnroll];
-            Pack<VEC> xv[kUnroll];
+        for (int j = 0; j < n; j += UNROLL) {
+            int s[UNROLL];
+            float w[UNROLL];
+            Pack<VEC> xv[UNROLL];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) s[u] = __shfl(s0, j + u, GROUP);
+            for (int u = 0; u < UNROLL; ++u) s[u] = __shfl(s0, j + u, GROUP);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < UNROLL; ++u)
                 if (j + u < n && col_ok) xv[u] = load_pack<VEC>(xcol + (size_t)s[u] * F);
             if (j == 0) {  // this lane's edge of the window
                 my_w = lane < n ? edge_weight(a_dst, a0, slope) : 0.0f;
                 if (newval && first_tile && lane < n) newval[eperm ? eperm[cb + lane] : cb + lane] = my_w;
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) w[u] = __shfl(my_w, j + u, GROUP);
+            for (int u = 0; u < UNROLL; ++u) w[u] = __shfl(my_w, j + u, GROUP);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u)
+            for (int u = 0; u < UNROLL; ++u)
                 if (j + u < n && col_ok) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w[u], acc[k]);
@@ -265,7 +265,8 @@ __device__ __forceinline__ void hub_arrive_and_fold_gat(const GatPlanArgs &a, in
 }
 
 // (forcing 6 waves/SIMD -- 80 VGPRs, 5-9 spilled -- changes nothing: 100.8 vs 101.5 us on fig10a, 13.8 vs 13.6 ms on config G)
-template <int VEC, int GROUP, bool SINGLE>
+// (UNROLL: see k_gcn_plan -- 4 on the 32-lane float4 geometry: arxiv-shaped 1 head F = 128, fused balanced 99.8 -> 96.1 us)
+template <int VEC, int GROUP, bool SINGLE, int UNROLL = kUnroll>
 __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArgs a)
 {
     constexpr int GPB = block_of<GROUP>() / GROUP;
@@ -307,10 +308,10 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
             const int cb = d.x + c * a.chunk;
             const int ce = cb + a.chunk < d.y ? cb + a.chunk : d.y;
             if constexpr (SINGLE)
-                chain_edges_gat1<VEC, GROUP>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, F, a.newval,
+                chain_edges_gat1<VEC, GROUP, UNROLL>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, F, a.newval,
                                              tile == 0);
             else
-                chain_edges_gat<VEC, GROUP>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval,
+                chain_edges_gat<VEC, GROUP, UNROLL>(acc, den, cb, ce, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, F, a.newval,
                                             h, head_leader);
             store_pack<VEC>(&stage[(c * GROUP + lane) * VEC], acc);
             stage_den[c * GROUP + lane] = den;
@@ -353,10 +354,10 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
     if (d.x < d.y) {
         const float a_dst = a.att[((size_t)row * H + h) * 2];
         if constexpr (SINGLE)
-            chain_edges_gat1<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, a.xpitch, a.newval,
+            chain_edges_gat1<VEC, GROUP, UNROLL>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, a_dst, a.slope, xcol, a.xpitch, a.newval,
                                          tile == 0, a.eperm);
         else
-            chain_edges_gat<VEC, GROUP>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, a.xpitch, a.newval,
+            chain_edges_gat<VEC, GROUP, UNROLL>(acc, den, d.x, d.y, lane, col_ok, a.idx, att_src, H, a_dst, a.slope, xcol, a.xpitch, a.newval,
                                         h, head_leader, a.eperm);
     }
     if (!col_ok) return;
@@ -470,7 +471,11 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
 #define CALL_GP                                                                                              \
         if (a.heads == 1) hipLaunchKernelGGL((k_gat_plan<VEC, GROUP, true>), dim3(grid), dim3(blk), 0, stream, a);   \
         else              hipLaunchKernelGGL((k_gat_plan<VEC, GROUP, false>), dim3(grid), dim3(blk), 0, stream, a);
-        DISPATCH_GEOM(g, CALL_GP)
+        static const int u4_env = getenv("GNNAGG_PLAN_UNROLL4") ? atoi(getenv("GNNAGG_PLAN_UNROLL4")) : 1;
+        if (u4_env && L.unroll == 4 && g.vec == 4 && g.group == 32 && !L.tile.on) {
+            if (a.heads == 1) hipLaunchKernelGGL((k_gat_plan<4, 32, true, 4>), dim3(grid), dim3(blk), 0, stream, a);
+            else              hipLaunchKernelGGL((k_gat_plan<4, 32, false, 4>), dim3(grid), dim3(blk), 0, stream, a);
+        } else DISPATCH_GEOM(g, CALL_GP)
 #undef CALL_GP
         HIP_TRY(hipGetLastError());
     }

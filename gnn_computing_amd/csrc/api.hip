@@ -962,6 +962,7 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
             if ((rc = reserve_hub_counters(c, p.n_mrows, feat, &P.hub_count_stride))) return rc;
             P.slot_hub = p.slot_hub.p; P.hub_count = c->hub_count.p;
         }
+        P.unroll = 4;
         return launch_gat_plan(P, c->stream);
     }
     if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors) {

@@ -242,6 +242,7 @@ struct GatPlanLaunch {
     int hub_count_stride = 0;
     TileSpec tile;              // 2-D blocked mode, as in GcnPlanLaunch
     const int *eperm = nullptr; // permuted orders: original edge of every position (newval is written in CSR edge order)
+    int unroll = 0;             // 4: four gathers per batch where the geometry has that instantiation (balanced / scheduled orders)
 };
 int launch_gat_plan(const GatPlanLaunch &a, void *stream);
 // Backward of the single-head fused GAT aggregation (k_rowdot + k_gat_bwd_edges); wl = chunked edge work items.
