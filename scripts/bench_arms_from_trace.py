@@ -8,8 +8,9 @@ import sys
 
 f, K, W = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rows = sorted((r for r in csv.DictReader(open(f)) if "k_gcn_plan" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
-real = [r for r in rows if "false, true>" not in r["Kernel_Name"]]
-probe = [r for r in rows if "false, true>" in r["Kernel_Name"]]
+is_probe = lambda r: "false, true>" in r["Kernel_Name"] or "false, true, " in r["Kernel_Name"]   # k_gcn_plan<VEC, GROUP, IS_MAX, PROBE[, UNROLL]>
+real = [r for r in rows if not is_probe(r)]
+probe = [r for r in rows if is_probe(r)]
 
 
 def arms(rs, names):
