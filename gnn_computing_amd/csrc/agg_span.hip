@@ -314,12 +314,18 @@ __device__ __forceinline__ float row_bcast_banks(float old, float v)
 // from a wave-uniform tile base), one broadcast per head of the tile for the weight (bank-masked: no select), the FMAs, the
 // denominator add and the group-end test.  Everything that happens once per window or once per group stays out of it.
 // PROBE: the same id / attention-term loads and tile-row gathers, XOR-consumed; no exp, no chain, no store (gnnagg_gat_probe_gather).
+#ifndef GAT_SPAN_U
+#define GAT_SPAN_U 16
+#endif
+#ifndef GAT_SPAN_WAVES
+#define GAT_SPAN_WAVES 4
+#endif
 template <int GROUP, int HT, bool SHIFT, bool PROBE>
-__global__ __launch_bounds__(256, (HT <= 2 ? 4 : 2)) void k_gat_span(const GatSpanArgs A)
+__global__ __launch_bounds__(256, (HT <= 2 ? GAT_SPAN_WAVES : 2)) void k_gat_span(const GatSpanArgs A)
 {
     const SpanArgs &a = A.s;
     // a whole 16-edge window of gathers in flight (8 per batch: 13.0 ms, 16: 9.7 ms on the reddit-shaped 8 x 32 case)
-    constexpr int VEC = 4, GPB = 256 / GROUP, U = GROUP < 16 ? GROUP : 16;
+    constexpr int VEC = 4, GPB = 256 / GROUP, U = GROUP < GAT_SPAN_U ? GROUP : GAT_SPAN_U;
     constexpr bool BANKED = GROUP == 16 && (HT == 2 || HT == 4);  // a head's lanes = whole DPP banks
     const int lane = threadIdx.x & (GROUP - 1);
     const int grp = (int)threadIdx.x / GROUP;
