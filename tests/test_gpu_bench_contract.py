@@ -1,0 +1,63 @@
+"""bench.py's output contract, exercised the way the driver runs it (one JSON line on stdout, the fields the round's
+instructions name, roofline.frac <= 1, the oracle check inside bench.py passing) -- short runs of the headline line, of one
+other config, and of the N > 1 code path with two ranks sharing the GPU over gloo (test hooks of bench.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline")
+
+
+def run(args, env=None, launcher=None):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one JSON line, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def check_common(d, n_gpus, steps, warmup):
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
+    assert d["unit"] == "edges/s" and d["higher_is_better"] is True and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert 0.0 < r["frac"] <= 1.0
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["num_e"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05 or n_gpus > 1
+
+
+def test_headline_line():
+    d = run(["--steps", "20", "--warmup", "3", "--cpu-budget", "1"])
+    check_common(d, 1, 20, 3)
+    assert d["metric"].startswith("aggregated edges/sec") and d["config"]["num_v"] == 169343 and d["config"]["num_e"] == 1166243
+    assert d["config"]["feat"] == 128
+    r = d["roofline"]
+    assert r["algorithmic_bytes"] == 693827352 and r["compulsory_bytes"] == 183414552 and r["ceiling_probe_us"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "edges/s" and c["sample"]
+    assert d["value"] > 8.07e9          # north_star: >= 60 % of the HBM-read roofline in gather-model bytes = 8.07 G edges/s
+
+
+def test_other_config_line():
+    d = run(["--config", "P1", "--steps", "3", "--warmup", "1", "--no-cpu"])
+    check_common(d, 1, 3, 1)
+    assert d["config"]["feat"] == 100 and d["roofline"]["ceiling_probe_us"] > 0
+
+
+def test_two_ranks_on_one_gpu_over_gloo():
+    d = run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu"], env={"BENCH_ONE_GPU": "1", "BENCH_BACKEND": "gloo"},
+            launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", "29571"])
+    check_common(d, 2, 3, 1)
+    assert d["scaling"] == "weak" and d["config"]["verified_against_oracle"] is True and d["config"]["num_e"] == 2 * 1166243
