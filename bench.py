@@ -66,6 +66,15 @@ def time_steps(step_fn, steps, warmup, barrier):
     for _ in range(warmup):
         step_fn()
     torch.cuda.synchronize()
+    # Host hygiene before the timed region (nothing of it is inside): the GPU boxes run this process in a CPU-quota'd
+    # container, where a host thread that has been busy-waiting can be descheduled for 45-55 ms (seen once per few hundred
+    # launches, scripts/exp_stall_hunt.py: GPU times unaffected); an idle period lets the quota window roll over, and the
+    # collector stays off while the K launches are issued.
+    import gc
+    gc.collect()
+    time.sleep(0.15)
+    gc_was_on = gc.isenabled()
+    gc.disable()
     barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,6 +87,8 @@ def time_steps(step_fn, steps, warmup, barrier):
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     dev = ev0.elapsed_time(ev1) * 1e-3 / steps
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     evs[0].record()
