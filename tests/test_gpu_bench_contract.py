@@ -61,3 +61,4 @@ def test_two_ranks_on_one_gpu_over_gloo():
                       "--master-port", "29571"])
     check_common(d, 2, 3, 1)
     assert d["scaling"] == "weak" and d["config"]["verified_against_oracle"] is True and d["config"]["num_e"] == 2 * 1166243
+    assert d["no_exchange_upper_bound"]["value"] >= d["value"] * 0.9
