@@ -242,8 +242,8 @@ __device__ __forceinline__ bool hub_arrive_and_fold(const PlanArgs &a, const int
 #else
 #define PLAN_WAVES_ATTR
 #endif
-// UNROLL: row gathers issued per batch before the first FMA.  8 by default; 4 for the 32-lane geometry (64 < F <= 128) of
-// the balanced / scheduled orders: 59 instead of 76 VGPRs, 8 instead of 6 waves per SIMD -- the arxiv-shaped headline
+// UNROLL: row gathers issued per batch before the first FMA.  8 by default; 4 for the 32- and 64-lane float4 geometries (F > 64)
+// of the balanced / scheduled orders: 59 instead of 76 VGPRs, 8 instead of 6 waves per SIMD -- the arxiv-shaped headline
 // with the locality reorder 77.9 -> 74.0 us (without reorder, and at F = 100: unchanged); the canonical rows mode keeps 8
 // (its chains are long: 182 -> 209 us with 4), and so do the narrow geometries (F = 32 balanced: 28.6 -> 36.3 us with 4).
 template <int VEC, int GROUP, bool IS_MAX, bool PROBE = false, int UNROLL = kUnroll>
@@ -880,7 +880,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     const bool fuse_nn = want_nn && !L.tile.on && !L.probe && g.ntiles == 1 && g.group >= 16 && !L.accumulate && !L.relu && !L.t0_partials && nn_fusion_enabled();
     // 4 gathers per batch on the 32-lane float4 geometry when the caller asks for it (see k_gcn_plan)
     static const int u4_env = getenv("GNNAGG_PLAN_UNROLL4") ? atoi(getenv("GNNAGG_PLAN_UNROLL4")) : 1;
-    const bool u4 = u4_env && L.unroll == 4 && g.vec == 4 && g.group == 32 && !L.tile.on && !fuse_nn;
+    const bool u4 = u4_env && L.unroll == 4 && g.vec == 4 && (g.group == 32 || g.group == 64) && !L.tile.on && !fuse_nn;
     const int blk = block_for(g.group);
     const int gpb = fuse_nn ? std::max(kNnRows, blk / g.group) : blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
@@ -902,7 +902,8 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
         if (!a.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
         if (grid > 0) {
 #define CALL_PROBE hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, false, true>), dim3(grid), dim3(blk), 0, stream, a);
-            if (u4) hipLaunchKernelGGL((k_gcn_plan<4, 32, false, true, 4>), dim3(grid), dim3(blk), 0, stream, a);
+            if (u4 && g.group == 32) hipLaunchKernelGGL((k_gcn_plan<4, 32, false, true, 4>), dim3(grid), dim3(blk), 0, stream, a);
+            else if (u4) hipLaunchKernelGGL((k_gcn_plan<4, 64, false, true, 4>), dim3(grid), dim3(blk), 0, stream, a);
             else DISPATCH_GEOM(g, CALL_PROBE)
 #undef CALL_PROBE
             HIP_TRY(hipGetLastError());
@@ -929,9 +930,12 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
 #define CALL_PLAN                                                                                            \
         if (is_max) hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, true>), dim3(grid), dim3(blk), 0, stream, a);        \
         else        hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, false>), dim3(grid), dim3(blk), 0, stream, a);
-        if (u4) {
+        if (u4 && g.group == 32) {
             if (is_max) hipLaunchKernelGGL((k_gcn_plan<4, 32, true, false, 4>), dim3(grid), dim3(blk), 0, stream, a);
             else        hipLaunchKernelGGL((k_gcn_plan<4, 32, false, false, 4>), dim3(grid), dim3(blk), 0, stream, a);
+        } else if (u4) {
+            if (is_max) hipLaunchKernelGGL((k_gcn_plan<4, 64, true, false, 4>), dim3(grid), dim3(blk), 0, stream, a);
+            else        hipLaunchKernelGGL((k_gcn_plan<4, 64, false, false, 4>), dim3(grid), dim3(blk), 0, stream, a);
         } else DISPATCH_GEOM(g, CALL_PLAN)
 #undef CALL_PLAN
         HIP_TRY(hipGetLastError());

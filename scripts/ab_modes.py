@@ -25,6 +25,11 @@ def t(fn, warm=5, iters=30):
 
 
 ptr, idx = gnc.graph.dataset("arxiv", device=dev)
+if os.environ.get("REORDER") == "1":   # the locality reorder bench.py applies on load
+    p, i = ptr.cpu().numpy(), idx.cpu().numpy()
+    rows, _ = gnc.cluster_reorder(p, i, order="cache_greedy", cluster_cap=1, cache_rows=8192)
+    p, i, _ = gnc.reorder_csr(p, i, rows)
+    ptr, idx = torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev)
 V, E = ptr.numel() - 1, idx.numel()
 val = torch.ones(E, device=dev)
 out = []
