@@ -24,6 +24,23 @@
 
 namespace gnnagg {
 
+#ifndef GNNAGG_PARTIAL_AUX
+#define GNNAGG_PARTIAL_AUX 2
+#endif
+static constexpr int kPartialAux = GNNAGG_PARTIAL_AUX;  // partial rows: streaming (nt) stores, see store_pack_wt
+// The id (and value) stream is read once per column tile and never again by this workgroup: streaming loads (A/B: GNNAGG_ID_NT)
+#ifndef GNNAGG_ID_NT
+#define GNNAGG_ID_NT 0
+#endif
+template <class T>
+__device__ __forceinline__ T stream_load(const T *p)
+{
+#if GNNAGG_ID_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 static constexpr unsigned kLastFlag = 0x80000000u;    // id word: last edge of its group
 static constexpr unsigned kDirectFlag = 0x40000000u;  // (with kLastFlag) the group is its row's only group: result goes to Y
 static constexpr unsigned kIdMask = 0x3fffffffu;
@@ -85,8 +102,8 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
     unsigned my_s = 0;
     float my_w = 1.0f;
     if (e0 + lane < e_end) {
-        my_s = (unsigned)a.idx_f[e0 + lane];
-        if (HAS_VAL) my_w = a.val_s[e0 + lane];
+        my_s = (unsigned)stream_load(&a.idx_f[e0 + lane]);
+        if (HAS_VAL) my_w = stream_load(&a.val_s[e0 + lane]);
     }
     // one batch of U edges of the window at cb: gathers issued together, then the chain in list order.  JC >= 0: a full window,
     // batch offset known at compile time (no bound checks; the id / value of edge JC + u comes by group_bcast: a DPP move for
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
                         if (a.relu) relu_pack<VEC>(acc);
                         if (col_ok) store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
                     } else if (col_ok) {
-                        if (a.ptile_bytes) store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
+                        if (a.ptile_bytes) store_pack_wt<VEC, kPartialAux>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
                         else store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
                     }
                     ++g;
@@ -165,8 +182,8 @@ __global__ __launch_bounds__(256) void k_gcn_span(const SpanArgs a)
         unsigned nx_s = 0;
         float nx_w = 1.0f;
         if (cb + GROUP + lane < e_end) {
-            nx_s = (unsigned)a.idx_f[cb + GROUP + lane];
-            if (HAS_VAL) nx_w = a.val_s[cb + GROUP + lane];
+            nx_s = (unsigned)stream_load(&a.idx_f[cb + GROUP + lane]);
+            if (HAS_VAL) nx_w = stream_load(&a.val_s[cb + GROUP + lane]);
         }
         const int n = e_end - cb < GROUP ? e_end - cb : GROUP;
         if (n == GROUP) {
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(256, (HT <= 2 ? GAT_SPAN_WAVES : 2)) void k_gat_spa
         if (valid) load_terms<HT>(as_hg + (size_t)(sw & kIdMask) * HT, as);
     };
     if (e0 + lane < e_end) {
-        my_s = (unsigned)a.idx_f[e0 + lane];
+        my_s = (unsigned)stream_load(&a.idx_f[e0 + lane]);
         if (A.newval) my_e = A.eperm[e0 + lane];
     }
     load_src_terms(my_s, e0 + lane < e_end, as_c);
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(256, (HT <= 2 ? GAT_SPAN_WAVES : 2)) void k_gat_spa
         int nx_e = 0;
         const bool nx_valid = cb + GROUP + lane < e_end;
         if (nx_valid) {
-            nx_s = (unsigned)a.idx_f[cb + GROUP + lane];
+            nx_s = (unsigned)stream_load(&a.idx_f[cb + GROUP + lane]);
             if (A.newval) nx_e = A.eperm[cb + GROUP + lane];
         }
         const int n = e_end - cb < GROUP ? e_end - cb : GROUP;
@@ -494,7 +511,7 @@ __global__ __launch_bounds__(256, (HT <= 2 ? GAT_SPAN_WAVES : 2)) void k_gat_spa
                             store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
                         }
                     } else {
-                        if (a.ptile_bytes) store_pack_wt<VEC>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
+                        if (a.ptile_bytes) store_pack_wt<VEC, kPartialAux>(ptile, a.ptile_bytes, (size_t)g * a.ppitch + lane * VEC, acc);
                         else store_pack<VEC>(ptile + (size_t)g * a.ppitch + lane * VEC, acc);
                         if (head_leader) A.partial_den[(size_t)g * H + col / A.dhead] = den;
                     }
