@@ -28,7 +28,8 @@ build() {  # <reference source> <output name>
       -I"$ROCM/include/hiprand" -I"$ROCM/include/hipblas" "$GEN/$2.hip" -o "$OUTDIR/$2.out" \
       -L"$HERE/../gnn_computing_amd" -lgnnagg -L"$ROCM/lib" -lhiprand -lhipblas -Wl,-rpath,'$ORIGIN/../../../gnn_computing_amd' -Wl,-rpath,"$ROCM/lib"
 }
-build Figure9/main.cu fig9_ref
-build Figure10/main_a.cu fig10a_ref
-build Figure10/main_b.cu fig10b_ref
+build Figure9/main.cu fig9_ref & p1=$!
+build Figure10/main_a.cu fig10a_ref & p2=$!
+build Figure10/main_b.cu fig10b_ref & p3=$!
+wait $p1 && wait $p2 && wait $p3
 echo "oracle/_ref/drivers: the reference's Figure9 / Figure10a / Figure10b drivers built against include/compat + libgnnagg.so"

@@ -39,8 +39,10 @@ GEN=$(mktemp -d "${TMPDIR:-/tmp}/gnnref.XXXXXX")
 trap 'rm -rf "$GEN"' EXIT
 mkdir -p "$GEN/include" "$GEN/src" "$HERE/_ref"
 # (args.hxx and dbg.h are vendored host-only libraries: used from the reference tree as they are, see -I"$REF/include" below)
-for f in "$REF"/include/*.h; do [ "$(basename "$f")" = dbg.h ] || "$HIPIFY" "$f" > "$GEN/include/$(basename "$f")" 2>/dev/null; done
-for f in data util; do "$HIPIFY" "$REF/src/$f.cu" > "$GEN/src/$f.hip" 2>/dev/null; done
+# (hipify-perl takes 2-10 s per file: the translations run side by side)
+for f in "$REF"/include/*.h; do [ "$(basename "$f")" = dbg.h ] || "$HIPIFY" "$f" > "$GEN/include/$(basename "$f")" 2>/dev/null & done
+for f in data util; do "$HIPIFY" "$REF/src/$f.cu" > "$GEN/src/$f.hip" 2>/dev/null & done
+wait
 sed -i 's/0xffffffff\b/0xffffffffffffffffULL/g' "$GEN"/include/aggregator.h "$GEN"/include/aggr_gat.h "$GEN"/include/aggr_gcn.h \
     "$GEN"/include/aggr_nn.h "$GEN"/include/aggr_sddmm.h "$GEN"/include/spmm.h "$GEN"/include/sample.h
 sed -i -e 's/asm volatile("mov.u64 %0, %%globaltimer;" : "=l"(first_reading));/first_reading = wall_clock64();/' \
