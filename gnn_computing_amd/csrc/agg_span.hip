@@ -285,11 +285,12 @@ __global__ __launch_bounds__(256) void k_zero_rows(const int *__restrict__ rows,
 
 // ------------------------------------------------------------------------------------------ GAT on the same stream
 // Fused edge softmax + weighted SpMM (reference aggr_gat / aggr_gat_fine, aggr_gat.h:116-205) over spans.  A column tile
-// covers HT = tile_w / dhead whole heads (or part of one head: HT = 1).  Per edge every lane gathers its head's source term
-// with the feature segment and exponentiates; the centre term changes with the GROUP, so the centre terms of the next 2 x
-// GROUP groups ride in two register windows (lane j: group gw0 + j, one register per head of the tile), refilled a whole
-// window ahead -- no dependent load at a group boundary.  Flush: numerator to the group's partial row, denominator to
-// partial_den[g, h] by the lane that holds the head's first column.
+// covers HT = tile_w / dhead whole heads (or part of one head: HT = 1).  Lane j of a window computes the weights of edge j once
+// per head of the tile (one load of its HT source terms from the compact image of k_tile_att, one exp each) and the group
+// shares them; the centre term changes with the GROUP, so the centre terms of the next 2 x GROUP groups ride in two register
+// windows (lane j: group gw0 + j, one register per head of the tile), shifted between edge windows -- no dependent load at a
+// group boundary.  Flush: numerator to the group's partial row (streaming store), denominator to partial_den[g, h] by the
+// lane that holds the head's first column.
 struct GatSpanArgs {
     SpanArgs s;
     const float *as_t;    // compact source terms [head group][att_rows][HT] (k_tile_att)
