@@ -47,9 +47,11 @@ static constexpr int kBlock = 256;  // 4 wavefronts
 template <int GROUP>
 constexpr int block_of() { return GROUP * 8 < kBlock ? GROUP * 8 : kBlock; }
 static inline int block_for(int group) { return group * 8 < kBlock ? group * 8 : kBlock; }
-// neighbor gathers in flight per lane group.  Measured on the arxiv-shaped input: 4 and 8 tie (73.7 / 74.5 us in community
-// order, 87.9 / 86.8 us un-reordered), 16 loses (96 us, register pressure), and forcing 8 waves/SIMD with
-// __launch_bounds__ spills (137 us): the kernel sits at the memory system's ceiling, not at an occupancy cliff.
+// neighbor gathers in flight per lane group: the default.  Round 1 (arxiv-shaped): 4 and 8 tie un-reordered (87.9 / 86.8 us), 16
+// loses (96 us, register pressure), forcing 8 waves/SIMD at 8 gathers spills (137 us).  Round 2: WITH the locality reorder 4
+// gathers (59 VGPRs, 8 waves per SIMD) beat 8 (76 VGPRs, 6 waves): 74.0 vs 77.9 us -- k_gcn_plan / k_gat_plan therefore
+// take the batch size as a template parameter (4 on the 32- and 64-lane float4 geometries of the balanced / scheduled
+// orders, this default elsewhere: long chains and narrow geometries want 8).
 #ifndef KUNROLL
 #define KUNROLL 8
 #endif
