@@ -172,6 +172,7 @@ struct Ctx {
     int use_spans = 1;         // GCN, tiled: the segmented-stream kernel (agg_span.hip); 0: one descriptor per lane group
     int fast_rows = 0;         // 1: `scheduled = 0` runs the balanced order (within 1e-5) instead of CSR-order chains
     int fast_scheduled = 0;    // 1: `scheduled = 1` runs the balanced order too (the user's groups keep describing num_target / get_schedule)
+    int use_aux_stream = 1;    // rows mode: hub rows on a second stream beside the short rows (0: same stream, one after the other)
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
     int xcd_remap = 2;         // 0 identity, 1 equal-count XCD ranges, 2 work-balanced XCD ranges
     DevBuf<int> hub_count;  // arrival counters of the in-kernel hub fold (zero between launches)
@@ -863,19 +864,22 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     if (mode == GNNAGG_MODE_ROWS && c->use_plan) {
         if (!c->rows_plan.valid && (rc = build_rows_plan(c))) return rc;
         RowsPlan &p = c->rows_plan;
-        if (p.n1 > 0) {  // fork: long rows on the auxiliary stream (disjoint output rows)
-            if (!c->aux_stream) {
-                HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        const bool fork = p.n1 > 0 && c->use_aux_stream;
+        if (p.n1 > 0) {  // long rows (disjoint output rows): forked to the auxiliary stream, or first on this one
+            if (fork) {
+                if (!c->aux_stream) {
+                    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
             }
-            HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-            HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
             GcnRowsLongLaunch R;
             R.r1 = p.r1.p; R.n1 = p.n1; R.idx = c->d_idx; R.val = c->d_val; R.x = x; R.y = y; R.feat = feat; R.reduce = reduce;
             R.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
-            if ((rc = launch_gcn_rows_long(R, c->aux_stream))) return rc;
-            HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
+            if ((rc = launch_gcn_rows_long(R, fork ? c->aux_stream : c->stream))) return rc;
+            if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
         }
         GcnPlanLaunch P;  // short rows: the descriptor path of the plan kernel (no segments, no hubs)
         P.t0 = p.r0.p; P.n0 = p.n0; P.t0_cost_prefix = p.r0_cost_prefix.data();
@@ -886,7 +890,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             P.nn_weight = nn->weight; P.nn_out = nn->out; P.nn_cols = nn->cols;
         }
         rc = launch_gcn_plan(P, c->stream);
-        if (p.n1 > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // join
+        if (fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // join
         if (rc || !nn) return rc;
         if (!nn_rows_ok) return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
         if (p.n1 > 0)  // the long rows' products, once their chains have joined
@@ -1027,26 +1031,29 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
         RowsPlan &p = c->rows_plan;
         const bool long_ok = p.n1 > 0 && ((feat / heads) % 32) == 0;
         if (p.n1 == 0 || long_ok) {
+            const bool fork = long_ok && c->use_aux_stream;
             if (long_ok) {
-                if (!c->aux_stream) {
-                    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-                    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+                if (fork) {
+                    if (!c->aux_stream) {
+                        HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+                        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                        HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+                    }
+                    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+                    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
                 }
-                HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-                HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
                 GcnRowsLongLaunch R;
                 R.r1 = p.r1.p; R.n1 = p.n1; R.idx = c->d_idx; R.x = x; R.y = y; R.feat = feat;
                 R.att = att; R.heads = heads; R.slope = slope;
-                if ((rc = launch_gcn_rows_long(R, c->aux_stream))) return rc;
-                HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
+                if ((rc = launch_gcn_rows_long(R, fork ? c->aux_stream : c->stream))) return rc;
+                if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
             }
             GatPlanLaunch P;
             P.t0 = p.r0.p; P.n0 = p.n0; P.t0_cost_prefix = p.r0_cost_prefix.data();
             P.idx = c->d_idx; P.att = att; P.x = x; P.y = y; P.feat = feat; P.heads = heads; P.slope = slope;
             P.xcd_remap = c->xcd_remap; P.rows_semantics = 1;
             rc = launch_gat_plan(P, c->stream);
-            if (long_ok) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            if (fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
             return rc;
         }
     }
@@ -1182,6 +1189,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_RETILE")) c->opt_retile = atoi(e);
     if (const char *e = getenv("GNNAGG_FAST_ROWS")) c->fast_rows = atoi(e);
     if (const char *e = getenv("GNNAGG_FAST_SCHEDULED")) c->fast_scheduled = atoi(e);
+    if (const char *e = getenv("GNNAGG_AUX_STREAM")) c->use_aux_stream = atoi(e);
     if (const char *e = getenv("GNNAGG_SPANS")) c->use_spans = atoi(e);
     if (const char *e = getenv("GNNAGG_OVERLAP_COMBINE")) c->overlap_combine = atoi(e);
     {
@@ -1247,6 +1255,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "tiled") c->tiled = value;
     else if (n == "fast_rows") c->fast_rows = value;
     else if (n == "fast_scheduled") c->fast_scheduled = value;
+    else if (n == "aux_stream") c->use_aux_stream = value;
     else if (n == "spans") { c->use_spans = value; replan = true; }
     else if (n == "overlap_combine") c->overlap_combine = value;
     else if (n == "inkernel_combine") c->inkernel_combine = value;

@@ -109,6 +109,9 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *   "fast_scheduled" [GNNAGG_FAST_SCHEDULED]  1: GNNAGG_MODE_SCHEDULED (`scheduled = 1`) runs the balanced order as well (a schedule
  *                                         must still have been made; num_target / get_schedule keep describing the user's groups;
  *                                         GAT calls that ask for newval keep the scheduled order); 0 (default): the user's groups
+ *   "aux_stream" [GNNAGG_AUX_STREAM]      0: GNNAGG_MODE_ROWS runs its hub rows on the handle's stream, before the short rows, instead of
+ *                                         beside them on an auxiliary stream (slower by the hub rows' duration, but the process keeps
+ *                                         a single queue); 1 (default)
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
 int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
 /* Aggregator_GCN::updateval, aggr_gcn.h:540-544: re-aliases the edge values (borrowed; read at run time). */

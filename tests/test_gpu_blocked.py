@@ -198,6 +198,25 @@ def test_fast_rows_option_gives_scheduled0_the_balanced_order():
     assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "fast rows gat")
 
 
+def test_aux_stream_option_keeps_rows_mode_bit_exact_on_one_stream():
+    """rows mode with hub rows: "aux_stream" = 0 runs the long-row kernel on the handle's stream instead of an auxiliary one."""
+    V, E, F = 5000, 150000, 128
+    ptr, idx = hub_graph(V, E, seed=9, alpha=1.0)
+    x, val, att = rand((V, F), 1), rand(E, 2), rand((V, 2), 3) * 0.4
+    seq = orc.gcn_seq(ptr, idx, val, x)
+    for aux in (0, 1):
+        agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+        agg.set_option("aux_stream", aux)
+        y = torch.full((V, F), 7.0, device=DEV)
+        agg.run(dev(x), y, 512, 0)
+        assert np.array_equal(y.cpu().numpy(), seq), aux
+        gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+        gat.set_option("aux_stream", aux)
+        gat.run(dev(x), dev(att), y, 128, 0)
+        ref = orc.gat_fused(ptr, idx, att, x)
+        assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "gat rows aux=%d" % aux)
+
+
 def test_fast_scheduled_option_gives_scheduled1_the_balanced_order():
     """reference drivers call schedule(neighbor_grouping, {NG}) + run(vin, vout, B, 1); with the option that call runs the
     balanced order too (same bits as mode "balanced"), the user's groups keep describing num_target / get_schedule, and a
