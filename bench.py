@@ -27,7 +27,9 @@ sys.path.insert(0, ROOT)
 
 FEAT = 128
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-L2_GATHER_PEAK_GBPS = 24500.0  # measured: 256-byte row gathers from an XCD's own L2 (profiles/r02/gather_ceiling.txt)
+L2_PEAK_GBPS = 34500.0  # same guide, "L2": 4 MiB per XCD, ~34.5 TB/s aggregate (the 2-D blocked order gathers from L2)
+L2_GATHER_MEASURED_GBPS = 24500.0  # measured here: 256-byte row gathers from an XCD's own L2 (profiles/r02/gather_ceiling.txt)
+PROFILE_ROUND = "r03"
 
 
 def algorithmic_bytes(V, E, F, explicit_val=True):
@@ -41,16 +43,32 @@ def compulsory_bytes(V, E, F, explicit_val=True):
     return 2 * V * 4 * F + E * (4 + (4 if explicit_val else 0)) + (V + 1) * 4
 
 
+def lib_md5():
+    """md5 (first 12 hex digits) of the libgnnagg.so this process loads -- the label scripts/profile_round.sh stamps on its
+    counter passes."""
+    import hashlib
+    p = os.environ.get("GNNAGG_LIB") or os.path.join(ROOT, "gnn_computing_amd", "libgnnagg.so")
+    try:
+        return hashlib.md5(open(p, "rb").read()).hexdigest()[:12]
+    except OSError:
+        return None
+
+
 def pmc_traffic(tag):
-    """Fabric-side bytes per launch from the committed rocprofv3 PMC passes (scripts/profile_bench.sh ->
-    scripts/pmc_summary.py -> profiles/r02/pmc_traffic.json); static: labelled with the build it was measured on."""
-    f = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-    if not os.path.exists(f):
-        return None, None
-    d = json.load(open(f)).get(tag)
-    if not d:
-        return None, None
-    return d.get("hbm_bytes_per_launch"), d.get("_label")
+    """Fabric-side bytes per launch of the config's kernels from the committed rocprofv3 PMC passes (scripts/profile_round.sh
+    -> scripts/prof_config.sh -> profiles/<round>/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, the
+    gfx950 correction of MI355X_MICROARCH.md).  Returns (dominant kernel's bytes, all kernels' bytes per step, label, stale):
+    `stale` is True when the build the counters were collected on is not the library running now."""
+    for rnd in (PROFILE_ROUND, "r02"):
+        f = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        if os.path.exists(f):
+            d = json.load(open(f)).get(tag)
+            if d:
+                label = d.get("_label", "")
+                build = d.get("build") or (label.split("build ")[1].split(";")[0].strip() if "build " in label else None)
+                return (d.get("hbm_bytes_per_launch"), d.get("all_kernels_bytes_per_step"),
+                        "profiles/%s/pmc_traffic.json: %s" % (rnd, label), build != lib_md5())
+    return None, None, None, None
 
 
 def log(*a):
@@ -153,6 +171,7 @@ def run_single(args, dev):
         if mode == "balanced":     # neighbor_grouping_schedule_time (graph_schedule.h:125-127)
             agg.schedule_balanced(0)
         elif mode == "scheduled":
+            agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
             agg.schedule(gnc.Schedule.neighbor_grouping, [int(os.environ.get("BENCH_NG", "32"))])
         torch.cuda.synchronize()
         prep["schedule_prep_s"] = time.perf_counter() - t_s
@@ -210,11 +229,18 @@ def run_single(args, dev):
     if mode == "balanced":
         agg_u.schedule_balanced(0)
     elif mode == "scheduled":
+        agg_u.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
         agg_u.schedule(gnc.Schedule.neighbor_grouping, [int(os.environ.get("BENCH_NG", "32"))])
     _, probe_u_s, _ = time_steps(lambda: agg_u.probe_gather(dx, mode), args.steps, args.warmup, lambda: None)
     _, kern_u_s, _ = time_steps(lambda: agg_u.run(dx, y, 512, mode), args.steps, args.warmup, lambda: None)
-    traffic, traffic_label = pmc_traffic("A")
+    traffic, _, traffic_label, traffic_stale = pmc_traffic("A")
     other = "no_reorder" if which == "reorder" else "reorder"
+    # roofline: bound = HBM / fabric bandwidth, 8 TB/s.  `achieved` = ALGORITHMIC (gather-model)
+    # bytes over the kernel's average launch time -- on this input most of those bytes are served by L2 / Infinity Cache, so it
+    # can exceed the peak (`algorithmic_frac` > 1) and is NOT a utilisation.  `frac` = what the counters say crossed the fabric
+    # (`traffic`) over the same time over 8 TB/s; the probe ratio (this launch's own gather pattern without chains or stores)
+    # is `probe_frac`; compulsory bytes beside them.
+    traffic_gbps = traffic / dev_s / 1e9 if traffic else None
     out = {
         "metric": "aggregated edges/sec, GCN SpMM feat=128", "value": E / (wall / args.steps), "unit": "edges/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -224,12 +250,18 @@ def run_single(args, dev):
                                    "locality reorder (cache-aware greedy order, gnnagg_cluster_reorder_ex) applied on load like a .reorder_thres_0.2 file" if which == "reorder" else "no reorder", mode),
                    "num_v": V, "num_e": E, "feat": FEAT},
         "achieved_gbps": achieved,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": B / probe_s / 1e9, "unit": "GB/s",
-                     "frac": probe_s / dev_s,
-                     "frac_is": "measured gather ceiling / kernel: time of the probe launch (same loads, no FMA chain, no store) "
-                                "over time of k_gcn_plan; achieved and peak are SURVEY 8d algorithmic (gather-model) bytes over "
-                                "those two times",
-                     "traffic": traffic, "traffic_source": traffic_label,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": (traffic_gbps / HBM_PEAK_GBPS) if traffic_gbps else achieved / HBM_PEAK_GBPS,
+                     "frac_is": ("counter traffic (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel, per launch) / average launch "
+                                 "time / 8 TB/s" if traffic_gbps else
+                                 "algorithmic bytes / average launch time / 8 TB/s (no counter file found)"),
+                     "traffic": traffic, "traffic_source": traffic_label, "traffic_stale": traffic_stale,
+                     "traffic_gbps": traffic_gbps,
+                     "algorithmic_frac": achieved / HBM_PEAK_GBPS,
+                     "probe_frac": probe_s / dev_s, "probe_gbps": B / probe_s / 1e9,
+                     "probe_is": "time of the probe launch (this kernel's descriptor / id / value loads and row gathers, same "
+                                 "addresses and batching, no FMA chain, no store) over the kernel's time: how far the kernel is "
+                                 "from what its own access pattern costs -- says nothing about whether the pattern is good",
                      "kernel": "k_gcn_plan", "algorithmic_bytes": B, "compulsory_bytes": C,
                      "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
                      "ceiling_probe_us": probe_s * 1e6, "ceiling_probe_median_us": probe_med * 1e6,
@@ -239,7 +271,7 @@ def run_single(args, dev):
                      "gather_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
                      "compulsory_gbps": C / dev_s / 1e9, "compulsory_frac_of_hbm_peak": C / dev_s / 1e9 / HBM_PEAK_GBPS,
                      "which_bytes": "algorithmic = one 512-B feature row + id + value per EDGE (mostly served by L2 / Infinity "
-                                    "Cache here: gather_frac_of_hbm_peak may exceed 1 and is not an HBM utilisation); compulsory "
+                                    "Cache here: achieved / peak may exceed 1 and is not an HBM utilisation); compulsory "
                                     "= X and Y once + CSR once (what HBM must move at least); traffic = rocprofv3 fabric-side "
                                     "bytes (Infinity-Cache hits included)"},
         other: {"value": E / (results[other][0] / args.steps), "avg_launch_us": results[other][1] * 1e6,
@@ -288,34 +320,43 @@ def run_other_config(args, dev):
     steps, warm = min(args.steps, 20), min(args.warmup, 3)
     wall, dev_s, med_s = time_steps(step, steps, warm, lambda: None)
     achieved = B / dev_s / 1e9
-    # ceiling: the gather probe of the same launch sequence (same id / value / attention-term loads and row gathers, no
-    # chains, no stores)
+    # the gather probe of the same launch sequence (same id / value / attention-term loads and row gathers, no chains, no stores)
     if args.config == "G":
         _, probe_s, _ = time_steps(lambda: agg.probe_gather(x, att, "balanced", heads=H), steps, warm, lambda: None)
     else:
         _, probe_s, _ = time_steps(lambda: agg.probe_gather(x, "balanced"), steps, warm, lambda: None)
-    peak = B / probe_s / 1e9 if probe_s else L2_GATHER_PEAK_GBPS
-    traffic, traffic_label = pmc_traffic(args.config)
+    traffic, traffic_step, traffic_label, traffic_stale = pmc_traffic(args.config)
     explicit = args.config == "P1"
     C = (2 * V * 4 * F + E * (4 + (4 if explicit else 0)) + (V + 1) * 4) + (V * 8 * H * 2 if args.config == "G" else 0)
+    blocked = agg.balanced_partitions() > 1
+    # roofline.  P1 (chunked plan, X far larger than the caches): HBM / fabric bound, frac = counter traffic
+    # of the step / step time / 8 TB/s.  R and G (2-D blocked order: the gathered tile rows are served by the XCDs' L2s): the
+    # bound is the L2, frac = gather-model bytes / step time / 34.5 TB/s (the guide's L2 figure); the rate measured here for
+    # 256-byte row gathers out of an L2 is 24.5 TB/s (`frac_of_measured_l2_gather`).  The probe ratio is `probe_frac`.
+    if blocked:
+        bound, peak, frac = "l2", L2_PEAK_GBPS, achieved / L2_PEAK_GBPS
+        frac_is = "gather-model (algorithmic) bytes / step time / 34.5 TB/s (MI355X_MICROARCH.md: aggregate L2 bandwidth)"
+    else:
+        bound, peak = "hbm", HBM_PEAK_GBPS
+        frac = (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else achieved / HBM_PEAK_GBPS
+        frac_is = ("counter traffic of the step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE) / step time / 8 TB/s" if traffic_step
+                   else "algorithmic bytes / step time / 8 TB/s (no counter file found)")
     return {"metric": "aggregated edges/sec, config %s" % args.config, "value": E / (wall / steps), "unit": "edges/s",
             "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": wall / steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "num_v": V, "num_e": E, "feat": F, "source_partitions": agg.balanced_partitions()},
             "achieved_gbps": achieved,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": min(1.0, achieved / peak),
-                         "frac_is": ("probe time / step time (same launch sequence, no FMA chains, no stores)" if probe_s else
-                                     "gather-model bytes per second over the measured L2-resident 256-B row-gather ceiling "
-                                     "(profiles/r02/gather_ceiling.txt)"),
-                         "traffic": traffic, "traffic_source": traffic_label, "kernel": kernel, "algorithmic_bytes": B,
+            "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": frac, "frac_is": frac_is,
+                         "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_label,
+                         "traffic_stale": traffic_stale, "kernel": kernel, "algorithmic_bytes": B,
                          "compulsory_bytes": C, "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
-                         "ceiling_probe_us": probe_s * 1e6 if probe_s else None,
+                         "probe_frac": probe_s / dev_s, "ceiling_probe_us": probe_s * 1e6,
+                         "frac_of_measured_l2_gather": achieved / L2_GATHER_MEASURED_GBPS if blocked else None,
                          "hbm_peak_gbps": HBM_PEAK_GBPS, "gather_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
-                         "traffic_frac_of_hbm_peak": (traffic / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "traffic_frac_of_hbm_peak": (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else None,
                          "compulsory_frac_of_hbm_peak": C / dev_s / 1e9 / HBM_PEAK_GBPS,
-                         "note": "the step is several launches (column-tiling of X, aggregation, ordered combine): times are of the "
-                                 "whole step, traffic of the dominant kernel; gather bytes are served by the L2 in the 2-D blocked "
-                                 "order, so gather_frac_of_hbm_peak is not an HBM utilisation"}}
+                         "note": "times are of the whole step (R / G: column-tiling of X, aggregation, ordered combine); `traffic` is "
+                                 "the dominant kernel's fabric-side bytes per launch, `traffic_step` all kernels of a step"}}
 
 
 def run_multi(args, dev, rank, world):
@@ -412,7 +453,9 @@ def run_multi(args, dev, rank, world):
         # is slower for this partition -- reported against the HBM figure for continuity with the 1-GPU line, not as a
         # kernel roofline (that is the N = 1 line's job)
         "roofline": {"bound": "hbm", "achieved": B / step_s / 1e9 / world, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": min(1.0, B / step_s / 1e9 / world / HBM_PEAK_GBPS), "traffic": None,
+                     "unit": "GB/s", "frac": B / step_s / 1e9 / world / HBM_PEAK_GBPS, "traffic": None,
+                     "frac_is": "per-GPU share of the gather-model bytes / step time (exchange included) / 8 TB/s; cache-served gathers "
+                                "count, so this is not an HBM utilisation",
                      "kernel": "per-GPU share of the step (halo exchange over xGMI included; gather-model bytes, cache-served "
                                "gathers count: see the N = 1 line for the measured ceiling)", "algorithmic_bytes": B,
                      "halo_bytes_per_rank": float(halo[0].item()) / world},

@@ -833,13 +833,6 @@ int launch_dense_rows(const int *rows, int n_rows, const float *Y, const float *
 // geometry of a 2-D blocked launch: 16-byte lanes over tiles of tile_w floats
 static Geometry tile_geometry(const TileSpec &t, int feat) { return {4, t.tile_w / 4, (feat + t.tile_w - 1) / t.tile_w}; }
 
-static unsigned *probe_sink()
-{
-    static unsigned *p = nullptr;
-    if (!p && hipMalloc((void **)&p, sizeof(unsigned)) != hipSuccess) p = nullptr;
-    return p;
-}
-
 int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
@@ -898,7 +891,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     const int grid = a.n1 * g.ntiles + grid0;
     if (L.probe) {
         if (is_max) return fail(GNNAGG_ERR_ARG, "probe: sum/mean only");
-        a.probe_sink = probe_sink();
+        a.probe_sink = device_probe_sink();
         if (!a.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
         if (grid > 0) {
 #define CALL_PROBE hipLaunchKernelGGL((k_gcn_plan<VEC, GROUP, false, true>), dim3(grid), dim3(blk), 0, stream, a);

@@ -589,13 +589,6 @@ __global__ __launch_bounds__(256) void k_combine_groups_gat(const CombineGroupsG
     store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
 }
 
-static unsigned *span_probe_sink()
-{
-    static unsigned *p = nullptr;
-    if (!p && hipMalloc((void **)&p, sizeof(unsigned)) != hipSuccess) p = nullptr;
-    return p;
-}
-
 // Launch plan shared by the GCN and GAT launchers: either ONE span launch over all tiles followed by one combine, or (with
 // an auxiliary stream) one span launch per tile on `stream`, each followed by its combine on the auxiliary stream.
 template <class SpanFn, class CombineFn>
@@ -672,7 +665,7 @@ int launch_gcn_span(const SpanLaunch &L, void *stream_v)
     SpanArgs a0;
     fill_span_args(a0, L, ntiles, group);
     if (L.probe) {
-        a0.probe_sink = span_probe_sink();
+        a0.probe_sink = device_probe_sink();
         if (!a0.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
     }
     auto span = [&](int tile0, int nt, hipStream_t st) -> int {
@@ -745,7 +738,7 @@ int launch_gat_span(const GatSpanLaunch &G, void *stream_v)
     A0.s.val_s = nullptr; A0.s.mean = 0; A0.s.relu = 0;
     if (!G.as_t || !G.ac_t || G.att_rows <= 0) return fail(GNNAGG_ERR_STATE, "internal: GAT span launch without the compact attention image");
     if (L.probe) {
-        A0.s.probe_sink = span_probe_sink();
+        A0.s.probe_sink = device_probe_sink();
         if (!A0.s.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
     }
     A0.as_t = G.as_t; A0.ac_t = G.ac_t; A0.att_rows = G.att_rows; A0.partial_den = G.partial_den; A0.newval = G.newval; A0.eperm = G.eperm; A0.heads = G.heads; A0.dhead = dhead;

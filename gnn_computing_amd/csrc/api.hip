@@ -170,8 +170,17 @@ struct Ctx {
     int opt_retile = 1;        // 0: gather from the caller's X when its rows are 128-byte aligned
     int opt_scratch_limit_mb = 0;  // > 0: the blocked order may not take more scratch than this (else: half of the free memory)
     int use_spans = 1;         // GCN, tiled: the segmented-stream kernel (agg_span.hip); 0: one descriptor per lane group
-    int fast_rows = 0;         // 1: `scheduled = 0` runs the balanced order (within 1e-5) instead of CSR-order chains
-    int fast_scheduled = 0;    // 1: `scheduled = 1` runs the balanced order too (the user's groups keep describing num_target / get_schedule)
+    // `scheduled = 0` (GNNAGG_MODE_ROWS): 0 = canonical CSR-order chains, bit-exact against a sequential loop -- the default of
+    // the status-returning API; 1 = the balanced order (within 1e-5 of it) -- the default of the reference-facing surfaces
+    // (flat *_impl API, class shim, pybind names: gnnagg_set_option "reference_defaults").  GNNAGG_FAST_ROWS overrides both.
+    int fast_rows = 0;
+    bool fast_rows_from_env = false;
+    // `scheduled = 1`: 1 (default) = the balanced order -- the reference's scheduled kernels add their group partials with
+    // atomicAdd (aggr_gcn.h:112, aggr_gat.h:196-203), so ANY association is one of its legal results; num_target /
+    // get_schedule / mode_params(SCHEDULED) keep describing the user's groups, the order that runs is the one
+    // get_schedule(BALANCED) / balanced_params describe.  0 = the user's groups folded in the restated order (what the
+    // bit-exact parity tests of the scheduled mode pin).  GNNAGG_FAST_SCHEDULED / option "fast_scheduled".
+    int fast_scheduled = 1;
     int use_aux_stream = 1;    // rows mode: hub rows on a second stream beside the short rows (0: same stream, one after the other)
     DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
     int xcd_remap = 2;         // 0 identity, 1 equal-count XCD ranges, 2 work-balanced XCD ranges
@@ -306,7 +315,10 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
         int mx = 0;
         for (int v : h_idx) mx = std::max(mx, v);
         if (par_num == -1) par_num = parts_for_cols(c, (long)mx + 1);
-        total_v = std::max(mx + 1, par_num);
+        // a forced range count ("partitions" / GNNAGG_PARTITIONS) above the column count would make the tiling kernels read
+        // total_cols rows of the caller's X and att past their ends: no more ranges than columns
+        par_num = std::max(1, std::min(par_num, mx + 1));
+        total_v = mx + 1;
     }
     s.par_num = par_num;
     s.reset();
@@ -1187,7 +1199,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_TILE_W")) { const int w = atoi(e); if (w == 32 || w == 64 || w == 128 || w == 256) c->opt_tile_w = w; }
     if (const char *e = getenv("GNNAGG_SLICE_KB")) c->opt_slice_kb = std::max(1, atoi(e));
     if (const char *e = getenv("GNNAGG_RETILE")) c->opt_retile = atoi(e);
-    if (const char *e = getenv("GNNAGG_FAST_ROWS")) c->fast_rows = atoi(e);
+    if (const char *e = getenv("GNNAGG_FAST_ROWS")) { c->fast_rows = atoi(e); c->fast_rows_from_env = true; }
     if (const char *e = getenv("GNNAGG_FAST_SCHEDULED")) c->fast_scheduled = atoi(e);
     if (const char *e = getenv("GNNAGG_AUX_STREAM")) c->use_aux_stream = atoi(e);
     if (const char *e = getenv("GNNAGG_SPANS")) c->use_spans = atoi(e);
@@ -1254,6 +1266,11 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "scratch_limit_mb") c->opt_scratch_limit_mb = value;
     else if (n == "tiled") c->tiled = value;
     else if (n == "fast_rows") c->fast_rows = value;
+    else if (n == "reference_defaults") {
+        // what a handle made through a reference-facing surface starts with: run(vin, vout, B, 0) takes the balanced order
+        // (the environment still has the last word)
+        if (!c->fast_rows_from_env) c->fast_rows = value != 0;
+    }
     else if (n == "fast_scheduled") c->fast_scheduled = value;
     else if (n == "aux_stream") c->use_aux_stream = value;
     else if (n == "spans") { c->use_spans = value; replan = true; }
@@ -1668,6 +1685,7 @@ int64_t GCN_init_impl(int *ptr, int *idx, float *val, int num_v, int num_e)
 {
     gnnagg_handle h = 0;
     die_if_abort(gnnagg_gcn_create(ptr, idx, val, num_v, num_e, &h), "GCN_init_impl");
+    if (h) (void)gnnagg_set_option(h, "reference_defaults", 1);
     return h;
 }
 
@@ -1693,6 +1711,7 @@ int64_t GAT_init_impl(int *ptr, int *idx, int num_v, int num_e)
 {
     gnnagg_handle h = 0;
     die_if_abort(gnnagg_gat_create(ptr, idx, num_v, num_e, &h), "GAT_init_impl");
+    if (h) (void)gnnagg_set_option(h, "reference_defaults", 1);
     return h;
 }
 

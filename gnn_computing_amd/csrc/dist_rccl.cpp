@@ -124,31 +124,96 @@ int gnnagg_dist_comm_create(const char *id128, int rank, int world, gnnagg_comm 
     return GNNAGG_OK;
 }
 
+// Rendezvous through the file system, safe against what an earlier (crashed) launch left at the same path: ranks > 0 each
+// publish a fresh random token (<path>.req.<rank>); rank 0 first removes whatever is at <path>, draws the id, collects the
+// tokens of THIS launch and publishes {magic, world, id, tokens} atomically; a rank accepts an id file only when it carries the
+// token it drew itself -- a stale file cannot, so nobody ever calls ncclCommInitRank with mismatched ids (which hangs forever).
+// A stale request file costs a round: rank 0 answers it, its owner rejects the answer and republishes its token, rank 0 notices
+// the changed token and publishes again.  Every wait is bounded by timeout_s.
+static bool read_file(const std::string &p, void *buf, size_t n)
+{
+    FILE *f = fopen(p.c_str(), "rb");
+    if (!f) return false;
+    const size_t got = fread(buf, 1, n, f);
+    const bool exact = got == n && fgetc(f) == EOF;
+    fclose(f);
+    return exact;
+}
+
+static bool publish_file(const std::string &p, const void *buf, size_t n)
+{
+    const std::string tmp = p + ".tmp." + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(buf, 1, n, f) == n;
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), p.c_str()) != 0) { (void)unlink(tmp.c_str()); return false; }  // atomic: all bytes or no file
+    return true;
+}
+
+static unsigned long long fresh_token()
+{
+    unsigned long long t = 0;
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (f) { if (fread(&t, sizeof(t), 1, f) != 1) t = 0; fclose(f); }
+    if (t == 0)
+        t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9e3779b97f4a7c15ULL ^ ((unsigned long long)getpid() << 32);
+    return t ? t : 1;
+}
+
 int gnnagg_dist_comm_create_from_file(const char *path, int rank, int world, int timeout_s, gnnagg_comm *out)
 {
     if (!path || !out) return fail(GNNAGG_ERR_ARG, "bad communicator arguments");
-    char id[GNNAGG_UNIQUE_ID_BYTES];
+    *out = 0;
+    if (world < 1 || rank < 0 || rank >= world) return fail(GNNAGG_ERR_ARG, "bad communicator arguments");
+    static constexpr unsigned long long kMagic = 0x31444947414e4e47ULL;  // "GNNAGID1"
     const std::string p(path);
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s > 0 ? timeout_s : 120);
+    const size_t n_words = 2 + GNNAGG_UNIQUE_ID_BYTES / 8 + (size_t)(world - 1);  // magic, world, id, one token per rank > 0
+    std::vector<unsigned long long> rec(n_words, 0);
+    char *id = reinterpret_cast<char *>(&rec[2]);
+    auto req_path = [&](int r) { return p + ".req." + std::to_string(r); };
     if (rank == 0) {
+        (void)unlink(p.c_str());  // whatever an earlier launch left here is not ours
         int rc = gnnagg_dist_unique_id(id);
         if (rc) return rc;
-        const std::string tmp = p + ".tmp." + std::to_string((long)getpid());
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { if (f) fclose(f); return fail(GNNAGG_ERR_IO, "cannot write " + tmp); }
-        fclose(f);
-        if (rename(tmp.c_str(), p.c_str()) != 0) return fail(GNNAGG_ERR_IO, "cannot publish " + p);  // atomic: readers see all 128 bytes or no file
-    } else {
-        const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s > 0 ? timeout_s : 120);
+        rec[0] = kMagic;
+        rec[1] = (unsigned long long)world;
+        std::vector<unsigned long long> seen((size_t)world, 0);
+        bool published = false;
         for (;;) {
-            FILE *f = fopen(p.c_str(), "rb");
-            if (f) {
-                const size_t got = fread(id, 1, sizeof(id), f);
-                fclose(f);
-                if (got == sizeof(id)) break;
+            bool all = true, changed = false;
+            for (int r = 1; r < world; ++r) {
+                unsigned long long t = 0;
+                if (!read_file(req_path(r), &t, sizeof(t)) || t == 0) { all = false; continue; }
+                if (t != seen[r]) { seen[r] = t; changed = true; }
             }
-            if (std::chrono::steady_clock::now() > t_end) return fail(GNNAGG_ERR_IO, "timed out waiting for " + p);
-            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            if (all && (changed || !published)) {
+                for (int r = 1; r < world; ++r) rec[2 + GNNAGG_UNIQUE_ID_BYTES / 8 + (size_t)(r - 1)] = seen[r];
+                if (!publish_file(p, rec.data(), n_words * 8)) return fail(GNNAGG_ERR_IO, "cannot publish " + p);
+                published = true;
+            }
+            // done when every request file is gone again: its owner accepted the id file and removed it
+            bool gone = published;
+            for (int r = 1; r < world && gone; ++r) gone = access(req_path(r).c_str(), F_OK) != 0;
+            if (gone) break;
+            if (std::chrono::steady_clock::now() > t_end) return fail(GNNAGG_ERR_IO, "timed out waiting for the other ranks at " + p);
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
+    } else {
+        const unsigned long long mine = fresh_token();
+        const std::string rq = req_path(rank);
+        if (!publish_file(rq, &mine, sizeof(mine))) return fail(GNNAGG_ERR_IO, "cannot write " + rq);
+        for (;;) {
+            if (read_file(p, rec.data(), n_words * 8) && rec[0] == kMagic && rec[1] == (unsigned long long)world &&
+                rec[2 + GNNAGG_UNIQUE_ID_BYTES / 8 + (size_t)(rank - 1)] == mine)
+                break;
+            if (std::chrono::steady_clock::now() > t_end) { (void)unlink(rq.c_str()); return fail(GNNAGG_ERR_IO, "timed out waiting for " + p); }
+            unsigned long long t = 0;   // (somebody cleaning the directory must not strand this rank: keep the request in place)
+            if (!read_file(rq, &t, sizeof(t)) || t != mine) (void)publish_file(rq, &mine, sizeof(mine));
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        (void)unlink(rq.c_str());
     }
     return gnnagg_dist_comm_create(id, rank, world, out);
 }
@@ -206,10 +271,17 @@ int gnnagg_dist_alltoallv(gnnagg_comm h, const void *d_send, const long long *h_
     }
     if (c->world == 1) return GNNAGG_OK;
     RCCL_TRY(R->GroupStart());
-    for (int p = 0; p < c->world; ++p) {
+    // an error inside the bracket must still close it: a thread left with an open group queues every later RCCL call
+    // (torch's too: it shares this librccl) and never issues it
+    ncclResult_t r = ncclSuccess;
+    for (int p = 0; p < c->world && r == ncclSuccess; ++p) {
         if (p == c->rank) continue;
-        if (h_send_counts[p] > 0) RCCL_TRY(R->Send(sp + so[p], (size_t)h_send_counts[p] * elem_bytes, ncclInt8, p, c->comm, stream));
-        if (h_recv_counts[p] > 0) RCCL_TRY(R->Recv(rp + ro[p], (size_t)h_recv_counts[p] * elem_bytes, ncclInt8, p, c->comm, stream));
+        if (h_send_counts[p] > 0) r = R->Send(sp + so[p], (size_t)h_send_counts[p] * elem_bytes, ncclInt8, p, c->comm, stream);
+        if (r == ncclSuccess && h_recv_counts[p] > 0) r = R->Recv(rp + ro[p], (size_t)h_recv_counts[p] * elem_bytes, ncclInt8, p, c->comm, stream);
+    }
+    if (r != ncclSuccess) {
+        (void)R->GroupEnd();
+        return fail(GNNAGG_ERR_HIP, std::string("ncclSend / ncclRecv: ") + (R->GetErrorString ? R->GetErrorString(r) : "rccl error"));
     }
     RCCL_TRY(R->GroupEnd());
     return GNNAGG_OK;

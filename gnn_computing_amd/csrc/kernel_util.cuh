@@ -446,6 +446,17 @@ static Geometry pick_geometry(int F, const void *p0, const void *p1, const void 
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// One word of device memory per DEVICE for the probe instantiations' never-taken store (a process-wide pointer allocated on
+// the first device would be dereferenced by kernels of handles that live on another one).
+static unsigned *device_probe_sink()
+{
+    static unsigned *sinks[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!sinks[dev] && hipMalloc((void **)&sinks[dev], sizeof(unsigned)) != hipSuccess) sinks[dev] = nullptr;
+    return sinks[dev];
+}
+
 // cost_prefix[i] = total cost of items [0,i) (host array, n_items+1 entries).  Cuts the item blocks
 // into 8 contiguous ranges of about equal cost; returns the longest range (in blocks).
 static int fill_xcd_ranges(const long *cost_prefix, int n_items, int items_per_block, int item_blocks, XcdRanges &xr)

@@ -12,11 +12,13 @@ public:
         : Aggregator(host_out_ptr, host_out_idx, dev_out_ptr, dev_out_idx, out_num_v, out_num_e, out_feat_in, out_feat_out)
     {
         checkGnnagg(gnnagg_gat_create(d_ptr, d_idx, num_v, num_e, &handle));
+        checkGnnagg(gnnagg_set_option(handle, "reference_defaults", 1));  // run(..., scheduled = 0) takes the balanced order
     }
     // reference aggr_gat.h:308
     Aggregator_GAT(CSRSubGraph g, int out_feat_in, int out_feat_out) : Aggregator(g, out_feat_in, out_feat_out)
     {
         checkGnnagg(gnnagg_gat_create(d_ptr, d_idx, num_v, num_e, &handle));
+        checkGnnagg(gnnagg_set_option(handle, "reference_defaults", 1));  // run(..., scheduled = 0) takes the balanced order
     }
     // two aggregators may share one CSR (Figure10/main_a.cu:66-70): only one of them may own it
     void releaseGraphOwnership() { d_ptr = nullptr; d_idx = nullptr; d_vset = nullptr; }

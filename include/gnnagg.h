@@ -105,10 +105,20 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *                                         whose allocation fails -- moves to the chunked plan for good
  *   "retile" [GNNAGG_RETILE], "tiled" [GNNAGG_TILED], "spans" [GNNAGG_SPANS], "overlap_combine", "inkernel_combine"   A/B switches
  *   "fast_rows" [GNNAGG_FAST_ROWS]        1: GNNAGG_MODE_ROWS (`scheduled = 0`) runs the balanced order -- results within the
- *                                         1e-5 bound instead of bit-exact CSR-order chains; 0 (default): canonical order
- *   "fast_scheduled" [GNNAGG_FAST_SCHEDULED]  1: GNNAGG_MODE_SCHEDULED (`scheduled = 1`) runs the balanced order as well (a schedule
- *                                         must still have been made; num_target / get_schedule keep describing the user's groups;
- *                                         GAT calls that ask for newval keep the scheduled order); 0 (default): the user's groups
+ *                                         1e-5 bound instead of bit-exact CSR-order chains; 0: canonical order.  Default 0 for
+ *                                         handles made through this section, 1 for the reference-facing surfaces (see
+ *                                         "reference_defaults"); the environment variable overrides both
+ *   "reference_defaults"                  1: what GCN_init_impl / GAT_init_impl, the C++ class shim (include/compat) and the pybind-
+ *                                         named Python functions apply to the handles they make: fast_rows = 1 unless
+ *                                         GNNAGG_FAST_ROWS says otherwise.  A reference driver's run(vin, vout, B, 0) is then as
+ *                                         fast as its scheduled run; aggr_gcn's own result differs from it by association only
+ *   "fast_scheduled" [GNNAGG_FAST_SCHEDULED]  1 (default): GNNAGG_MODE_SCHEDULED (`scheduled = 1`) runs the balanced order.  The
+ *                                         reference's scheduled kernels add group partials with atomicAdd (aggr_gcn.h:112,
+ *                                         aggr_gat.h:196-203): every association is one of its legal results.  A schedule must
+ *                                         still have been made; num_target / get_schedule / mode_params of GNNAGG_MODE_SCHEDULED
+ *                                         keep describing the user's groups, the order that RUNS is the one GNNAGG_MODE_BALANCED's
+ *                                         queries describe; GAT calls that ask for newval keep the scheduled order.  0: the user's
+ *                                         groups, folded in the restated order (bit-exact against the oracle)
  *   "aux_stream" [GNNAGG_AUX_STREAM]      0: GNNAGG_MODE_ROWS runs its hub rows on the handle's stream, before the short rows, instead of
  *                                         beside them on an auxiliary stream (slower by the hub rows' duration, but the process keeps
  *                                         a single queue); 1 (default)
@@ -294,8 +304,13 @@ int gnnagg_pack_rows(const float *d_x, const int *d_ids, int n, int feat, float 
  *   gnnagg_dist_unique_id            rank 0 creates the 128-byte id; the launcher hands it to the other ranks (a file, an
  *                                    environment variable, MPI, a torch.distributed broadcast ...)
  *   gnnagg_dist_comm_create          every rank, same id (collective: returns when all `world` ranks have called it)
- *   gnnagg_dist_comm_create_from_file  the same with the id passed through `path` (rank 0 writes it atomically, the others
- *                                    poll for up to timeout_s seconds): all a C++ driver started once per GPU needs
+ *   gnnagg_dist_comm_create_from_file  the same with the id passed through `path`: all a C++ driver started once per GPU needs.
+ *                                    Ranks > 0 publish a fresh random token (<path>.req.<rank>); rank 0 removes whatever an earlier
+ *                                    launch left at `path`, draws the id and publishes {magic, world, id, tokens} atomically; a
+ *                                    rank accepts only a file that carries ITS token, so a stale file from a crashed run can never
+ *                                    feed mismatched ids to ncclCommInitRank (which would hang).  Every wait is bounded by
+ *                                    timeout_s (120 when <= 0).  `path` should still be unique per launch (two concurrent
+ *                                    launches on one path would fight over it)
  *   gnnagg_dist_alltoallv            h_send_counts[p] / h_recv_counts[p] elements of elem_bytes bytes to / from rank p,
  *                                    packed contiguously in rank order in d_send / d_recv; asynchronous on hip_stream
  *   gnnagg_dist_halo_exchange        one aggregation's halo pull: packs x_local[send_ids] (rows the peers asked for, in

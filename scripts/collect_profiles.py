@@ -18,7 +18,7 @@ for f in sorted(glob.glob(os.path.join(src, "summary_*.json"))):
     res[d["config"]] = {
         "_label": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/run_config_once.py %s, build %s; %s" % (
             d["config"], d["build"], d["_correction"]),
-        "kernel": dom["kernel"], "avg_us": dom["avg_us"], "l2_hit": dom["l2_hit"],
+        "build": d["build"], "kernel": dom["kernel"], "avg_us": dom["avg_us"], "l2_hit": dom["l2_hit"],
         "hbm_bytes_per_launch": int(dom["traffic_bytes"]),
         "all_kernels_bytes_per_step": int(sum(k["traffic_bytes"] for k in ks)),
         "all_kernels_us_per_step": sum(k["avg_us"] for k in ks),

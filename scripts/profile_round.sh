@@ -16,7 +16,7 @@ for cfg in A ${CONFIGS:-R G P1}; do
   SQ=${SQ:-0} scripts/prof_config.sh $OUT $cfg > /dev/null 2>&1
 done
 python3 scripts/collect_profiles.py $OUT $OUT/pmc_traffic.json
-mkdir -p profiles/r02 && cp $OUT/pmc_traffic.json profiles/r02/pmc_traffic.json
+ROUND=${ROUND:-r03}; mkdir -p profiles/$ROUND && cp $OUT/pmc_traffic.json profiles/$ROUND/pmc_traffic.json
 python3 bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
 for cfg in ${CONFIGS:-R G P1}; do python3 bench.py --config $cfg --no-cpu >> $OUT/bench_configs.jsonl 2>> $OUT/bench.err; done
 rm -rf $OUT/trace_* $OUT/pmc_[A-Z]*_*

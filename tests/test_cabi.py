@@ -62,3 +62,23 @@ def test_bad_handle_and_arguments():
     n = ctypes.c_int(0)
     assert L.gnnagg_neighbor_grouping_schedule(None, 4, 3, None, None, ctypes.byref(n)) == _lib.ERR_ARG
     assert L.gnnagg_partition_rows(None, 3, 2, None) == _lib.ERR_ARG
+
+
+def test_file_rendezvous_rejects_what_a_crashed_launch_left_behind(tmp_path):
+    """gnnagg_dist_comm_create_from_file: a rank > 0 must never take a stale id file -- ncclCommInitRank with
+    mismatched ids hangs forever.  It accepts only a file that carries the token it published itself; anything else at the path
+    (an id file of the old 128-byte format, a well-formed record of another launch) is ignored until the wait times out, and the
+    request file is cleaned up."""
+    import struct
+    import time
+    L = gnc.lib()
+    path = str(tmp_path / "gnnagg.id")
+    out = ctypes.c_int64(0)
+    for stale in (b"\x07" * 128, struct.pack("<QQ", 0x31444947414E4E47, 2) + b"\x01" * 128 + struct.pack("<Q", 0xDEADBEEF)):
+        open(path, "wb").write(stale)
+        t0 = time.time()
+        rc = L.gnnagg_dist_comm_create_from_file(path.encode(), 1, 2, 1, ctypes.byref(out))
+        assert rc == _lib.ERR_IO and out.value == 0 and b"timed out" in L.gnnagg_last_error()
+        assert 0.9 < time.time() - t0 < 10
+        assert not os.path.exists(path + ".req.1")
+    assert L.gnnagg_dist_comm_create_from_file(path.encode(), 2, 2, 1, ctypes.byref(out)) == _lib.ERR_ARG

@@ -1,6 +1,7 @@
 """bench.py's output contract, exercised the way the driver runs it (one JSON line on stdout, the fields the round's
-instructions name, roofline.frac <= 1, the oracle check inside bench.py passing) -- short runs of the headline line, of one
-other config, and of the N > 1 code path with two ranks sharing the GPU over gloo (test hooks of bench.py)."""
+instructions name, roofline.frac tied to a hardware peak, the oracle check inside bench.py passing) -- short runs of the
+headline line, of one other config, and of the N > 1 code paths (weak arxiv-shaped line, strong products-shaped --config P) with
+two ranks sharing the GPU over gloo (test hooks of bench.py)."""
 import json
 import os
 import subprocess
@@ -33,7 +34,9 @@ def check_common(d, n_gpus, steps, warmup):
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert 0.0 < r["frac"] <= 1.0
+    # frac is counter traffic (or gather-model bytes) over a HARDWARE peak, never a probe of the same kernel, and is not clamped:
+    # cache-served gather bytes may exceed the HBM figure -- that is reported, not hidden
+    assert 0.0 < r["frac"] < 2.0 and r["peak"] in (8000.0, 34500.0) and r["bound"] in ("hbm", "l2")
     assert d["value"] > 0 and abs(d["value"] - d["config"]["num_e"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.05 or n_gpus > 1
 
 
@@ -44,6 +47,10 @@ def test_headline_line():
     assert d["config"]["feat"] == 128
     r = d["roofline"]
     assert r["algorithmic_bytes"] == 693827352 and r["compulsory_bytes"] == 183414552 and r["ceiling_probe_us"] > 0
+    assert r["peak"] == 8000.0 and abs(r["achieved"] - 693827352 / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert 0.5 < r["probe_frac"] < 1.2 and "traffic_stale" in r
+    if r["traffic"]:   # frac = counter traffic / time / 8 TB/s, recomputable from the line
+        assert abs(r["frac"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "edges/s" and c["sample"]
     assert d["value"] > 8.07e9          # north_star: >= 60 % of the HBM-read roofline in gather-model bytes = 8.07 G edges/s
@@ -62,3 +69,15 @@ def test_two_ranks_on_one_gpu_over_gloo():
     check_common(d, 2, 3, 1)
     assert d["scaling"] == "weak" and d["config"]["verified_against_oracle"] is True and d["config"]["num_e"] == 2 * 1166243
     assert d["no_exchange_upper_bound"]["value"] >= d["value"] * 0.9
+
+
+def test_products_strong_scaling_two_ranks_on_one_gpu_over_gloo():
+    """BASELINE configs[4] through the N > 1 code: ONE products-shaped graph (2 449 029 x 123 718 280, feat 100) row-partitioned over
+    the ranks, halo pull inside every timed step, every rank checked against the oracle before the timed region."""
+    d = run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--config", "P"], env={"BENCH_ONE_GPU": "1", "BENCH_BACKEND": "gloo"},
+            launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", "29573"])
+    check_common(d, 2, 2, 1)
+    assert d["scaling"] == "strong" and d["config"]["verified_against_oracle"] is True
+    assert d["config"]["num_v"] == 2449029 and d["config"]["num_e"] == 123718280 and d["config"]["feat"] == 100
+    assert d["config"]["halo_bytes_per_step_all_ranks"] > 0

@@ -217,15 +217,15 @@ def test_aux_stream_option_keeps_rows_mode_bit_exact_on_one_stream():
         assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "gat rows aux=%d" % aux)
 
 
-def test_fast_scheduled_option_gives_scheduled1_the_balanced_order():
-    """reference drivers call schedule(neighbor_grouping, {NG}) + run(vin, vout, B, 1); with the option that call runs the
-    balanced order too (same bits as mode "balanced"), the user's groups keep describing num_target / get_schedule, and a
-    scheduled run without a schedule still fails."""
+def test_scheduled1_runs_the_balanced_order_by_default_and_the_users_groups_on_request():
+    """reference drivers call schedule(neighbor_grouping, {NG}) + run(vin, vout, B, 1).  Default ("fast_scheduled" = 1): that call
+    runs the balanced order (same bits as mode "balanced": the reference's aggr_gcn_target adds with atomicAdd, aggr_gcn.h:112, so
+    any association is one of its results), the user's groups keep describing num_target / get_schedule, and a scheduled run
+    without a schedule still fails.  "fast_scheduled" = 0: the user's groups in the restated order, bit-exact."""
     V, E, F = 5000, 150000, 128
     ptr, idx = hub_graph(V, E, seed=9, alpha=1.0)
     x, val = rand((V, F), 1), rand(E, 2)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
-    agg.set_option("fast_scheduled", 1)
     y = torch.empty((V, F), device=DEV)
     with pytest.raises(Exception):
         agg.run(dev(x), y, 512, 1)
@@ -235,17 +235,53 @@ def test_fast_scheduled_option_gives_scheduled1_the_balanced_order():
     yb = torch.empty((V, F), device=DEV)
     agg.run(dev(x), yb, 512, "balanced")
     assert torch.equal(y, yb)
+    chunk, seg = agg.balanced_params()
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(*orc.neighbor_grouping(ptr, chunk), idx, val, x, V, seg=seg))
     assert agg.num_target == len(tg) and np.array_equal(agg.get_schedule("scheduled")[0], ps)
     assert_within(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x), "fast scheduled vs CSR order")
     agg.set_option("fast_scheduled", 0)
     agg.run(dev(x), y, 512, 1)
     assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, idx, val, x, V, seg=agg.mode_params("scheduled")[1]))
+    agg.set_option("fast_scheduled", 1)
+    agg.run(dev(x), y, 512, 1)
+    assert torch.equal(y, yb)
     att = rand((V, 2), 3) * 0.4
     gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
-    gat.set_option("fast_scheduled", 1)
     gat.schedule(gnc.Schedule.neighbor_grouping, [32])
     gat.run(dev(x), dev(att), y, 128, 1)
     gat.run(dev(x), dev(att), yb, 128, "balanced")
+    assert torch.equal(y, yb)
+    # a GAT call that asks for newval keeps the user's groups (newval is defined per scheduled edge weight)
+    nv = torch.empty(E, device=DEV)
+    gat.run(dev(x), dev(att), y, 128, 1, newval=nv)
+    ref, ref_nv, _ = orc.gat_grouped(ps, tg, idx, att, x, V, 1, seg=gat.mode_params("scheduled")[1])
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "gat scheduled with newval")
+
+
+def test_reference_facing_surfaces_default_to_the_balanced_order_for_scheduled0():
+    """The pybind-named functions (Figure7/kernel.cpp:166-179) make handles with the reference-facing defaults: gcn_run(., ., ., B, 0)
+    runs the balanced order (within 1e-5 of aggr_gcn's chain, bit-equal to mode "balanced"); the class API of this package keeps
+    the canonical chains for scheduled = 0; GNNAGG_MODE_ROWS on a section-B handle stays canonical."""
+    V, E, F = 5000, 150000, 128
+    ptr, idx = hub_graph(V, E, seed=9, alpha=1.0)
+    x, val = rand((V, F), 1), rand(E, 2)
+    seq, scale = orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x)
+    at = gnc.gcn_init(dev(ptr), dev(idx), dev(val))
+    y, yb = torch.empty((V, F), device=DEV), torch.empty((V, F), device=DEV)
+    gnc.gcn_run(at, dev(x), y, 128, 0)
+    at.run(dev(x), yb, 128, "balanced")
+    assert torch.equal(y, yb)
+    assert_within(y.cpu().numpy(), seq, scale, "reference-facing scheduled = 0")
+    at.set_option("fast_rows", 0)
+    gnc.gcn_run(at, dev(x), y, 128, 0)
+    assert np.array_equal(y.cpu().numpy(), seq)
+    cls = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    cls.run(dev(x), y, 512, 0)
+    assert np.array_equal(y.cpu().numpy(), seq)
+    att = rand((V, 2), 3) * 0.4
+    g = gnc.gat_init(dev(ptr), dev(idx))
+    gnc.gat_run(g, dev(x), dev(att), y, 128, 0)
+    g.run(dev(x), dev(att), yb, 128, "balanced")
     assert torch.equal(y, yb)
 
 
@@ -258,6 +294,7 @@ def test_user_locality_schedule_follows_updateval(kind, param):
     x, v1, v2, v3 = rand((V, F), 1), rand(E, 2), rand(E, 3), rand(E, 4)
     dv = dev(v1)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dv, F, F)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule[kind], param)
     ng = param[1] if len(param) > 1 else 0
     y = torch.empty((V, F), device=DEV)
@@ -314,6 +351,7 @@ def test_gather_probe_runs_the_same_work_and_writes_nothing(case):
     elif case == "chunked":
         agg.set_option("partitions", 0)
     else:
+        agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
         agg.schedule(gnc.Schedule.neighbor_grouping, [256])   # few rows split: the plan kernel runs this schedule
         mode = "scheduled"
         assert agg.mode_params("scheduled") == (256, 16)
@@ -431,3 +469,32 @@ def test_blocked_order_demotes_to_the_chunked_plan_when_its_scratch_does_not_fit
     ch, sg = gat.balanced_params()
     ref, _, _ = orc.gat_grouped(*orc.neighbor_grouping(ptr, ch), idx, att, x, V, 1, seg=sg)
     assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, 1) + np.abs(ref), "demoted gat")
+
+
+def test_forced_partition_count_is_clamped_to_the_column_count():
+    """"partitions" / GNNAGG_PARTITIONS above the number of columns used to inflate total_cols, and the tiling kernels
+    then read that many rows of the caller's X (and att) -- past their ends.  The count is clamped to the columns that occur."""
+    V, F = 300, 64
+    rng = np.random.default_rng(5)
+    deg = rng.integers(1, 40, V)
+    ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    idx = np.sort(rng.integers(0, 3, int(ptr[-1]))).astype(np.int32)          # only columns 0..2 occur
+    for r in range(V):
+        idx[ptr[r]:ptr[r + 1]].sort()
+    x = rand((3, F), 1)                                                         # X has exactly as many rows as there are columns
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None, F, F)
+    agg.set_option("partitions", 8)
+    y = torch.full((V, F), 7.0, device=DEV)
+    agg.run(dev(x), y, 128, "balanced")
+    parts, cols = agg.balanced_partitions(), agg.balanced_partition_columns()
+    assert 1 <= parts <= 3 and cols == 3
+    ps, ix, tg, _ = orc.locality_schedule(ptr, idx, parts, cols, ng=agg.balanced_params()[0])
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, None, x, V, seg=0))
+    att = rand((V, 2), 3) * 0.3                                                 # GAT: att has V rows (> columns), X 3 rows
+    gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gat.set_option("partitions", 8)
+    xg = np.zeros((V, F), np.float32)
+    xg[:3] = x
+    gat.run(dev(xg), dev(att), y, 128, "balanced")
+    ref = orc.gat_fused(ptr, idx, att, xg)
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, xg, 1) + np.abs(ref), "clamped partitions, gat")

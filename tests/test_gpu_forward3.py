@@ -27,11 +27,9 @@ def graph(V=5000, E=70000):
 
 def order_of(agg, sched, ptr):
     """(ptr_s, target, seg) of the summation order the run used, from what the library reports."""
-    if sched == 1:
-        chunk, seg = agg.mode_params("scheduled")
-        assert chunk == NG
-    else:
-        chunk, seg = agg.balanced_params()
+    if sched == 1:   # default ("fast_scheduled" = 1): scheduled = 1 runs the balanced order; the user's groups keep describing the schedule
+        assert agg.mode_params("scheduled")[0] == NG
+    chunk, seg = agg.balanced_params()
     ps, tg = orc.neighbor_grouping(ptr, chunk)
     return ps, tg, seg
 

@@ -69,6 +69,7 @@ def test_gcn_neighbor_grouping_bit_exact(V, E, F, ng):
     ptr, idx = make_graph(V, E, seed=V + ng)
     x, val = rand((V, F), 3), rand(E, 4)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule.neighbor_grouping, [ng])
     ps_ref, tg_ref = orc.neighbor_grouping(ptr, ng)
     ps, ix, tg = agg.get_schedule("scheduled")
@@ -91,6 +92,7 @@ def test_gcn_locality_schedules(kind, param):
     ptr, idx = make_graph(V, E, seed=11)
     x, val = rand((V, F), 5), rand(E, 6)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule[kind], param)
     ng = param[1] if len(param) > 1 else 0
     ps_ref, ix_ref, tg_ref, vs_ref = orc.locality_schedule(ptr, idx, param[0], V, ng, val)
@@ -136,6 +138,7 @@ def test_gcn_mean_max(mode, F):
     ptr, idx = make_graph(V, E, seed=31)
     x, val = rand((V, F), 9), rand(E, 10)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule.neighbor_grouping, [4])
     y = torch.full((V, F), 7.0, device=DEV)
     sched = mode == "scheduled"
@@ -159,6 +162,7 @@ def test_gcn_update_val_aliases():
     ptr, idx = make_graph(V, E, seed=41)
     x, v1, v2 = rand((V, F), 1), rand(E, 2), rand(E, 3)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(v1), F, F)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule.neighbor_grouping, [16])
     agg.updateval(dev(v2))  # aggr_gcn.h:540-544: both the CSR and the scheduled val follow
     y = torch.empty((V, F), device=DEV)
@@ -243,6 +247,7 @@ def test_gat_scheduled(F, H, ng):
     ptr, idx = make_graph(V, E, seed=81)
     x, att = rand((V, F), 1), rand((V, H, 2), 2)
     agg = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule.neighbor_grouping, [ng])
     y = torch.full((V, F), 7.0, device=DEV)
     newval = torch.full((E, H), 7.0, device=DEV)
@@ -296,6 +301,7 @@ def test_error_behaviour():
         agg.run(x, y, 512, 1)  # scheduled run without schedule(): reference asserts (aggr_gcn.h:392)
     assert ei.value.code == _lib.ERR_STATE
     with pytest.raises(gnc.GnnAggError):
+        agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
         agg.schedule(gnc.Schedule.neighbor_grouping, [0])
     with pytest.raises(ValueError):
         agg.run(x.cpu(), y, 512, 0)
@@ -320,9 +326,32 @@ def test_flat_reference_api():
     assert at != 0
     arr = (ctypes.c_int * 1)(32)
     L.GCN_schedule_impl(at, arr)
+    # defaults of the reference-facing surface: scheduled = 0 and scheduled = 1 both run the balanced order (the reference's
+    # scheduled kernel adds with atomics, any association is one of its results; scheduled = 0 differs from aggr_gcn's chain by
+    # association only) -- bit-equal to the restatement of THAT order, within the 1e-5 bound of the sequential chain
+    n = ctypes.c_int(0)
+    _lib.check(L.gnnagg_num_target(at, _lib.MODE_BALANCED, ctypes.byref(n)))
+    bps, btg = np.empty(n.value + 1, np.int32), np.empty(n.value, np.int32)
+    _lib.check(L.gnnagg_get_schedule(at, _lib.MODE_BALANCED, bps.ctypes.data, None, btg.ctypes.data, None))
+    bch, bsg = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(L.gnnagg_balanced_params(at, ctypes.byref(bch), ctypes.byref(bsg)))
+    y_bal = orc.gcn_grouped(bps, btg, idx, val, x, V, seg=bsg.value)
+    y_seq, scale = orc.gcn_seq(ptr, idx, val, x), orc.gcn_abs_scale(ptr, idx, val, x)
+    for sched in (1, 0):
+        y.fill_(7.0)
+        L.GCN_run_impl(at, dx.data_ptr(), y.data_ptr(), 128, sched, F)
+        torch.cuda.synchronize()
+        assert np.array_equal(y.cpu().numpy(), y_bal), "flat API default, scheduled = %d" % sched
+        assert_within(y.cpu().numpy(), y_seq, scale, "flat API default vs the sequential chain")
+    # num_target / get_schedule / mode_params of the scheduled mode keep describing the user's groups
+    ps, tg = orc.neighbor_grouping(ptr, 32)
+    _lib.check(L.gnnagg_num_target(at, _lib.MODE_SCHEDULED, ctypes.byref(n)))
+    assert n.value == len(tg)
+    # the canonical orders, one option away
+    _lib.check(L.gnnagg_set_option(at, b"fast_scheduled", 0))
+    _lib.check(L.gnnagg_set_option(at, b"fast_rows", 0))
     L.GCN_run_impl(at, dx.data_ptr(), y.data_ptr(), 128, 1, F)
     torch.cuda.synchronize()
-    ps, tg = orc.neighbor_grouping(ptr, 32)
     ch, sg = ctypes.c_int(0), ctypes.c_int(0)
     _lib.check(L.gnnagg_mode_params(at, _lib.MODE_SCHEDULED, ctypes.byref(ch), ctypes.byref(sg)))
     assert ch.value == 32
@@ -426,6 +455,7 @@ def test_hub_rows_block_cooperative_combine(F, ng):
     idx = rng.integers(0, V, E).astype(np.int32)
     x, val = rand((V, F), 1), rand(E, 2)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule.neighbor_grouping, [ng])
     ps, tg = orc.neighbor_grouping(ptr, ng)
     y = torch.full((V, F), 7.0, device=DEV)
@@ -453,6 +483,7 @@ def test_hub_rows_block_cooperative_combine(F, ng):
         H = 2
         att = rand((V, H, 2), 3) * 0.3
         gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+        gat.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
         gat.schedule(gnc.Schedule.neighbor_grouping, [ng])
         gat.run(dev(x), dev(att), y, 128, 1, heads=H)
         ref, _, _ = orc.gat_grouped(ps, tg, idx, att, x, V, H, seg=gat.mode_params("scheduled")[1])
@@ -543,6 +574,7 @@ def test_run_with_nn():
     ptr, idx = make_graph(V, E, seed=77)
     x, val, w = rand((V, F), 1), rand(E, 2), rand((F, OUT), 3)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, OUT)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule.neighbor_grouping, [16])
     y = torch.full((V, F), 7.0, device=DEV)
     t = torch.full((V, OUT), 7.0, device=DEV)
@@ -565,8 +597,10 @@ def test_gcn_fused_relu(mode, reduce):
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
     m = {"rows": 0, "scheduled": 1, "balanced": "balanced", "scheduled_items": 1}[mode]
     if mode == "scheduled":
+        agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
         agg.schedule(gnc.Schedule.neighbor_grouping, [32])
     if mode == "scheduled_items":
+        agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
         agg.schedule(gnc.Schedule.neighbor_grouping, [2])
     if mode == "balanced":
         agg.schedule_balanced(16)
@@ -636,6 +670,7 @@ def test_run_with_nn_fused_epilogue(mode, F, OUT):
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, OUT)
     m = {"rows": 0, "scheduled": 1, "balanced": "balanced"}[mode]
     if mode == "scheduled":
+        agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
         agg.schedule(gnc.Schedule.neighbor_grouping, [32])
     dx, dw = dev(x), dev(w)
     y_plain = torch.empty((V, F), device=DEV)
@@ -1013,6 +1048,7 @@ def test_run_clock_instrumentation():
     ptr, idx = ptr_t.numpy(), idx_t.numpy()
     x, val = rand((V, F), 1), rand(E, 2)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule.neighbor_grouping, [16])
     y = torch.full((V, F), 7.0, device=DEV)
     hz = gnc.lib().gnnagg_wall_clock_hz()
@@ -1039,6 +1075,7 @@ def test_hipgraph_capture_and_replay(mode):
     ptr, idx = ptr_t.numpy(), idx_t.numpy()
     x1, x2, val = rand((V, F), 1), rand((V, F), 2), rand(E, 3)
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
     agg.schedule(gnc.Schedule.neighbor_grouping, [16])
     dx, y = dev(x1), torch.empty((V, F), device=DEV)
     agg.run(dx, y, 512, mode)  # warm-up: plans, scratch
@@ -1150,6 +1187,7 @@ def test_fuzz_gcn_modes_reductions_alignment():
         reduce = str(rng.choice(["sum", "mean", "max"]))
         ng = int(rng.choice([1, 3, 16, 32, 64]))
         if mode == "scheduled":
+            agg.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
             agg.schedule(gnc.Schedule.neighbor_grouping, [ng])
         elif mode == "balanced":
             agg.schedule_balanced(int(rng.choice([0, 4, 64])))
@@ -1205,6 +1243,7 @@ def test_fuzz_gat_modes_heads():
         mode = str(rng.choice(["rows", "scheduled", "balanced"]))
         ng = int(rng.choice([2, 16, 32]))
         if mode == "scheduled":
+            gat.set_option("fast_scheduled", 0)  # the user's groups in the restated order (the default runs the balanced order)
             gat.schedule(gnc.Schedule.neighbor_grouping, [ng])
         elif mode == "balanced":
             gat.schedule_balanced(int(rng.choice([0, 4, 64])))
