@@ -1419,9 +1419,11 @@ int gnnagg_gcn_run_clock(gnnagg_handle h, const float *d_x, float *d_y, int feat
     if (mode != GNNAGG_MODE_ROWS && mode != GNNAGG_MODE_SCHEDULED) return fail(GNNAGG_ERR_ARG, "run_clock: mode must be rows or scheduled");
     if (!num_blocks) return fail(GNNAGG_ERR_ARG, "null num_blocks");
     if (d_timer && (!d_x || !d_y)) return fail(GNNAGG_ERR_ARG, "null feature pointer");
+    // the instrumented kernel runs one work item per lane group: the CSR rows themselves (rows) or the user's groups
+    // (scheduled) -- "fast_rows" / "fast_scheduled" do not apply here, the load-balance study is about exactly these two
     Schedule *s = nullptr;
-    int rc = get_sched(c, mode, &s);
-    if (rc) return rc;
+    int rc = GNNAGG_OK;
+    if (mode == GNNAGG_MODE_SCHEDULED && (rc = get_sched(c, mode, &s))) return rc;
     GcnLaunch L;
     L.row_ptr = c->d_ptr; L.x = d_x; L.y = d_y; L.feat = feat; L.reduce = GNNAGG_REDUCE_SUM; L.xcd_remap = 0;
     L.timer = d_timer; L.timer_blocks_out = num_blocks;

@@ -23,11 +23,16 @@ static __global__ void aggr_gcn_clock(int *, int *, float *, float *, float *, i
 static __global__ void aggr_gcn_target_clock(int *, int *, float *, int *, float *, float *, int, int, int, clocktype *) {}
 // Figure8/main.cu:143-150 indexes an 80-entry array (V100's SM count) with the stamp's third word; the MI355X's hardware CU
 // id (XCC / SE / CU bits) goes up to 511.  For a caller that sized the timer itself -- the reference's driver -- the id is folded
-// into [0, 80) so that its bookkeeping stays inside its array (drivers/fig8.cpp, which asks clock_blocks(), gets the raw id).
-static __global__ void gnnagg_compat_fold_smid(clocktype *timer, int nb, int nsm)
+// into [0, 80) so that its bookkeeping stays inside its array, and the stamps are converted from wall-clock ticks to the
+// nanoseconds of the reference's %globaltimer (its analysis divides by 1e9, :166-181).  drivers/fig8.cpp, which asks
+// clock_blocks(), gets the raw ticks and ids.
+static __global__ void gnnagg_compat_fold_smid(clocktype *timer, int nb, int nsm, double ns_per_tick)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nb) timer[3 * (size_t)b + 2] %= (clocktype)nsm;
+    if (b >= nb) return;
+    timer[3 * (size_t)b] = (clocktype)((double)timer[3 * (size_t)b] * ns_per_tick);
+    timer[3 * (size_t)b + 1] = (clocktype)((double)timer[3 * (size_t)b + 1] * ns_per_tick);
+    timer[3 * (size_t)b + 2] %= (clocktype)nsm;
 }
 #endif
 
@@ -116,7 +121,8 @@ public:
         timestamp(t1);
 #if defined(__HIPCC__)
         if (self_sized && nb > 0) {
-            hipLaunchKernelGGL(gnnagg_compat_fold_smid, dim3((nb + 255) / 256), dim3(256), 0, 0, timer, nb, 80);
+            hipLaunchKernelGGL(gnnagg_compat_fold_smid, dim3((nb + 255) / 256), dim3(256), 0, 0, timer, nb, 80,
+                               1e9 / (double)gnnagg_wall_clock_hz());
             checkHipErrors(hipDeviceSynchronize());
         }
 #endif

@@ -108,8 +108,10 @@ def test_rccl_transport_behind_the_cabi_single_rank(tmp_path):
     assert L.gnnagg_dist_comm_destroy(comm) == _lib.ERR_ARG
     comm2 = ctypes.c_int64(0)
     path = str(tmp_path / "id.bin")
+    open(path, "wb").write(b"\x07" * 128)   # what a crashed earlier launch left: rank 0 replaces it
     _lib.check(L.gnnagg_dist_comm_create_from_file(path.encode(), 0, 1, 5, ctypes.byref(comm2)))
-    assert os.path.getsize(path) == 128
+    rec = open(path, "rb").read()
+    assert len(rec) == 16 + 128 and rec[:8] == b"GNNAGID1" and rec[16:] != b"\x07" * 128   # {magic, world, id}; no tokens at world 1
     _lib.check(L.gnnagg_dist_comm_destroy(comm2))
     assert L.gnnagg_dist_comm_create(buf, 3, 2, ctypes.byref(comm2)) == _lib.ERR_ARG
 
