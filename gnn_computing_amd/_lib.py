@@ -44,6 +44,7 @@ SIGNATURES = {
     "gnnagg_set_stream": (c_int, [c_int64, c_void_p]),
     "gnnagg_set_option": (c_int, [c_int64, c_char_p, c_int]),
     "gnnagg_update_val": (c_int, [c_int64, c_void_p]),
+    "gnnagg_set_row_aux": (c_int, [c_int64, c_void_p]),
     "gnnagg_schedule": (c_int, [c_int64, c_int, P_INT, c_int]),
     "gnnagg_schedule_balanced": (c_int, [c_int64, c_int]),
     "gnnagg_balanced_params": (c_int, [c_int64, P_INT, P_INT]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "gnnagg_matmul_nn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gnnagg_gcn_run_with_nn": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "gnnagg_gat_run": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+    "gnnagg_gat_run_part": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "gnnagg_gat_run_att": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_float]),
     "gnnagg_gat_run_u_add_v": (c_int, [c_int64, c_void_p, c_void_p]),
     "gnnagg_gat_run_add_to_center": (c_int, [c_int64, c_void_p, c_void_p]),
@@ -95,6 +97,13 @@ SIGNATURES = {
     "gnnagg_dist_comm_info": (c_int, [c_int64, P_INT, P_INT]),
     "gnnagg_dist_alltoallv": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gnnagg_dist_halo_exchange": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gnnagg_pack_rows2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "gnnagg_unpack_rows2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gnnagg_dist_step_create": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64)]),
+    "gnnagg_dist_step_destroy": (c_int, [c_int64]),
+    "gnnagg_dist_step_gcn": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gnnagg_dist_step_gat": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                     c_void_p]),
 }
 
 _lib = None

@@ -219,6 +219,12 @@ class Aggregator_GCN(Aggregator):
         check(lib().gnnagg_gcn_run_bwd(self._h, _dev_ptr(doutput, torch.float32, "doutput"),
                                        _dev_ptr(dinput, torch.float32, "dinput"), int(doutput.shape[1])))
 
+    def set_row_aux(self, row_aux):
+        """gnnagg_set_row_aux: per-row degrees (int32 device tensor, or None) for means / maxima computed in two passes over
+        disjoint edge sets -- the divisor of reduce="mean", the edges already folded into y for reduce="max" + accumulate."""
+        self._row_aux = row_aux
+        check(lib().gnnagg_set_row_aux(self._h, _dev_ptr(row_aux, torch.int32, "row_aux")))
+
     def updateval(self, val):
         """aggr_gcn.h:540-544"""
         self.val = val
@@ -246,6 +252,14 @@ class Aggregator_GAT(Aggregator):
                                    _dev_ptr(vout, torch.float32, "vout"), int(feat), int(heads),
                                    ctypes.c_float(slope), _mode(scheduled), _dev_ptr(newval, torch.float32, "newval")))
         return 0.0
+
+    def run_part(self, vin, vatt, vout, den_io, part, heads=1, slope=0.2):
+        """gnnagg_gat_run_part: the fused aggregation in two passes over disjoint edge sets of the same rows.  part=1: vout
+        receives the numerators, den_io [V, heads] the denominators; part=2: both are added to and the rows divided."""
+        self._use_current_stream()
+        check(lib().gnnagg_gat_run_part(self._h, _dev_ptr(vin, torch.float32, "vin"), _dev_ptr(vatt, torch.float32, "vatt"),
+                                        _dev_ptr(vout, torch.float32, "vout"), int(vin.shape[1]), int(heads), ctypes.c_float(slope),
+                                        int(part), _dev_ptr(den_io, torch.float32, "den_io")))
 
     def probe_gather(self, vin, vatt, scheduled="balanced", heads=1):
         """Measurement aid (gnnagg_gat_probe_gather): the loads of run(vin, vatt, ., ., scheduled, heads) on the 2-D blocked

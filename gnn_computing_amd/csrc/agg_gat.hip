@@ -195,8 +195,33 @@ struct GatPlanArgs {
     long x_tile_stride, p_tile_stride;
     unsigned ptile_bytes;
     const int *eperm;
+    // two-pass form (gnnagg_gat_run_part; the row-partitioned step): 1 = first pass, y receives the NUMERATOR and den_io[row, h]
+    // the denominator, no division; 2 = last pass, both are added to what the first pass left and the row is divided
+    int part_mode;
+    float *den_io;
     XcdRanges xr;
 };
+
+// Last step of a GAT row: softmax division (scaleArray, aggr_gat.h:207-213), or its two-pass form.
+template <int VEC>
+__device__ __forceinline__ void finish_gat_row(const GatPlanArgs &a, float (&acc)[VEC], float den, int row, int h, bool head_leader,
+                                               const float *yold, bool always_divide)
+{
+    if (a.part_mode == 1) {
+        if (head_leader) a.den_io[(size_t)row * a.heads + h] = den;
+        return;
+    }
+    if (a.part_mode == 2) {
+        const Pack<VEC> old = load_pack<VEC>(yold);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
+        den = a.den_io[(size_t)row * a.heads + h] + den;
+    }
+    if (den != 0.0f || always_divide) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
+    }
+}
 
 // GAT counterpart of hub_arrive_and_fold: numerator rows and per-head denominators of the hub's segments, ascending
 // slot order, one division at the end (scaleArray, aggr_gat.h:207-213) -- the order of k_combine<.., IS_GAT>.
@@ -256,10 +281,7 @@ __device__ __forceinline__ void hub_arrive_and_fold_gat(const GatPlanArgs &a, in
         __syncthreads();
     }
     if (grp == 0 && col_ok) {
-        if (den != 0.0f) {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
-        }
+        finish_gat_row<VEC>(a, acc, den, row, h, head_leader, a.y + (size_t)row * F + col, false);
         store_pack<VEC>(a.y + (size_t)row * F + col, acc);
     }
 }
@@ -337,10 +359,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
             return;
         }
         if (row_or_dest >= 0) {
-            if (den != 0.0f) {  // scaleArray, aggr_gat.h:207-213
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
-            }
+            finish_gat_row<VEC>(a, acc, den, row_or_dest, h, head_leader, a.y + (size_t)row_or_dest * F + col, false);
             store_pack<VEC>(a.y + (size_t)row_or_dest * F + col, acc);
         } else {
             store_pack<VEC>(a.partial + (size_t)(~row_or_dest) * F + col, acc);
@@ -368,10 +387,8 @@ __global__ __launch_bounds__(block_of<GROUP>()) void k_gat_plan(const GatPlanArg
         if (head_leader) a.partial_den[(size_t)(~d.z) * H + h] = den;
         return;
     }
-    if (d.x < d.y && (den != 0.0f || a.rows_semantics)) {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
-    }
+    if (a.part_mode != 0) finish_gat_row<VEC>(a, acc, den, row, h, head_leader, a.y + (size_t)row * F + col, false);
+    else if (d.x < d.y) finish_gat_row<VEC>(a, acc, den, row, h, head_leader, nullptr, a.rows_semantics != 0);
     if (a.yvec < VEC || F - col < VEC) store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
     else store_pack<VEC>(a.y + (size_t)row * F + col, acc);
 }
@@ -438,6 +455,9 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     a.hub_count = L.hub_count; a.hub_count_stride = L.hub_count_stride; a.partial_bytes = a.partial_den_bytes = 0;
     a.xpitch = L.feat; a.ppitch = L.feat; a.x_tile_stride = a.p_tile_stride = g.group * g.vec; a.yvec = g.vec;
     a.tile_major = 0; a.item_blocks = 0; a.ptile_bytes = 0; a.eperm = L.eperm;
+    a.part_mode = L.part_mode; a.den_io = L.den_io;
+    if (L.part_mode != 0 && (L.tile.on || !L.den_io || L.newval || g.vec != 4 || g.ntiles != 1))
+        return fail(GNNAGG_ERR_ARG, "two-pass GAT: 16-byte aligned rows of at most 256 columns on the chunked plan, no newval");
     if (L.tile.on) {
         a.xpitch = L.tile.xpitch; a.x_tile_stride = L.tile.x_tile_stride; a.ppitch = L.tile.ppitch;
         a.p_tile_stride = L.tile.p_tile_stride; a.yvec = L.tile.yvec; a.tile_major = 1;
@@ -483,6 +503,8 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
 #undef CALL_GP
         HIP_TRY(hipGetLastError());
     }
+    if (L.hubs.n_mrows > 0 && !hubs_in_kernel && L.part_mode != 0)
+        return fail(GNNAGG_ERR_STATE, "two-pass GAT: hub rows are folded inside the plan kernel only (GNNAGG_INKERNEL_COMBINE=0 set?)");
     if (L.hubs.n_mrows > 0 && !hubs_in_kernel) {
         CombineArgs c;
         combine_strides(c, L.feat, g, &L.tile);

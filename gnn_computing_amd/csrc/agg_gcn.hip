@@ -96,7 +96,8 @@ struct PlanArgs {
     float *y;
     float *partial;
     int n0, n1, feat, ntiles, chunk, mean, remap, nblocks0;
-    int accumulate;  // 1: y += result (rows without edges are left untouched); sum only
+    int accumulate;  // 1: y += result (rows without edges are left untouched); mean / max with row_aux only
+    const int *row_aux;  // gnnagg_set_row_aux (finish_gcn_row); nullptr otherwise
     int relu;        // 1: y = max(result, 0)
     int wt;          // 1: write-through (sc1) stores of the short-row results
     unsigned ybytes;
@@ -221,17 +222,8 @@ __device__ __forceinline__ bool hub_arrive_and_fold(const PlanArgs &a, const int
         __syncthreads();
     }
     if (grp == 0 && col_ok) {
-        if (a.mean) {
-            const float dg = (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
-        }
-        if (a.accumulate) {
-            const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)row * F + col);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
-        }
-        if (a.relu) relu_pack<VEC>(acc);
+        finish_gcn_row<VEC, IS_MAX>(acc, a.mean ? a.row_ptr[row + 1] - a.row_ptr[row] : 1, row, a.y + (size_t)row * F + col, a.mean,
+                                    a.accumulate, a.relu, a.row_aux);
         store_pack<VEC>(a.y + (size_t)row * F + col, acc);
     }
     return true;
@@ -306,17 +298,7 @@ __global__ __launch_bounds__(block_of<GROUP>()) PLAN_WAVES_ATTR void k_gcn_plan(
             int row;
             hub_arrive_and_fold<VEC, GROUP, IS_MAX>(a, d, tile, col, col_ok, grp, lane, acc, stage, row);
         } else if (d.z >= 0) {
-            if (a.mean) {
-                const float dg = (float)(d.y - d.x);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
-            }
-            if (a.accumulate) {
-                const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)d.z * F + col);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
-            }
-            if (a.relu) relu_pack<VEC>(acc);
+            finish_gcn_row<VEC, IS_MAX>(acc, d.y - d.x, d.z, a.y + (size_t)d.z * F + col, a.mean, a.accumulate, a.relu, a.row_aux);
             store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
         } else {
             store_pack<VEC>(a.partial + (size_t)(~d.z) * F + col, acc);
@@ -352,19 +334,13 @@ __global__ __launch_bounds__(block_of<GROUP>()) PLAN_WAVES_ATTR void k_gcn_plan(
         else store_pack<VEC>(a.partial + (size_t)tile * a.p_tile_stride + poff, acc);
         return;
     }
-    if (a.accumulate) {
-        const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)d.z * F + col);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
-    } else if (d.x == d.y) {
+    if (d.x == d.y) {  // no edges: 0 (an accumulating run that comes here applies the ReLU to what the row holds)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-    } else if (a.mean) {
-        const float dg = (float)(d.y - d.x);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
+        finish_gcn_row<VEC, false>(acc, 1, d.z, a.y + (size_t)d.z * F + col, 0, a.accumulate, a.relu, nullptr);
+    } else {
+        finish_gcn_row<VEC, IS_MAX>(acc, d.y - d.x, d.z, a.y + (size_t)d.z * F + col, a.mean, a.accumulate, a.relu, a.row_aux);
     }
-    if (a.relu) relu_pack<VEC>(acc);
     if (a.yvec < VEC || F - col < VEC) store_pack_any<VEC>(a.y + (size_t)d.z * F + col, acc, F - col, a.yvec);
     else if (a.wt) store_pack_wt<VEC>(a.y, a.ybytes, (size_t)d.z * F + col, acc);
     else store_pack<VEC>(a.y + (size_t)d.z * F + col, acc);
@@ -793,7 +769,7 @@ static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max
         c.mrow_id = L.wl.mrow_id; c.mrow_ptr = L.wl.mrow_ptr; c.row_ptr = L.row_ptr; c.partial = L.partial;
         c.partial_den = nullptr; c.y = L.y; c.n_mrows = L.wl.n_mrows; c.feat = L.feat; c.ntiles = g.ntiles;
         c.heads = 1; c.dhead = L.feat; c.mean = L.reduce == GNNAGG_REDUCE_MEAN;
-        c.accumulate = L.accumulate; c.relu = L.relu;
+        c.accumulate = L.accumulate; c.relu = L.relu; c.row_aux = L.row_aux;
         c.nn_weight = nn_weight; c.nn_out = nn_out; c.nn_cols = nn_cols;
         c.big_rows = L.wl.big_rows; c.n_big = L.wl.n_big;
         c.nblocks_small = ceil_div(c.n_mrows, kBlock / g.group) * g.ntiles;
@@ -845,6 +821,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y; a.partial = L.partial;
     a.n0 = L.n0; a.n1 = L.n1; a.feat = L.feat; a.ntiles = g.ntiles; a.chunk = L.chunk;
     a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.remap = L.xcd_remap; a.accumulate = L.accumulate; a.relu = L.relu;
+    a.row_aux = L.row_aux;
     a.slot_hub = L.slot_hub; a.mrow_ptr = L.hubs.mrow_ptr; a.mrow_id = L.hubs.mrow_id; a.row_ptr = L.row_ptr;
     a.hub_count = L.hub_count; a.hub_count_stride = L.hub_count_stride; a.partial_bytes = 0;
     a.xpitch = L.feat; a.ppitch = L.feat; a.x_tile_stride = a.p_tile_stride = g.group * g.vec; a.yvec = g.vec;
@@ -935,7 +912,7 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     }
     GcnLaunch C;
     C.wl = L.hubs; C.row_ptr = L.row_ptr; C.y = L.y; C.partial = L.partial; C.feat = L.feat; C.reduce = L.reduce;
-    C.accumulate = L.accumulate; C.relu = L.relu;
+    C.accumulate = L.accumulate; C.relu = L.relu; C.row_aux = L.row_aux;
     const int rc = hubs_in_kernel ? GNNAGG_OK : launch_combine_gcn(C, g, is_max, stream, nullptr, nullptr, 0, &L.tile);
     if (rc || !want_nn) return rc;
     return launch_dense_nn(L.y, L.nn_weight, L.nn_out, L.num_rows, L.nn_cols, L.feat, stream);

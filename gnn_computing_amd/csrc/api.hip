@@ -144,6 +144,7 @@ struct Ctx {
     const int *d_ptr = nullptr;
     const int *d_idx = nullptr;
     const float *d_val = nullptr;
+    const int *row_aux = nullptr;  // gnnagg_set_row_aux (row-partitioned mean / max: see finish_gcn_row)
     hipStream_t stream = nullptr;
     std::vector<int> h_ptr;  // host mirror, fetched on first schedule (reference ctor: aggregator.h:50)
     Schedule sched[2];       // [0] user schedule (MODE_SCHEDULED), [1] balanced (MODE_BALANCED; GAT, and the
@@ -781,8 +782,12 @@ struct NnRequest {  // run_with_nn: transformed[V, cols] = y . weight[feat, cols
 static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0, const NnRequest *nn = nullptr,
                    int probe = 0)
 {
-    if ((flags & GNNAGG_FLAG_ACCUMULATE) && (mode != GNNAGG_MODE_BALANCED || reduce != GNNAGG_REDUCE_SUM || !c->use_plan))
-        return fail(GNNAGG_ERR_ARG, "GNNAGG_FLAG_ACCUMULATE needs GNNAGG_MODE_BALANCED and GNNAGG_REDUCE_SUM");
+    if ((flags & GNNAGG_FLAG_ACCUMULATE) && (mode != GNNAGG_MODE_BALANCED || (reduce != GNNAGG_REDUCE_SUM && !c->row_aux) || !c->use_plan))
+        return fail(GNNAGG_ERR_ARG, "GNNAGG_FLAG_ACCUMULATE needs GNNAGG_MODE_BALANCED and GNNAGG_REDUCE_SUM (mean / max: gnnagg_set_row_aux first)");
+    // a row_aux array changes what mean / max compute (the row-partitioned step's two passes): the chunked plan kernel implements it
+    const bool aux_run = c->row_aux != nullptr && reduce != GNNAGG_REDUCE_SUM;
+    if (aux_run && (mode != GNNAGG_MODE_BALANCED || !c->use_plan || nn || probe))
+        return fail(GNNAGG_ERR_ARG, "gnnagg_set_row_aux applies to plain GNNAGG_MODE_BALANCED runs only");
     if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
     if ((flags & GNNAGG_FLAG_RELU) && nn) return fail(GNNAGG_ERR_ARG, "GNNAGG_FLAG_RELU is not available in run_with_nn");
     if (flags & ~(GNNAGG_FLAG_ACCUMULATE | GNNAGG_FLAG_RELU)) return fail(GNNAGG_ERR_ARG, "unknown flag bits");
@@ -794,7 +799,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
-    const bool acc_on_partitioned = (flags & GNNAGG_FLAG_ACCUMULATE) && c->partitions > 0;
+    const bool acc_on_partitioned = ((flags & GNNAGG_FLAG_ACCUMULATE) || aux_run) && c->partitions > 0;
     if (acc_on_partitioned && !c->plan.valid && (rc = build_balanced_plan_keep(c))) return rc;  // y += A.x needs the plan kernel
     if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && (c->partitions == 0 || acc_on_partitioned)) ||
         (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
@@ -810,6 +815,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         P.hubs.n_slots = p.n_slots; P.hubs.big_rows = p.big_rows.p; P.hubs.n_big = p.n_big;
         P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
         P.xcd_remap = c->xcd_remap; P.accumulate = (flags & GNNAGG_FLAG_ACCUMULATE) ? 1 : 0; P.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
+        P.row_aux = aux_run ? c->row_aux : nullptr;
         P.num_rows = c->V;
         if (p.n_slots > 0) {
             if ((rc = c->partial.reserve((size_t)p.n_slots * feat))) return rc;
@@ -944,7 +950,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
 }
 
 static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat, int heads, float slope, int mode,
-                   float *newval, int probe = 0)
+                   float *newval, int probe = 0, int part = 0, float *den_io = nullptr)
 {
     if (c->kind != Ctx::GAT) return fail(GNNAGG_ERR_ARG, "handle is not a GAT aggregator");
     if (!x || !y || !att) return fail(GNNAGG_ERR_ARG, "null feature/attention pointer");
@@ -954,9 +960,14 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
+    if (part != 0) {  // two-pass form: the chunked plan kernel implements it (a handle on the 2-D blocked order gets a plan beside it)
+        if (mode != GNNAGG_MODE_BALANCED || !c->use_plan || newval || probe || !den_io || (part != 1 && part != 2))
+            return fail(GNNAGG_ERR_ARG, "gat_run_part: GNNAGG_MODE_BALANCED, part 1 or 2, a denominator array, no newval");
+        if (!c->plan.valid && (rc = build_balanced_plan_keep(c))) return rc;
+    }
     if (probe && !(mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors))
         return fail(GNNAGG_ERR_ARG, "GAT probe: only the 2-D blocked balanced order has a probe instantiation");
-    if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && c->partitions == 0) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
+    if ((mode == GNNAGG_MODE_BALANCED && c->use_plan && (c->partitions == 0 || part != 0)) || (mode == GNNAGG_MODE_SCHEDULED && c->plan_sched.valid)) {
         BalancedPlan &p = mode == GNNAGG_MODE_BALANCED ? c->plan : c->plan_sched;
         GatPlanLaunch P;
         P.t0 = p.t0.p; P.t1 = p.t1.p; P.n0 = p.n0; P.n1 = p.n1; P.chunk = p.chunk; P.t0_cost_prefix = p.t0_cost_prefix.data();
@@ -979,6 +990,7 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
             P.slot_hub = p.slot_hub.p; P.hub_count = c->hub_count.p;
         }
         P.unroll = 4;
+        P.part_mode = part; P.den_io = den_io;
         return launch_gat_plan(P, c->stream);
     }
     if (mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors) {
@@ -1294,6 +1306,14 @@ int gnnagg_update_val(gnnagg_handle h, const float *d_val)
     return GNNAGG_OK;
 }
 
+int gnnagg_set_row_aux(gnnagg_handle h, const int *d_row_aux)
+{
+    GET_CTX(h);
+    if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
+    c->row_aux = d_row_aux;  // borrowed, read at run time
+    return GNNAGG_OK;
+}
+
 int gnnagg_schedule(gnnagg_handle h, int kind, const int *param, int total_num_v)
 {
     GET_CTX(h);
@@ -1507,6 +1527,13 @@ int gnnagg_gat_run(gnnagg_handle h, const float *d_x, const float *d_att, float 
 {
     GET_CTX(h);
     return gat_run(c, d_x, d_att, d_y, feat, heads, slope, mode, d_newval);
+}
+
+int gnnagg_gat_run_part(gnnagg_handle h, const float *d_x, const float *d_att, float *d_y, int feat, int heads, float slope, int part,
+                        float *d_den_io)
+{
+    GET_CTX(h);
+    return gat_run(c, d_x, d_att, d_y, feat, heads, slope, GNNAGG_MODE_BALANCED, nullptr, 0, part, d_den_io);
 }
 
 int gnnagg_gat_probe_gather(gnnagg_handle h, const float *d_x, const float *d_att, int feat, int heads, int mode)

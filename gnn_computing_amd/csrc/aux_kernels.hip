@@ -552,6 +552,53 @@ int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out
     return GNNAGG_OK;
 }
 
+// GAT halo rows: one exchange carries the feature row AND the attention terms of every requested row.
+// out[i, 0 .. F) = x[ids[i], :], out[i, F .. F + A) = att[ids[i], :]   (A = 2 * heads)
+__global__ __launch_bounds__(256) void k_pack_rows2(const float *__restrict__ x, const float *__restrict__ att, const int *__restrict__ ids,
+                                                    long n, int F, int A, float *__restrict__ out)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int W = F + A;
+    if (t >= n * W) return;
+    const long i = t / W;
+    const int c = (int)(t - i * W);
+    const size_t r = (size_t)ids[i];
+    out[t] = c < F ? x[r * F + c] : att[r * A + (c - F)];
+}
+
+// the receiving side: in[i, :] -> x_out[i, 0 .. F), att_out[i, 0 .. A)   (the halo tails of X_ext / att_ext)
+__global__ __launch_bounds__(256) void k_unpack_rows2(const float *__restrict__ in, long n, int F, int A, float *__restrict__ x_out,
+                                                      float *__restrict__ att_out)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int W = F + A;
+    if (t >= n * W) return;
+    const long i = t / W;
+    const int c = (int)(t - i * W);
+    if (c < F) x_out[(size_t)i * F + c] = in[t];
+    else att_out[(size_t)i * A + (c - F)] = in[t];
+}
+
+int launch_pack_rows2(const float *x, const float *att, const int *ids, int n, int feat, int att_w, float *out, void *stream_v)
+{
+    if (n <= 0) return GNNAGG_OK;
+    const long total = (long)n * (feat + att_w);
+    hipLaunchKernelGGL(k_pack_rows2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, x, att, ids, (long)n, feat,
+                       att_w, out);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_unpack_rows2(const float *in, int n, int feat, int att_w, float *x_out, float *att_out, void *stream_v)
+{
+    if (n <= 0) return GNNAGG_OK;
+    const long total = (long)n * (feat + att_w);
+    hipLaunchKernelGGL(k_unpack_rows2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, in, (long)n, feat, att_w,
+                       x_out, att_out);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
 // ------------------------------------------------------------------ column-tiled image of X (2-D blocked mode)
 // xt[t][r][0 .. tile_w) = x[r][t * tile_w ..], zero beyond feat.  Rows of x whose pitch is not a multiple of a 128-byte
 // line (F = 602: 2408 B) make every 256-byte tile segment of a gather straddle three lines -- 1.5x the L2 footprint and

@@ -10,6 +10,7 @@ struct CombineArgs {
     int n_big, nblocks_small;
     int accumulate;  // 1: y += (sum of partials)
     int relu = 0;    // 1: y = max(result, 0) (GCN)
+    const int *row_aux = nullptr;  // gnnagg_set_row_aux (finish_gcn_row)
     // run_with_nn: nn_out[row, :] = (finished row) . nn_weight for the rows finished here (ntiles == 1)
     const float *nn_weight;
     float *nn_out;
@@ -102,11 +103,13 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
         if (sum_ok) {
             if (IS_GAT) {
                 if (den != 0.0f) acc = acc / den;
-            } else if (a.mean) {
-                acc = acc / (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
+                if (a.accumulate) acc = a.y[(size_t)row * F + col0 + c] + acc;
+            } else {
+                float one[1] = {acc};
+                finish_gcn_row<1, IS_MAX>(one, a.mean ? a.row_ptr[row + 1] - a.row_ptr[row] : 1, row, a.y + (size_t)row * F + col0 + c, a.mean,
+                                          a.accumulate, a.relu, a.row_aux);
+                acc = one[0];
             }
-            if (a.accumulate) acc = a.y[(size_t)row * F + col0 + c] + acc;
-            if (!IS_GAT && a.relu) acc = acc > 0.0f ? acc : 0.0f;
             a.y[(size_t)row * F + col0 + c] = acc;
             if (nn) stage[c] = acc;  // the staging rounds are over
         }
@@ -168,17 +171,15 @@ __global__ __launch_bounds__(kBlock) void k_combine(const CombineArgs a)
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / den;
             }
-        } else if (a.mean) {
-            const float d = (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
+            if (a.accumulate) {
+                const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)row * F + col);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / d;
+                for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
+            }
+        } else {
+            finish_gcn_row<VEC, IS_MAX>(acc, a.mean ? a.row_ptr[row + 1] - a.row_ptr[row] : 1, row, a.y + (size_t)row * F + col, a.mean,
+                                        a.accumulate, a.relu, a.row_aux);
         }
-        if (a.accumulate) {
-            const Pack<VEC> old = load_pack<VEC>(a.y + (size_t)row * F + col);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
-        }
-        if (!IS_GAT && a.relu) relu_pack<VEC>(acc);
         if (a.yvec < VEC || F - col < VEC) store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
         else store_pack<VEC>(a.y + (size_t)row * F + col, acc);
         if (nn) store_pack<VEC>(&stage[grp * GROUP * VEC + col], acc);  // ntiles == 1: col = lane * VEC

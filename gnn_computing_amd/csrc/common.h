@@ -79,6 +79,7 @@ struct GcnLaunch {
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 1;
     int accumulate = 0;  // combine only: y += sum of partials
+    const int *row_aux = nullptr;
     int relu = 0;        // y = max(result, 0)
     void *timer = nullptr;          // run_clock: unsigned long long[3 * blocks]
     int *timer_blocks_out = nullptr;  // run_clock: receives the number of workgroups of the items kernel
@@ -103,7 +104,8 @@ struct GcnPlanLaunch {
     int feat = 0;
     int reduce = GNNAGG_REDUCE_SUM;
     int xcd_remap = 2;
-    int accumulate = 0;  // y += A.x (sum only); rows without edges keep their value
+    int accumulate = 0;  // y += A.x (sum; mean / max with row_aux); rows without edges keep their value
+    const int *row_aux = nullptr;  // gnnagg_set_row_aux: mean divisor / edges already folded into y (finish_gcn_row)
     int relu = 0;        // y = max(result, 0)
     int num_rows = 0;    // rows of y
     int t0_partials = 0; // short-row descriptors may carry scratch slots (dest < 0): source-partitioned order
@@ -243,6 +245,8 @@ struct GatPlanLaunch {
     TileSpec tile;              // 2-D blocked mode, as in GcnPlanLaunch
     const int *eperm = nullptr; // permuted orders: original edge of every position (newval is written in CSR edge order)
     int unroll = 0;             // 4: four gathers per batch where the geometry has that instantiation (balanced / scheduled orders)
+    int part_mode = 0;          // two-pass form (gnnagg_gat_run_part): 1 = numerator / denominator out, 2 = add to them and divide
+    float *den_io = nullptr;    // [num_v, heads]
 };
 int launch_gat_plan(const GatPlanLaunch &a, void *stream);
 // Backward of the single-head fused GAT aggregation (k_rowdot + k_gat_bwd_edges); wl = chunked edge work items.
@@ -275,6 +279,8 @@ int launch_dense_rows(const int *rows, int n_rows, const float *Y, const float *
 int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream);
 int launch_check_csr(const int *ptr, const int *idx, int V, int E, int num_cols, int *d_counts, void *stream);
 int launch_pack_rows(const float *x, const int *ids, int n, int feat, float *out, void *stream);
+int launch_pack_rows2(const float *x, const float *att, const int *ids, int n, int feat, int att_w, float *out, void *stream);
+int launch_unpack_rows2(const float *in, int n, int feat, int att_w, float *x_out, float *att_out, void *stream);
 // xt[t][r][0..tile_w) = x[r][t*tile_w ..] (zero beyond feat): the column-tiled image of X the 2-D blocked mode gathers from
 int launch_tile_x(const float *x, float *xt, int rows, int feat, int tile_w, void *stream);
 int launch_tile_att(const float *att, float *as_t, float *ac_t, int rows, int heads, int ht, void *stream);

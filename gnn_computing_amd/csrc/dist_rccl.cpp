@@ -8,7 +8,7 @@
 // librccl is loaded lazily with dlopen: libgnnagg.so has no link-time dependency on it (the single-GPU path never needs
 // it), and a process that already holds a copy -- torch ships one -- keeps using that copy (RTLD_NOLOAD first).
 #include <dlfcn.h>
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <unistd.h>
 
@@ -301,6 +301,171 @@ int gnnagg_dist_halo_exchange(gnnagg_comm h, const float *d_x_local, const int *
         if (rc) return rc;
     }
     return gnnagg_dist_alltoallv(h, d_send_buf, h_send_rows, d_x_halo, h_recv_rows, feat * (int)sizeof(float), hip_stream);
+}
+
+int gnnagg_pack_rows2(const float *d_x, const float *d_att, const int *d_ids, int n, int feat, int att_width, float *d_out, void *hip_stream)
+{
+    if (n < 0 || feat <= 0 || att_width <= 0 || (n > 0 && (!d_x || !d_att || !d_ids || !d_out))) return fail(GNNAGG_ERR_ARG, "bad pack_rows2 arguments");
+    return launch_pack_rows2(d_x, d_att, d_ids, n, feat, att_width, d_out, hip_stream);
+}
+
+int gnnagg_unpack_rows2(const float *d_in, int n, int feat, int att_width, float *d_x_out, float *d_att_out, void *hip_stream)
+{
+    if (n < 0 || feat <= 0 || att_width <= 0 || (n > 0 && (!d_in || !d_x_out || !d_att_out))) return fail(GNNAGG_ERR_ARG, "bad unpack_rows2 arguments");
+    return launch_unpack_rows2(d_in, n, feat, att_width, d_x_out, d_att_out, hip_stream);
+}
+
+// ---------------------------------------------------------------------------------------------- one call per step
+// The row-partitioned aggregation step behind ONE host call: on the caller's stream the local-source pass; on
+// the step's communication stream, forked and joined with events, the pack kernel and the grouped send / recv; then the
+// halo-source pass, which adds to what the local pass wrote.  Everything is enqueued asynchronously -- stream operations only,
+// so a warm step can be captured into a HIP graph like any fork / join of two streams -- and nothing is allocated per step.
+// A rank without peers (world 1) or without halo rows never creates the second stream: its step is the local pass alone.
+namespace gnnagg {
+struct DistStep {
+    gnnagg_comm comm = 0;
+    int world = 1, rank = 0;
+    gnnagg_handle agg_local = 0, agg_remote = 0;
+    const int *d_send_ids = nullptr;
+    std::vector<long long> send_rows, recv_rows, send_el, recv_el;
+    long long n_send = 0, n_recv = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool exchanging() const { return world > 1 && (n_send > 0 || n_recv > 0); }
+};
+static std::mutex g_step_mu;
+static std::set<DistStep *> g_steps;
+static DistStep *lookup_step(gnnagg_dist_step_t h)
+{
+    std::lock_guard<std::mutex> lk(g_step_mu);
+    DistStep *p = reinterpret_cast<DistStep *>(h);
+    return g_steps.count(p) ? p : nullptr;
+}
+#define HIPD_TRY(expr)                                                                                              \
+    do {                                                                                                            \
+        hipError_t _e = (expr);                                                                                     \
+        if (_e != hipSuccess) return fail(GNNAGG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+static int step_fork(DistStep *st, hipStream_t stream)
+{
+    if (!st->comm_stream) {  // first exchanging step: never inside a capture of a warm step
+        HIPD_TRY(hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking));
+        HIPD_TRY(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
+        HIPD_TRY(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
+    }
+    HIPD_TRY(hipEventRecord(st->ev_fork, stream));            // x_local is ready where the caller's stream stands now
+    HIPD_TRY(hipStreamWaitEvent(st->comm_stream, st->ev_fork, 0));
+    return GNNAGG_OK;
+}
+}  // namespace gnnagg
+
+int gnnagg_dist_step_create(gnnagg_comm comm, gnnagg_handle agg_local, gnnagg_handle agg_remote, const int *d_send_ids,
+                            const long long *h_send_rows, const long long *h_recv_rows, gnnagg_dist_step_t *out)
+{
+    if (!out) return fail(GNNAGG_ERR_ARG, "null output step");
+    *out = 0;
+    if (!agg_local) return fail(GNNAGG_ERR_ARG, "dist_step: no local aggregator");
+    DistStep *st = new DistStep;
+    st->comm = comm; st->agg_local = agg_local; st->agg_remote = agg_remote; st->d_send_ids = d_send_ids;
+    if (comm) {
+        int rc = gnnagg_dist_comm_info(comm, &st->rank, &st->world);
+        if (rc) { delete st; return rc; }
+        if (!h_send_rows || !h_recv_rows) { delete st; return fail(GNNAGG_ERR_ARG, "dist_step: null row counts"); }
+        st->send_rows.assign(h_send_rows, h_send_rows + st->world);
+        st->recv_rows.assign(h_recv_rows, h_recv_rows + st->world);
+        for (int p = 0; p < st->world; ++p) {
+            if (st->send_rows[p] < 0 || st->recv_rows[p] < 0) { delete st; return fail(GNNAGG_ERR_ARG, "dist_step: negative row count"); }
+            st->n_send += st->send_rows[p];
+            st->n_recv += st->recv_rows[p];
+        }
+        if (st->n_send > 0x7fffffffLL || st->n_recv > 0x7fffffffLL) { delete st; return fail(GNNAGG_ERR_ARG, "dist_step: too many halo rows"); }
+        if (st->n_send > 0 && !d_send_ids) { delete st; return fail(GNNAGG_ERR_ARG, "dist_step: null send ids"); }
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_step_mu);
+        g_steps.insert(st);
+    }
+    *out = reinterpret_cast<gnnagg_dist_step_t>(st);
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_step_destroy(gnnagg_dist_step_t h)
+{
+    DistStep *st;
+    {
+        std::lock_guard<std::mutex> lk(g_step_mu);
+        st = reinterpret_cast<DistStep *>(h);
+        if (!g_steps.count(st)) return fail(GNNAGG_ERR_ARG, "invalid or destroyed step");
+        g_steps.erase(st);
+    }
+    if (st->comm_stream) {
+        (void)hipStreamSynchronize(st->comm_stream);
+        (void)hipStreamDestroy(st->comm_stream);
+        (void)hipEventDestroy(st->ev_fork);
+        (void)hipEventDestroy(st->ev_join);
+    }
+    delete st;
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_step_gcn(gnnagg_dist_step_t h, const float *d_x_local, float *d_x_halo, float *d_send_buf, float *d_y, int feat, int reduce,
+                         void *hip_stream)
+{
+    DistStep *st = lookup_step(h);
+    if (!st) return fail(GNNAGG_ERR_ARG, "invalid or destroyed step");
+    if (!d_x_local || !d_y || feat <= 0) return fail(GNNAGG_ERR_ARG, "bad dist_step arguments");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int rc;
+    const bool ex = st->exchanging();
+    if (ex) {
+        if ((st->n_send > 0 && !d_send_buf) || (st->n_recv > 0 && !d_x_halo)) return fail(GNNAGG_ERR_ARG, "dist_step: null exchange buffer");
+        if ((rc = step_fork(st, stream))) return rc;
+        if ((rc = gnnagg_dist_halo_exchange(st->comm, d_x_local, st->d_send_ids, st->send_rows.data(), st->recv_rows.data(), feat, d_send_buf,
+                                            d_x_halo, st->comm_stream)))
+            return rc;
+        HIPD_TRY(hipEventRecord(st->ev_join, st->comm_stream));
+    }
+    if ((rc = gnnagg_set_stream(st->agg_local, stream))) return rc;
+    if ((rc = gnnagg_gcn_run_ex(st->agg_local, d_x_local, d_y, feat, GNNAGG_MODE_BALANCED, reduce, 0))) return rc;   // overlaps the exchange
+    if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));
+    if (st->agg_remote && st->n_recv > 0) {
+        if ((rc = gnnagg_set_stream(st->agg_remote, stream))) return rc;
+        if ((rc = gnnagg_gcn_run_ex(st->agg_remote, d_x_halo, d_y, feat, GNNAGG_MODE_BALANCED, reduce, GNNAGG_FLAG_ACCUMULATE))) return rc;
+    }
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_step_gat(gnnagg_dist_step_t h, float *d_x_ext, float *d_att_ext, int n_local, float *d_send_buf, float *d_recv_buf,
+                         float *d_den, float *d_y, int feat, int heads, float slope, void *hip_stream)
+{
+    DistStep *st = lookup_step(h);
+    if (!st) return fail(GNNAGG_ERR_ARG, "invalid or destroyed step");
+    if (!d_x_ext || !d_att_ext || !d_y || !d_den || feat <= 0 || heads <= 0 || n_local < 0) return fail(GNNAGG_ERR_ARG, "bad dist_step arguments");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const int aw = 2 * heads, w = feat + aw;
+    int rc;
+    const bool ex = st->exchanging();
+    if (ex) {
+        if ((st->n_send > 0 && !d_send_buf) || (st->n_recv > 0 && !d_recv_buf)) return fail(GNNAGG_ERR_ARG, "dist_step: null exchange buffer");
+        if ((rc = step_fork(st, stream))) return rc;
+        // ONE exchange carries [feature row | attention terms] of every requested row
+        if ((rc = launch_pack_rows2(d_x_ext, d_att_ext, st->d_send_ids, (int)st->n_send, feat, aw, d_send_buf, st->comm_stream))) return rc;
+        if ((rc = gnnagg_dist_alltoallv(st->comm, d_send_buf, st->send_rows.data(), d_recv_buf, st->recv_rows.data(), w * (int)sizeof(float),
+                                        st->comm_stream)))
+            return rc;
+        if ((rc = launch_unpack_rows2(d_recv_buf, (int)st->n_recv, feat, aw, d_x_ext + (size_t)n_local * feat, d_att_ext + (size_t)n_local * aw,
+                                      st->comm_stream)))
+            return rc;
+        HIPD_TRY(hipEventRecord(st->ev_join, st->comm_stream));
+    }
+    // numerators and denominators of the local-source edges while the exchange is in flight; the halo-source pass adds its own
+    // and divides (it runs for every row: a row without halo sources is divided all the same)
+    if ((rc = gnnagg_set_stream(st->agg_local, stream))) return rc;
+    if (!st->agg_remote) return gnnagg_gat_run(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, GNNAGG_MODE_BALANCED, nullptr);
+    if ((rc = gnnagg_gat_run_part(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, 1, d_den))) return rc;
+    if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));
+    if ((rc = gnnagg_set_stream(st->agg_remote, stream))) return rc;
+    return gnnagg_gat_run_part(st->agg_remote, d_x_ext, d_att_ext, d_y, feat, heads, slope, 2, d_den);
 }
 
 }  // extern "C"

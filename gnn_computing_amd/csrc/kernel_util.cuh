@@ -101,6 +101,39 @@ __device__ __forceinline__ void store_pack(float *p, const float (&a)[VEC])
     }
 }
 
+// Last step of a GCN / SAGE row: mean division, the join with what the row already holds (GNNAGG_FLAG_ACCUMULATE), ReLU.
+// row_aux (gnnagg_set_row_aux; the row-partitioned step's two passes) changes two things: the mean divides by row_aux[row]
+// -- the row's degree in the WHOLE graph -- instead of the edges this handle holds, so that local and halo parts can be
+// added; and a max joins as max(old, new) only where row_aux[row] edges > 0 were already folded into y (else y = new).
+template <int VEC, bool IS_MAX>
+__device__ __forceinline__ void finish_gcn_row(float (&acc)[VEC], int own_deg, int row, const float *yold, int mean, int accumulate,
+                                               int relu, const int *__restrict__ row_aux)
+{
+    if (mean) {
+        const float dg = (float)(row_aux ? row_aux[row] : own_deg);
+        if (dg > 0.0f) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] / dg;
+        }
+    }
+    if (accumulate) {
+        const Pack<VEC> old = load_pack<VEC>(yold);
+        if (IS_MAX) {
+            if (!row_aux || row_aux[row] > 0) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] > acc[k] ? old.v[k] : acc[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
+        }
+    }
+    if (relu) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] > 0.0f ? acc[k] : 0.0f;
+    }
+}
+
 // Store of a lane's VEC results when the destination's alignment class (`avec` = 4 / 2 / 1: 16-, 8- or 4-byte aligned
 // rows) or the number of valid columns (`nvalid`, the ragged last tile) is below VEC: the 2-D blocked mode computes on
 // 16-byte lanes (re-tiled X) whatever the caller's row pitch is.

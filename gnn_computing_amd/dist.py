@@ -28,7 +28,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .aggregator import Aggregator_GAT, Aggregator_GCN, halo_plan, partition_rows
+from .aggregator import REDUCE, Aggregator_GAT, Aggregator_GCN, halo_plan, partition_rows
 from ._lib import check, lib
 
 
@@ -215,7 +215,13 @@ class HaloExchange:
 
 
 class PartitionedGCN:
-    """Row-partitioned GCN/SAGE aggregation: y_local = A[rows of this rank, :] @ X (global)."""
+    """Row-partitioned GCN/SAGE aggregation: y_local = A[rows of this rank, :] @ X (global).
+
+    overlap=True (balanced mode): the local-source edges run while the exchange is in flight, the halo-source edges add to them
+    afterwards -- for sums directly (GNNAGG_FLAG_ACCUMULATE), for means with the row's TOTAL degree as the divisor of both passes,
+    for maxima as max(old, new) where the first pass folded any edge (gnnagg_set_row_aux).  With the "rccl" transport, or on a
+    single rank, the whole step is ONE C-ABI call (gnnagg_dist_step_gcn: pack, grouped send / recv on a communication stream,
+    local pass, event wait, halo pass)."""
 
     def __init__(self, ptr, idx, val=None, feat=128, group=None, device=None, mode="balanced", rank=None, world=None,
                  overlap=True, offline=False, row_slice=False, bounds=None, num_cols=None, transport="torch"):
@@ -238,6 +244,7 @@ class PartitionedGCN:
         self.send_buf = torch.empty((max(hx.n_send, 1), feat), dtype=torch.float32, device=device)
         self.y = torch.empty((hx.n_local, feat), dtype=torch.float32, device=device)
         self.num_e_local = hx.e1 - hx.e0
+        self._step = ctypes.c_int64(0)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
         if self.overlap:
             pl, il, pr, ir, is_loc = hx.split_local_remote()
@@ -246,61 +253,206 @@ class PartitionedGCN:
             self.agg_loc.schedule_balanced(0)
             self.agg_rem.schedule_balanced(0)
             self.num_e_remote = int(len(ir))
+            self.deg_total = t(np.diff(hx.local_ptr).astype(np.int32))   # the row's degree in the whole graph (mean divisor)
+            self.deg_local = t(np.diff(pl).astype(np.int32))             # edges the first pass folds (max join)
+            if device.type == "cuda" and not offline and (hx.rccl is not None or hx.world == 1):
+                n = hx.world
+                sc = (ctypes.c_longlong * n)(*[int(v) for v in hx.send_counts])
+                rc = (ctypes.c_longlong * n)(*[int(v) for v in hx.recv_counts])
+                check(lib().gnnagg_dist_step_create(hx.rccl._h if hx.rccl is not None else ctypes.c_int64(0), self.agg_loc._h,
+                                                    self.agg_rem._h if hx.n_halo else ctypes.c_int64(0),
+                                                    ctypes.c_void_p(hx.send_ids.data_ptr()) if hx.n_send else None, sc, rc,
+                                                    ctypes.byref(self._step)))
         else:
             self.agg = Aggregator_GCN(t(hx.local_ptr), t(hx.local_idx), None if val_loc is None else t(val_loc), feat, feat)
             if mode == "balanced":
                 self.agg.schedule_balanced(0)
 
+    def close(self):
+        if self._step.value:
+            lib().gnnagg_dist_step_destroy(self._step)
+            self._step = ctypes.c_int64(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def set_local_x(self, x_local):
         self.x_local.copy_(x_local)
 
+    def _set_aux(self, reduce):
+        """what the two passes need to know about each other's rows (gnnagg_set_row_aux)"""
+        if reduce == "mean":
+            self.agg_loc.set_row_aux(self.deg_total)
+            self.agg_rem.set_row_aux(self.deg_total)
+        elif reduce == "max":
+            self.agg_loc.set_row_aux(None)
+            self.agg_rem.set_row_aux(self.deg_local)
+        else:
+            self.agg_loc.set_row_aux(None)
+            self.agg_rem.set_row_aux(None)
+
     def compute(self, reduce="sum", work=None):
         """The aggregation kernels of one step, given that the exchange `work` (or None) fills x_halo."""
-        if self.overlap and reduce == "sum":
-            self.agg_loc.run(self.x_local, self.y, 512, "balanced")          # overlaps the all-to-all
+        if self.overlap:
+            self._set_aux(reduce)
+            self.agg_loc.run(self.x_local, self.y, 512, "balanced", reduce=reduce)   # overlaps the all-to-all
             if work is not None:
-                work.wait()                                                    # current stream waits for the halo
+                work.wait()                                                            # current stream waits for the halo
             if self.hx.n_halo:
-                self.agg_rem.run(self.x_halo, self.y, 512, "balanced", accumulate=True)
+                self.agg_rem.run(self.x_halo, self.y, 512, "balanced", reduce=reduce, accumulate=True)
         else:
             if work is not None:
                 work.wait()
-            if self.overlap:  # mean / max need the whole row at once: fall back to the one-pass plan lazily
-                raise NotImplementedError("overlap plan supports reduce='sum'; build with overlap=False for mean/max")
             self.agg.run(self.x_ext, self.y, 512, self.mode, reduce=reduce)
         return self.y
 
     def step(self, reduce="sum"):
         """One aggregation: halo all-to-all (asynchronous when overlapping) + kernels."""
+        if self._step.value:   # ONE host call: pack, grouped send / recv on the step's stream, local pass, wait, halo pass
+            self._set_aux(reduce)
+            hx = self.hx
+            check(lib().gnnagg_dist_step_gcn(self._step, ctypes.c_void_p(self.x_local.data_ptr()),
+                                             ctypes.c_void_p(self.x_halo.data_ptr()) if hx.n_halo else None,
+                                             ctypes.c_void_p(self.send_buf.data_ptr()), ctypes.c_void_p(self.y.data_ptr()), int(self.feat),
+                                             REDUCE[reduce], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return self.y
         work = self.hx.exchange(self.x_local, self.x_halo, self.send_buf, async_op=self.overlap)
         return self.compute(reduce, work)
 
 
+def _hip_pack_rows2(x, att, ids, out):
+    check(lib().gnnagg_pack_rows2(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(att.data_ptr()), ctypes.c_void_p(ids.data_ptr()),
+                                  int(ids.numel()), int(x.shape[1]), int(att.shape[1]), ctypes.c_void_p(out.data_ptr()),
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+def _hip_unpack_rows2(buf, n, x_out, att_out):
+    check(lib().gnnagg_unpack_rows2(ctypes.c_void_p(buf.data_ptr()), int(n), int(x_out.shape[1]), int(att_out.shape[1]),
+                                    ctypes.c_void_p(x_out.data_ptr()), ctypes.c_void_p(att_out.data_ptr()),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
 class PartitionedGAT:
-    """Row-partitioned fused GAT; att rows travel with the feature rows (one extra exchange)."""
+    """Row-partitioned fused GAT.  The attention terms of a halo row travel WITH its feature row: ONE exchange of rows
+    [x | att] (feat + 2 heads floats) per step.  overlap=True (balanced mode): the local-source edges' numerators and denominators
+    are computed while the exchange is in flight, the halo-source pass adds its own and divides (gnnagg_gat_run_part); both passes
+    index X_ext = [X_local ; X_halo] and att_ext slots.  row_slice / bounds / num_cols / transport as in PartitionedGCN; with the
+    "rccl" transport, or on a single rank, the whole step is ONE C-ABI call (gnnagg_dist_step_gat)."""
 
     def __init__(self, ptr, idx, feat=256, heads=8, group=None, device=None, mode="balanced", rank=None, world=None,
-                 offline=False):
+                 offline=False, row_slice=False, bounds=None, num_cols=None, transport="torch", overlap=True, pack_fn2=None,
+                 unpack_fn2=None, build_aggregators=True):
+        """pack_fn2 / unpack_fn2 / build_aggregators=False: test doubles for the CPU tests of the exchange (the product's pack,
+        unpack and aggregation are HIP kernels without a CPU fallback)."""
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.hx = HaloExchange(ptr, idx, rank=rank, world=world, group=group, device=device, offline=offline)
+        self.hx = HaloExchange(ptr, idx, rank=rank, world=world, group=group, device=device, offline=offline,
+                               row_slice=row_slice, bounds=bounds, num_cols=num_cols, transport=transport)
         hx = self.hx
         self.feat, self.heads, self.mode = feat, heads, mode
-        self.d_ptr = torch.from_numpy(hx.local_ptr).to(device)
-        self.d_idx = torch.from_numpy(hx.local_idx).to(device)
-        self.agg = Aggregator_GAT(self.d_ptr, self.d_idx, feat, feat)
-        if mode == "balanced":
-            self.agg.schedule_balanced(0)
+        self.pack_fn2, self.unpack_fn2 = pack_fn2 or _hip_pack_rows2, unpack_fn2 or _hip_unpack_rows2
+        aw = 2 * heads
+        # the two-pass form runs on 16-byte lanes over one column tile (gnnagg_gat_run_part)
+        self.overlap = bool(overlap) and mode == "balanced" and feat % 4 == 0 and (feat // heads) % 4 == 0 and feat <= 256
         self.x_ext = hx.alloc_x_ext(feat)
-        self.att_ext = hx.alloc_x_ext(heads * 2)
+        self.att_ext = hx.alloc_x_ext(aw)
         self.y = torch.empty((hx.n_local, feat), dtype=torch.float32, device=device)
+        self.den = torch.empty((max(hx.n_local, 1), heads), dtype=torch.float32, device=device)
+        self.send_buf = torch.empty((max(hx.n_send, 1), feat + aw), dtype=torch.float32, device=device)
+        self.recv_buf = torch.empty((max(hx.n_halo, 1), feat + aw), dtype=torch.float32, device=device)
+        self._step = ctypes.c_int64(0)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        if not build_aggregators:
+            return
+        if self.overlap:
+            pl, il, pr, ir, _ = hx.split_local_remote()
+            self.agg_loc = Aggregator_GAT(t(pl), t(il), feat, feat)
+            self.agg_rem = Aggregator_GAT(t(pr), t((ir + hx.n_local).astype(np.int32)), feat, feat)   # X_ext slots, like agg_loc
+            if device.type == "cuda" and not offline and (hx.rccl is not None or hx.world == 1):
+                n = hx.world
+                sc = (ctypes.c_longlong * n)(*[int(v) for v in hx.send_counts])
+                rc = (ctypes.c_longlong * n)(*[int(v) for v in hx.recv_counts])
+                check(lib().gnnagg_dist_step_create(hx.rccl._h if hx.rccl is not None else ctypes.c_int64(0), self.agg_loc._h,
+                                                    self.agg_rem._h, ctypes.c_void_p(hx.send_ids.data_ptr()) if hx.n_send else None,
+                                                    sc, rc, ctypes.byref(self._step)))
+        else:
+            self.d_ptr = t(hx.local_ptr)
+            self.d_idx = t(hx.local_idx)
+            self.agg = Aggregator_GAT(self.d_ptr, self.d_idx, feat, feat)
+            if mode == "balanced":
+                self.agg.schedule_balanced(0)
 
-    def compute(self, slope=0.2):
-        # the kernel indexes att by X_ext slot; only the first n_local rows are destinations
-        self.agg.run_with_feat(self.x_ext, self.att_ext, self.y, 128, self.mode, self.feat, self.heads, slope)
+    def close(self):
+        if self._step.value:
+            lib().gnnagg_dist_step_destroy(self._step)
+            self._step = ctypes.c_int64(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_local(self, x_local, att_local):
+        n = self.hx.n_local
+        self.x_ext[:n].copy_(x_local)
+        self.att_ext[:n].copy_(att_local.reshape(n, -1))
+
+    def exchange(self, async_op=False):
+        """ONE all-to-all of [x | att] rows into recv_buf; returns the work handle (None: nothing to wait for).  The received
+        rows still have to be split into the halo tails (finish_exchange)."""
+        hx = self.hx
+        if hx.offline or (hx.world == 1 and not (dist.is_available() and dist.is_initialized())):
+            return None
+        n = hx.n_local
+        if hx.n_send:
+            self.pack_fn2(self.x_ext[:n], self.att_ext[:n], hx.send_ids, self.send_buf)
+        if hx.rccl is not None:
+            st = hx.rccl.stream if async_op else torch.cuda.current_stream()
+            if async_op:
+                st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                hx.rccl.alltoallv(self.send_buf, [int(v) * self.send_buf.shape[1] for v in hx.send_counts], self.recv_buf,
+                                  [int(v) * self.recv_buf.shape[1] for v in hx.recv_counts])
+            return _StreamWork(st) if async_op else None
+        return dist.all_to_all_single(self.recv_buf[:hx.n_halo], self.send_buf[:hx.n_send],
+                                      output_split_sizes=hx.recv_counts.tolist(), input_split_sizes=hx.send_counts.tolist(),
+                                      group=hx.group, async_op=async_op)
+
+    def finish_exchange(self):
+        hx = self.hx
+        if hx.n_halo and not hx.offline:
+            self.unpack_fn2(self.recv_buf, hx.n_halo, self.x_ext[hx.n_local:], self.att_ext[hx.n_local:])
+
+    def compute(self, slope=0.2, work=None):
+        """The aggregation kernels of one step (the halo tails of x_ext / att_ext are filled by `work` + finish_exchange, or by
+        hand in the single-process tests)."""
+        if self.overlap:
+            self.agg_loc.run_part(self.x_ext, self.att_ext, self.y, self.den, 1, self.heads, slope)   # overlaps the all-to-all
+            if work is not None:
+                work.wait()
+                self.finish_exchange()
+            self.agg_rem.run_part(self.x_ext, self.att_ext, self.y, self.den, 2, self.heads, slope)
+        else:
+            if work is not None:
+                work.wait()
+                self.finish_exchange()
+            # the kernel indexes att by X_ext slot; only the first n_local rows are destinations
+            self.agg.run_with_feat(self.x_ext, self.att_ext, self.y, 128, self.mode, self.feat, self.heads, slope)
         return self.y
 
     def step(self, slope=0.2):
-        n = self.hx.n_local
-        self.hx.exchange(self.x_ext[:n], self.x_ext[n:])
-        self.hx.exchange(self.att_ext[:n], self.att_ext[n:])
-        return self.compute(slope)
+        if self._step.value:   # ONE host call (gnnagg_dist_step_gat)
+            hx = self.hx
+            check(lib().gnnagg_dist_step_gat(self._step, ctypes.c_void_p(self.x_ext.data_ptr()), ctypes.c_void_p(self.att_ext.data_ptr()),
+                                             int(hx.n_local), ctypes.c_void_p(self.send_buf.data_ptr()),
+                                             ctypes.c_void_p(self.recv_buf.data_ptr()), ctypes.c_void_p(self.den.data_ptr()),
+                                             ctypes.c_void_p(self.y.data_ptr()), int(self.feat), int(self.heads), ctypes.c_float(slope),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return self.y
+        work = self.exchange(async_op=self.overlap)
+        if work is None:
+            self.finish_exchange()
+        return self.compute(slope, work)

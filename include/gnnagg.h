@@ -127,6 +127,17 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
 /* Aggregator_GCN::updateval, aggr_gcn.h:540-544: re-aliases the edge values (borrowed; read at run time). */
 int gnnagg_update_val(gnnagg_handle h, const float *d_val);
 
+/* Per-row degrees for aggregations that are computed in TWO passes over disjoint edge sets of the same rows (the row-partitioned
+ * step of section D: local-source edges while the halo exchange is in flight, halo-source edges after it).  d_row_aux[num_v]
+ * (int32, borrowed, read at run time; NULL switches it off) changes GNNAGG_MODE_BALANCED runs of this handle as follows:
+ *   GNNAGG_REDUCE_MEAN  divides by d_row_aux[row] -- the row's degree in the WHOLE graph -- instead of the edges this handle holds
+ *                       (the reference's mean is val = 1/deg per edge, Figure7/our.py: every term is x/deg, so the two passes add);
+ *                       GNNAGG_FLAG_ACCUMULATE then adds the pass's quotient to what the row holds
+ *   GNNAGG_REDUCE_MAX   with GNNAGG_FLAG_ACCUMULATE: y = max(y, result) where d_row_aux[row] > 0 edges were already folded into y
+ *                       by the earlier pass, y = result where none were (y then holds the empty row's 0, not a maximum)
+ * GNNAGG_REDUCE_SUM is not affected.  Rows this handle has no edges for are left untouched by an accumulating run. */
+int gnnagg_set_row_aux(gnnagg_handle h, const int *d_row_aux);
+
 /* Aggregator::schedule, aggregator.h:67-99 / Aggregator_GCN::schedule aggr_gcn.h:501-538.
  * kind = GNNAGG_SCHED_*; param[0] = NG or par_num, param[1] = NG for the combined schedule.
  * total_num_v: the reference reads the global `n` (aggregator.h:79); pass num_v for a full graph. */
@@ -212,6 +223,14 @@ int gnnagg_csr2edgelist(gnnagg_handle h, int *d_edgelist);
  * un-normalised edge weights [E,heads] the reference's scheduled kernel materialises (:187). */
 int gnnagg_gat_run(gnnagg_handle h, const float *d_x, const float *d_att, float *d_y, int feat, int heads,
                    float slope, int mode, float *d_newval);
+/* The fused GAT aggregation in TWO passes over disjoint edge sets of the same rows (two handles over the same rows: the
+ * row-partitioned step's local-source edges, then its halo-source edges once the exchange has landed).  GNNAGG_MODE_BALANCED on
+ * the chunked plan; 16-byte aligned rows of at most 256 columns.
+ *   part = 1  d_y[row, :] receives the NUMERATOR sum_e w_e x_e and d_den_io[row, h] the denominator sum_e w_e; no division
+ *   part = 2  both are added to what part 1 left (old + new, one fp32 add per element), then the row is divided
+ *             (scaleArray, aggr_gat.h:207-213); rows this handle has no edges for are divided all the same */
+int gnnagg_gat_run_part(gnnagg_handle h, const float *d_x, const float *d_att, float *d_y, int feat, int heads, float slope, int part,
+                        float *d_den_io);
 /* Aggregator_GAT::run_att, aggr_gat.h:395-401 (attGat :5-31): out_val[E,heads] = softmax weights */
 int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, int heads, float slope);
 /* Backward of the GCN / SAGE sum aggregation y = A.x (no reference counterpart: the reference is forward-only):
@@ -326,6 +345,34 @@ int gnnagg_dist_alltoallv(gnnagg_comm c, const void *d_send, const long long *h_
                           const long long *h_recv_counts, int elem_bytes, void *hip_stream);
 int gnnagg_dist_halo_exchange(gnnagg_comm c, const float *d_x_local, const int *d_send_ids, const long long *h_send_rows,
                               const long long *h_recv_rows, int feat, float *d_send_buf, float *d_x_halo, void *hip_stream);
+
+/* GAT halo rows travel with their attention terms in ONE exchange: out[i, :] = [x[ids[i], 0 .. feat) | att[ids[i], 0 .. att_width)]
+ * (att_width = 2 * heads), and the receiving side's split into the halo tails of X_ext / att_ext. */
+int gnnagg_pack_rows2(const float *d_x, const float *d_att, const int *d_ids, int n, int feat, int att_width, float *d_out, void *hip_stream);
+int gnnagg_unpack_rows2(const float *d_in, int n, int feat, int att_width, float *d_x_out, float *d_att_out, void *hip_stream);
+
+/* The whole row-partitioned step behind ONE host call (pack -> grouped send / recv on a communication stream ->
+ * local-source pass -> event wait -> halo-source pass).  Asynchronous: stream operations only (fork / join of the caller's stream
+ * and the step's own communication stream through events), nothing allocated per step, so a warm step can be captured into a HIP
+ * graph.  A rank without peers (comm = 0 or world 1) or without halo rows never creates the second stream.
+ *   gnnagg_dist_step_create   comm (0: single rank); agg_local = aggregator over the edges whose source is an owned row, agg_remote
+ *                             = aggregator over the halo-source edges (0: none); d_send_ids / h_send_rows / h_recv_rows = the plan
+ *                             of gnnagg_dist_halo_exchange (the counts are copied)
+ *   gnnagg_dist_step_gcn      y = A_loc . x_local, then y += A_rem . x_halo (GNNAGG_FLAG_ACCUMULATE); agg_remote's column ids are
+ *                             halo slots (0-based); reduce = mean / max need gnnagg_set_row_aux on the aggregators (total degrees on
+ *                             both for mean; local-source degrees on agg_remote for max)
+ *   gnnagg_dist_step_gat      x_ext = [X_local ; X_halo], att_ext likewise ([., heads, 2]); ONE exchange carries [x | att] rows
+ *                             (d_send_buf [n_send, feat + 2 heads], d_recv_buf [n_halo, feat + 2 heads]); both aggregators index
+ *                             X_ext slots; d_den [n_local, heads] carries the denominators between the two passes
+ *                             (gnnagg_gat_run_part) */
+typedef int64_t gnnagg_dist_step_t;
+int gnnagg_dist_step_create(gnnagg_comm comm, gnnagg_handle agg_local, gnnagg_handle agg_remote, const int *d_send_ids,
+                            const long long *h_send_rows, const long long *h_recv_rows, gnnagg_dist_step_t *out);
+int gnnagg_dist_step_destroy(gnnagg_dist_step_t step);
+int gnnagg_dist_step_gcn(gnnagg_dist_step_t step, const float *d_x_local, float *d_x_halo, float *d_send_buf, float *d_y, int feat, int reduce,
+                         void *hip_stream);
+int gnnagg_dist_step_gat(gnnagg_dist_step_t step, float *d_x_ext, float *d_att_ext, int n_local, float *d_send_buf, float *d_recv_buf,
+                         float *d_den, float *d_y, int feat, int heads, float slope, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -235,8 +235,10 @@ def gat_bwd(ptr, idx, output, doutput, newval, div, infeat, slope=0.2):
     return d_a_b, d_feat
 
 
-def gat_grouped(ptr_s, target, idx, att, X, num_v, heads=1, slope=0.2, seg=0):
-    """Returns (Y, newval[E,H] un-normalised, scalar[V,H]); seg as in gcn_grouped."""
+def gat_grouped(ptr_s, target, idx, att, X, num_v, heads=1, slope=0.2, seg=0, parts=False):
+    """Returns (Y, newval[E,H] un-normalised, scalar[V,H]); seg as in gcn_grouped.  parts=True: the third element is
+    (numerator[V,F], denominator[V,H]) in float64 instead -- Y times its denominator, for checks of the two-pass form
+    (tolerance-compared: the product re-rounds)."""
     ptr_s, target, idx, att, X = _ci(ptr_s), _ci(target), _ci(idx), _cf(att), _cf(X)
     F = X.shape[1]
     Y = np.empty((num_v, F), np.float32)
@@ -244,6 +246,9 @@ def gat_grouped(ptr_s, target, idx, att, X, num_v, heads=1, slope=0.2, seg=0):
     scalar = np.empty((num_v, heads), np.float32)
     lib().orc_gat_grouped_seg(_i(ptr_s), _i(target), len(target), _i(idx), _f(att), _f(X), _f(Y), _f(newval),
                               _f(scalar), int(num_v), int(heads), F // heads, ctypes.c_float(slope), int(seg))
+    if parts:
+        den = scalar.astype(np.float64)
+        return Y, newval, (Y.astype(np.float64) * np.repeat(den, F // heads, axis=1), den)
     return Y, newval, scalar
 
 

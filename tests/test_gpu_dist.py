@@ -49,6 +49,29 @@ def _worker(rank, world, port, overlap, q):
             scale = orc.gcn_abs_scale(ptr, idx, val, x)[r0:r1]
             ok = ok and bool(np.all(np.abs(y - ref) <= 1e-5 * scale + 1e-30))
         ok_halo = np.array_equal(pg.x_halo.cpu().numpy(), x[pg.hx.halo_ids])
+        # mean and max through the same step (overlap plan: total-degree divisor / guarded max join, gnnagg_set_row_aux)
+        deg = np.maximum(np.diff(ptr), 1)[r0:r1, None].astype(np.float32)
+        ym = pg.step(reduce="mean").cpu().numpy()
+        ok = ok and bool(np.all(np.abs(ym - ref / deg) <= 1e-5 * scale / deg + 1e-30))
+        yx = pg.step(reduce="max").cpu().numpy()
+        ok = ok and np.array_equal(yx, orc.gcn_max(ptr, idx, val, x)[r0:r1])
+        # GAT, 8 heads: ONE exchange carries [x | att] rows; numerator / denominator passes around it when overlapping
+        from gnn_computing_amd.dist import PartitionedGAT
+        H, FG = 8, 256
+        xg = rng.standard_normal((V, FG), dtype=np.float32)
+        att = (rng.standard_normal((V, H, 2), dtype=np.float32) * 0.4).astype(np.float32)
+        gat = PartitionedGAT(ptr, idx, FG, H, device="cuda:0", overlap=overlap)
+        gat.set_local(torch.from_numpy(xg[r0:r1]).cuda(), torch.from_numpy(att[r0:r1]).cuda())
+        y_ref = orc.gat_fused(ptr, idx, att, xg, H)[r0:r1]
+        wn = orc.gat_att(ptr, idx, att, H, 0.2)                       # normalised weights [E, H]
+        sc = np.zeros((V, FG))
+        np.add.at(sc, np.repeat(np.arange(V), np.diff(ptr)), np.repeat(wn, FG // H, axis=1).astype(np.float64) * np.abs(xg[idx]))
+        sc = sc[r0:r1]                                                # sum_e w_e |x_e| / sum_e w_e: the error scale of the output
+        for _ in range(2):
+            yg = gat.step().cpu().numpy()
+            ok = ok and bool(np.all(np.abs(yg - y_ref) <= 1e-5 * (sc + np.abs(y_ref)) + 1e-30))
+        ok_halo = ok_halo and np.array_equal(gat.x_ext[gat.hx.n_local:].cpu().numpy(), xg[gat.hx.halo_ids]) and \
+            np.array_equal(gat.att_ext[gat.hx.n_local:].cpu().numpy(), att[gat.hx.halo_ids].reshape(-1, 2 * H))
         q.put((rank, ok, ok_halo, pg.hx.n_halo, pg.hx.n_send))
     finally:
         dist.destroy_process_group()
@@ -136,3 +159,71 @@ def test_dist_step_driver_single_rank(tmp_path):
     lines = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")]
     assert len(lines) == 2 and lines[0]["n_local"] == 5000 and lines[0]["n_halo"] == 0 and lines[0]["seconds"] > 0
     assert lines[1]["summary"] == "slowest rank" and lines[1]["edges_per_s"] > 0
+
+
+def test_single_call_step_at_world_one_costs_what_a_launch_costs():
+    """gnnagg_dist_step_gcn / _gat: the whole row-partitioned step behind ONE C-ABI call.  At world 1 the
+    exchange is degenerate -- no communication stream is ever created -- and the call must cost what the single-GPU launch costs:
+    host time per step within 10 us of the plain balanced run, results bit-equal to it; the step is HIP-graph capturable."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import gnn_computing_amd as gnc
+    from gnn_computing_amd.dist import PartitionedGAT, PartitionedGCN
+    dev = torch.device("cuda", 0)
+    V, E, F = 20000, 400000, 128
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=5)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    rng = np.random.default_rng(1)
+    x, val = rng.standard_normal((V, F), dtype=np.float32), rng.standard_normal(E, dtype=np.float32)
+    pg = PartitionedGCN(ptr, idx, val, F, device=dev, rank=0, world=1)
+    assert pg._step.value != 0 and pg.hx.n_halo == 0
+    pg.set_local_x(torch.from_numpy(x).to(dev))
+    agg = gnc.Aggregator_GCN(ptr_t.to(dev), idx_t.to(dev), torch.from_numpy(val).to(dev), F, F)
+    agg.schedule_balanced(0)
+    y1 = torch.empty((V, F), device=dev)
+    for red in ("sum", "mean", "max"):
+        agg.run(pg.x_local, y1, 512, "balanced", reduce=red)
+        assert torch.equal(pg.step(reduce=red), y1), red
+
+    def host_us(fn, n=300):
+        for _ in range(30):
+            fn()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            best = min(best, (time.perf_counter() - t0) / n * 1e6)   # host side: the queue absorbs the launches
+            torch.cuda.synchronize()
+        return best
+    t_step = host_us(lambda: pg.step())
+    t_run = host_us(lambda: agg.run(pg.x_local, y1, 512, "balanced"))
+    print("host time per call: dist step %.1f us, plain run %.1f us" % (t_step, t_run))
+    assert t_step <= t_run + 10.0
+    # capture: the step is stream operations only
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        pg.step()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            pg.step()
+    pg.y.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    agg.run(pg.x_local, y1, 512, "balanced")
+    assert torch.equal(pg.y, y1)
+    # GAT: the two-pass form is skipped at world 1 (no halo-source edges), the fused kernel runs
+    H, FG = 8, 256
+    xg = rng.standard_normal((V, FG), dtype=np.float32)
+    att = (rng.standard_normal((V, H, 2)) * 0.4).astype(np.float32)
+    gat = PartitionedGAT(ptr, idx, FG, H, device=dev, rank=0, world=1)
+    assert gat._step.value != 0
+    gat.set_local(torch.from_numpy(xg).to(dev), torch.from_numpy(att).to(dev))
+    one = gnc.Aggregator_GAT(ptr_t.to(dev), idx_t.to(dev), FG, FG)
+    y2 = torch.empty((V, FG), device=dev)
+    one.run(gat.x_ext, gat.att_ext, y2, 128, "balanced", heads=H)
+    yg = gat.step()
+    assert torch.allclose(yg, y2, rtol=1e-5, atol=1e-6)

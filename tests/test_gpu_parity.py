@@ -729,6 +729,16 @@ def test_partitioned_gcn_single_gpu_emulation(world, overlap):
             b = orc.gcn_grouped(*orc.neighbor_grouping(pr, cr), ir, vl[~is_loc], x[hx.halo_ids], r1 - r0, seg=sr)
             has_rem = (np.diff(pr) > 0)[:, None]
             assert np.array_equal(y, np.where(has_rem, a + b, a))
+            # mean and max on the overlap plan: the total degree divides both passes; the halo pass joins a maximum
+            # only where the local pass folded an edge (gnnagg_set_row_aux)
+            deg = np.maximum(np.diff(hx.local_ptr), 1)[:, None].astype(np.float32)
+            ym = pg.step(reduce="mean").cpu().numpy()
+            assert np.array_equal(ym, np.where(has_rem, a / deg + b / deg, a / deg))
+            assert_within(ym, y_ref[r0:r1] / deg, scale[r0:r1] / deg, "mean, rank %d/%d" % (r, world))
+            yx = pg.step(reduce="max").cpu().numpy()
+            assert np.array_equal(yx, orc.gcn_max(ptr, idx, val, x)[r0:r1])
+            ys = pg.step().cpu().numpy()                     # and back: the aux arrays do not leak into a sum
+            assert np.array_equal(ys, y)
         else:
             ch, sg = pg.agg.balanced_params()
             ps, tg = orc.neighbor_grouping(hx.local_ptr, ch)
@@ -739,9 +749,11 @@ def test_partitioned_gcn_single_gpu_emulation(world, overlap):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("F,H", [(64, 1), (256, 8)])
-def test_partitioned_gat_single_gpu_emulation(world, F, H):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_partitioned_gat_single_gpu_emulation(world, F, H, overlap):
     """PartitionedGAT (att rows travel with the feature rows): every rank's plan run on this GPU with the halo filled by
-    hand, against the single-GPU fused result and against the rank-local order restated exactly."""
+    hand, against the single-GPU fused result and against the rank-local order restated exactly.  overlap: numerators and
+    denominators of the local-source edges first, the halo-source pass adds its own and divides (gnnagg_gat_run_part)."""
     from gnn_computing_amd.dist import PartitionedGAT
     V, E = 3000, 80000
     ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=17)
@@ -751,7 +763,8 @@ def test_partitioned_gat_single_gpu_emulation(world, F, H):
     scale = gat_scale(ptr, idx, att, x, H) + np.abs(y_ref)
     seen = 0
     for r in range(world):
-        pg = PartitionedGAT(ptr, idx, F, H, device=DEV, rank=r, world=world, offline=True)
+        pg = PartitionedGAT(ptr, idx, F, H, device=DEV, rank=r, world=world, offline=True, overlap=overlap)
+        assert pg.overlap == overlap
         hx = pg.hx
         r0, r1 = int(hx.bounds[r]), int(hx.bounds[r + 1])
         n = r1 - r0
@@ -762,9 +775,19 @@ def test_partitioned_gat_single_gpu_emulation(world, F, H):
         y = pg.compute().cpu().numpy()
         seen += n
         assert_within(y, y_ref[r0:r1], scale[r0:r1], "gat rank %d/%d" % (r, world))
-        ch, sg = pg.agg.balanced_params()
-        assert pg.agg.balanced_partitions() == 0
-        ref, _, _ = orc.gat_grouped(*orc.neighbor_grouping(hx.local_ptr, ch), hx.local_idx, att_ext, x_ext, n, H, seg=sg)
+        if overlap:
+            # restated: (numerator, denominator) of the local-source edges + those of the halo-source edges, one division
+            pl, il, pr, ir, _ = hx.split_local_remote()
+            cl, sl = pg.agg_loc.balanced_params()
+            cr, sr = pg.agg_rem.balanced_params()
+            _, _, (na, da) = orc.gat_grouped(*orc.neighbor_grouping(pl, cl), il, att_ext, x_ext, n, H, seg=sl, parts=True)
+            _, _, (nb, db) = orc.gat_grouped(*orc.neighbor_grouping(pr, cr), (ir + n).astype(np.int32), att_ext, x_ext, n, H, seg=sr, parts=True)
+            den = np.repeat(da + db, F // H, axis=1)
+            ref = np.where(den != 0, (na + nb) / np.where(den != 0, den, 1), 0).astype(np.float32)
+        else:
+            ch, sg = pg.agg.balanced_params()
+            assert pg.agg.balanced_partitions() == 0
+            ref, _, _ = orc.gat_grouped(*orc.neighbor_grouping(hx.local_ptr, ch), hx.local_idx, att_ext, x_ext, n, H, seg=sg)
         assert_within(y, ref, scale[r0:r1], "gat rank %d/%d, restated order" % (r, world))
         assert np.all(y[np.diff(hx.local_ptr) == 0] == 0)
     assert seen == V
