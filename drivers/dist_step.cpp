@@ -5,8 +5,10 @@
 //     for r in 0 1 2 3 4 5 6 7; do RANK=$r WORLD_SIZE=8 LOCAL_RANK=$r ./dist_step.out --dataset products --datadir D \
 //         --feature-len 100 --idfile /tmp/gnnagg.id & done; wait
 // Every rank loads the graph, keeps ITS row slice (gnnagg_partition_rows + gnnagg_halo_plan_slice), exchanges the request
-// lists once (gnnagg_dist_alltoallv), then times `--iters` steps of  halo pull (gnnagg_dist_halo_exchange)  +  balanced
-// aggregation over [X_local ; X_halo].  One JSON line per rank on stderr; rank 0 also prints the slowest rank's time.
+// lists once (gnnagg_dist_alltoallv), then times `--iters` steps.  --plan overlap (default): ONE host call per step,
+// gnnagg_dist_step_gcn -- pack + grouped send / recv on the step's communication stream, the local-source edges beside it, the
+// halo-source edges after the join (GNNAGG_FLAG_ACCUMULATE).  --plan onepass: halo pull (gnnagg_dist_halo_exchange), then the
+// unchanged single-GPU kernel over [X_local ; X_halo].  One JSON line per rank on stderr; rank 0 also prints the slowest rank's time.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -49,7 +51,7 @@ static T *to_device(const std::vector<T> &h)
 
 int main(int argc, char **argv)
 {
-    std::string dataset, datadir = "../data/", idfile = "/tmp/gnnagg_dist.id";
+    std::string dataset, datadir = "../data/", idfile = "/tmp/gnnagg_dist.id", plan = "overlap";
     int feat = 128, iters = 20;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
@@ -58,9 +60,10 @@ int main(int argc, char **argv)
         else if (k == "--feature-len") feat = atoi(argv[i + 1]);
         else if (k == "--iters") iters = atoi(argv[i + 1]);
         else if (k == "--idfile") idfile = argv[i + 1];
+        else if (k == "--plan") plan = argv[i + 1];
         else { fprintf(stderr, "unknown flag %s\n", k.c_str()); return 2; }
     }
-    if (dataset.empty()) { fprintf(stderr, "usage: dist_step.out --dataset D [--datadir DIR] [--feature-len F] [--iters K] [--idfile PATH]\n"); return 2; }
+    if (dataset.empty()) { fprintf(stderr, "usage: dist_step.out --dataset D [--datadir DIR] [--feature-len F] [--iters K] [--idfile PATH] [--plan overlap|onepass]\n"); return 2; }
     const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), local_rank = env_int("LOCAL_RANK", 0);
     HCK(hipSetDevice(local_rank));
     gnnagg_set_abort_on_error(0);
@@ -121,13 +124,39 @@ int main(int argc, char **argv)
     HCK(hipMemcpy(d_x_ext, hx.data(), sizeof(float) * hx.size(), hipMemcpyHostToDevice));
     float *d_x_halo = d_x_ext + (size_t)n_local * feat;
 
-    gnnagg_handle agg = 0;
-    CK(gnnagg_gcn_create(d_ptr, d_idx, nullptr, n_local, nnz, &agg));
-    CK(gnnagg_set_stream(agg, stream));
-    CK(gnnagg_schedule_balanced(agg, 0));
+    gnnagg_handle agg = 0, agg_loc = 0, agg_rem = 0;
+    gnnagg_dist_step_t dstep = 0;
+    int *d_pl = nullptr, *d_il = nullptr, *d_pr = nullptr, *d_ir = nullptr;
+    if (plan == "overlap") {
+        // the rank's CSR as two: edges whose source is an owned row (columns = local rows) and edges whose source is a halo
+        // row (columns = halo slots); in-row order kept
+        std::vector<int> pl((size_t)n_local + 1, 0), pr((size_t)n_local + 1, 0), il, ir;
+        for (int r = 0; r < n_local; ++r) {
+            for (int e = lptr[r]; e < lptr[r + 1]; ++e) {
+                if (lidx[e] < n_local) il.push_back(lidx[e]);
+                else ir.push_back(lidx[e] - n_local);
+            }
+            pl[r + 1] = (int)il.size();
+            pr[r + 1] = (int)ir.size();
+        }
+        d_pl = to_device(pl); d_il = to_device(il); d_pr = to_device(pr); d_ir = to_device(ir);
+        CK(gnnagg_gcn_create(d_pl, d_il, nullptr, n_local, (int)il.size(), &agg_loc));
+        CK(gnnagg_gcn_create(d_pr, d_ir, nullptr, n_local, (int)ir.size(), &agg_rem));
+        CK(gnnagg_schedule_balanced(agg_loc, 0));
+        CK(gnnagg_schedule_balanced(agg_rem, 0));
+        CK(gnnagg_dist_step_create(comm, agg_loc, n_halo > 0 ? agg_rem : 0, d_send_ids, send_rows.data(), recv_rows.data(), &dstep));
+    } else {
+        CK(gnnagg_gcn_create(d_ptr, d_idx, nullptr, n_local, nnz, &agg));
+        CK(gnnagg_set_stream(agg, stream));
+        CK(gnnagg_schedule_balanced(agg, 0));
+    }
     auto step = [&] {
-        CK(gnnagg_dist_halo_exchange(comm, d_x_ext, d_send_ids, send_rows.data(), recv_rows.data(), feat, d_send, d_x_halo, stream));
-        CK(gnnagg_gcn_run(agg, d_x_ext, d_y, feat, GNNAGG_MODE_BALANCED, GNNAGG_REDUCE_SUM));
+        if (dstep) {
+            CK(gnnagg_dist_step_gcn(dstep, d_x_ext, d_x_halo, d_send, d_y, feat, GNNAGG_REDUCE_SUM, stream));
+        } else {
+            CK(gnnagg_dist_halo_exchange(comm, d_x_ext, d_send_ids, send_rows.data(), recv_rows.data(), feat, d_send, d_x_halo, stream));
+            CK(gnnagg_gcn_run(agg, d_x_ext, d_y, feat, GNNAGG_MODE_BALANCED, GNNAGG_REDUCE_SUM));
+        }
     };
     for (int i = 0; i < 3; ++i) step();
     HCK(hipStreamSynchronize(stream));
@@ -142,9 +171,9 @@ int main(int argc, char **argv)
     const double sec = ms * 1e-3 / iters;
     // a checksum of the halo rows against what their owners hold is the launcher's job at world > 1; at world == 1 there is
     // no halo and the step is the single-GPU aggregation
-    fprintf(stderr, "{\"rank\": %d, \"world\": %d, \"n_local\": %d, \"nnz_local\": %d, \"n_halo\": %d, \"n_send\": %lld, \"seconds\": %.9f, "
+    fprintf(stderr, "{\"plan\": \"%s\", \"rank\": %d, \"world\": %d, \"n_local\": %d, \"nnz_local\": %d, \"n_halo\": %d, \"n_send\": %lld, \"seconds\": %.9f, "
                     "\"edges_per_s\": %.6e, \"halo_bytes\": %.0f}\n",
-            rank, world, n_local, nnz, n_halo, n_send, sec, (double)nnz / sec, (double)n_halo * feat * 4.0);
+            plan.c_str(), rank, world, n_local, nnz, n_halo, n_send, sec, (double)nnz / sec, (double)n_halo * feat * 4.0);
     // the slowest rank bounds the step: gather the times on rank 0
     {
         std::vector<double> mine(1, sec), all((size_t)world, 0.0);
@@ -161,7 +190,10 @@ int main(int argc, char **argv)
         }
         (void)hipFree(d_m); (void)hipFree(d_all);
     }
-    CK(gnnagg_destroy(agg));
+    if (dstep) CK(gnnagg_dist_step_destroy(dstep));
+    if (agg) CK(gnnagg_destroy(agg));
+    if (agg_loc) CK(gnnagg_destroy(agg_loc));
+    if (agg_rem) CK(gnnagg_destroy(agg_rem));
     CK(gnnagg_dist_comm_destroy(comm));
     gnnagg_free_host(halo_ids); gnnagg_free_host(h_ptr); gnnagg_free_host(h_idx);
     if (rank == 0) remove(idfile.c_str());

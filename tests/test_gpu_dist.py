@@ -153,12 +153,13 @@ def test_dist_step_driver_single_rank(tmp_path):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")])
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    r = subprocess.run([exe, "--dataset", "tiny", "--datadir", d, "--feature-len", "64", "--iters", "5", "--idfile", d + "id"],
-                       capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")]
-    assert len(lines) == 2 and lines[0]["n_local"] == 5000 and lines[0]["n_halo"] == 0 and lines[0]["seconds"] > 0
-    assert lines[1]["summary"] == "slowest rank" and lines[1]["edges_per_s"] > 0
+    for plan in ("overlap", "onepass"):   # overlap: ONE host call per step (gnnagg_dist_step_gcn)
+        r = subprocess.run([exe, "--dataset", "tiny", "--datadir", d, "--feature-len", "64", "--iters", "5", "--idfile", d + "id", "--plan", plan],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")]
+        assert len(lines) == 2 and lines[0]["n_local"] == 5000 and lines[0]["n_halo"] == 0 and lines[0]["seconds"] > 0
+        assert lines[0]["plan"] == plan and lines[1]["summary"] == "slowest rank" and lines[1]["edges_per_s"] > 0
 
 
 def test_single_call_step_at_world_one_costs_what_a_launch_costs():
