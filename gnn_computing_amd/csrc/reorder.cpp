@@ -21,9 +21,12 @@
 // source is not part of the reference tree, so the candidate sets -- and therefore the exact permutation --
 // are not reproducible here ("parity unpinned" for reorder GENERATION).  Tests pin the
 // algorithmic contract instead: valid permutation, planted clusters recovered, cluster cap respected.
+#include <omp.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <queue>
 #include <unordered_map>
@@ -208,6 +211,230 @@ static void emit_cache_greedy(const int *ptr, const int *idx, int V, const std::
     }
 }
 
+// int -> T open-addressing hash map (linear probing, backward-shift deletion, power-of-two capacity): the walkers' candidate
+// tables see billions of operations on graphs of the products-shaped size, where std::unordered_map's node allocations cost 4x.
+template <class T>
+struct IntMap {
+    std::vector<int> keys;   // -1 = empty
+    std::vector<T> vals;
+    size_t mask = 0, n = 0;
+    explicit IntMap(size_t cap_pow2 = 1 << 16) : keys(cap_pow2, -1), vals(cap_pow2), mask(cap_pow2 - 1) {}
+    static size_t hash(int k) { return (size_t)((uint32_t)k * 2654435761u); }
+    T *find(int k)
+    {
+        for (size_t i = hash(k) & mask;; i = (i + 1) & mask) {
+            if (keys[i] == k) return &vals[i];
+            if (keys[i] < 0) return nullptr;
+        }
+    }
+    T *insert(int k, const T &v)   // k must not be present
+    {
+        if ((n + 1) * 2 > keys.size()) grow();
+        size_t i = hash(k) & mask;
+        while (keys[i] >= 0) i = (i + 1) & mask;
+        keys[i] = k; vals[i] = v; ++n;
+        return &vals[i];
+    }
+    void erase(int k)
+    {
+        size_t i = hash(k) & mask;
+        while (keys[i] != k) { if (keys[i] < 0) return; i = (i + 1) & mask; }
+        --n;
+        for (size_t j = (i + 1) & mask;; j = (j + 1) & mask) {   // backward shift: keep every probe sequence unbroken
+            if (keys[j] < 0) break;
+            const size_t home = hash(keys[j]) & mask;
+            if (((j - home) & mask) >= ((j - i) & mask)) { keys[i] = keys[j]; vals[i] = vals[j]; i = j; }
+        }
+        keys[i] = -1;
+    }
+    void grow()
+    {
+        std::vector<int> ok;
+        std::vector<T> ov;
+        ok.swap(keys); ov.swap(vals);
+        keys.assign(ok.size() * 2, -1); vals.resize(ok.size() * 2); mask = keys.size() - 1; n = 0;
+        for (size_t i = 0; i < ok.size(); ++i)
+            if (ok[i] >= 0) insert(ok[i], ov[i]);
+    }
+};
+
+// The same greedy with SEVERAL WALKERS (one per thread) for graphs where the serial pass takes minutes (products-shaped: 5.4
+// minutes of one core).  Every walker runs the serial algorithm with its OWN state -- its own LRU model of an L2, its own
+// scores and bucket queue (hash-mapped: only the clusters its cached sources vote for have an entry) -- and the walkers
+// share nothing but the read-only lists and one `placed` flag per cluster, taken with an atomic exchange when a walker pops
+// the cluster (a candidate somebody else placed meanwhile is dropped).  A walker without candidates takes the next unplaced
+// cluster in first-member order as a new seed.  The walkers' sequences are concatenated; source-less clusters follow.  (A
+// first version let a cluster be the candidate of ONE walker at a time so that the dense score arrays could be shared: a
+// popular source entering one walker's cache then claimed thousands of clusters all over the graph and hid them from the
+// walker they belonged to -- window footprint 0.44 serial, 0.49 / 0.54 / 0.63 with 2 / 4 / 8 walkers.)  The result depends
+// on thread timing (it is always a valid permutation); the single-walker path stays deterministic.
+static void emit_cache_greedy_parallel(const int *ptr, const int *idx, int V, const std::vector<std::vector<int>> &members,
+                                       int cache_rows, int walkers, int *rows_out)
+{
+    const int NC = (int)members.size();
+    const long E = ptr[V];
+    // cluster -> (source, multiplicity) and its transpose, as in emit_cache_greedy (built in parallel here)
+    std::vector<long> cp((size_t)NC + 1, 0);
+    std::vector<long> edges((size_t)NC);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int c = 0; c < NC; ++c) {
+        std::vector<int> tmp;
+        long e = 0;
+        for (int v : members[c])
+            if (ptr[v + 1] - ptr[v] <= kLongRow) { tmp.insert(tmp.end(), idx + ptr[v], idx + ptr[v + 1]); e += ptr[v + 1] - ptr[v]; }
+        std::sort(tmp.begin(), tmp.end());
+        long d = 0;
+        for (size_t a = 0; a < tmp.size();) { size_t b = a; while (b < tmp.size() && tmp[b] == tmp[a]) ++b; ++d; a = b; }
+        cp[c + 1] = d;
+        edges[c] = std::max(1L, e);
+    }
+    for (int c = 0; c < NC; ++c) cp[c + 1] += cp[c];
+    const long NZ = cp[NC];
+    std::vector<int> cs((size_t)NZ), cm((size_t)NZ);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int c = 0; c < NC; ++c) {
+        std::vector<int> tmp;
+        for (int v : members[c])
+            if (ptr[v + 1] - ptr[v] <= kLongRow) tmp.insert(tmp.end(), idx + ptr[v], idx + ptr[v + 1]);
+        std::sort(tmp.begin(), tmp.end());
+        long k = cp[c];
+        for (size_t a = 0; a < tmp.size();) {
+            size_t b = a;
+            while (b < tmp.size() && tmp[b] == tmp[a]) ++b;
+            cs[k] = tmp[a]; cm[k] = (int)(b - a); ++k;
+            a = b;
+        }
+    }
+    (void)E;
+    std::vector<long> tp((size_t)V + 1, 0);
+    for (long k = 0; k < NZ; ++k) ++tp[(size_t)cs[k] + 1];
+    for (int v = 0; v < V; ++v) tp[v + 1] += tp[v];
+    std::vector<int> tc((size_t)NZ), tm((size_t)NZ);
+    {
+        std::vector<long> cur(tp.begin(), tp.end() - 1);
+        for (int c = 0; c < NC; ++c)
+            for (long k = cp[c]; k < cp[c + 1]; ++k) {
+                const long pos = cur[cs[k]]++;
+                tc[pos] = c;
+                tm[pos] = cm[k];
+            }
+    }
+    constexpr int kBuckets = 128;
+    std::vector<char> placed((size_t)NC, 0);   // accessed through __atomic builtins
+    std::vector<std::vector<int>> seqs((size_t)walkers);
+    int seed_cursor = 0;   // shared, atomic
+#pragma omp parallel num_threads(walkers)
+    {
+        const int w = omp_get_thread_num();
+        std::vector<int> &out = seqs[w];
+        struct Cand { long score; int bprev, bnext, inb; };
+        IntMap<Cand> cand((size_t)1 << 20);    // clusters this walker's cached sources vote for
+        std::vector<int> bhead(kBuckets + 1, -1);
+        int top = -1;
+        // LRU over source rows of THIS walker: slots in a ring of cache_rows + 1 entries, key -> slot in a hash map
+        std::unordered_map<int, int> slot_of;
+        slot_of.reserve((size_t)cache_rows * 2);
+        std::vector<int> skey((size_t)cache_rows + 1), sprev((size_t)cache_rows + 1, -1), snext((size_t)cache_rows + 1, -1), free_slots;
+        for (int i = cache_rows; i >= 0; --i) free_slots.push_back(i);
+        int head = -1, tail = -1;
+        auto b_unlink = [&](int c, Cand &e) {
+            const int b = e.inb;
+            if (b < 0) return;
+            if (e.bprev >= 0) cand.find(e.bprev)->bnext = e.bnext; else bhead[b] = e.bnext;
+            if (e.bnext >= 0) cand.find(e.bnext)->bprev = e.bprev;
+            e.inb = -1;
+            (void)c;
+        };
+        auto b_link = [&](int c, Cand &e) {   // to the front of the bucket its score belongs to
+            const int b = e.score <= 0 ? -1 : (int)std::min<long>(e.score * kBuckets / edges[c], kBuckets);
+            if (b < 0) return;
+            e.bprev = -1; e.bnext = bhead[b];
+            if (bhead[b] >= 0) cand.find(bhead[b])->bprev = c;
+            bhead[b] = c;
+            e.inb = b;
+            if (b > top) top = b;
+        };
+        auto vote = [&](int s, int sign) {   // source s entered (+1) / left (-1) this walker's cache
+            if (tp[s + 1] - tp[s] > kHubCut) return;
+            for (long k = tp[s]; k < tp[s + 1]; ++k) {
+                const int c = tc[k];
+                if (__atomic_load_n(&placed[c], __ATOMIC_RELAXED)) continue;
+                Cand *e = cand.find(c);
+                if (!e) {
+                    if (sign < 0) continue;
+                    e = cand.insert(c, Cand{0, -1, -1, -1});
+                }
+                b_unlink(c, *e);
+                e->score += sign * (long)tm[k];
+                if (e->score <= 0) cand.erase(c);
+                else b_link(c, *e);
+            }
+        };
+        auto lru_unlink = [&](int sl) {
+            if (sprev[sl] >= 0) snext[sprev[sl]] = snext[sl]; else head = snext[sl];
+            if (snext[sl] >= 0) sprev[snext[sl]] = sprev[sl]; else tail = sprev[sl];
+        };
+        auto lru_front = [&](int sl) {
+            sprev[sl] = -1; snext[sl] = head;
+            if (head >= 0) sprev[head] = sl;
+            head = sl;
+            if (tail < 0) tail = sl;
+        };
+        auto touch = [&](int s) {
+            auto it = slot_of.find(s);
+            if (it != slot_of.end()) { lru_unlink(it->second); lru_front(it->second); return; }
+            const int sl = free_slots.back();
+            free_slots.pop_back();
+            skey[sl] = s;
+            slot_of.emplace(s, sl);
+            lru_front(sl);
+            vote(s, +1);
+            if ((int)slot_of.size() > cache_rows) {
+                const int old = tail;
+                lru_unlink(old);
+                const int so = skey[old];
+                slot_of.erase(so);
+                free_slots.push_back(old);
+                vote(so, -1);
+            }
+        };
+        for (;;) {
+            int c = -1;
+            for (;;) {   // best candidate nobody else has placed meanwhile
+                while (top >= 0 && bhead[top] < 0) --top;
+                if (top < 0) break;
+                const int t = bhead[top];
+                b_unlink(t, *cand.find(t));
+                cand.erase(t);
+                if (!__atomic_exchange_n(&placed[t], (char)1, __ATOMIC_ACQ_REL)) { c = t; break; }
+            }
+            if (c < 0) {   // no candidate related to this walker's cache: a new seed from the unplaced pool
+                for (;;) {
+                    const int sd = __atomic_fetch_add(&seed_cursor, 1, __ATOMIC_RELAXED);
+                    if (sd >= NC) break;
+                    if (cp[sd] == cp[sd + 1]) continue;   // source-less clusters are written last
+                    if (!__atomic_exchange_n(&placed[sd], (char)1, __ATOMIC_ACQ_REL)) { c = sd; break; }
+                }
+                if (c < 0) break;
+                if (Cand *e = cand.find(c)) { b_unlink(c, *e); cand.erase(c); }
+            }
+            out.push_back(c);
+            for (long k = cp[c]; k < cp[c + 1]; ++k) touch(cs[k]);
+        }
+    }
+    int pos = 0;
+    for (int w = 0; w < walkers; ++w)
+        for (int c : seqs[w])
+            for (int v : members[c]) rows_out[pos++] = v;
+    long left = 0;
+    for (int c = 0; c < NC; ++c)
+        if (!placed[c]) {   // the source-less clusters, in first-member order
+            ++left;
+            for (int v : members[c]) rows_out[pos++] = v;
+        }
+    if (getenv("GNNAGG_REORDER_DEBUG")) fprintf(stderr, "parallel greedy: %d walkers, %d clusters, %ld left for the tail\n", walkers, NC, left);
+}
+
 int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int num_perm, int cap, uint64_t seed,
                     int max_bucket, int *rows_out, int *num_clusters_out, int order_mode, int cache_rows)
 {
@@ -318,7 +545,13 @@ int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int
         members[first_pos[ro]].push_back(i);
     }
     if (order_mode == 1) {
-        emit_cache_greedy(ptr, idx, V, members, cache_rows, rows_out);
+        // several walkers from the size on where the serial pass takes tens of seconds (GNNAGG_REORDER_WALKERS: 1 = always the
+        // deterministic serial pass, N = N walkers)
+        const int walkers_env = getenv("GNNAGG_REORDER_WALKERS") ? atoi(getenv("GNNAGG_REORDER_WALKERS")) : 0;  // (read per call: tests switch it)
+        int walkers = walkers_env > 0 ? walkers_env : (ptr[V] >= 20000000 ? std::min(omp_get_max_threads(), 64) : 1);
+        walkers = std::max(1, std::min(walkers, (int)members.size() / 4096 + 1));
+        if (walkers > 1) emit_cache_greedy_parallel(ptr, idx, V, members, cache_rows, walkers, rows_out);
+        else emit_cache_greedy(ptr, idx, V, members, cache_rows, rows_out);
     } else {
         int pos = 0;
         for (auto &mset : members) for (int v : mset) rows_out[pos++] = v;

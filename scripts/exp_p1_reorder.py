@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """P1 (products-shaped GCN F=100, one GPU) with the locality reorder applied on load.  The cache-aware greedy order of this
-124 M-edge graph takes 5.4 minutes of one CPU core (gnnagg_cluster_reorder_ex, order_mode 1, cluster_cap 1, 8192 cache rows),
-so it is computed off-line and passed in like a <dset>.reorder_thres_0.2 file:
-    python -c "import numpy as np, gnn_computing_amd as g; p, i = g.graph.dataset('products'); \\
-               np.save('scripts/cache/products_greedy_rows.npy', g.cluster_reorder(p.numpy(), i.numpy(), order='cache_greedy', cluster_cap=1, cache_rows=8192)[0])"
-The graph is generated on the CPU here (the CPU and GPU generators of torch draw different graphs for the same seed)."""
+124 M-edge graph (gnnagg_cluster_reorder_ex, order_mode 1, cluster_cap 1, 8192 cache rows) took 5.4 minutes of one core in
+round 2; round 3 runs it with one walker per thread (reorder.cpp, emit_cache_greedy_parallel): computed here, on the box's host
+cores, and timed.  GNNAGG_REORDER_WALKERS=1 gives the serial pass.  The graph is generated on the CPU (the CPU and GPU
+generators of torch draw different graphs for the same seed)."""
+import time
 import json
 import os
 import sys
@@ -45,7 +45,10 @@ def run(ptr, idx, tag):
 
 
 run(ptr, idx, "plain (as generated)")
-rows = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "products_greedy_rows.npy"))
-assert len(rows) == V
+t0 = time.perf_counter()
+rows, _ = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=8192)
+print(json.dumps({"reorder_generator_s": time.perf_counter() - t0, "host_threads": os.cpu_count(),
+                  "walkers": os.environ.get("GNNAGG_REORDER_WALKERS", "auto (min(threads, 64))")}), flush=True)
+assert len(rows) == V and np.array_equal(np.sort(rows), np.arange(V))
 nptr, nidx, _ = gnc.reorder_csr(ptr, idx, rows)
 run(nptr, nidx, "cache-aware greedy reorder applied on load")
