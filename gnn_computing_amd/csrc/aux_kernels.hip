@@ -392,6 +392,117 @@ __global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, c
     }
 }
 
+// Wide-N variant (N > 64: the 512 -> 128 layer of the 3-layer models): a workgroup owns a 128 x 128 output tile, so A is read
+// from HBM once whatever N is (k_dense_nn re-reads it per 32-column block), and every wavefront owns 64 x 64 of it -- four 32 x 32
+// accumulators, 64 registers: a k-step of 2 feeds 4 MFMAs from 4 operand reads (k_dense_nn: 1 MFMA from 2), which is what the
+// matrix pipe needs to stay busy (k_dense_nn: 59 TFLOP/s on 169 343 x 512 @ 512 x 128, rocBLAS 89).  K in chunks of 32 through a
+// double-buffered LDS image (A: pitch 33, B: as is): the next chunk's global loads are in flight during the current chunk's 64
+// MFMAs, one barrier per chunk.  Every accumulator is still one ascending-k chain of v_mfma_f32_32x32x2_f32 steps: bit-exact
+// against the oracle's GEMM like the other two kernels.
+static constexpr int kBigT = 128, kBigKC = 32, kBigPA = 33;
+
+template <bool VEC>   // VEC: K % 4 == 0, N % 4 == 0, A and B 16-byte aligned -- every 4-float piece is one aligned load
+__global__ __launch_bounds__(256, 2) void k_dense_nn_big(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                         int M, int N, int K)
+{
+    extern __shared__ float big_lds[];
+    float *As0 = big_lds, *As1 = big_lds + kBigT * kBigPA, *Bs0 = big_lds + 2 * kBigT * kBigPA, *Bs1 = Bs0 + kBigKC * kBigT;
+    const int row0 = blockIdx.x * kBigT, col0 = blockIdx.y * kBigT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float4 ra[4], rb[4];
+    // global -> registers: A chunk [128 rows][32 k]: thread t rows t/8 + 32 j, floats (t % 8) * 4; B chunk [32 k][128 cols]:
+    // thread t k-rows t/32 + 8 j, floats (t % 32) * 4.  Branch-free: out-of-range pieces are loaded from a clamped (valid)
+    // address and replaced by zeros, so the eight loads of a chunk are issued back to back (with per-piece branches the compiler
+    // put a wait behind every load and the fetch, not the matrix pipe, set the pace)
+    auto piece = [&](const float *base, long pitch, int r, int rmax, int c, int cmax) -> float4 {
+        const int rc = r < rmax ? r : rmax - 1;
+        float4 v;
+        if (VEC) {
+            const int cc = c < cmax ? c : cmax - 4;
+            v = *reinterpret_cast<const float4 *>(base + (size_t)rc * pitch + cc);
+            // (a bit mask, not a select: the compiler turns `cond ? 0 : load` into a branch around the load)
+            const unsigned keep = (r < rmax && c < cmax) ? 0xffffffffu : 0u;
+            v.x = __uint_as_float(__float_as_uint(v.x) & keep); v.y = __uint_as_float(__float_as_uint(v.y) & keep);
+            v.z = __uint_as_float(__float_as_uint(v.z) & keep); v.w = __uint_as_float(__float_as_uint(v.w) & keep);
+        } else {
+            const float *src = base + (size_t)rc * pitch;
+            const int c0 = c < cmax ? c : cmax - 1, c1 = c + 1 < cmax ? c + 1 : cmax - 1, c2 = c + 2 < cmax ? c + 2 : cmax - 1,
+                      c3 = c + 3 < cmax ? c + 3 : cmax - 1;
+            v = make_float4(src[c0], src[c1], src[c2], src[c3]);
+            const bool rok = r < rmax;
+            v.x = __uint_as_float(__float_as_uint(v.x) & ((rok && c < cmax) ? 0xffffffffu : 0u));
+            v.y = __uint_as_float(__float_as_uint(v.y) & ((rok && c + 1 < cmax) ? 0xffffffffu : 0u));
+            v.z = __uint_as_float(__float_as_uint(v.z) & ((rok && c + 2 < cmax) ? 0xffffffffu : 0u));
+            v.w = __uint_as_float(__float_as_uint(v.w) & ((rok && c + 3 < cmax) ? 0xffffffffu : 0u));
+        }
+        return v;
+    };
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = piece(A, K, row0 + (threadIdx.x >> 3) + 32 * j, M, k0 + (threadIdx.x & 7) * 4, K);
+            rb[j] = piece(B, N, k0 + (threadIdx.x >> 5) + 8 * j, K, col0 + (threadIdx.x & 31) * 4, N);
+        }
+    };
+    auto stash = [&](float *As, float *Bs) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float *da = As + ((threadIdx.x >> 3) + 32 * j) * kBigPA + (threadIdx.x & 7) * 4;
+            da[0] = ra[j].x; da[1] = ra[j].y; da[2] = ra[j].z; da[3] = ra[j].w;
+            *reinterpret_cast<float4 *>(Bs + ((threadIdx.x >> 5) + 8 * j) * kBigT + (threadIdx.x & 31) * 4) = rb[j];
+        }
+    };
+    fetch(0);
+    stash(As0, Bs0);
+    __syncthreads();
+    const int nchunks = (K + kBigKC - 1) / kBigKC;
+    for (int c = 0; c < nchunks; ++c) {
+        const float *As = (c & 1) ? As1 : As0, *Bs = (c & 1) ? Bs1 : Bs0;
+        if (c + 1 < nchunks) fetch((c + 1) * kBigKC);   // in flight during this chunk's MFMAs
+        const float *ap = As + (wr + (lane & 31)) * kBigPA + (lane >> 5);
+        const float *bp = Bs + (lane >> 5) * kBigT + wc + (lane & 31);
+        // all operands of the chunk into registers first (2 wavefronts per SIMD: 256 VGPRs each), then 64 MFMAs back to back:
+        // with just-in-time operand reads the matrix pipe waited on LDS latency every other instruction
+        float a0[kBigKC / 2], a1[kBigKC / 2], b0[kBigKC / 2], b1[kBigKC / 2];
+#pragma unroll
+        for (int t = 0; t < kBigKC / 2; ++t) {
+            a0[t] = ap[2 * t]; a1[t] = ap[32 * kBigPA + 2 * t];
+            b0[t] = bp[2 * t * kBigT]; b1[t] = bp[2 * t * kBigT + 32];
+        }
+#pragma unroll
+        for (int t = 0; t < kBigKC / 2; ++t) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) stash((c & 1) ? As0 : As1, (c & 1) ? Bs0 : Bs1);   // the other buffer: last read in chunk c - 1
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wc + 32 * j + (lane & 31);
+            if (col < N) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = row0 + wr + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    if (row < M) C[(size_t)row * N + col] = acc[i][j][reg];
+                }
+            }
+        }
+}
+
 // Tall-skinny variant for the aggregation widths (K <= 128, K % 4 == 0): every wavefront keeps its B operands -- the
 // whole W[K, 32] column block, 64 VGPRs -- in registers for the life of the kernel and walks 32-row tiles of A on its own:
 // 16 coalesced 16-byte loads per lane fetch the NEXT tile while the current one is multiplied; the tile passes through a
@@ -498,6 +609,23 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
     if (K <= 0) {
         HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream));
         return GNNAGG_OK;
+    }
+    {
+        static const int big = getenv("GNNAGG_GEMM_BIG") ? atoi(getenv("GNNAGG_GEMM_BIG")) : 1;
+        if (big && N > 64 && M >= 1024) {   // wide outputs: 128 x 128 tiles, A read once (k_dense_nn_big)
+            const size_t lds = (size_t)(2 * kBigT * kBigPA + 2 * kBigKC * kBigT) * sizeof(float);
+            static bool attr_ok = false;
+            if (!attr_ok) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_ok = true;
+            }
+            const bool vec = (K & 3) == 0 && (N & 3) == 0 && K >= 4 && N >= 4 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
+            if (vec) hipLaunchKernelGGL(k_dense_nn_big<true>, dim3(ceil_div(M, kBigT), ceil_div(N, kBigT)), dim3(256), lds, stream, A, B, C, M, N, K);
+            else     hipLaunchKernelGGL(k_dense_nn_big<false>, dim3(ceil_div(M, kBigT), ceil_div(N, kBigT)), dim3(256), lds, stream, A, B, C, M, N, K);
+            HIP_TRY(hipGetLastError());
+            return GNNAGG_OK;
+        }
     }
     const dim3 grid(ceil_div(M, kGemmRows), ceil_div(N, kGemmCols));
     hipLaunchKernelGGL(k_dense_nn, grid, dim3(256), 0, stream, A, B, C, M, N, K);

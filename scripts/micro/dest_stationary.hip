@@ -194,17 +194,15 @@ int main(int argc, char **argv)
     struct Case { const char *name; int nt; int pfid; int wg_per_cu; int rows_lds; long slice; int per_span; int jit; int slack; int waves; int glen; int mode; int samewin; };
     std::vector<Case> cases;
     cases.push_back({"1 range free-running   ", 512, 0, 2, 256, 2 << 20, 256, 0, 0, 60, 32, 0, 1});
-    for (int pfid : {0, 1})
-        for (int mode : {0, 1, 2, 3})
-            for (int jit : {0, 20})
-                cases.push_back({"same window            ", 512, pfid, 2, 256, 2L << 20, 256, jit, 1, 4, 32, mode, 1});
-    for (long slice : {4L << 20, 2L << 20, 1L << 20})
-        for (int slack : {0, 1})
-            for (int jit : {0, 20})
-                cases.push_back({"sweep                  ", 512, 1, 2, 256, slice, 256, jit, slack, 2, 32, 3, 0});
-    cases.push_back({"sweep 4x256thr 32 KB   ", 256, 1, 4, 128, 2L << 20, 256, 20, 1, 2, 32, 3, 0});
-    cases.push_back({"sweep 4x256thr 32 KB   ", 256, 1, 4, 128, 2L << 20, 256, 20, 0, 2, 32, 3, 0});
-    cases.push_back({"sweep 3x512thr 48 KB   ", 512, 1, 3, 192, 2L << 20, 256, 20, 1, 2, 32, 3, 0});
+    // what the real reddit-shaped case offers: (rows per lane group) x (edges per (row, range)) edges per span and phase
+    for (int jit : {0, 20}) {
+        cases.push_back({"sweep 2x512thr span 128", 512, 0, 2, 256, 2L << 20, 128, jit, 1, 2, 16, 3, 0});
+        cases.push_back({"sweep 2x512thr span 256", 512, 0, 2, 256, 2L << 20, 256, jit, 1, 2, 16, 3, 0});
+        cases.push_back({"sweep 2x256thr span 256", 256, 0, 2, 256, 2L << 20, 256, jit, 1, 2, 16, 3, 0});
+        cases.push_back({"sweep 2x256thr span 512", 256, 0, 2, 256, 4L << 20, 512, jit, 1, 2, 32, 3, 0});
+        cases.push_back({"sweep 2x512thr span 256 4MB", 512, 0, 2, 256, 4L << 20, 256, jit, 1, 2, 32, 3, 0});
+        cases.push_back({"sweep 1x1024.. n/a        ", 512, 0, 1, 512, 2L << 20, 256, jit, 1, 2, 16, 3, 0});
+    }
     size_t ids_cap = 0;
     unsigned *ids = nullptr, *cnt = nullptr; float *x = nullptr, *y = nullptr;
     CK(hipMalloc(&x, (size_t)64 * (4 << 20)));

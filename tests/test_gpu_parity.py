@@ -559,6 +559,17 @@ def test_matmul_nn_bit_exact(M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), A.astype(np.float64) @ B.astype(np.float64), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(1500, 128, 512), (1100, 100, 70), (2049, 200, 33), (1024, 65, 1), (3000, 129, 602)])
+def test_matmul_nn_wide_kernel_bit_exact(M, N, K):
+    """The wide-output kernel (k_dense_nn_big: 128 x 128 tiles, 64 x 64 per wavefront, double-buffered K chunks; taken for N > 64,
+    M >= 1024 -- the 512 -> 128 layer): ragged M / N / K, unaligned rows, still the oracle's ascending-k chain bit for bit."""
+    A, B = rand((M, K), 1), rand((K, N), 2)
+    C = gnc.matmul_NN(dev(A), dev(B))
+    torch.cuda.synchronize()
+    assert np.array_equal(C.cpu().numpy(), orc.matmul_nn(A, B))
+    np.testing.assert_allclose(C.cpu().numpy(), A.astype(np.float64) @ B.astype(np.float64), rtol=1e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("M,N,K", [(500001, 33, 100), (520000, 32, 128), (500017, 7, 68)])
 def test_matmul_nn_tall_kernel_bit_exact(M, N, K):
     """The large-M kernel (k_dense_nn_tall: W held in registers, per-wavefront tiles, taken for M >= 500 k and 64 < K <= 128):
