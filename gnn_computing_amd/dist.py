@@ -284,6 +284,10 @@ class PartitionedGCN:
 
     def _set_aux(self, reduce):
         """what the two passes need to know about each other's rows (gnnagg_set_row_aux)"""
+        kind = reduce if reduce in ("mean", "max") else "sum"
+        if getattr(self, "_aux_kind", None) == kind:
+            return            # (two host calls saved per step: the step is a handful of launches)
+        self._aux_kind = kind
         if reduce == "mean":
             self.agg_loc.set_row_aux(self.deg_total)
             self.agg_rem.set_row_aux(self.deg_total)

@@ -10,7 +10,9 @@
  * evaluates it: fp32, one fused multiply-add per edge, accumulation in CSR order
  * (nvcc --use_fast_math contracts `rs += a * b` into an FMA, CMakeLists.txt:40).
  *
- * PARITY PINNING: the reference ships no tests, golden vectors or CPU compute path (SURVEY.md
+ * PARITY PINNING -- by the letter of the rule "parity unpinned": the reference has no golden vectors and cannot be built with its
+ * own toolchain here (CUDA); what follows anchors this file on the reference's sources PORTED by hipify-perl, the strongest anchor
+ * obtainable on this pool.  The reference ships no tests, golden vectors or CPU compute path (SURVEY.md
  * section 4).  This oracle is pinned against the REFERENCE ITSELF: oracle/ref_build.sh translates
  * the reference's sources where they lie with ROCm's hipify-perl and compiles them for gfx950
  * (oracle/_ref/libref_gnn.so, git-ignored; oracle/ref_shim.hip are the C entry points).
