@@ -498,3 +498,87 @@ def test_forced_partition_count_is_clamped_to_the_column_count():
     gat.run(dev(xg), dev(att), y, 128, "balanced")
     ref = orc.gat_fused(ptr, idx, att, xg)
     assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, xg, 1) + np.abs(ref), "clamped partitions, gat")
+
+
+def _split_edges(ptr, idx, val, seed, frac=0.4):
+    """two CSRs over the same rows: a random `frac` of every row's edges and the rest, in-row order kept"""
+    rng = np.random.default_rng(seed)
+    first = rng.random(len(idx)) < frac
+    rows = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+
+    def sub(mask):
+        p = np.zeros(len(ptr), np.int32)
+        p[1:] = np.cumsum(np.bincount(rows[mask], minlength=len(ptr) - 1))
+        return p, idx[mask].astype(np.int32), (None if val is None else val[mask])
+    return sub(first), sub(~first)
+
+
+@pytest.mark.parametrize("F", [128, 100, 30])
+@pytest.mark.parametrize("chunk", [0, 8])
+def test_two_pass_mean_and_max_with_row_aux_on_hub_rows(F, chunk):
+    """gnnagg_set_row_aux (the row-partitioned step's two passes) on every finishing site of the plan kernel: short rows,
+    single-segment long rows, hubs folded by the last segment workgroup to arrive, and -- with the in-kernel fold switched off -- the
+    ordered combine.  Mean: both passes divide by the row's TOTAL degree and add; max: the second pass joins only where the first
+    folded an edge.  Restated exactly with the oracle's grouped fold of each half."""
+    V, E = 3000, 120000
+    ptr, idx = hub_graph(V, E, seed=21, alpha=1.0)      # rows with thousands of edges: segments and hubs in both halves
+    val, x = rand(E, 2), rand((V, F), 1)
+    (pa, ia, va), (pb, ib, vb) = _split_edges(ptr, idx, val, seed=5)
+    deg_tot, deg_a = dev(np.diff(ptr).astype(np.int32)), dev(np.diff(pa).astype(np.int32))
+    for inkernel in (1, 0):
+        a = gnc.Aggregator_GCN(dev(pa), dev(ia), dev(va), F, F)
+        b = gnc.Aggregator_GCN(dev(pb), dev(ib), dev(vb), F, F)
+        for h in (a, b):
+            h.set_option("inkernel_combine", inkernel)
+            h.set_option("partitions", 0)
+            h.schedule_balanced(chunk)
+        ca, sa = a.balanced_params()
+        cb, sb = b.balanced_params()
+        ya = orc.gcn_grouped(*orc.neighbor_grouping(pa, ca), ia, va, x, V, seg=sa)
+        yb = orc.gcn_grouped(*orc.neighbor_grouping(pb, cb), ib, vb, x, V, seg=sb)
+        has_b = (np.diff(pb) > 0)[:, None]
+        d = np.maximum(np.diff(ptr), 1)[:, None].astype(np.float32)
+        y = torch.full((V, F), 7.0, device=DEV)
+        a.set_row_aux(deg_tot)
+        b.set_row_aux(deg_tot)
+        a.run(dev(x), y, 512, "balanced", reduce="mean")
+        b.run(dev(x), y, 512, "balanced", reduce="mean", accumulate=True)
+        has_a = (np.diff(pa) > 0)[:, None]
+        want = np.where(has_a, ya / d, 0.0).astype(np.float32)
+        want = np.where(has_b, want + (yb / d).astype(np.float32), want)
+        assert np.array_equal(y.cpu().numpy(), want), ("mean", inkernel)
+        assert_within(y.cpu().numpy(), orc.gcn_seq(ptr, idx, val, x) / d, orc.gcn_abs_scale(ptr, idx, val, x) / d, "two-pass mean")
+        a.set_row_aux(None)
+        b.set_row_aux(deg_a)
+        a.run(dev(x), y, 512, "balanced", reduce="max")
+        b.run(dev(x), y, 512, "balanced", reduce="max", accumulate=True)
+        assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, val, x)), ("max", inkernel)
+        b.set_row_aux(None)      # without the array a mean / max accumulate is refused, a sum is what it always was
+        with pytest.raises(Exception):
+            b.run(dev(x), y, 512, "balanced", reduce="max", accumulate=True)
+        a.run(dev(x), y, 512, "balanced")
+        b.run(dev(x), y, 512, "balanced", accumulate=True)
+        assert np.array_equal(y.cpu().numpy(), np.where(has_b, ya + yb, ya))
+
+
+@pytest.mark.parametrize("F,H", [(128, 1), (256, 8), (64, 2)])
+def test_two_pass_gat_on_hub_rows(F, H):
+    """gnnagg_gat_run_part: numerators and denominators of one half of every row's edges, then the other half added and the rows
+    divided -- on short rows, segments and hubs -- against the fused single pass and the oracle."""
+    V, E = 3000, 120000
+    ptr, idx = hub_graph(V, E, seed=22, alpha=1.0)
+    x, att = rand((V, F), 1), rand((V, H, 2), 3) * 0.4
+    (pa, ia, _), (pb, ib, _) = _split_edges(ptr, idx, None, seed=6)
+    a, b = gnc.Aggregator_GAT(dev(pa), dev(ia), F, F), gnc.Aggregator_GAT(dev(pb), dev(ib), F, F)
+    y, den = torch.full((V, F), 7.0, device=DEV), torch.full((V, H), 7.0, device=DEV)
+    a.run_part(dev(x), dev(att), y, den, 1, heads=H)
+    _, _, (na, da) = orc.gat_grouped(*orc.neighbor_grouping(pa, a.balanced_params()[0]), ia, att, x, V, H, seg=a.balanced_params()[1], parts=True)
+    assert np.allclose(den.cpu().numpy(), da, rtol=1e-5, atol=1e-6)          # part 1 leaves raw numerators / denominators
+    num_scale = (gat_scale(pa, ia, att, x, H).astype(np.float64) * np.repeat(da, F // H, axis=1)).astype(np.float32)   # sum_e w_e |x_e|
+    assert_within(y.cpu().numpy(), na.astype(np.float32), 2 * num_scale + 1e-6, "two-pass gat, numerators")
+    b.run_part(dev(x), dev(att), y, den, 2, heads=H)
+    ref = orc.gat_fused(ptr, idx, att, x, H)
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "two-pass gat")
+    assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0)
+    with pytest.raises(Exception):
+        a.run_part(dev(x), dev(att), y, den, 3, heads=H)
