@@ -1,0 +1,238 @@
+// agg_ds.hip -- GCN / GraphSAGE aggregation in the 2-D blocked order, DESTINATION-STATIONARY form (option "dest_stationary",
+// default off: an experiment of round 3, VERDICT r2 item 1 -- see DESIGN.md section 4 for what it measured).
+//
+// The streaming form (agg_span.hip) flushes one partial row per (row, source range, column tile) and k_combine_groups adds them
+// in a second pass.  Here the partial rows never leave the chip: a persistent workgroup owns a UNIT -- RB output rows of one
+// 64-float column tile -- keeps their accumulators in LDS, and sweeps the P source ranges in ascending order ("phases"); in a
+// phase its lane groups walk the unit's edges of that range (spans of the permuted edge list, ids in coalesced windows, DPP row
+// broadcasts, 8 tile-row gathers per batch) and add every finished group -- a (row, range) sub-row, cut every NG edges -- into
+// the row's LDS accumulator.  So that the L2 of an XCD still holds ONE slice of the tiled image of X at a time, all workgroups
+// of an XCD run the same column tile and are kept within `slack` phases of each other by one arrival counter per (XCD, phase):
+// fire-and-forget atomic add at the end of a phase, the counter of phase q - 1 - slack requested at the START of phase q and
+// only re-read (bounded spin) when that early value says "not yet".  The counters are a performance device only: no result
+// depends on them, and the spin is bounded, so progress never depends on the workgroups being co-resident.
+//
+// Summation order: exactly the groups of the reference's localityNeighborGrouping arrays (graph_schedule.h:156-243), each an FMA
+// chain from 0 in list order, folded into the row in ascending group order -- the order of k_combine_groups, restated by
+// orc_locality_schedule + orc_gcn_grouped_seg(seg = 0), bit-exact.  A sub-row longer than a span continues in the next lane
+// group(s): its first group is added directly by the lane group that holds it, the continuation groups at the head of the later
+// spans go to slots of the workgroup's staging pool (numbered by the host in group order, 64 per unit and phase) and lane group 0
+// adds them after the phase's barrier in slot order = ascending group order.
+#include "kernel_util.cuh"
+
+namespace gnnagg {
+
+static constexpr unsigned kDsLast = 0x80000000u;   // id word: last edge of its group
+static constexpr unsigned kDsStaged = 0x40000000u; // (with kDsLast) continuation group: the sum goes to the lane group's staging slot
+static constexpr int kDsRowShift = 21;             // bits 29..21: LDS row (<= 512 rows per unit); bits 20..0: row inside the range
+static constexpr unsigned kDsIdMask = 0x1fffffu;
+
+struct DsArgs {
+    const unsigned *idw;  // edge words, (unit, phase, lane group)-major
+    const float *val;     // edge values in the same order, or nullptr (implicit 1)
+    const int *dsp;       // [(U * P) * (LG + 1)] span bounds
+    const int *dstage;    // [(U * P) * (LG + 1)] first staging-pool slot of every span; last entry: slots used by the (unit, range)
+    const int *urows;     // [U * RB] global row of every LDS row, -1 = unused
+    const int *row_ptr;   // CSR ptr (degrees for mean)
+    const float *xt;      // tiled image of X: [T][cols][64]
+    float *y;
+    unsigned *cnt;        // [8][n_waves * P] arrival counters, zero on entry
+    int U, P, T, RB, WPX, n_jobs, n_waves, feat, mean, relu, yvec, width, slack, spin_limit;
+    long x_tile_stride;   // floats between tile images
+};
+
+template <int SRC>
+__device__ __forceinline__ unsigned ds_bcast(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x150 + SRC, 0xf, 0xf, true);
+}
+template <int SRC>
+__device__ __forceinline__ float ds_bcastf(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + SRC, 0xf, 0xf, true));
+}
+
+template <int NT, bool HAS_VAL>
+__global__ __launch_bounds__(NT) void k_gcn_ds(const DsArgs a)
+{
+    extern __shared__ float ds_lds[];
+    constexpr int LG = NT / 16;
+    float *rows = ds_lds;                                   // [RB][64]
+    float *stage = ds_lds + (size_t)a.RB * 64;              // [LG][kDsStage][64]
+    int *staged_row = reinterpret_cast<int *>(stage + (size_t)LG * kDsStage * 64);  // [LG][kDsStage]
+    const int lane = threadIdx.x & 15, lg = threadIdx.x >> 4;
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int F = a.feat;
+    const unsigned lane_boff = (unsigned)lane * 16u;
+    for (int w = 0; w < a.n_waves; ++w) {
+        const long job = ((long)w * 8 + xcd) * a.WPX + slot;
+        const bool active = job < a.n_jobs;   // workgroup-uniform; idle workgroups still take part in the flow control
+        const int tile = active ? (int)(job / a.U) : 0, u = active ? (int)(job % a.U) : 0;
+        const int col = tile * 64 + lane * 4;
+        const bool col_ok = active && col < F;
+        for (int i = threadIdx.x; i < a.RB * 16; i += NT) reinterpret_cast<float4 *>(rows)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x < LG * kDsStage) staged_row[threadIdx.x] = -1;
+        __syncthreads();
+        const char *xtile = reinterpret_cast<const char *>(a.xt + (size_t)tile * a.x_tile_stride);
+        for (int p = 0; p < a.P; ++p) {
+            const int gq = w * a.P + p;   // phase index of this XCD's sequence
+            unsigned early = 0;
+            const int wq = gq - 1 - a.slack;
+            if (threadIdx.x == 0 && wq >= 0)
+                early = __hip_atomic_load(&a.cnt[(size_t)xcd * a.n_waves * a.P + wq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (active) {
+                const int *sp = a.dsp + ((size_t)u * a.P + p) * (LG + 1) + lg;
+                const int e0 = sp[0], e1 = sp[1];
+                const char *xr = xtile + (size_t)p * a.width * 256;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                int nstaged = a.dstage[((size_t)u * a.P + p) * (LG + 1) + lg];   // this span's first slot of the workgroup's staging pool
+                unsigned cur = e0 + lane < e1 ? a.idw[e0 + lane] : 0u;
+                float curw = 1.0f;
+                if (HAS_VAL && e0 + lane < e1) curw = a.val[e0 + lane];
+                auto finish_group = [&](unsigned sid) {
+                    if (sid & kDsStaged) {   // continuation of a sub-row that began in an earlier span: ordered behind it after the barrier
+                        if (col_ok) *reinterpret_cast<float4 *>(stage + (size_t)nstaged * 64 + lane * 4) = acc;
+                        if (lane == 0) staged_row[nstaged] = (int)((sid >> kDsRowShift) & 0x1ffu);
+                        ++nstaged;
+                    } else if (col_ok) {
+                        float4 *pl = reinterpret_cast<float4 *>(rows + (size_t)((sid >> kDsRowShift) & 0x1ffu) * 64 + lane * 4);
+                        float4 t = *pl;
+                        t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+                        *pl = t;
+                    }
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                };
+                for (int cb = e0; cb < e1; cb += 16) {
+                    unsigned nxt = 0u;
+                    float nxtw = 1.0f;
+                    if (cb + 16 + lane < e1) {
+                        nxt = a.idw[cb + 16 + lane];
+                        if (HAS_VAL) nxtw = a.val[cb + 16 + lane];
+                    }
+                    const int n = e1 - cb < 16 ? e1 - cb : 16;
+                    if (n == 16) {
+                        static_for<2>([&](auto hc) {
+                            constexpr int J = decltype(hc)::value * 8;
+                            float4 xv[8];
+                            static_for<8>([&](auto uc) {
+                                constexpr int uu = decltype(uc)::value;
+                                const unsigned sid = ds_bcast<J + uu>(cur);
+                                if (col_ok) xv[uu] = *reinterpret_cast<const float4 *>(xr + (((sid & kDsIdMask) << 8) | lane_boff));
+                            });
+                            static_for<8>([&](auto uc) {
+                                constexpr int uu = decltype(uc)::value;
+                                const unsigned sid = ds_bcast<J + uu>(cur);
+                                // (the DPP reads stay outside the col_ok branch: a lane switched off by the branch reads as 0 when it
+                                // is the SOURCE of a row broadcast)
+                                const float wv = HAS_VAL ? ds_bcastf<J + uu>(curw) : 1.0f;
+                                if (col_ok) {
+                                    if (HAS_VAL) {
+                                        acc.x = __builtin_fmaf(xv[uu].x, wv, acc.x); acc.y = __builtin_fmaf(xv[uu].y, wv, acc.y);
+                                        acc.z = __builtin_fmaf(xv[uu].z, wv, acc.z); acc.w = __builtin_fmaf(xv[uu].w, wv, acc.w);
+                                    } else {
+                                        acc.x += xv[uu].x; acc.y += xv[uu].y; acc.z += xv[uu].z; acc.w += xv[uu].w;
+                                    }
+                                }
+                                if (sid & kDsLast) finish_group(sid);
+                            });
+                        });
+                    } else {
+                        for (int j = 0; j < n; ++j) {   // the span's last, partial window
+                            const unsigned sid = (unsigned)__shfl((int)cur, j, 16);
+                            const float wv = HAS_VAL ? __shfl(curw, j, 16) : 1.0f;
+                            if (col_ok) {
+                                const float4 xv = *reinterpret_cast<const float4 *>(xr + (((sid & kDsIdMask) << 8) | lane_boff));
+                                if (HAS_VAL) {
+                                    acc.x = __builtin_fmaf(xv.x, wv, acc.x); acc.y = __builtin_fmaf(xv.y, wv, acc.y);
+                                    acc.z = __builtin_fmaf(xv.z, wv, acc.z); acc.w = __builtin_fmaf(xv.w, wv, acc.w);
+                                } else {
+                                    acc.x += xv.x; acc.y += xv.y; acc.z += xv.z; acc.w += xv.w;
+                                }
+                            }
+                            if (sid & kDsLast) finish_group(sid);
+                        }
+                    }
+                    cur = nxt;
+                    curw = nxtw;
+                }
+            }
+            __syncthreads();   // every lane group is done with range p
+            if (active && lg == 0) {   // continuation groups, in slot order = ascending group order
+                const int n_staged = a.dstage[((size_t)u * a.P + p) * (LG + 1) + LG];
+                for (int j = 0; j < n_staged; ++j) {
+                    const int r = staged_row[j];
+                    if (r >= 0) {
+                        if (col_ok) {
+                            float4 *pl = reinterpret_cast<float4 *>(rows + (size_t)r * 64 + lane * 4);
+                            const float4 s = *reinterpret_cast<const float4 *>(stage + (size_t)j * 64 + lane * 4);
+                            float4 t = *pl;
+                            t.x += s.x; t.y += s.y; t.z += s.z; t.w += s.w;
+                            *pl = t;
+                        }
+                        if (lane == 0) staged_row[j] = -1;
+                    }
+                }
+            }
+            if (threadIdx.x == 0) {
+                unsigned *cq = a.cnt + (size_t)xcd * a.n_waves * a.P;
+                if (wq >= 0 && early < (unsigned)a.WPX) {
+                    int it = 0;
+                    while (__hip_atomic_load(&cq[wq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.WPX && it < a.spin_limit) {
+                        __builtin_amdgcn_s_sleep(8);
+                        ++it;
+                    }
+                }
+                __hip_atomic_fetch_add(&cq[gq], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // result unused: no wait
+            }
+            __syncthreads();
+        }
+        if (active) {   // the unit's rows are complete: mean / ReLU, one 256-byte segment per row and tile
+            for (int i = lg; i < a.RB; i += LG) {
+                const int row = a.urows[(size_t)u * a.RB + i];
+                if (row < 0 || !col_ok) continue;
+                const float4 t = *reinterpret_cast<const float4 *>(rows + (size_t)i * 64 + lane * 4);
+                float v[4] = {t.x, t.y, t.z, t.w};
+                if (a.mean) {
+                    const float dg = (float)(a.row_ptr[row + 1] - a.row_ptr[row]);
+                    if (dg > 0.0f) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = v[k] / dg;
+                    }
+                }
+                if (a.relu) relu_pack<4>(v);
+                store_pack_any<4>(a.y + (size_t)row * F + col, v, F - col, a.yvec);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_gcn_ds(const DsLaunch &L, void *stream_v)
+{
+    hipStream_t stream = (hipStream_t)stream_v;
+    constexpr int NT = 512;
+    DsArgs a;
+    a.idw = L.idw; a.val = L.val; a.dsp = L.dsp; a.dstage = L.dstage; a.urows = L.urows; a.row_ptr = L.row_ptr; a.xt = L.xt; a.y = L.y; a.cnt = L.cnt;
+    a.U = L.U; a.P = L.P; a.T = L.T; a.RB = L.RB; a.WPX = L.WPX; a.n_jobs = L.U * L.T; a.feat = L.feat;
+    a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.relu = L.relu; a.yvec = L.yvec; a.width = L.width; a.slack = L.slack; a.spin_limit = 20000;
+    a.x_tile_stride = L.x_tile_stride;
+    const long chunks = ((long)a.n_jobs + a.WPX - 1) / a.WPX;
+    a.n_waves = (int)((chunks + 7) / 8);
+    if ((size_t)8 * a.n_waves * a.P > L.cnt_capacity) return fail(GNNAGG_ERR_STATE, "internal: phase counters too small");
+    HIP_TRY(hipMemsetAsync(a.cnt, 0, (size_t)8 * a.n_waves * a.P * sizeof(unsigned), stream));
+    const size_t lds = ((size_t)L.RB * 64 + (size_t)(NT / 16) * kDsStage * 64) * sizeof(float) + (size_t)(NT / 16) * kDsStage * sizeof(int);
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gcn_ds<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gcn_ds<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr = true;
+    }
+    if (lds > 96 * 1024) return fail(GNNAGG_ERR_STATE, "internal: destination-stationary unit too large for LDS");
+    const int grid = 8 * a.WPX;
+    if (a.val) hipLaunchKernelGGL((k_gcn_ds<NT, true>), dim3(grid), dim3(NT), lds, stream, a);
+    else       hipLaunchKernelGGL((k_gcn_ds<NT, false>), dim3(grid), dim3(NT), lds, stream, a);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+}  // namespace gnnagg

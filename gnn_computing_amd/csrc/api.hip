@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <queue>
 #include <set>
 #include <vector>
 
@@ -72,6 +73,7 @@ struct Schedule {
     int total_cols = 0;     // locality schedules: the column count the ranges were cut from
     int par_num = 0;        // locality schedules: the number of column ranges
     std::vector<int> h_ptr_s, h_target, h_idx_s, h_slot, h_empty;
+    std::vector<int> h_eperm;  // library-built permuted schedules: host copy of eperm (the destination-stationary plan is cut from it)
     std::vector<float> h_val_s;
     DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s, big_rows;
     DevBuf<int> eperm;      // library-built permuted schedules: original edge of every permuted position (val follows its edges)
@@ -91,7 +93,7 @@ struct Schedule {
         mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release(); big_rows.release(); eperm.release(); n_big = 0;
         idx_f.release(); span_g.release(); crows.release(); rg_ptr.release(); rg_idx.release(); n_spans = n_crows = 0;
         span_cost_prefix.clear();
-        h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear(); h_slot.clear(); h_empty.clear();
+        h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear(); h_slot.clear(); h_empty.clear(); h_eperm.clear();
         cost_prefix.clear();
         num_target = n_empty = n_mrows = n_slots = 0;
         permuted = false;
@@ -136,6 +138,22 @@ struct RowsPlan {
     std::vector<long> r0_cost_prefix;
 };
 
+// Destination-stationary plan of the 2-D blocked order (agg_ds.hip; option "dest_stationary"): cut from sched[1]
+struct DsPlan {
+    bool valid = false, failed = false;
+    int U = 0, RB = 208, P = 0, WPX = 64, width = 0;
+    size_t n_edges = 0;
+    DevBuf<unsigned> idw, cnt;
+    DevBuf<float> val;
+    DevBuf<int> dsp, dstage, urows, eperm;
+    void reset()
+    {
+        valid = failed = false;
+        idw.release(); cnt.release(); val.release(); dsp.release(); dstage.release(); urows.release(); eperm.release();
+        U = P = width = 0; n_edges = 0;
+    }
+};
+
 static constexpr int kItemCost = 2;  // fixed per-item overhead in edge-equivalents (XCD range balancing)
 
 struct Ctx {
@@ -152,6 +170,9 @@ struct Ctx {
     BalancedPlan plan;       // balanced mode
     BalancedPlan plan_sched; // `scheduled = 1` with a neighbor-grouping schedule, when the plan kernel suits that NG
     BalancedPlan plan_part;  // source-partitioned balanced mode: one short-row descriptor per group of sched[1]
+    DsPlan ds;               // destination-stationary form of that order (option "dest_stationary")
+    Schedule sched_hub;      // ... and the rows it leaves to the streaming form (sub-rows of thousands of edges): their groups of sched[1]
+    int opt_ds = 0, opt_ds_slack = 0, opt_ds_hub_edges = 4096;
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -341,6 +362,7 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
         eid.resize((size_t)kept);
         int rc2 = s.eperm.upload(eid);
         if (rc2) return rc2;
+        if (c->opt_ds) s.h_eperm = eid;
     }
     s.h_idx_s.resize((size_t)kept);
     if (!s.h_val_s.empty()) s.h_val_s.resize((size_t)kept);
@@ -568,6 +590,8 @@ static int build_partitioned(Ctx *c, int parts)
 {
     c->plan.reset();
     c->plan_part.reset();
+    c->ds.reset();
+    c->sched_hub.reset();
     Schedule &s = c->sched[1];
     // the segmented-stream kernel wants several groups per span: groups of at most 128 edges there
     static const int span_chunk = getenv("GNNAGG_SPAN_CHUNK") ? std::max(1, atoi(getenv("GNNAGG_SPAN_CHUNK"))) : 128;
@@ -650,6 +674,216 @@ static int build_spans(Ctx *c, Schedule &s)
     return GNNAGG_OK;
 }
 
+// Destination-stationary plan: units of RB output rows (dealt so that every unit sees about the same number of edges in every
+// source range: rows are bucketed by their heaviest range, sorted by degree inside a bucket and dealt to the units in snake
+// order), and per (unit, range) the unit's groups of sched[1] in LDS-row order, cut into at most 32 spans of whole groups.  A
+// sub-row that continues into the next span has its continuation groups flagged for the staging slots (at most kDsStage at the
+// head of a span); the words carry the group-end flag, the LDS row and the source row inside the range.
+static int build_ds_plan(Ctx *c, Schedule &s, DsPlan &d)
+{
+    constexpr int LG = 32;
+    d.reset();
+    const int V = c->V, G = s.num_target, P = s.par_num;
+    const int width = P > 0 ? s.total_cols / P : 0;
+    if (G == 0 || P < 2 || width <= 0 || s.h_eperm.size() != s.h_idx_s.size() || (long)s.total_cols - (long)(P - 1) * width > (1L << 21)) {
+        if (getenv("GNNAGG_DS_DEBUG")) fprintf(stderr, "dest-stationary plan: not applicable (G %d P %d width %d eperm %zu idx %zu)\n", G, P, width, s.h_eperm.size(), s.h_idx_s.size());
+        d.failed = true;
+        return GNNAGG_OK;
+    }
+    auto part_of = [&](int col) { const int p = col / width; return p >= P ? P - 1 : p; };
+    std::vector<int> gp((size_t)G);
+#pragma omp parallel for schedule(static)
+    for (int g = 0; g < G; ++g) gp[g] = part_of(s.h_idx_s[s.h_ptr_s[g]]);
+    // heaviest range of every row
+    std::vector<int> dom((size_t)V, P), best((size_t)V, 0);
+    for (int g = 0; g < G;) {
+        const int r = s.h_target[g], p = gp[g];
+        int e = 0, h = g;
+        while (h < G && s.h_target[h] == r && gp[h] == p) { e += s.h_ptr_s[h + 1] - s.h_ptr_s[h]; ++h; }
+        if (e > best[r]) { best[r] = e; dom[r] = p; }
+        g = h;
+    }
+    // Rows with a sub-row of more than kDsHubEdges edges (a hub's home range: thousands of edges, hundreds of groups) would need
+    // hundreds of staged continuation groups per phase: they stay on the streaming form (their groups of sched[1], compacted
+    // into sched_hub; a few hundred rows, a few percent of the edges on the reddit-shaped graph).
+    const int hub_edges = c->opt_ds_hub_edges;
+    std::vector<char> is_hub((size_t)V, 0);
+    int n_hub = 0;
+    for (int r = 0; r < V; ++r)
+        if (best[r] > hub_edges) { is_hub[r] = 1; ++n_hub; }
+    Schedule &sh = c->sched_hub;
+    sh.reset();
+    if (n_hub > 0) {
+        sh.kind = s.kind; sh.permuted = true; sh.total_cols = s.total_cols; sh.par_num = s.par_num;
+        sh.h_ptr_s.push_back(0);
+        for (int g = 0; g < G; ++g) {
+            if (!is_hub[s.h_target[g]]) continue;
+            sh.h_target.push_back(s.h_target[g]);
+            sh.h_idx_s.insert(sh.h_idx_s.end(), s.h_idx_s.begin() + s.h_ptr_s[g], s.h_idx_s.begin() + s.h_ptr_s[g + 1]);
+            sh.h_eperm.insert(sh.h_eperm.end(), s.h_eperm.begin() + s.h_ptr_s[g], s.h_eperm.begin() + s.h_ptr_s[g + 1]);
+            sh.h_ptr_s.push_back((int)sh.h_idx_s.size());
+        }
+        int rc0 = finalize_schedule(c, sh);
+        if (rc0) return rc0;
+        if ((rc0 = sh.eperm.upload(sh.h_eperm))) return rc0;
+        if ((rc0 = build_spans(c, sh))) return rc0;
+        if (sh.n_spans == 0) { d.failed = true; return GNNAGG_OK; }
+    }
+    d.RB = 208;
+    const int U = (V - n_hub + (d.RB - 8) - 1) / (d.RB - 8) + 1;
+    // Rows -> units.  The ranges are swept in lock step, so a phase lasts as long as its heaviest unit: every unit should see about
+    // the same number of edges in EVERY range.  Longest-processing-time dealing on the total degree (a heap of units by edges so
+    // far) settles the totals; among the eight lightest units that still have room the row goes where the resulting heaviest range
+    // stays lightest (per-row edge counts per range from the groups) -- which spreads the rows of one community, whose edges
+    // concentrate in their home range, over different units.
+    std::vector<int> rp_ptr((size_t)V + 1, 0);
+    for (int g = 0; g < G;) {   // (row, range) pairs per row: count, then fill
+        const int r = s.h_target[g], pp = gp[g];
+        int h = g;
+        while (h < G && s.h_target[h] == r && gp[h] == pp) ++h;
+        ++rp_ptr[(size_t)r + 1];
+        g = h;
+    }
+    for (int r = 0; r < V; ++r) rp_ptr[r + 1] += rp_ptr[r];
+    std::vector<int> rp_p((size_t)rp_ptr[V]), rp_e((size_t)rp_ptr[V]);
+    {
+        std::vector<int> cur(rp_ptr.begin(), rp_ptr.end() - 1);
+        for (int g = 0; g < G;) {
+            const int r = s.h_target[g], pp = gp[g];
+            int e = 0, h = g;
+            while (h < G && s.h_target[h] == r && gp[h] == pp) { e += s.h_ptr_s[h + 1] - s.h_ptr_s[h]; ++h; }
+            rp_p[cur[r]] = pp;
+            rp_e[cur[r]++] = e;
+            g = h;
+        }
+    }
+    std::vector<int> order;
+    order.reserve((size_t)V - n_hub);
+    for (int r = 0; r < V; ++r)
+        if (!is_hub[r]) order.push_back(r);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return c->h_ptr[x + 1] - c->h_ptr[x] > c->h_ptr[y + 1] - c->h_ptr[y]; });
+    std::vector<int> unit_of((size_t)V, -1), lrow((size_t)V, 0), fill((size_t)U, 0);
+    std::vector<long> load((size_t)U * P, 0);
+    const int cap = d.RB - 2;
+    typedef std::pair<long, int> HeapEnt;
+    std::priority_queue<HeapEnt, std::vector<HeapEnt>, std::greater<HeapEnt>> pq;
+    for (int u = 0; u < U; ++u) pq.push({0L, u});
+    for (int r : order) {
+        HeapEnt cand[8];
+        int nc = 0;
+        while (nc < 8 && !pq.empty()) { cand[nc++] = pq.top(); pq.pop(); }
+        if (nc == 0) { d.failed = true; return GNNAGG_OK; }
+        int pick = 0;
+        long pick_score = -1;
+        for (int q = 0; q < nc; ++q) {
+            const long *L = &load[(size_t)cand[q].second * P];
+            long worst = 0;
+            for (int k2 = rp_ptr[r]; k2 < rp_ptr[r + 1]; ++k2) worst = std::max(worst, L[rp_p[k2]] + rp_e[k2]);
+            if (pick_score < 0 || worst < pick_score) { pick_score = worst; pick = q; }
+        }
+        const int u = cand[pick].second;
+        unit_of[r] = u;
+        lrow[r] = fill[u]++;
+        long *L = &load[(size_t)u * P];
+        for (int k2 = rp_ptr[r]; k2 < rp_ptr[r + 1]; ++k2) L[rp_p[k2]] += rp_e[k2];
+        for (int q = 0; q < nc; ++q) {
+            if (q == pick) { if (fill[u] < cap) pq.push({cand[q].first + (c->h_ptr[r + 1] - c->h_ptr[r]), u}); }
+            else pq.push(cand[q]);
+        }
+    }
+    for (int u = 0; u < U; ++u)
+        if (fill[u] > d.RB) { if (getenv("GNNAGG_DS_DEBUG")) fprintf(stderr, "dest-stationary plan: unit %d holds %d rows\n", u, fill[u]); d.failed = true; return GNNAGG_OK; }
+    // groups per (unit, range), in (LDS row, group) order
+    const size_t NK = (size_t)U * P;
+    std::vector<int> kcnt(NK + 1, 0);
+    for (int g = 0; g < G; ++g)
+        if (!is_hub[s.h_target[g]]) ++kcnt[(size_t)unit_of[s.h_target[g]] * P + gp[g] + 1];
+    for (size_t k = 0; k < NK; ++k) kcnt[k + 1] += kcnt[k];
+    std::vector<int> kg((size_t)kcnt[NK]);
+    {
+        std::vector<int> cur(kcnt.begin(), kcnt.end() - 1);
+        for (int g = 0; g < G; ++g)
+            if (!is_hub[s.h_target[g]]) kg[cur[(size_t)unit_of[s.h_target[g]] * P + gp[g]]++] = g;   // ascending g inside a key
+    }
+    const size_t NE = s.h_idx_s.size() - sh.h_idx_s.size();
+    std::vector<unsigned> idw(NE);
+    std::vector<int> eperm(NE), dsp(NK * (LG + 1), 0), dstage(NK * (LG + 1), 0);
+    // edge offsets of the keys
+    std::vector<long> koff(NK + 1, 0);
+    for (size_t k = 0; k < NK; ++k) {
+        long e = 0;
+        for (int q = kcnt[k]; q < kcnt[k + 1]; ++q) e += s.h_ptr_s[kg[q] + 1] - s.h_ptr_s[kg[q]];
+        koff[k + 1] = koff[k] + e;
+    }
+    bool overflow = false;
+    long worst = 0, total = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(|| : overflow) reduction(max : worst) reduction(+ : total)
+    for (long k = 0; k < (long)NK; ++k) {
+        std::vector<int> gl(kg.begin() + kcnt[k], kg.begin() + kcnt[k + 1]);
+        std::stable_sort(gl.begin(), gl.end(), [&](int x, int y) { return lrow[s.h_target[x]] < lrow[s.h_target[y]]; });
+        const int p = (int)(k % P);
+        const long tot = koff[k + 1] - koff[k];
+        worst = std::max(worst, tot);
+        total += tot;
+        const long target = std::max<long>(64, (tot + LG - 1) / LG);
+        long pos = koff[k], span_edges = 0;
+        int span = 0, in_span = 0, prev_row = -1, pool = 0;
+        bool prev_staged = false;
+        int *sp = &dsp[(size_t)k * (LG + 1)];
+        int *sb = &dstage[(size_t)k * (LG + 1)];
+        sp[0] = (int)pos;
+        sb[0] = 0;
+        for (size_t q = 0; q < gl.size(); ++q) {
+            const int g = gl[q], r = s.h_target[g];
+            const bool is_cont = r == prev_row;
+            // a continuation group at the head of a span (its sub-row began in an earlier span), and the continuation groups
+            // right behind it, are staged: they take the next slot of the workgroup's pool, in group order
+            const bool staged = is_cont && (in_span == 0 || prev_staged);
+            if (staged && ++pool > LG * kDsStage) {
+                if (!overflow && getenv("GNNAGG_DS_DEBUG"))
+                    fprintf(stderr, "dest-stationary plan: staging pool overflow in unit %ld range %d: %ld edges in %zu groups, target %ld, row %d (%d edges in its heaviest range)\n",
+                            k / P, p, tot, gl.size(), target, r, best[r]);
+                overflow = true;
+            }
+            const int b0 = s.h_ptr_s[g], b1 = s.h_ptr_s[g + 1];
+            for (int e = b0; e < b1; ++e) {
+                unsigned w = (unsigned)(s.h_idx_s[e] - p * width) | ((unsigned)lrow[r] << 21);
+                if (e == b1 - 1) w |= 0x80000000u | (staged ? 0x40000000u : 0u);
+                idw[pos] = w;
+                eperm[pos] = s.h_eperm[e];
+                ++pos;
+            }
+            span_edges += b1 - b0;
+            ++in_span;
+            prev_row = r;
+            prev_staged = staged;
+            if (span_edges >= target && span < LG - 1 && q + 1 < gl.size()) { sp[++span] = (int)pos; sb[span] = pool; in_span = 0; span_edges = 0; }
+        }
+        for (int j = span + 1; j <= LG; ++j) sb[j] = pool;   // sb[LG] = staged groups of this (unit, range)
+        for (int j = span + 1; j <= LG; ++j) sp[j] = (int)pos;
+    }
+    if (overflow || koff[NK] > 0x7fffffffL) {
+        if (getenv("GNNAGG_DS_DEBUG")) fprintf(stderr, "dest-stationary plan: span overflow %d, edges %ld\n", (int)overflow, koff[NK]);
+        d.failed = true;
+        return GNNAGG_OK;
+    }
+    std::vector<int> urows((size_t)U * d.RB, -1);
+    for (int r = 0; r < V; ++r)
+        if (!is_hub[r]) urows[(size_t)unit_of[r] * d.RB + lrow[r]] = r;
+    d.U = U; d.P = P; d.width = width; d.n_edges = NE;
+    if (getenv("GNNAGG_DS_DEBUG"))
+        fprintf(stderr, "dest-stationary plan: %d units x %d ranges, %zu edges, heaviest (unit, range) %ld edges vs mean %.0f; %d hub rows "
+                        "(%zu edges, %d groups) stay on the streaming form\n", U, P, NE, worst, (double)total / (double)NK, n_hub,
+                sh.h_idx_s.size(), sh.num_target);
+    int rc;
+    if ((rc = d.idw.upload(idw)) || (rc = d.dsp.upload(dsp)) || (rc = d.dstage.upload(dstage)) || (rc = d.urows.upload(urows)) ||
+        (rc = d.eperm.upload(eperm)))
+        return rc;
+    if ((rc = d.cnt.reserve((size_t)8 * 4096 * 8))) return rc;
+    d.valid = true;
+    return GNNAGG_OK;
+}
+
 // The source-partitioned order was chosen by the library, not by the caller, so the aliasing contract of updateval
 // (aggr_gcn.h:540-544: the aggregator reads the caller's array at run time) has to survive the permutation: the permuted
 // copy of the edge values is re-gathered from the caller's array before every run (E floats; 0.13 ms at 115 M edges).
@@ -672,6 +906,8 @@ static int demote_partitioned(Ctx *c)
     c->no_auto_partition = 1;
     c->sched[1].reset();
     c->plan_part.reset();
+    c->ds.reset();
+    c->sched_hub.reset();
     c->xt.release();
     return build_balanced_plan(c, pick_chunk(c));
 }
@@ -843,10 +1079,15 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             tr.spec.p_tile_stride = (long)s->num_target * tr.spec.tile_w;
             tr.partial_floats = (size_t)s->num_target * tr.spec.tile_w * tr.ntiles;
         }
+        // option "dest_stationary": accumulators in LDS instead of partial rows -- no partial scratch, no permuted value copy
+        const bool ds_run = span_run && c->opt_ds && tr.retile && tr.spec.tile_w == 64 && reduce != GNNAGG_REDUCE_MAX && !probe;
+        if (ds_run && !c->ds.valid && !c->ds.failed && (rc = build_ds_plan(c, *s, c->ds))) return rc;
+        const bool ds_ok = ds_run && c->ds.valid;
+        if (ds_ok) tr.partial_floats = (size_t)c->sched_hub.num_target * tr.spec.tile_w * tr.ntiles;   // the hub rows' partial rows only
         bool demoted = false;
         if ((rc = reserve_partitioned_scratch(c, tr.partial_floats, 0, tr.xt_floats, &demoted))) return rc;
         if (demoted) return gcn_run(c, x, y, feat, mode, reduce, flags, nn, probe);
-        if ((rc = refresh_partitioned_val(c, s))) return rc;
+        if (!ds_ok && (rc = refresh_partitioned_val(c, s))) return rc;
         if (span_run) {
             SpanLaunch S;
             S.span_g = s->span_g.p; S.n_spans = s->n_spans; S.span_cost_prefix = s->span_cost_prefix.data();
@@ -859,6 +1100,36 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             if (tr.retile) {
                 if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
                 S.x = c->xt.p;
+            }
+            // option "dest_stationary": the same groups with LDS-resident accumulators instead of partial rows (agg_ds.hip)
+            if (ds_ok) {
+                {
+                    DsPlan &d = c->ds;
+                    DsLaunch D;
+                    if (c->d_val) {
+                        if ((rc = d.val.reserve(d.n_edges))) return rc;
+                        if ((rc = launch_permute_val(d.eperm.p, c->d_val, d.val.p, (int)d.n_edges, c->stream))) return rc;
+                        D.val = d.val.p;
+                    }
+                    D.idw = d.idw.p; D.dsp = d.dsp.p; D.dstage = d.dstage.p; D.urows = d.urows.p; D.row_ptr = c->d_ptr; D.xt = c->xt.p; D.y = y;
+                    D.cnt = d.cnt.p; D.cnt_capacity = d.cnt.n; D.U = d.U; D.P = d.P; D.T = tr.ntiles; D.RB = d.RB; D.WPX = d.WPX; D.feat = feat;
+                    D.reduce = reduce; D.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0; D.yvec = tr.spec.yvec; D.width = d.width;
+                    D.slack = c->opt_ds_slack; D.x_tile_stride = tr.spec.x_tile_stride;
+                    Schedule &sh = c->sched_hub;
+                    if (sh.valid && sh.n_spans > 0) {   // the hub rows: streaming form on their own groups, ahead of the units
+                        if ((rc = refresh_partitioned_val(c, &sh))) return rc;
+                        SpanLaunch H = S;
+                        H.span_g = sh.span_g.p; H.n_spans = sh.n_spans; H.span_cost_prefix = sh.span_cost_prefix.data();
+                        H.ptr_s = sh.ptr_s.p; H.idx_f = sh.idx_f.p; H.val_s = c->d_val ? sh.val_s.p : nullptr; H.target = sh.target.p;
+                        H.n_groups = sh.num_target; H.crows = sh.crows.p; H.n_crows = sh.n_crows; H.rg_ptr = sh.rg_ptr.p; H.rg_idx = sh.rg_idx.p;
+                        H.empty_rows = nullptr; H.n_empty = 0;
+                        H.tile.p_tile_stride = (long)sh.num_target * tr.spec.tile_w;
+                        H.aux_stream = nullptr; H.events = nullptr; H.n_events = 0; H.join_event = nullptr;
+                        if ((rc = launch_gcn_span(H, c->stream))) return rc;
+                    }
+                    if ((rc = launch_gcn_ds(D, c->stream)) || !nn) return rc;
+                    return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
+                }
             }
             if ((rc = launch_gcn_span(S, c->stream)) || !nn || probe) return rc;
             return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
@@ -1216,6 +1487,9 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_AUX_STREAM")) c->use_aux_stream = atoi(e);
     if (const char *e = getenv("GNNAGG_SPANS")) c->use_spans = atoi(e);
     if (const char *e = getenv("GNNAGG_OVERLAP_COMBINE")) c->overlap_combine = atoi(e);
+    if (const char *e = getenv("GNNAGG_DEST_STATIONARY")) c->opt_ds = atoi(e);
+    if (const char *e = getenv("GNNAGG_DS_SLACK")) c->opt_ds_slack = atoi(e);
+    if (const char *e = getenv("GNNAGG_DS_HUB_EDGES")) c->opt_ds_hub_edges = std::max(1, atoi(e));
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);
@@ -1287,6 +1561,9 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "aux_stream") c->use_aux_stream = value;
     else if (n == "spans") { c->use_spans = value; replan = true; }
     else if (n == "overlap_combine") c->overlap_combine = value;
+    else if (n == "dest_stationary") { c->opt_ds = value; replan = true; }
+    else if (n == "ds_slack") c->opt_ds_slack = value;
+    else if (n == "ds_hub_edges") { c->opt_ds_hub_edges = std::max(1, value); replan = true; }
     else if (n == "inkernel_combine") c->inkernel_combine = value;
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
     if (replan) {
@@ -1294,6 +1571,8 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
         c->sched[1].reset();
         c->plan_part.reset();
         c->plan.reset();
+        c->ds.reset();
+        c->sched_hub.reset();
     }
     return GNNAGG_OK;
 }

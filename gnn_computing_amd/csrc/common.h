@@ -154,6 +154,24 @@ struct SpanLaunch {
     void *join_event = nullptr;
 };
 int launch_gcn_span(const SpanLaunch &a, void *stream);
+// Destination-stationary form of the same order (agg_ds.hip; option "dest_stationary"): units of RB output rows per column tile
+// with LDS accumulators, phases = source ranges, per-XCD arrival counters.
+static constexpr int kDsStage = 3;   // staging pool of a workgroup = 32 lane groups x kDsStage slots, handed out in group order
+struct DsLaunch {
+    const unsigned *idw = nullptr;   // edge words: last / staged flags, LDS row, row inside the range
+    const float *val = nullptr;      // edge values in stream order, nullptr => implicit 1
+    const int *dsp = nullptr;        // [(U * P) * (LG + 1)] span bounds, LG = 32 lane groups
+    const int *dstage = nullptr;     // [(U * P) * (LG + 1)] first staging-pool slot of every span, then the total
+    const int *urows = nullptr;      // [U * RB]
+    const int *row_ptr = nullptr;
+    const float *xt = nullptr;       // tiled image of X
+    float *y = nullptr;
+    unsigned *cnt = nullptr;         // phase counters
+    size_t cnt_capacity = 0;
+    int U = 0, P = 0, T = 0, RB = 0, WPX = 64, feat = 0, reduce = GNNAGG_REDUCE_SUM, relu = 0, yvec = 1, width = 0, slack = 0;
+    long x_tile_stride = 0;
+};
+int launch_gcn_ds(const DsLaunch &a, void *stream);
 struct GatSpanLaunch {
     SpanLaunch s;                   // val_s unused
     const float *att = nullptr;     // [V, H, 2]

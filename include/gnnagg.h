@@ -122,6 +122,12 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *   "aux_stream" [GNNAGG_AUX_STREAM]      0: GNNAGG_MODE_ROWS runs its hub rows on the handle's stream, before the short rows, instead of
  *                                         beside them on an auxiliary stream (slower by the hub rows' duration, but the process keeps
  *                                         a single queue); 1 (default)
+ *   "dest_stationary" [GNNAGG_DEST_STATIONARY]  1: GCN / SAGE runs of the 2-D blocked balanced order keep the output rows of a unit in
+ *                                         LDS and sweep the source ranges in phase (agg_ds.hip) instead of streaming partial rows to a
+ *                                         combine pass.  Same groups, same fold: bit-equal to the streaming form.  Slower on every
+ *                                         graph measured ("Measured (round 3)"): default 0, kept for A/B.
+ *   "ds_slack" [GNNAGG_DS_SLACK]          phases a workgroup may run ahead of the slowest one of its XCD (0)
+ *   "ds_hub_edges" [GNNAGG_DS_HUB_EDGES]  rows with a (row, range) group above this many edges stay on the streaming form (4096)
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
 int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
 /* Aggregator_GCN::updateval, aggr_gcn.h:540-544: re-aliases the edge values (borrowed; read at run time). */

@@ -582,3 +582,40 @@ def test_two_pass_gat_on_hub_rows(F, H):
     assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0)
     with pytest.raises(Exception):
         a.run_part(dev(x), dev(att), y, den, 3, heads=H)
+
+
+@pytest.mark.parametrize("F", [602, 100, 64, 30, 256])
+@pytest.mark.parametrize("slice_kb,hub_edges", [(16, 4096), (4, 4096), (16, 300), (4, 60)])
+def test_destination_stationary_form_keeps_the_restated_order(F, slice_kb, hub_edges):
+    """Option "dest_stationary" (agg_ds.hip; an experiment of round 3, default off): the groups of the 2-D blocked order with the
+    accumulators of a unit's rows resident in LDS and the source ranges swept as phases -- no partial rows, no combine pass.  Same
+    groups, same ascending fold: bit-equal to the streaming form and to the oracle's restatement, sum / mean / ReLU, explicit and
+    implicit weights, hub sub-rows that continue across lane groups (staged continuation groups), hub rows routed to the streaming
+    form beside the units, rows without edges."""
+    V, E = 900, 260000
+    ptr, idx = hub_graph(V, E, seed=5)
+    x, val = rand((V, F), 1), rand(E, 2)
+    for v in (val, None):
+        ds = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if v is None else dev(v), F, F)
+        ds.set_option("slice_kb", slice_kb)
+        ds.set_option("dest_stationary", 1)
+        ds.set_option("ds_hub_edges", hub_edges)     # rows with a heavier sub-row stay on the streaming form (their own spans + combine)
+        st = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if v is None else dev(v), F, F)
+        st.set_option("slice_kb", slice_kb)
+        assert ds.balanced_partitions() == st.balanced_partitions() > 1
+        ps, ix, tg, vs = blocked_reference(ds, ptr, idx, v)
+        ref = orc.gcn_grouped(ps, tg, ix, vs, x, V, seg=0)
+        y, y2 = torch.full((V, F), 7.0, device=DEV), torch.full((V, F), 7.0, device=DEV)
+        for kw in ({}, {"reduce": "mean"}, {"relu": True}):
+            ds.run(dev(x), y, 128, "balanced", **kw)
+            st.run(dev(x), y2, 128, "balanced", **kw)
+            assert torch.equal(y, y2), kw
+        ds.run(dev(x), y, 128, "balanced")
+        assert np.array_equal(y.cpu().numpy(), ref)
+        ds.run(dev(x), y, 128, "balanced", reduce="max")      # max stays on the streaming form
+        assert np.array_equal(y.cpu().numpy(), orc.gcn_max(ptr, idx, v, x))
+        if v is not None:                                       # the edge values follow the caller's array (updateval)
+            v2 = rand(E, 9)
+            ds.updateval(dev(v2))
+            ds.run(dev(x), y, 128, "balanced")
+            assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, blocked_reference(ds, ptr, idx, v2)[3], x, V, seg=0))
