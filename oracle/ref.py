@@ -38,7 +38,7 @@ def lib():
             raise RuntimeError("oracle/_ref/libref_gnn.so is not built (oracle/ref_build.sh needs the reference tree)")
         _lib = ctypes.CDLL(_SO)
         for name in ("ref_device_count", "ref_neighbor_grouping", "ref_locality_schedule", "ref_locality_neighbor_grouping",
-                     "ref_reorder_csr", "ref_load_graph", "ref_gcn_run", "ref_csr2edgelist", "ref_gat_run", "ref_gat_edge_stage", "ref_time_run", "ref_spmm_naive", "ref_valid", "ref_gcn_variant"):
+                     "ref_reorder_csr", "ref_load_graph", "ref_gcn_run", "ref_csr2edgelist", "ref_gat_run", "ref_gat_edge_stage", "ref_time_run", "ref_spmm_naive", "ref_valid", "ref_gcn_variant", "ref_matmul_nn"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
 
@@ -249,3 +249,15 @@ def gcn_run_with_nn(ptr, idx, val, x, weight, block=128, ng=64):
     if lib().ref_gcn_variant(1, _i(ptr), _i(idx), _f(val), V, E, _f(x), _f(y), F, int(block), int(ng), _f(weight), _f(tr), out) < 0:
         raise RuntimeError("ref_gcn_variant(run_with_nn) failed")
     return y, tr
+
+
+def matmul_nn(a, b):
+    """matmul_NN (dense.h:4-23): row-major C = A . B through the vendor GEMM + transposing geam."""
+    a, b = _cf(a), _cf(b)
+    M, K = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K
+    c = np.zeros((M, N), np.float32)
+    if lib().ref_matmul_nn(_f(a), _f(b), _f(c), M, N, K) < 0:
+        raise RuntimeError("ref_matmul_nn failed")
+    return c

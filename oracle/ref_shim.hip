@@ -40,6 +40,19 @@
 #include "aggr_gat.h"
 #include "spmm.h"
 
+// dense.h:16-22 hands cublasSgeam a NULL beta and a NULL B ("C = alpha * A^T", cuBLAS reads neither when beta is absent);
+// hipBLAS rejects NULL there.  The reference's call is kept and reaches hipBLAS through this forwarder, which supplies the
+// beta = 0 / B = C that cuBLAS implies.  The arithmetic (the T,T Sgemm, then an exact transposing copy) is the library's.
+static hipblasStatus_t shim_sgeam(hipblasHandle_t h, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, const float *alpha,
+                                  const float *A, int lda, const float *beta, const float *B, int ldb, float *C, int ldc)
+{
+    static const float zero = 0.f;
+    return hipblasSgeam(h, ta, tb, m, n, alpha, A, lda, beta ? beta : &zero, B ? B : C, ldb, C, ldc);
+}
+#define hipblasSgeam shim_sgeam
+#include "dense.h"
+#undef hipblasSgeam
+
 // src/data.cu:4 (not declared in data.h with this signature)
 void reorderCSR(const int *ptr, const int *idx, const int *map, const int *reverse_map, int num_v, int num_e, int *&newptr, int *&newidx);
 
@@ -322,6 +335,24 @@ REF_API int ref_gcn_variant(int what, const int *ptr, const int *idx, const floa
         if (what == 1 && hipMemcpy(transformed, d_t, (size_t)num_v * out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
     }
     (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_w); (void)hipFree(d_t);
+    return rc;
+}
+
+// ---- device: matmul_NN (dense.h:4-23): C[M, N] = A[M, K] . B[K, N], all row-major, through the vendor GEMM (T,T into a column-major
+// scratch) and a transposing geam.  The handle is made the way Figure10/main_b.cu:31 makes it.
+REF_API int ref_matmul_nn(const float *a, const float *b, float *c, int M, int N, int K)
+{
+    float *d_a = to_dev(a, (size_t)M * K), *d_b = to_dev(b, (size_t)K * N), *d_c = nullptr, *d_t = nullptr;
+    if (!d_a || !d_b || hipMalloc((void **)&d_c, (size_t)M * N * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&d_t, (size_t)M * N * sizeof(float)) != hipSuccess) return -2;
+    static bool have_handle = false;   // util.cu:175 new[]s the handle array without initialising it
+    if (!have_handle && hipblasCreate(&cublasHs[0]) != HIPBLAS_STATUS_SUCCESS) return -4;
+    have_handle = true;
+    matmul_NN(d_a, d_b, d_c, M, N, K, d_t);
+    int rc = 0;
+    if (hipDeviceSynchronize() != hipSuccess) rc = -3;
+    if (hipMemcpy(c, d_c, (size_t)M * N * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_c); (void)hipFree(d_t);
     return rc;
 }
 
