@@ -27,7 +27,7 @@ namespace gnnagg {
 #ifndef GNNAGG_PARTIAL_AUX
 #define GNNAGG_PARTIAL_AUX 2
 #endif
-static constexpr int kPartialAux = GNNAGG_PARTIAL_AUX;  // partial rows: streaming (nt) stores, see store_pack_wt
+static constexpr int kPartialAux = GNNAGG_PARTIAL_AUX;  // (the flushes cost 0.8 ms of R's 15.05: a build without them runs 14.25 ms)  // partial rows: streaming (nt) stores, see store_pack_wt
 // The id (and value) stream is read once per column tile and never again by this workgroup: streaming loads (A/B: GNNAGG_ID_NT)
 #ifndef GNNAGG_ID_NT
 #define GNNAGG_ID_NT 0
