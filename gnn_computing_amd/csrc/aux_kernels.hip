@@ -392,52 +392,73 @@ __global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, c
     }
 }
 
-// Wide-N variant (N > 64: the 512 -> 128 layer of the 3-layer models): a workgroup owns a 128 x 128 output tile, so A is read
-// from HBM once whatever N is (k_dense_nn re-reads it per 32-column block), and every wavefront owns 64 x 64 of it -- four 32 x 32
-// accumulators, 64 registers: a k-step of 2 feeds 4 MFMAs from 4 operand reads (k_dense_nn: 1 MFMA from 2), which is what the
-// matrix pipe needs to stay busy (k_dense_nn: 59 TFLOP/s on 169 343 x 512 @ 512 x 128, rocBLAS 89).  K in chunks of 32 through a
-// double-buffered LDS image (A: pitch 33, B: as is): the next chunk's global loads are in flight during the current chunk's 64
-// MFMAs, one barrier per chunk.  Every accumulator is still one ascending-k chain of v_mfma_f32_32x32x2_f32 steps: bit-exact
-// against the oracle's GEMM like the other two kernels.
-static constexpr int kBigT = 128, kBigKC = 32, kBigPA = 33;
+// Wide-N variant (N > 64: the 512 -> 128 layer of the 3-layer models): a workgroup owns a TM x 128 output tile (TM = 128 for the
+// bulk), so A is read from HBM once whatever N is (k_dense_nn re-reads it per 32-column block); wavefront w owns the tile's columns
+// [32 w, 32 w + 32) over all TM rows -- TM / 32 accumulators of 32 x 32: a k-step of 2 feeds TM / 32 MFMAs from TM / 32 + 1 operand
+// reads (k_dense_nn: 1 MFMA from 2), which is what the matrix pipe needs to stay busy (k_dense_nn: 59 TFLOP/s on 169 343 x 512 @
+// 512 x 128, rocBLAS 89).  K in chunks of 32 through a double-buffered LDS image (A: pitch 33, B: as is): the next chunk's global
+// loads are in flight during the current chunk's MFMAs, one barrier per chunk.  Every accumulator is still one ascending-k chain of
+// v_mfma_f32_32x32x2_f32 steps: bit-exact against the oracle's GEMM like the other two kernels.
+// Tail: two workgroups fit a CU (LDS, 256 registers), so the chip runs 2 x CUs tiles at a time and 169 343 rows = 1323 tiles of 128
+// are 2.58 rounds of 512 -- the third round 58 % full.  The rows beyond the last full round are cut into at most one round of
+// SMALLER tiles instead (TMT = 32 / 64 / 96 rows: 2 rounds of 128 + 1 of 96 here, 2.75 round-times instead of 3).
+// (K chunk 16 with 3 or 4 workgroups per CU, 8 with 4: 273-294 us on 169 343 x 512 @ 512 x 128 against 266 us for 32 with 2 --
+// more wavefronts per SIMD buy nothing here)
+#ifndef GNNAGG_GEMM_KC
+#define GNNAGG_GEMM_KC 32
+#endif
+static constexpr int kBigT = 128, kBigKC = GNNAGG_GEMM_KC, kBigPA = kBigKC + 1;
+#ifndef GNNAGG_GEMM_WGS
+#define GNNAGG_GEMM_WGS (GNNAGG_GEMM_KC <= 16 ? 3 : 2)
+#endif
+static constexpr int kBigWgs = GNNAGG_GEMM_WGS;   // workgroups per CU (LDS: 33.8 KB each at 16, 66.6 KB at 32)
 
-template <bool VEC>   // VEC: K % 4 == 0, N % 4 == 0, A and B 16-byte aligned -- every 4-float piece is one aligned load
-__global__ __launch_bounds__(256, 2) void k_dense_nn_big(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
-                                                         int M, int N, int K)
+// AV: floats per aligned load of A (4: K % 4 == 0 and A 16-byte aligned; 2: K even, A 8-byte aligned -- the 602-wide layer; 1: any).
+// AV > 1 also says N % 4 == 0 and B 16-byte aligned: every 4-float piece of B is one aligned load.
+template <int TM, int AV>
+__device__ __forceinline__ void dense_tile(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K,
+                                           int row0, int col0, float *lds)
 {
-    extern __shared__ float big_lds[];
-    float *As0 = big_lds, *As1 = big_lds + kBigT * kBigPA, *Bs0 = big_lds + 2 * kBigT * kBigPA, *Bs1 = Bs0 + kBigKC * kBigT;
-    const int row0 = blockIdx.x * kBigT, col0 = blockIdx.y * kBigT;
+    constexpr int RB = TM / 32;   // 32-row blocks = accumulators per wavefront
+    constexpr int KQ = kBigKC / 4;                      // 4-float pieces per row of an A chunk
+    constexpr int NA = (TM * KQ + 255) / 256;           // A pieces per thread
+    constexpr int NB = kBigKC * (kBigT / 4) / 256;      // B pieces per thread
+    float *As0 = lds, *As1 = lds + kBigT * kBigPA, *Bs0 = lds + 2 * kBigT * kBigPA, *Bs1 = Bs0 + kBigKC * kBigT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    f32x16 acc[RB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float4 ra[4], rb[4];
-    // global -> registers: A chunk [128 rows][32 k]: thread t rows t/8 + 32 j, floats (t % 8) * 4; B chunk [32 k][128 cols]:
-    // thread t k-rows t/32 + 8 j, floats (t % 32) * 4.  Branch-free: out-of-range pieces are loaded from a clamped (valid)
-    // address and replaced by zeros, so the eight loads of a chunk are issued back to back (with per-piece branches the compiler
-    // put a wait behind every load and the fetch, not the matrix pipe, set the pace)
-    auto piece = [&](const float *base, long pitch, int r, int rmax, int c, int cmax) -> float4 {
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float4 ra[NA], rb[NB];
+    // global -> registers: A chunk [TM rows][KC k]: piece p = thread + 256 j is row p / KQ, floats (p % KQ) * 4 (pieces beyond the
+    // tile's rows are loaded from a clamped address, zeroed, and land in LDS rows the operand reads never touch); B chunk
+    // [KC k][128 cols]: thread t k-rows t/32 + 8 j, floats (t % 32) * 4.  Branch-free: out-of-range pieces are loaded from a
+    // clamped (valid) address and replaced by zeros, so the loads of a chunk are issued back to back (with per-piece branches
+    // the compiler put a wait behind every load and the fetch, not the matrix pipe, set the pace)
+    auto piece = [&](auto vtag, const float *base, long pitch, int r, int rmax, int c, int cmax) -> float4 {
+        constexpr int V = decltype(vtag)::value;
         const int rc = r < rmax ? r : rmax - 1;
+        const float *src = base + (size_t)rc * pitch;
+        const bool rok = r < rmax;
         float4 v;
-        if (VEC) {
+        // (bit masks, not selects: the compiler turns `cond ? 0 : load` into a branch around the load)
+        if constexpr (V == 4) {
             const int cc = c < cmax ? c : cmax - 4;
-            v = *reinterpret_cast<const float4 *>(base + (size_t)rc * pitch + cc);
-            // (a bit mask, not a select: the compiler turns `cond ? 0 : load` into a branch around the load)
-            const unsigned keep = (r < rmax && c < cmax) ? 0xffffffffu : 0u;
+            v = *reinterpret_cast<const float4 *>(src + cc);
+            const unsigned keep = (rok && c < cmax) ? 0xffffffffu : 0u;
             v.x = __uint_as_float(__float_as_uint(v.x) & keep); v.y = __uint_as_float(__float_as_uint(v.y) & keep);
             v.z = __uint_as_float(__float_as_uint(v.z) & keep); v.w = __uint_as_float(__float_as_uint(v.w) & keep);
+        } else if constexpr (V == 2) {
+            const int ca = c < cmax ? c : cmax - 2, cb = c + 2 < cmax ? c + 2 : cmax - 2;
+            const float2 lo = *reinterpret_cast<const float2 *>(src + ca), hi = *reinterpret_cast<const float2 *>(src + cb);
+            const unsigned k0 = (rok && c < cmax) ? 0xffffffffu : 0u, k1 = (rok && c + 2 < cmax) ? 0xffffffffu : 0u;
+            v.x = __uint_as_float(__float_as_uint(lo.x) & k0); v.y = __uint_as_float(__float_as_uint(lo.y) & k0);
+            v.z = __uint_as_float(__float_as_uint(hi.x) & k1); v.w = __uint_as_float(__float_as_uint(hi.y) & k1);
         } else {
-            const float *src = base + (size_t)rc * pitch;
             const int c0 = c < cmax ? c : cmax - 1, c1 = c + 1 < cmax ? c + 1 : cmax - 1, c2 = c + 2 < cmax ? c + 2 : cmax - 1,
                       c3 = c + 3 < cmax ? c + 3 : cmax - 1;
             v = make_float4(src[c0], src[c1], src[c2], src[c3]);
-            const bool rok = r < rmax;
             v.x = __uint_as_float(__float_as_uint(v.x) & ((rok && c < cmax) ? 0xffffffffu : 0u));
             v.y = __uint_as_float(__float_as_uint(v.y) & ((rok && c + 1 < cmax) ? 0xffffffffu : 0u));
             v.z = __uint_as_float(__float_as_uint(v.z) & ((rok && c + 2 < cmax) ? 0xffffffffu : 0u));
@@ -447,18 +468,23 @@ __global__ __launch_bounds__(256, 2) void k_dense_nn_big(const float *__restrict
     };
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ra[j] = piece(A, K, row0 + (threadIdx.x >> 3) + 32 * j, M, k0 + (threadIdx.x & 7) * 4, K);
-            rb[j] = piece(B, N, k0 + (threadIdx.x >> 5) + 8 * j, K, col0 + (threadIdx.x & 31) * 4, N);
+        for (int j = 0; j < NA; ++j) {
+            const int p = (int)threadIdx.x + 256 * j;
+            ra[j] = piece(std::integral_constant<int, AV>{}, A, K, row0 + p / KQ, M, k0 + (p % KQ) * 4, K);
         }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            rb[j] = piece(std::integral_constant<int, (AV > 1 ? 4 : 1)>{}, B, N, k0 + (threadIdx.x >> 5) + 8 * j, K, col0 + (threadIdx.x & 31) * 4, N);
     };
     auto stash = [&](float *As, float *Bs) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float *da = As + ((threadIdx.x >> 3) + 32 * j) * kBigPA + (threadIdx.x & 7) * 4;
+        for (int j = 0; j < NA; ++j) {
+            const int p = (int)threadIdx.x + 256 * j;   // p / KQ < 128: inside the image whatever TM is
+            float *da = As + (p / KQ) * kBigPA + (p % KQ) * 4;
             da[0] = ra[j].x; da[1] = ra[j].y; da[2] = ra[j].z; da[3] = ra[j].w;
-            *reinterpret_cast<float4 *>(Bs + ((threadIdx.x >> 5) + 8 * j) * kBigT + (threadIdx.x & 31) * 4) = rb[j];
         }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<float4 *>(Bs + ((threadIdx.x >> 5) + 8 * j) * kBigT + (threadIdx.x & 31) * 4) = rb[j];
     };
     fetch(0);
     stash(As0, Bs0);
@@ -467,40 +493,44 @@ __global__ __launch_bounds__(256, 2) void k_dense_nn_big(const float *__restrict
     for (int c = 0; c < nchunks; ++c) {
         const float *As = (c & 1) ? As1 : As0, *Bs = (c & 1) ? Bs1 : Bs0;
         if (c + 1 < nchunks) fetch((c + 1) * kBigKC);   // in flight during this chunk's MFMAs
-        const float *ap = As + (wr + (lane & 31)) * kBigPA + (lane >> 5);
-        const float *bp = Bs + (lane >> 5) * kBigT + wc + (lane & 31);
-        // all operands of the chunk into registers first (2 wavefronts per SIMD: 256 VGPRs each), then 64 MFMAs back to back:
-        // with just-in-time operand reads the matrix pipe waited on LDS latency every other instruction
-        float a0[kBigKC / 2], a1[kBigKC / 2], b0[kBigKC / 2], b1[kBigKC / 2];
+        const float *ap = As + (lane & 31) * kBigPA + (lane >> 5);
+        const float *bp = Bs + (lane >> 5) * kBigT + 32 * wave + (lane & 31);
+        float av[RB][kBigKC / 2], bv[kBigKC / 2];
 #pragma unroll
         for (int t = 0; t < kBigKC / 2; ++t) {
-            a0[t] = ap[2 * t]; a1[t] = ap[32 * kBigPA + 2 * t];
-            b0[t] = bp[2 * t * kBigT]; b1[t] = bp[2 * t * kBigT + 32];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) av[i][t] = ap[i * 32 * kBigPA + 2 * t];
+            bv[t] = bp[2 * t * kBigT];
         }
 #pragma unroll
-        for (int t = 0; t < kBigKC / 2; ++t) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
-        }
+        for (int t = 0; t < kBigKC / 2; ++t)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
         if (c + 1 < nchunks) stash((c & 1) ? As0 : As1, (c & 1) ? Bs0 : Bs1);   // the other buffer: last read in chunk c - 1
         __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col = col0 + 32 * wave + (lane & 31);
+    if (col < N) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = col0 + wc + 32 * j + (lane & 31);
-            if (col < N) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = row0 + wr + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    if (row < M) C[(size_t)row * N + col] = acc[i][j][reg];
-                }
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = row0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (row < M) C[(size_t)row * N + col] = acc[i][reg];
             }
-        }
+    }
+}
+
+// blocks [0, n_main): 128-row tiles from row 0; blocks beyond: TMT-row tiles from row n_main * 128
+template <int TMT, int AV>
+__global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_big(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                               int M, int N, int K, int n_main)
+{
+    extern __shared__ float big_lds[];
+    const int col0 = blockIdx.y * kBigT;
+    if (TMT == kBigT || (int)blockIdx.x < n_main) dense_tile<kBigT, AV>(A, B, C, M, N, K, blockIdx.x * kBigT, col0, big_lds);
+    else dense_tile<TMT, AV>(A, B, C, M, N, K, n_main * kBigT + ((int)blockIdx.x - n_main) * TMT, col0, big_lds);
 }
 
 // Tall-skinny variant for the aggregation widths (K <= 128, K % 4 == 0): every wavefront keeps its B operands -- the
@@ -614,15 +644,38 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
         static const int big = getenv("GNNAGG_GEMM_BIG") ? atoi(getenv("GNNAGG_GEMM_BIG")) : 1;
         if (big && N > 64 && M >= 1024) {   // wide outputs: 128 x 128 tiles, A read once (k_dense_nn_big)
             const size_t lds = (size_t)(2 * kBigT * kBigPA + 2 * kBigKC * kBigT) * sizeof(float);
-            static bool attr_ok = false;
-            if (!attr_ok) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_ok = true;
+            const bool bvec = (N & 3) == 0 && N >= 4 && ((uintptr_t)B & 15) == 0;
+            const int av = !bvec ? 1 : ((K & 3) == 0 && K >= 4 && ((uintptr_t)A & 15) == 0) ? 4 : ((K & 1) == 0 && K >= 2 && ((uintptr_t)A & 7) == 0) ? 2 : 1;
+            // tiles the chip runs at a time: kBigWgs workgroups per CU, shared by the column tiles
+            static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
+            const int ncol = ceil_div(N, kBigT), slots = std::max(1, kBigWgs * cus / ncol);
+            const int n_main = (int)(((long)M / kBigT) / slots) * slots;   // whole rounds of full 128-row tiles
+            const int rem = M - n_main * kBigT;
+            int tmt = kBigT;
+            static const int tail_env = getenv("GNNAGG_GEMM_TAIL") ? atoi(getenv("GNNAGG_GEMM_TAIL")) : 1;
+            if (tail_env)
+                for (int t = 32; t < kBigT; t += 32)
+                    if (ceil_div(rem, t) <= slots) { tmt = t; break; }
+            const dim3 grid(n_main + ceil_div(rem, tmt), ncol);
+#define BIG_CALL(T_, V_)                                                                                                               \
+            {                                                                                                                           \
+                static bool attr_ok = false;                                                                                            \
+                if (!attr_ok) {                                                                                                         \
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_big<T_, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                    attr_ok = true;                                                                                                     \
+                }                                                                                                                       \
+                hipLaunchKernelGGL((k_dense_nn_big<T_, V_>), grid, dim3(256), lds, stream, A, B, C, M, N, K, n_main);                   \
             }
-            const bool vec = (K & 3) == 0 && (N & 3) == 0 && K >= 4 && N >= 4 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
-            if (vec) hipLaunchKernelGGL(k_dense_nn_big<true>, dim3(ceil_div(M, kBigT), ceil_div(N, kBigT)), dim3(256), lds, stream, A, B, C, M, N, K);
-            else     hipLaunchKernelGGL(k_dense_nn_big<false>, dim3(ceil_div(M, kBigT), ceil_div(N, kBigT)), dim3(256), lds, stream, A, B, C, M, N, K);
+#define BIG_TAIL(V_)                                                                    \
+            switch (tmt) {                                                              \
+                case 32: BIG_CALL(32, V_) break;                                        \
+                case 64: BIG_CALL(64, V_) break;                                        \
+                case 96: BIG_CALL(96, V_) break;                                        \
+                default: BIG_CALL(128, V_) break;                                       \
+            }
+            if (av == 4) BIG_TAIL(4) else if (av == 2) BIG_TAIL(2) else BIG_TAIL(1)
+#undef BIG_TAIL
+#undef BIG_CALL
             HIP_TRY(hipGetLastError());
             return GNNAGG_OK;
         }
