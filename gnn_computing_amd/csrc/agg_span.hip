@@ -128,8 +128,13 @@ __device__ __forceinline__ void hot_gathers_landed(f32x4 (&x)[U])
 
 // FAST_ADDR: every byte offset inside one tile image of X fits 32 bits and ids fit 24 (host-checked): the gather address
 // is (uniform tile base) + a 32-bit lane offset -- one 24-bit multiply per gather instead of 64-bit address arithmetic.
+#ifdef GNNAGG_SPAN_WAVES  // A/B: ask the register allocator for this many waves per SIMD (default: what 64-80 VGPRs give, 6-8)
+#define SPAN_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(GNNAGG_SPAN_WAVES, GNNAGG_SPAN_WAVES)))
+#else
+#define SPAN_WAVES_ATTR
+#endif
 template <int GROUP, bool IS_MAX, bool HAS_VAL, bool PROBE, bool FAST_ADDR, bool HOT = false>
-__global__ __launch_bounds__(HOT ? kHotThreads : 256) void k_gcn_span(const SpanArgs a)
+__global__ __launch_bounds__(HOT ? kHotThreads : 256) SPAN_WAVES_ATTR void k_gcn_span(const SpanArgs a)
 {
     constexpr int NT = HOT ? kHotThreads : 256;
     constexpr int VEC = 4, GPB = NT / GROUP, U = kUnroll;
@@ -712,12 +717,15 @@ static int run_span_plan(const SpanLaunch &L, int ntiles, hipStream_t stream, Sp
         if (L.n_spans > 0) { const int rc = span(0, ntiles, stream); if (rc) return rc; }
         if (!L.probe && L.n_crows > 0) { const int rc = combine(0, ntiles, stream); if (rc) return rc; }
     } else {
-        for (int t = 0; t < ntiles; ++t) {
-            if (L.n_spans > 0) { const int rc = span(t, 1, stream); if (rc) return rc; }
+        // overlap_chunks >= 2: that many launches of consecutive tiles instead of one per tile (fewer breaks of the tile-major walk)
+        const int step = L.overlap_chunks >= 2 ? (ntiles + L.overlap_chunks - 1) / L.overlap_chunks : 1;
+        for (int t = 0; t < ntiles; t += step) {
+            const int nt = t + step <= ntiles ? step : ntiles - t;
+            if (L.n_spans > 0) { const int rc = span(t, nt, stream); if (rc) return rc; }
             hipEvent_t ev = (hipEvent_t)L.events[t];
             HIP_TRY(hipEventRecord(ev, stream));
             HIP_TRY(hipStreamWaitEvent(aux, ev, 0));
-            const int rc = combine(t, 1, aux);
+            const int rc = combine(t, nt, aux);
             if (rc) return rc;
         }
         HIP_TRY(hipEventRecord((hipEvent_t)L.join_event, aux));

@@ -594,6 +594,7 @@ static int span_overlap(Ctx *c, int ntiles, SpanLaunch &S)
         c->tile_events.push_back(e);
     }
     S.aux_stream = c->aux_stream;
+    S.overlap_chunks = c->overlap_combine >= 2 ? c->overlap_combine : 0;
     S.events = reinterpret_cast<void **>(c->tile_events.data());
     S.n_events = (int)c->tile_events.size();
     S.join_event = c->ev_join;

@@ -156,6 +156,7 @@ struct SpanLaunch {
     void **events = nullptr;
     int n_events = 0;
     void *join_event = nullptr;
+    int overlap_chunks = 0;   // >= 2: that many launches of consecutive tiles instead of one per tile
 };
 int launch_gcn_span(const SpanLaunch &a, void *stream);
 // Destination-stationary form of the same order (agg_ds.hip; option "dest_stationary"): units of RB output rows per column tile

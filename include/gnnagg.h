@@ -103,7 +103,10 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *   "scratch_limit_mb"                    > 0: cap on the scratch (partial rows + tiled image of X) the blocked order may take;
  *                                         a handle that would need more -- or more than half of the free device memory, or
  *                                         whose allocation fails -- moves to the chunked plan for good
- *   "retile" [GNNAGG_RETILE], "tiled" [GNNAGG_TILED], "spans" [GNNAGG_SPANS], "overlap_combine", "inkernel_combine"   A/B switches
+ *   "retile" [GNNAGG_RETILE], "tiled" [GNNAGG_TILED], "spans" [GNNAGG_SPANS], "inkernel_combine"   A/B switches
+ *   "overlap_combine" [GNNAGG_OVERLAP_COMBINE]  2-D blocked order: 1: one launch per column tile, tile t's ordered combine on an
+ *                                         auxiliary stream beside tile t + 1's aggregation; N >= 2: N launches of consecutive tiles.
+ *                                         Measured slower or within noise: default 0
  *   "fast_rows" [GNNAGG_FAST_ROWS]        1: GNNAGG_MODE_ROWS (`scheduled = 0`) runs the balanced order -- results within the
  *                                         1e-5 bound instead of bit-exact CSR-order chains; 0: canonical order.  Default 0 for
  *                                         handles made through this section, 1 for the reference-facing surfaces (see
