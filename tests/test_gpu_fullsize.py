@@ -155,3 +155,35 @@ def test_products_gcn_f100():
     y2 = torch.empty_like(y)
     agg.run(x * 2.0, y2, 512, "balanced")
     assert bool(torch.all(y2 == 2.0 * y))
+
+
+def test_offsets_beyond_2_pow_31_elements():
+    """Maximum sizes: feature matrices of more than 2^31 elements (4.3 M rows x 512 floats = 8.8 GB each), so every row offset
+    above row 4 194 304 needs 64-bit arithmetic.  Two neighbors per row with unit weights: fma(x1, 1, fma(x0, 1, 0)) = x0 + x1
+    exactly, whatever the order -- the check is a torch gather-add on the device, bit for bit, for the canonical rows mode, the
+    balanced order and the mean."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * (1 << 30):
+        pytest.skip("needs ~45 GB of device memory")
+    V, F = 4_300_000, 512
+    assert V * F > (1 << 31)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    idx2 = torch.randint(0, V, (V, 2), generator=g, device=DEV, dtype=torch.int32)
+    idx2[:, 1] = (idx2[:, 1] // 2 + V // 2).clamp_(max=V - 1)     # every row reads at least one source beyond the 2^31-element mark
+    idx2, _ = torch.sort(idx2, dim=1)
+    ptr = torch.arange(0, 2 * V + 1, 2, dtype=torch.int32, device=DEV)
+    x = torch.randn((V, F), generator=g, device=DEV)
+    agg = gnc.Aggregator_GCN(ptr, idx2.reshape(-1).contiguous(), None, F, F)
+    y = torch.full((V, F), 7.0, device=DEV)
+    ref = torch.empty_like(x)
+    step = 1 << 20
+    for r0 in range(0, V, step):
+        r1 = min(V, r0 + step)
+        ref[r0:r1] = x[idx2[r0:r1, 0].long()] + x[idx2[r0:r1, 1].long()]
+    for mode in (0, "balanced"):
+        y.fill_(7.0)
+        agg.run(x, y, 128, mode)
+        assert torch.equal(y, ref), mode
+    agg.run(x, y, 128, "balanced", reduce="mean")
+    assert torch.equal(y, ref / 2)

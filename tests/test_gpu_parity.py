@@ -1298,3 +1298,44 @@ def test_fuzz_gat_modes_heads():
         # same association as the kernel; device expf vs libm differ by ulps per edge: 1e-5 of the weighted magnitude
         assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), what)
         assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0), what
+
+
+@pytest.mark.parametrize("F", [1, 4, 33, 128])
+def test_degenerate_graphs(F):
+    """Graphs at the edge of the input domain: no edges at all (every row empty: Y = 0 in every mode, the reference memsets vout,
+    aggr_gcn.h:393), a single row with a self loop, a single row with many parallel edges to itself, rows that all name one source;
+    GCN in the three modes and all reductions, GAT fused, the edge-softmax stages, schedules on them."""
+    cases = []
+    V = 5
+    cases.append((np.zeros(V + 1, np.int32), np.zeros(0, np.int32)))                                   # edgeless
+    cases.append((np.array([0, 1], np.int32), np.array([0], np.int32)))                                # one self loop
+    cases.append((np.array([0, 300], np.int32), np.zeros(300, np.int32)))                              # 300 parallel self loops
+    cases.append((np.arange(0, 4 * 7 + 1, 7, dtype=np.int32), np.full(28, 2, np.int32)))               # 4 rows x 7 edges, all from row 2
+    for ptr, idx in cases:
+        V, E = len(ptr) - 1, len(idx)
+        x, val = rand((V, F), 1), rand(E, 2)
+        agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val) if E else None, F, F)
+        agg.set_option("fast_scheduled", 0)
+        agg.schedule(gnc.Schedule.neighbor_grouping, [4])
+        v_or_none = val if E else None
+        for mode in (0, 1, "balanced"):
+            for red, ref in (("sum", orc.gcn_seq), ("mean", orc.gcn_mean), ("max", orc.gcn_max)):
+                y = torch.full((V, F), 7.0, device=DEV)
+                agg.run(dev(x), y, 128, mode, reduce=red)
+                expect = ref(ptr, idx, v_or_none if E else np.zeros(0, np.float32), x)
+                scale = orc.gcn_abs_scale(ptr, idx, v_or_none if E else np.zeros(0, np.float32), x)
+                assert_within(y.cpu().numpy(), expect, scale + np.abs(expect), "degenerate %s %s V=%d E=%d" % (mode, red, V, E))
+                if E == 0:
+                    assert torch.count_nonzero(y) == 0
+        H = 1
+        att = rand((V, H, 2), 3) * 0.4
+        gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+        for mode in (0, "balanced"):
+            y = torch.full((V, F), 7.0, device=DEV)
+            gat.run(dev(x), dev(att), y, 128, mode, heads=H)
+            expect = orc.gat_fused(ptr, idx, att, x, H)
+            assert_within(y.cpu().numpy(), expect, np.abs(expect) + 1e-6, "degenerate gat %s V=%d E=%d" % (mode, V, E))
+        out = torch.full((max(E, 1), H), 7.0, device=DEV)[:E]
+        gat.run_att(dev(att), out, 128, heads=H)
+        if E:
+            np.testing.assert_allclose(out.cpu().numpy(), orc.gat_att(ptr, idx, att, H), rtol=RTOL)
