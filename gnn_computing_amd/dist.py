@@ -173,7 +173,14 @@ class HaloExchange:
         # rows of the LOCAL x to pack, in the order the peers expect them
         self.send_ids = (serve - self.row0).to(self.device)
         self.n_send = int(self.send_ids.numel())
+        self._split_lists = None
         assert self.n_send == 0 or (int(self.send_ids.min()) >= 0 and int(self.send_ids.max()) < self.n_local)
+
+    def split_lists(self):
+        """(rows received from, rows sent to) every rank as Python lists -- what all_to_all_single wants; made once, not per step."""
+        if getattr(self, "_split_lists", None) is None:
+            self._split_lists = ([int(v) for v in self.recv_counts], [int(v) for v in self.send_counts])
+        return self._split_lists
 
     def halo_bytes(self, feat):
         return self.n_halo * feat * 4
@@ -210,8 +217,8 @@ class HaloExchange:
         if self.n_send:
             self.pack_fn(x_local, self.send_ids, send_buf)
         return dist.all_to_all_single(x_halo, send_buf[:self.n_send],
-                                      output_split_sizes=self.recv_counts.tolist(),
-                                      input_split_sizes=self.send_counts.tolist(), group=self.group, async_op=async_op)
+                                      output_split_sizes=self.split_lists()[0],
+                                      input_split_sizes=self.split_lists()[1], group=self.group, async_op=async_op)
 
 
 class PartitionedGCN:
@@ -422,7 +429,7 @@ class PartitionedGAT:
                                   [int(v) * self.recv_buf.shape[1] for v in hx.recv_counts])
             return _StreamWork(st) if async_op else None
         return dist.all_to_all_single(self.recv_buf[:hx.n_halo], self.send_buf[:hx.n_send],
-                                      output_split_sizes=hx.recv_counts.tolist(), input_split_sizes=hx.send_counts.tolist(),
+                                      output_split_sizes=hx.split_lists()[0], input_split_sizes=hx.split_lists()[1],
                                       group=hx.group, async_op=async_op)
 
     def finish_exchange(self):
