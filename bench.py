@@ -149,7 +149,15 @@ def cpu_baseline(ptr, idx, val, x, budget_s=10.0):
         times.append(time.perf_counter() - t0)
     orc.set_num_threads(hw)
     med = float(np.median(times))
-    return {"value": len(idx) / med, "unit": "edges/s", "cores": best_n, "kind": "port",
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": len(idx) / med, "unit": "edges/s", "cores": best_n, "kind": "port", "cpu_model": model, "hardware_threads": hw,
             "sample": "%d full passes of the same arxiv-shaped workload (median %.2f ms) on %d of %d hardware threads "
                       "(best of a thread-count sweep), OpenMP over rows" % (len(times), med * 1e3, best_n, hw)}
 
