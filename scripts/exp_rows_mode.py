@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Rows mode (`scheduled = 0`, canonical CSR-order chains) timings: the long rows are workgroups at the head of the short-row
-launch (k_gcn_rows / k_gat_rows, round 3) instead of a kernel on an auxiliary stream (round 2: arxiv-shaped 182-186 us,
-products-shaped 9.7 ms, reddit-shaped SAGE F=602 41 ms, GAT 8x32 16.8 ms).  Also: a balanced launch before / after a rows
-launch in the same process (the second stream of round 2 cost every later launch ~4 us).  usage: exp_rows_mode.py [A R G P1 ...]"""
+"""Rows mode (`scheduled = 0`, canonical CSR-order chains) timings, and a balanced launch before / after a rows launch in the same
+process (the auxiliary stream the rows mode opens for its hub rows costs every later launch ~4 us).  Written for the round-3
+experiment that made the hub rows a role of the short-row launch (scripts/attic/rows_long_merged_role.cuh, measured slower and not
+kept: profiles/r03/rows_mode_merged_role.txt); profiles/r03/rows_mode.txt is the library as it is.  usage: exp_rows_mode.py [A R G P1 ...]"""
 import json
 import os
 import sys
