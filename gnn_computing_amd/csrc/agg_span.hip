@@ -44,13 +44,6 @@ __device__ __forceinline__ T stream_load(const T *p)
 static constexpr unsigned kLastFlag = 0x80000000u;    // id word: last edge of its group
 static constexpr unsigned kDirectFlag = 0x40000000u;  // (with kLastFlag) the group is its row's only group: result goes to Y
 static constexpr unsigned kIdMask = 0x3fffffffu;
-// Hot rows (option "hot_rows"): the most-referenced rows of a (source range, column tile) slice are copied into LDS by every
-// workgroup of the slice; an id word with kHotFlag names an LDS slot (low 16 bits) instead of a row, and its tile row comes from
-// LDS -- past the texture path that bounds these kernels (64 B per clock and CU; LDS has its own 128; scripts/micro/hot_lds.hip:
-// x1.10 at 17 % hot edges, x1.135 at 22 %).  Hot launches use workgroups of 512 threads (32 spans, all of one range) so that
-// two of them with 64 KB of rows each keep 16 wavefronts on a CU.  The order of the edges, and so every sum, is unchanged.
-static constexpr unsigned kHotFlag = 0x20000000u;
-static constexpr int kHotThreads = 512;
 
 struct SpanArgs {
     const int *span_g;   // [n_spans + 1]
@@ -68,63 +61,7 @@ struct SpanArgs {
     unsigned ptile_bytes;
     unsigned *probe_sink;
     XcdRanges xr;
-    const int *hot_ids;    // [ranges][hot_rows] rows of the tile image held in LDS (HOT launches)
-    const int *blk_range;  // [span_blocks] source range of every block of kHotThreads / GROUP spans
-    int hot_rows;
 };
-
-// HOT launches: the workgroup's copy of its slice's hot rows (and, for GAT, of their source terms)
-template <int GROUP, int NT>
-__device__ __forceinline__ void fill_hot_rows(float4 *hot, const SpanArgs &a, const float *xtile, int sb)
-{
-    const int *__restrict__ hid = a.hot_ids + (size_t)a.blk_range[sb] * a.hot_rows;
-    const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(xtile);
-    const unsigned pitch4 = (unsigned)a.xpitch / 4;
-    for (int i = threadIdx.x; i < a.hot_rows * GROUP; i += NT) hot[i] = x4[(size_t)hid[i / GROUP] * pitch4 + (i & (GROUP - 1))];
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ Pack<4> pack_of(const f32x4 v)
-{
-    Pack<4> r;
-    r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
-    return r;
-}
-
-// One tile-row gather of a HOT launch: the lanes whose id word carries kHotFlag read their 16 bytes from LDS, the others through
-// the texture path, both INTO THE SAME four registers (the lanes are disjoint).  Written in assembly because the compiler, which
-// cannot know that, would wait for the LDS read before it issues the global load to the same registers (8 serialised waits per
-// batch -- measured: the hot form then loses to the plain one).  Neither load is known to the compiler's wait-count bookkeeping:
-// hot_gathers_landed() must stand between the gathers and the first use.
-__device__ __forceinline__ void hot_gather(f32x4 &x, unsigned word, unsigned lds_byte, unsigned x_byte, const float *xtile)
-{
-    unsigned long long sv;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "v_cmp_ne_u32_e32 vcc, 0, %[hot]\n\t"
-        "s_and_b64 exec, %[sv], vcc\n\t"
-        "ds_read_b128 %[x], %[la]\n\t"
-        "s_andn2_b64 exec, %[sv], vcc\n\t"
-        "global_load_dwordx4 %[x], %[vo], %[sb]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [x] "=&v"(x), [sv] "=&s"(sv)
-        : [hot] "v"(word & kHotFlag), [la] "v"(lds_byte), [vo] "v"(x_byte), [sb] "s"(xtile)
-        : "vcc", "memory");
-}
-
-template <int U>
-__device__ __forceinline__ void hot_gathers_landed(f32x4 (&x)[U])
-{
-    static_assert(U == 8 || U == 16, "batch size");
-    if constexpr (U == 8)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])::"memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]),
-                       "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])::"memory");
-}
 
 // FAST_ADDR: every byte offset inside one tile image of X fits 32 bits and ids fit 24 (host-checked): the gather address
 // is (uniform tile base) + a 32-bit lane offset -- one 24-bit multiply per gather instead of 64-bit address arithmetic.
@@ -133,12 +70,10 @@ __device__ __forceinline__ void hot_gathers_landed(f32x4 (&x)[U])
 #else
 #define SPAN_WAVES_ATTR
 #endif
-template <int GROUP, bool IS_MAX, bool HAS_VAL, bool PROBE, bool FAST_ADDR, bool HOT = false>
-__global__ __launch_bounds__(HOT ? kHotThreads : 256) SPAN_WAVES_ATTR void k_gcn_span(const SpanArgs a)
+template <int GROUP, bool IS_MAX, bool HAS_VAL, bool PROBE, bool FAST_ADDR>
+__global__ __launch_bounds__(256) SPAN_WAVES_ATTR void k_gcn_span(const SpanArgs a)
 {
-    constexpr int NT = HOT ? kHotThreads : 256;
-    constexpr int VEC = 4, GPB = NT / GROUP, U = kUnroll;
-    extern __shared__ float4 hot_lds[];
+    constexpr int VEC = 4, GPB = 256 / GROUP, U = kUnroll;
     const int lane = threadIdx.x & (GROUP - 1);
     const int grp = (int)threadIdx.x / GROUP;
     int tile, sb;
@@ -149,10 +84,6 @@ __global__ __launch_bounds__(HOT ? kHotThreads : 256) SPAN_WAVES_ATTR void k_gcn
         tile = L / a.span_blocks;
         sb = L - tile * a.span_blocks;
         tile = __builtin_amdgcn_readfirstlane(tile + a.tile0);  // workgroup-uniform: tile bases and buffer resources in SGPRs
-    }
-    if constexpr (HOT) {
-        fill_hot_rows<GROUP, NT>(hot_lds, a, a.x + (size_t)tile * a.x_tile_stride, sb);
-        __syncthreads();
     }
     const int s = sb * GPB + grp;
     if (s >= a.n_spans) return;
@@ -167,7 +98,6 @@ __global__ __launch_bounds__(HOT ? kHotThreads : 256) SPAN_WAVES_ATTR void k_gcn
     const float *__restrict__ xtile = a.x + (size_t)tile * a.x_tile_stride;  // wave-uniform
     const float *__restrict__ xcol = xtile + lane * VEC;
     const unsigned lane_off = (unsigned)(lane * VEC), xpitch = (unsigned)a.xpitch;
-    const unsigned hot_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)hot_lds;  // LDS byte address of the hot rows
     float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride;
     float acc[VEC];
 #pragma unroll
@@ -202,23 +132,12 @@ __global__ __launch_bounds__(HOT ? kHotThreads : 256) SPAN_WAVES_ATTR void k_gcn
                 if (HAS_VAL) w[u] = __shfl(my_w, j + u, GROUP);
             }
         }
-        if constexpr (HOT) {  // (xpitch == GROUP * VEC floats: host-checked)
-            f32x4 hx[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if ((FULL || j + u < n) && col_ok)
-                    hot_gather(hx[u], sr[u], hot_base + (((sr[u] & 0xffffu) * GROUP + lane) << 4), ((sr[u] & 0xffffffu) << 8) | (lane_off << 2), xtile);
-            hot_gathers_landed<U>(hx);
-#pragma unroll
-            for (int u = 0; u < U; ++u) xv[u] = pack_of(hx[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if ((FULL || j + u < n) && col_ok) {
-                    if constexpr (FAST_ADDR) xv[u] = load_pack<VEC>(xtile + (__umul24(sr[u] & kIdMask, xpitch) + lane_off));
-                    else xv[u] = load_pack<VEC>(xcol + (size_t)(sr[u] & kIdMask) * a.xpitch);
-                }
-        }
+        for (int u = 0; u < U; ++u)
+            if ((FULL || j + u < n) && col_ok) {
+                if constexpr (FAST_ADDR) xv[u] = load_pack<VEC>(xtile + (__umul24(sr[u] & kIdMask, xpitch) + lane_off));
+                else xv[u] = load_pack<VEC>(xcol + (size_t)(sr[u] & kIdMask) * a.xpitch);
+            }
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (FULL || j + u < n) {
@@ -424,14 +343,12 @@ __device__ __forceinline__ float row_bcast_banks(float old, float v)
 #ifndef GAT_SPAN_WAVES
 #define GAT_SPAN_WAVES 4
 #endif
-template <int GROUP, int HT, bool SHIFT, bool PROBE, bool HOT = false>
-__global__ __launch_bounds__(HOT ? kHotThreads : 256, (HT <= 2 ? GAT_SPAN_WAVES : 2)) void k_gat_span(const GatSpanArgs A)
+template <int GROUP, int HT, bool SHIFT, bool PROBE>
+__global__ __launch_bounds__(256, (HT <= 2 ? GAT_SPAN_WAVES : 2)) void k_gat_span(const GatSpanArgs A)
 {
     const SpanArgs &a = A.s;
     // a whole 16-edge window of gathers in flight (8 per batch: 13.0 ms, 16: 9.7 ms on the reddit-shaped 8 x 32 case)
-    constexpr int NT = HOT ? kHotThreads : 256;
-    constexpr int VEC = 4, GPB = NT / GROUP, U = GROUP < GAT_SPAN_U ? GROUP : GAT_SPAN_U;
-    extern __shared__ float4 hot_lds[];
+    constexpr int VEC = 4, GPB = 256 / GROUP, U = GROUP < GAT_SPAN_U ? GROUP : GAT_SPAN_U;
     constexpr bool BANKED = GROUP == 16 && (HT == 2 || HT == 4);  // a head's lanes = whole DPP banks
     const int lane = threadIdx.x & (GROUP - 1);
     const int grp = (int)threadIdx.x / GROUP;
@@ -444,22 +361,12 @@ __global__ __launch_bounds__(HOT ? kHotThreads : 256, (HT <= 2 ? GAT_SPAN_WAVES 
         sb = L - tile * a.span_blocks;
         tile = __builtin_amdgcn_readfirstlane(tile + a.tile0);  // workgroup-uniform: tile bases and buffer resources in SGPRs
     }
-    const int F = a.feat, H = A.heads;
-    const int h0 = (tile * GROUP * VEC) / A.dhead;            // first head of this tile
-    const float *hot_as = nullptr;  // HOT: source terms of the hot rows, [hot_rows][HT] behind the rows
-    if constexpr (HOT) {
-        fill_hot_rows<GROUP, NT>(hot_lds, a, a.x + (size_t)tile * a.x_tile_stride, sb);
-        float *has = reinterpret_cast<float *>(hot_lds + a.hot_rows * GROUP);
-        const int *__restrict__ hid = a.hot_ids + (size_t)a.blk_range[sb] * a.hot_rows;
-        const float *__restrict__ src = A.as_t + (size_t)(h0 / HT) * A.att_rows * HT;
-        for (int i = threadIdx.x; i < a.hot_rows * HT; i += NT) has[i] = src[(size_t)hid[i / HT] * HT + i % HT];
-        hot_as = has;
-        __syncthreads();
-    }
     const int s = sb * GPB + grp;
     if (s >= a.n_spans) return;
+    const int F = a.feat, H = A.heads;
     const int col = (tile * GROUP + lane) * VEC;
     const bool col_ok = col < F;
+    const int h0 = (tile * GROUP * VEC) / A.dhead;            // first head of this tile
     const int hl = (HT > 1 && col_ok) ? col / A.dhead - h0 : 0;  // this lane's head inside the tile
     // which heads of the tile have their first column here (they write newval / partial_den): all of them when a tile
     // holds whole heads; with a head wider than the tile, only the tile where that head starts
@@ -471,7 +378,6 @@ __global__ __launch_bounds__(HOT ? kHotThreads : 256, (HT <= 2 ? GAT_SPAN_WAVES 
     const float *__restrict__ xtile = a.x + (size_t)tile * a.x_tile_stride;  // wave-uniform
     const float *__restrict__ xcol = xtile + lane * VEC;
     const unsigned lane_boff = (unsigned)(lane * VEC * sizeof(float)), xshift = (unsigned)a.xshift_bytes;
-    const unsigned hot_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)hot_lds;  // LDS byte address of the hot rows
     float *__restrict__ ptile = a.partial + (size_t)tile * a.p_tile_stride;
     const int lane_bit_base = ((int)threadIdx.x & 63) & ~(GROUP - 1);  // first lane of this group inside the wavefront
     // compact attention terms of this tile's head group (k_tile_att): [att_rows][HT]
@@ -499,13 +405,7 @@ __global__ __launch_bounds__(HOT ? kHotThreads : 256, (HT <= 2 ? GAT_SPAN_WAVES 
 #pragma unroll
     for (int k = 0; k < HT; ++k) as_c[k] = 0.0f;
     auto load_src_terms = [&](unsigned sw, bool valid, float (&as)[HT]) {
-        if (!valid) return;
-        if (HOT && (sw & kHotFlag)) {
-#pragma unroll
-            for (int k = 0; k < HT; ++k) as[k] = hot_as[(sw & 0xffffu) * HT + k];
-        } else {
-            load_terms<HT>(as_hg + (size_t)(sw & kIdMask) * HT, as);
-        }
+        if (valid) load_terms<HT>(as_hg + (size_t)(sw & kIdMask) * HT, as);
     };
     if (e0 + lane < e_end) {
         my_s = (unsigned)stream_load(&a.idx_f[e0 + lane]);
@@ -568,26 +468,14 @@ __global__ __launch_bounds__(HOT ? kHotThreads : 256, (HT <= 2 ? GAT_SPAN_WAVES 
         static_for<GROUP / U>([&](auto bc) {
             constexpr int J = decltype(bc)::value * U;
             Pack<VEC> xv[U];
-            if constexpr (HOT) {  // (row pitch 256 bytes: host-checked)
-                f32x4 hx[U];
-                static_for<U>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    const unsigned sid = (unsigned)group_bcast<GROUP, J + u>((int)my_s);
-                    hot_gather(hx[u], sid, hot_base + (((sid & 0xffffu) * GROUP + lane) << 4), ((sid & 0xffffffu) << 8) | lane_boff, xtile);
-                });
-                hot_gathers_landed<U>(hx);
-#pragma unroll
-                for (int u = 0; u < U; ++u) xv[u] = pack_of(hx[u]);
-            } else {
-                static_for<U>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value;
-                    const unsigned sid = (unsigned)group_bcast<GROUP, J + u>((int)my_s);
-                    if constexpr (SHIFT)  // the shift drops the flag bits (ids < 2^24, host-checked)
-                        xv[u] = load_pack<VEC>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(xtile) + ((sid << xshift) | lane_boff)));
-                    else
-                        xv[u] = load_pack<VEC>(xcol + (size_t)(sid & kIdMask) * a.xpitch);
-                });
-            }
+            static_for<U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const unsigned sid = (unsigned)group_bcast<GROUP, J + u>((int)my_s);
+                if constexpr (SHIFT)  // the shift drops the flag bits (ids < 2^24, host-checked)
+                    xv[u] = load_pack<VEC>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(xtile) + ((sid << xshift) | lane_boff)));
+                else
+                    xv[u] = load_pack<VEC>(xcol + (size_t)(sid & kIdMask) * a.xpitch);
+            });
             static_for<U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 // (the id word is fetched from its lane again instead of being kept: 16 registers fewer per lane, and
@@ -751,8 +639,7 @@ static void fill_span_args(SpanArgs &a, const SpanLaunch &L, int ntiles_total, i
     a.ptile_bytes = (wt_env && tb < 0x7fffffffULL) ? (unsigned)tb : 0u;
     a.probe_sink = nullptr;
     a.tile0 = 0;
-    a.span_blocks = ceil_div(L.n_spans, (L.hot_rows > 0 ? kHotThreads : 256) / group);
-    a.hot_ids = L.hot_ids; a.blk_range = L.blk_range; a.hot_rows = L.hot_rows;
+    a.span_blocks = ceil_div(L.n_spans, 256 / group);
     a.xshift_bytes = -1;
     const size_t pitch_b = (size_t)L.tile.xpitch * sizeof(float);
     if (L.x_rows > 0 && L.x_rows < (1 << 24) && (pitch_b & (pitch_b - 1)) == 0 && pitch_b >= 16 && (size_t)L.x_rows * pitch_b < 0xffffffffULL) {
@@ -789,28 +676,11 @@ int launch_gcn_span(const SpanLaunch &L, void *stream_v)
         a0.probe_sink = device_probe_sink();
         if (!a0.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
     }
-    if (L.hot_rows > 0 && (group != 16 || !fast || L.tile.xpitch != tw || !L.hot_ids || !L.blk_range || L.hot_rows > 0xffff))
-        return fail(GNNAGG_ERR_STATE, "internal: hot-row span launch on a geometry without that kernel");
     auto span = [&](int tile0, int nt, hipStream_t st) -> int {
         SpanArgs a = a0;
         a.tile0 = tile0;
-        const int gpb = (L.hot_rows > 0 ? kHotThreads : 256) / group;
+        const int gpb = 256 / group;
         const int grid = 8 * fill_xcd_ranges_tile_major(L.span_cost_prefix, L.n_spans, gpb, a.span_blocks, nt, a.xr);
-        if (L.hot_rows > 0) {
-            const size_t lds = (size_t)L.hot_rows * 16 * sizeof(float4);
-#define HOT_K(MAXF, VALF, PROBEF)                                                                                              \
-            {                                                                                                                   \
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gcn_span<16, MAXF, VALF, PROBEF, true, true>),     \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
-                hipLaunchKernelGGL((k_gcn_span<16, MAXF, VALF, PROBEF, true, true>), dim3(grid), dim3(kHotThreads), lds, st, a); \
-            }
-            if (L.probe) { if (has_val) HOT_K(false, true, true) else HOT_K(false, false, true) }
-            else if (is_max) { if (has_val) HOT_K(true, true, false) else HOT_K(true, false, false) }
-            else { if (has_val) HOT_K(false, true, false) else HOT_K(false, false, false) }
-#undef HOT_K
-            HIP_TRY(hipGetLastError());
-            return GNNAGG_OK;
-        }
 #define SPAN_K(G, MAXF, VALF, PROBEF)                                                                                 \
         {                                                                                                               \
             if (fast) hipLaunchKernelGGL((k_gcn_span<G, MAXF, VALF, PROBEF, true>), dim3(grid), dim3(256), 0, st, a);    \
@@ -881,27 +751,11 @@ int launch_gat_span(const GatSpanLaunch &G, void *stream_v)
     }
     A0.as_t = G.as_t; A0.ac_t = G.ac_t; A0.att_rows = G.att_rows; A0.partial_den = G.partial_den; A0.newval = G.newval; A0.eperm = G.eperm; A0.heads = G.heads; A0.dhead = dhead;
     A0.slope = G.slope;
-    if (L.hot_rows > 0 && (group != 16 || (ht != 1 && ht != 2) || A0.s.xshift_bytes < 0 || L.tile.xpitch != tw || !L.hot_ids || !L.blk_range || L.hot_rows > 0xffff))
-        return fail(GNNAGG_ERR_STATE, "internal: hot-row GAT span launch on a geometry without that kernel");
     auto span = [&](int tile0, int nt, hipStream_t st) -> int {
         GatSpanArgs A = A0;
         A.s.tile0 = tile0;
-        const int gpb = (L.hot_rows > 0 ? kHotThreads : 256) / group;
+        const int gpb = 256 / group;
         const int grid = 8 * fill_xcd_ranges_tile_major(L.span_cost_prefix, L.n_spans, gpb, A.s.span_blocks, nt, A.s.xr);
-        if (L.hot_rows > 0) {
-            const size_t lds = (size_t)L.hot_rows * (16 * sizeof(float4) + ht * sizeof(float));
-#define HOT_GAT(HT_, PROBEF)                                                                                                   \
-            {                                                                                                                   \
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gat_span<16, HT_, true, PROBEF, true>),            \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
-                hipLaunchKernelGGL((k_gat_span<16, HT_, true, PROBEF, true>), dim3(grid), dim3(kHotThreads), lds, st, A);        \
-            }
-            if (ht == 1) { if (L.probe) HOT_GAT(1, true) else HOT_GAT(1, false) }
-            else { if (L.probe) HOT_GAT(2, true) else HOT_GAT(2, false) }
-#undef HOT_GAT
-            HIP_TRY(hipGetLastError());
-            return GNNAGG_OK;
-        }
 #define GAT_SPAN_HT(G_, HT_)                                                                                                   \
         {                                                                                                                      \
             if (L.probe) {                                                                                                     \

@@ -81,13 +81,6 @@ struct Schedule {
     DevBuf<int> idx_f, span_g, crows, rg_ptr, rg_idx;
     int n_spans = 0, n_crows = 0;
     std::vector<long> span_cost_prefix;
-    // hot form of the same groups (option "hot_rows", build_hot_spans): ids of a range's hottest rows replaced by LDS slots,
-    // spans grouped into blocks of one range
-    DevBuf<int> idx_h, span_gh, hot_ids, blk_range;
-    int n_spans_h = 0, hot_rows = 0;
-    bool hot_tried = false;
-    double hot_cover = 0.0;   // share of the edges that name a hot row
-    std::vector<long> span_cost_prefix_h;
     int n_big = 0;
     DevBuf<float> val_s;
     int n_empty = 0, n_mrows = 0, n_slots = 0;
@@ -100,16 +93,10 @@ struct Schedule {
         mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release(); big_rows.release(); eperm.release(); n_big = 0;
         idx_f.release(); span_g.release(); crows.release(); rg_ptr.release(); rg_idx.release(); n_spans = n_crows = 0;
         span_cost_prefix.clear();
-        drop_hot();
         h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear(); h_slot.clear(); h_empty.clear(); h_eperm.clear();
         cost_prefix.clear();
         num_target = n_empty = n_mrows = n_slots = 0;
         permuted = false;
-    }
-    void drop_hot()
-    {
-        idx_h.release(); span_gh.release(); hot_ids.release(); blk_range.release();
-        n_spans_h = hot_rows = 0; hot_tried = false; hot_cover = 0.0; span_cost_prefix_h.clear();
     }
     WorkList worklist() const
     {
@@ -186,7 +173,6 @@ struct Ctx {
     DsPlan ds;               // destination-stationary form of that order (option "dest_stationary")
     Schedule sched_hub;      // ... and the rows it leaves to the streaming form (sub-rows of thousands of edges): their groups of sched[1]
     int opt_ds = 0, opt_ds_slack = 0, opt_ds_hub_edges = 4096;
-    int opt_hot_rows = 0;    // option "hot_rows": 0 off, N > 0: the N hottest rows of every slice in LDS, -1: 256 where they cover >= 10 % of the edges
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -689,84 +675,6 @@ static int build_spans(Ctx *c, Schedule &s)
     return GNNAGG_OK;
 }
 
-// Hot form of a library-built partitioned order (option "hot_rows"; kernels: HOT instantiations of agg_span.hip).  Per source
-// range the `hot` rows that most edges name are listed (hot_ids) -- every workgroup of a (range, column tile) slice copies them
-// into LDS -- and the edges that name them carry the LDS slot instead of the row.  Same groups, same edge order as the plain
-// form; only the span list differs: spans of ~kHotSpanEdges edges in blocks of 32 that never straddle two ranges (a block fills
-// its LDS once).  Left unbuilt (hot_rows == 0) when the library decides and the hot rows cover too few edges to pay.
-static constexpr int kHotSpanEdges = 1024;
-
-static int build_hot_spans(Ctx *c, Schedule &s)
-{
-    s.hot_tried = true;
-    const int H = c->opt_hot_rows > 0 ? c->opt_hot_rows : 256;
-    const int G = s.num_target, P = s.par_num, V = c->V, cols = s.total_cols;
-    const int width = P > 0 ? cols / P : 0;
-    const size_t E = s.h_idx_s.size();
-    if (G == 0 || P < 1 || width <= 0 || cols >= (1 << 24) || E == 0) return GNNAGG_OK;
-    if (c->opt_hot_rows < 0 && E < ((size_t)1 << 23)) return GNNAGG_OK;   // a few blocks of 32k edges per CU at least
-    auto part_of = [&](int col) { const int p = col / width; return p >= P ? P - 1 : p; };
-    std::vector<int> cnt((size_t)cols, 0);
-    for (int v : s.h_idx_s) cnt[v]++;
-    std::vector<int> slot_of((size_t)cols, -1), hot_ids((size_t)P * H), cand;
-    size_t covered = 0;
-    for (int p = 0; p < P; ++p) {
-        const int lo = p * width, hi = p == P - 1 ? cols : lo + width;
-        cand.resize((size_t)(hi - lo));
-        for (int i = lo; i < hi; ++i) cand[(size_t)(i - lo)] = i;
-        const int k = std::min(H, hi - lo);
-        std::partial_sort(cand.begin(), cand.begin() + k, cand.end(), [&](int a, int b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
-        for (int j = 0; j < H; ++j) {
-            const int id = j < k ? cand[(size_t)j] : lo;
-            hot_ids[(size_t)p * H + j] = id;
-            if (j < k && cnt[id] > 1) { slot_of[id] = j; covered += (size_t)cnt[id]; }   // a row named once gains nothing from LDS
-        }
-    }
-    s.hot_cover = (double)covered / (double)E;
-    if (getenv("GNNAGG_HOT_DEBUG")) fprintf(stderr, "hot rows: %d per range x %d ranges cover %.3f of %zu edges\n", H, P, s.hot_cover, E);
-    if (c->opt_hot_rows < 0 && s.hot_cover < 0.10) return GNNAGG_OK;
-    std::vector<int> groups_of((size_t)V, 0);
-    for (int g = 0; g < G; ++g) groups_of[s.h_target[g]]++;
-    std::vector<int> idx_h(E);
-    for (size_t e = 0; e < E; ++e) {
-        const int id = s.h_idx_s[e], sl = slot_of[id];
-        idx_h[e] = sl >= 0 ? (int)(0x20000000u | (unsigned)sl) : id;
-    }
-    for (int g = 0; g < G; ++g) {
-        const int last = s.h_ptr_s[g + 1] - 1;
-        unsigned w = (unsigned)idx_h[last] | 0x80000000u;
-        if (groups_of[s.h_target[g]] == 1) w |= 0x40000000u;
-        idx_h[last] = (int)w;
-    }
-    static const int span_env = getenv("GNNAGG_HOT_SPAN_EDGES") ? atoi(getenv("GNNAGG_HOT_SPAN_EDGES")) : kHotSpanEdges;
-    const int span_edges = std::max(1, span_env), gpb = 32;
-    std::vector<int> span_g(1, 0), blk_range;
-    s.span_cost_prefix_h.assign(1, 0);
-    for (int g = 0; g < G;) {
-        const int p = part_of(s.h_idx_s[s.h_ptr_s[g]]);
-        const size_t first_blk = (span_g.size() - 1) / gpb;
-        while (g < G && part_of(s.h_idx_s[s.h_ptr_s[g]]) == p) {
-            const int e0 = s.h_ptr_s[g];
-            int h = g + 1;
-            while (h < G && s.h_ptr_s[h] - e0 < span_edges && part_of(s.h_idx_s[s.h_ptr_s[h]]) == p) ++h;
-            span_g.push_back(h);
-            s.span_cost_prefix_h.push_back((long)s.h_ptr_s[h]);
-            g = h;
-        }
-        while ((span_g.size() - 1) % gpb) {   // the range's last block: empty spans
-            span_g.push_back(g);
-            s.span_cost_prefix_h.push_back((long)s.h_ptr_s[g]);
-        }
-        blk_range.insert(blk_range.end(), (span_g.size() - 1) / gpb - first_blk, p);
-    }
-    int rc;
-    if ((rc = s.idx_h.upload(idx_h)) || (rc = s.span_gh.upload(span_g)) || (rc = s.hot_ids.upload(hot_ids)) || (rc = s.blk_range.upload(blk_range)))
-        return rc;
-    s.n_spans_h = (int)span_g.size() - 1;
-    s.hot_rows = H;
-    return GNNAGG_OK;
-}
-
 // Destination-stationary plan: units of RB output rows (dealt so that every unit sees about the same number of edges in every
 // source range: rows are bucketed by their heaviest range, sorted by degree inside a bucket and dealt to the units in snake
 // order), and per (unit, range) the unit's groups of sched[1] in LDS-row order, cut into at most 32 spans of whole groups.  A
@@ -1194,15 +1102,6 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
                 if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
                 S.x = c->xt.p;
             }
-            // option "hot_rows": the hottest rows of every slice in LDS (same groups and order; the hot form of the span list)
-            if (!ds_ok && c->opt_hot_rows != 0 && tr.spec.tile_w == 64 && tr.spec.xpitch == 64 && s->total_cols < (1 << 24) &&
-                (size_t)s->total_cols * 256 < 0xffffffffULL) {
-                if (!s->hot_tried && (rc = build_hot_spans(c, *s))) return rc;
-                if (s->hot_rows > 0) {
-                    S.span_g = s->span_gh.p; S.n_spans = s->n_spans_h; S.span_cost_prefix = s->span_cost_prefix_h.data(); S.idx_f = s->idx_h.p;
-                    S.hot_rows = s->hot_rows; S.hot_ids = s->hot_ids.p; S.blk_range = s->blk_range.p;
-                }
-            }
             // option "dest_stationary": the same groups with LDS-resident accumulators instead of partial rows (agg_ds.hip)
             if (ds_ok) {
                 {
@@ -1403,15 +1302,6 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
                 if ((rc = c->att_t.reserve(2 * half))) return rc;
                 if ((rc = launch_tile_att(att, c->att_t.p, c->att_t.p + half, arows, heads, ht, c->stream))) return rc;
                 G.as_t = c->att_t.p; G.ac_t = c->att_t.p + half; G.att_rows = arows;
-                // option "hot_rows" (see gcn_run): 1 or 2 heads per 64-float tile
-                if (c->opt_hot_rows != 0 && ht <= 2 && tr.spec.tile_w == 64 && tr.spec.xpitch == 64 && s->total_cols < (1 << 24) &&
-                    (size_t)s->total_cols * 256 < 0xffffffffULL) {
-                    if (!s->hot_tried && (rc = build_hot_spans(c, *s))) return rc;
-                    if (s->hot_rows > 0) {
-                        S.span_g = s->span_gh.p; S.n_spans = s->n_spans_h; S.span_cost_prefix = s->span_cost_prefix_h.data(); S.idx_f = s->idx_h.p;
-                        S.hot_rows = s->hot_rows; S.hot_ids = s->hot_ids.p; S.blk_range = s->blk_range.p;
-                    }
-                }
             }
             return launch_gat_span(G, c->stream);
         }
@@ -1601,7 +1491,6 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_DEST_STATIONARY")) c->opt_ds = atoi(e);
     if (const char *e = getenv("GNNAGG_DS_SLACK")) c->opt_ds_slack = atoi(e);
     if (const char *e = getenv("GNNAGG_DS_HUB_EDGES")) c->opt_ds_hub_edges = std::max(1, atoi(e));
-    if (const char *e = getenv("GNNAGG_HOT_ROWS")) c->opt_hot_rows = std::max(-1, std::min(256, atoi(e)));
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);
@@ -1677,11 +1566,6 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "ds_slack") c->opt_ds_slack = value;
     else if (n == "ds_hub_edges") { c->opt_ds_hub_edges = std::max(1, value); replan = true; }
     else if (n == "inkernel_combine") c->inkernel_combine = value;
-    else if (n == "hot_rows") {
-        if (value < -1 || value > 256) return fail(GNNAGG_ERR_ARG, "hot_rows: -1 (the library decides), 0 (off) or 1..256");
-        c->opt_hot_rows = value;
-        c->sched[1].drop_hot();
-    }
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
     if (replan) {
         c->partitions = 0;

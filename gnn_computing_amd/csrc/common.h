@@ -145,10 +145,6 @@ struct SpanLaunch {
     int feat = 0, reduce = GNNAGG_REDUCE_SUM, relu = 0;
     TileSpec tile;
     int probe = 0;
-    // Hot rows (option "hot_rows"): span_g / n_spans / span_cost_prefix / idx_f are then the hot form of the same groups (blocks of
-    // 32 spans of one source range; ids of hot rows replaced by LDS slots), hot_ids [ranges][hot_rows], blk_range [blocks]
-    int hot_rows = 0;
-    const int *hot_ids = nullptr, *blk_range = nullptr;
     // Overlap of the ordered combine with the aggregation: one launch per column tile, tile t's combine (HBM-bound: it
     // streams the partial rows) runs on aux_stream beside tile t + 1's span kernel (bound by L1 / address processing).
     // events: ntiles hipEvent_t (tile t's span kernel done), join_event: the last combine done.  All null: one launch.

@@ -131,11 +131,6 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *                                         graph measured ("Measured (round 3)"): default 0, kept for A/B.
  *   "ds_slack" [GNNAGG_DS_SLACK]          phases a workgroup may run ahead of the slowest one of its XCD (0)
  *   "ds_hub_edges" [GNNAGG_DS_HUB_EDGES]  rows with a (row, range) group above this many edges stay on the streaming form (4096)
- *   "hot_rows" [GNNAGG_HOT_ROWS]          N in 1..256: the N most-referenced rows of every (source range, column tile) slice of the 2-D
- *                                         blocked order are copied into LDS by the workgroups of the slice and read from there (64-float
- *                                         tiles; GCN / SAGE, GAT with 1 or 2 heads per tile).  Same groups and edge order: bit-equal to
- *                                         the plain form.  -1: 256 where they cover >= 10 % of the edges of a graph of >= 8 M edges.
- *                                         No gain measured ("Measured (round 3)"): default 0, kept for A/B.
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
 int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
 /* Aggregator_GCN::updateval, aggr_gcn.h:540-544: re-aliases the edge values (borrowed; read at run time). */

@@ -619,76 +619,3 @@ def test_destination_stationary_form_keeps_the_restated_order(F, slice_kb, hub_e
             ds.updateval(dev(v2))
             ds.run(dev(x), y, 128, "balanced")
             assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, blocked_reference(ds, ptr, idx, v2)[3], x, V, seg=0))
-
-
-@pytest.mark.parametrize("F", [602, 100, 64, 256])
-@pytest.mark.parametrize("slice_kb,hot", [(16, 256), (4, 16), (64, 40), (16, 1)])
-def test_hot_rows_in_lds_keep_every_bit_gcn(F, slice_kb, hot):
-    """Option "hot_rows": the most-referenced rows of every (source range, column tile) slice are read from LDS instead of through
-    the texture path.  Groups and edge order are those of the plain streaming form: bit-equal to it and to the oracle's restatement,
-    for sum / mean / max / ReLU, explicit and implicit weights, edge values replaced by updateval, the probe writing nothing."""
-    V, E = 900, 260000
-    ptr, idx = hub_graph(V, E, seed=5)
-    x, val = rand((V, F), 1), rand(E, 2)
-    for v in (val, None):
-        ht = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if v is None else dev(v), F, F)
-        ht.set_option("slice_kb", slice_kb)
-        ht.set_option("hot_rows", hot)
-        st = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if v is None else dev(v), F, F)
-        st.set_option("slice_kb", slice_kb)
-        assert ht.balanced_partitions() == st.balanced_partitions() > 1
-        ps, ix, tg, vs = blocked_reference(ht, ptr, idx, v)
-        y, y2 = torch.full((V, F), 7.0, device=DEV), torch.full((V, F), 7.0, device=DEV)
-        for kw in ({}, {"reduce": "mean"}, {"relu": True}, {"reduce": "max"}):
-            ht.run(dev(x), y, 128, "balanced", **kw)
-            st.run(dev(x), y2, 128, "balanced", **kw)
-            assert torch.equal(y, y2), kw
-        ht.run(dev(x), y, 128, "balanced")
-        assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, vs, x, V, seg=0))
-        y0 = y.clone()
-        ht.probe_gather(dev(x), "balanced")
-        torch.cuda.synchronize()
-        assert torch.equal(y, y0)
-        if v is not None:
-            v2 = rand(E, 9)
-            ht.updateval(dev(v2))
-            ht.run(dev(x), y, 128, "balanced")
-            assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, blocked_reference(ht, ptr, idx, v2)[3], x, V, seg=0))
-        ht.set_option("hot_rows", 0)   # back to the plain form on the same handle
-        if v is not None:
-            st.updateval(dev(v2))
-        ht.run(dev(x), y2, 128, "balanced")
-        st.run(dev(x), y, 128, "balanced")
-        assert torch.equal(y, y2)
-
-
-@pytest.mark.parametrize("F,H", [(256, 8), (64, 1), (128, 2), (96, 3), (256, 2)])
-@pytest.mark.parametrize("slice_kb,hot", [(16, 256), (4, 24)])
-def test_hot_rows_in_lds_keep_every_bit_gat(F, H, slice_kb, hot):
-    """The same for the fused GAT kernel (1 or 2 heads per 64-float tile): tile rows and source attention terms of the hot rows
-    come from LDS; outputs and the weights written to newval are bit-equal to the plain streaming form."""
-    V, E = 900, 260000
-    ptr, idx = hub_graph(V, E, seed=11)
-    x, att = rand((V, F), 5), rand((V, H, 2), 6) * 0.4
-    outs = []
-    for h in (hot, 0):
-        gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
-        gat.set_option("slice_kb", slice_kb)
-        gat.set_option("hot_rows", h)
-        assert gat.balanced_partitions() > 1
-        y = torch.full((V, F), 7.0, device=DEV)
-        nv = torch.full((E, H), 7.0, device=DEV)
-        gat.run(dev(x), dev(att), y, 128, "balanced", heads=H, newval=nv)
-        y_plain = torch.full((V, F), 7.0, device=DEV)
-        gat.run(dev(x), dev(att), y_plain, 128, "balanced", heads=H)
-        assert torch.equal(y, y_plain)
-        y0 = y.clone()
-        gat.probe_gather(dev(x), dev(att), "balanced", heads=H)
-        torch.cuda.synchronize()
-        assert torch.equal(y, y0)
-        outs.append((y, nv))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    parts = gat.balanced_partitions()
-    ops, oix, otg, _ = orc.locality_schedule(ptr, idx, parts, gat.balanced_partition_columns(), ng=gat.balanced_params()[0])
-    ref, _, _ = orc.gat_grouped(ops, otg, oix, att, x, V, H, seg=0)
-    assert_within(outs[0][0].cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "hot-row gat")
