@@ -619,3 +619,39 @@ def test_destination_stationary_form_keeps_the_restated_order(F, slice_kb, hub_e
             ds.updateval(dev(v2))
             ds.run(dev(x), y, 128, "balanced")
             assert np.array_equal(y.cpu().numpy(), orc.gcn_grouped(ps, tg, ix, blocked_reference(ds, ptr, idx, v2)[3], x, V, seg=0))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7])
+def test_overlap_combine_chunks_keep_every_bit(n):
+    """Option "overlap_combine" = 1 (one launch per column tile) / N >= 2 (N launches of consecutive tiles), the ordered combine of a
+    chunk on the auxiliary stream beside the next chunk's aggregation: the same groups and folds as the single launch, bit for bit,
+    GCN (sum / mean / max, 10 tiles of which the last is ragged) and GAT (4 tiles)."""
+    V, E = 900, 260000
+    ptr, idx = hub_graph(V, E, seed=5)
+    F = 602
+    x, val = rand((V, F), 1), rand(E, 2)
+    a = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    b = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    for h in (a, b):
+        h.set_option("slice_kb", 16)
+    b.set_option("overlap_combine", n)
+    assert a.balanced_partitions() == b.balanced_partitions() > 1
+    y, y2 = torch.full((V, F), 7.0, device=DEV), torch.full((V, F), 7.0, device=DEV)
+    for kw in ({}, {"reduce": "mean"}, {"reduce": "max"}, {"relu": True}):
+        for _ in range(2):   # the second call reuses the stream and the events
+            a.run(dev(x), y, 128, "balanced", **kw)
+            b.run(dev(x), y2, 128, "balanced", **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(y, y2), (n, kw)
+    F, H = 256, 8
+    x, att = rand((V, F), 5), rand((V, H, 2), 6) * 0.4
+    ga = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    gb = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    for h in (ga, gb):
+        h.set_option("slice_kb", 16)
+    gb.set_option("overlap_combine", n)
+    y, y2 = torch.full((V, F), 7.0, device=DEV), torch.full((V, F), 7.0, device=DEV)
+    ga.run(dev(x), dev(att), y, 128, "balanced", heads=H)
+    gb.run(dev(x), dev(att), y2, 128, "balanced", heads=H)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
