@@ -49,6 +49,7 @@ SIGNATURES = {
     "gnnagg_schedule_balanced": (c_int, [c_int64, c_int]),
     "gnnagg_balanced_params": (c_int, [c_int64, P_INT, P_INT]),
     "gnnagg_balanced_partitions": (c_int, [c_int64, P_INT, P_INT]),
+    "gnnagg_rows_blocked_ranges": (c_int, [c_int64, P_INT]),
     "gnnagg_mode_params": (c_int, [c_int64, c_int, P_INT, P_INT]),
     "gnnagg_num_target": (c_int, [c_int64, c_int, P_INT]),
     "gnnagg_get_schedule": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

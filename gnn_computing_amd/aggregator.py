@@ -97,6 +97,13 @@ class Aggregator:
         check(lib().gnnagg_balanced_params(self._h, ctypes.byref(ch), ctypes.byref(sg)))
         return ch.value, sg.value
 
+    def rows_blocked_ranges(self):
+        """0, or the number of source ranges when `scheduled = 0` runs its canonical chains on the 2-D blocked order
+        (gnnagg_rows_blocked_ranges; GCN handles)."""
+        n = ctypes.c_int(0)
+        check(lib().gnnagg_rows_blocked_ranges(self._h, ctypes.byref(n)))
+        return n.value
+
     def balanced_partitions(self):
         """0, or the number of source partitions when the balanced mode chose the partitioned order (gnnagg_balanced_partitions)."""
         n = ctypes.c_int(0)

@@ -70,7 +70,12 @@ struct SpanArgs {
 #else
 #define SPAN_WAVES_ATTR
 #endif
-template <int GROUP, bool IS_MAX, bool HAS_VAL, bool PROBE, bool FAST_ADDR>
+// CHAIN (canonical rows mode on the blocked order, gnnagg "rows_blocked"): a launch covers ONE source range; a group is a whole
+// (row, range) sub-row; its chain starts from what the row's earlier ranges left in the tiled image of Y (`partial` = Yt[tile][row],
+// zeroed before the first range) and goes back there -- for rows whose neighbors are sorted, range after range IS the CSR order, so
+// every (row, column) is the reference's one sequential chain (aggr_gcn.h:13-35), bit for bit, with the gathers served by the L2.
+// The carry of the NEXT group is requested while the current one is walked (its row comes from a 16-group window of targets).
+template <int GROUP, bool IS_MAX, bool HAS_VAL, bool PROBE, bool FAST_ADDR, bool CHAIN = false>
 __global__ __launch_bounds__(256) SPAN_WAVES_ATTR void k_gcn_span(const SpanArgs a)
 {
     constexpr int VEC = 4, GPB = 256 / GROUP, U = kUnroll;
@@ -102,6 +107,24 @@ __global__ __launch_bounds__(256) SPAN_WAVES_ATTR void k_gcn_span(const SpanArgs
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = IS_MAX ? -INFINITY : 0.0f;
+    // CHAIN: targets of the groups gw0 .. gw0 + GROUP - 1 (lane j: group gw0 + j), the current group's row, the next one's row and carry
+    int gw0 = g, tw = 0, row_cur = 0, row_n = 0;
+    Pack<VEC> cn;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) cn.v[k] = 0.0f;
+    if constexpr (CHAIN) {
+        tw = g + lane < g1 ? a.target[g + lane] : 0;
+        row_cur = __shfl(tw, 0, GROUP);
+        if (col_ok) {
+            const Pack<VEC> c0 = load_pack<VEC>(ptile + (size_t)row_cur * a.ppitch + lane * VEC);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = c0.v[k];
+        }
+        if (g + 1 < g1) {
+            row_n = __shfl(tw, 1, GROUP);
+            if (col_ok) cn = load_pack<VEC>(ptile + (size_t)row_n * a.ppitch + lane * VEC);
+        }
+    }
     unsigned sig = 0;
     int gstart = e0;  // first edge of the current group (its length = the degree of a single-group row: mean)
     unsigned my_s = 0;
@@ -161,7 +184,24 @@ __global__ __launch_bounds__(256) SPAN_WAVES_ATTR void k_gcn_span(const SpanArgs
                         }
                     }
                 }
-                if (sr[u] & kLastFlag) {  // lane-group uniform: the group ends here
+                if (CHAIN && (sr[u] & kLastFlag)) {  // the sub-row ends: its chain goes back to Yt, the next row's carry takes over
+                    if (col_ok) {
+                        if (a.ptile_bytes) store_pack_wt<VEC, kPartialAux>(ptile, a.ptile_bytes, (size_t)row_cur * a.ppitch + lane * VEC, acc);
+                        else store_pack<VEC>(ptile + (size_t)row_cur * a.ppitch + lane * VEC, acc);
+                    }
+                    ++g;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = cn.v[k];
+                    row_cur = row_n;
+                    if (g + 1 < g1) {
+                        if (g + 1 - gw0 >= GROUP) {   // (a window of GROUP groups is ~ a span: rarely more than once per span)
+                            gw0 += GROUP;
+                            tw = gw0 + lane < g1 ? a.target[gw0 + lane] : 0;
+                        }
+                        row_n = __shfl(tw, g + 1 - gw0, GROUP);
+                        if (col_ok) cn = load_pack<VEC>(ptile + (size_t)row_n * a.ppitch + lane * VEC);
+                    }
+                } else if (sr[u] & kLastFlag) {  // lane-group uniform: the group ends here
                     const int e_next = cb + j + u + 1;
                     if (sr[u] & kDirectFlag) {
                         const int row = a.target[g];
@@ -676,11 +716,19 @@ int launch_gcn_span(const SpanLaunch &L, void *stream_v)
         a0.probe_sink = device_probe_sink();
         if (!a0.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
     }
+    if (L.chain && (group != 16 || !fast || is_max || L.probe))
+        return fail(GNNAGG_ERR_STATE, "internal: chained span launch on a geometry without that kernel");
     auto span = [&](int tile0, int nt, hipStream_t st) -> int {
         SpanArgs a = a0;
         a.tile0 = tile0;
         const int gpb = 256 / group;
         const int grid = 8 * fill_xcd_ranges_tile_major(L.span_cost_prefix, L.n_spans, gpb, a.span_blocks, nt, a.xr);
+        if (L.chain) {   // canonical rows mode on the blocked order: one source range per launch, carries through Yt
+            if (has_val) hipLaunchKernelGGL((k_gcn_span<16, false, true, false, true, true>), dim3(grid), dim3(256), 0, st, a);
+            else         hipLaunchKernelGGL((k_gcn_span<16, false, false, false, true, true>), dim3(grid), dim3(256), 0, st, a);
+            HIP_TRY(hipGetLastError());
+            return GNNAGG_OK;
+        }
 #define SPAN_K(G, MAXF, VALF, PROBEF)                                                                                 \
         {                                                                                                               \
             if (fast) hipLaunchKernelGGL((k_gcn_span<G, MAXF, VALF, PROBEF, true>), dim3(grid), dim3(256), 0, st, a);    \

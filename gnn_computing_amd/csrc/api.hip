@@ -173,6 +173,21 @@ struct Ctx {
     DsPlan ds;               // destination-stationary form of that order (option "dest_stationary")
     Schedule sched_hub;      // ... and the rows it leaves to the streaming form (sub-rows of thousands of edges): their groups of sched[1]
     int opt_ds = 0, opt_ds_slack = 0, opt_ds_hub_edges = 4096;
+    // canonical rows mode on the blocked order (option "rows_blocked"; build_rows_blocked / run_rows_blocked)
+    struct RowsBlocked {
+        bool tried = false, ok = false;
+        Schedule sched;                          // the reference's locality_schedule arrays: one group per (row, range)
+        DevBuf<int> span_g, idx_f;
+        DevBuf<int> r1;                          // rows with a sub-row too long for one lane group: {beg, end, row, 0} for k_gcn_rows_long
+        DevBuf<unsigned char> hub_mask;          // [V] 1 for those rows (the un-tiling pass leaves their rows of y alone)
+        int n1 = 0;
+        std::vector<int> span0;                  // [ranges + 1] first span of every range
+        std::vector<std::vector<long>> cost;     // per range: edges before every span of the range
+        void reset() { tried = ok = false; sched.reset(); span_g.release(); idx_f.release(); r1.release(); hub_mask.release(); n1 = 0; span0.clear(); cost.clear(); }
+    } rb;
+    bool keep_h_eperm = false;   // build_locality keeps the host copy of eperm (the plan being built filters its groups)
+    DevBuf<float> yt;        // tiled image of Y the chains of that mode pass through
+    int opt_rows_blocked = 1;
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -362,7 +377,7 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
         eid.resize((size_t)kept);
         int rc2 = s.eperm.upload(eid);
         if (rc2) return rc2;
-        if (c->opt_ds) s.h_eperm = eid;
+        if (c->opt_ds || c->keep_h_eperm) s.h_eperm = eid;
     }
     s.h_idx_s.resize((size_t)kept);
     if (!s.h_val_s.empty()) s.h_val_s.resize((size_t)kept);
@@ -1016,6 +1031,194 @@ struct NnRequest {  // run_with_nn: transformed[V, cols] = y . weight[feat, cols
     int cols;
 };
 
+// Canonical rows mode (GNNAGG_MODE_ROWS: one sequential chain per (row, column) in CSR order, aggr_gcn.h:13-35) on the 2-D blocked
+// order.  If every row lists its neighbors in ascending order, the row's sub-rows per source range, taken range after range, ARE the
+// row in CSR order: the reference's locality_schedule arrays (graph_schedule.h:17-63, one group per (row, range), no neighbor
+// grouping) walked one range per launch, every group's chain starting from what the row's earlier ranges left in a tiled image of Y
+// and returning there (k_gcn_span<..., CHAIN>), give exactly the canonical chains -- with the gathers served by the L2 instead of
+// the fabric (reddit-shaped SAGE F = 602: 41 ms on the row kernels).  Applies to graphs the balanced mode would block as well
+// (average degree >= partition_min_degree), sum / mean, 64-float tiles; everything else stays on the row kernels.
+static int build_rows_blocked(Ctx *c, int ntiles_hint)
+{
+    Ctx::RowsBlocked &rb = c->rb;
+    rb.reset();
+    rb.tried = true;
+    int rc = fetch_host_ptr(c);
+    if (rc) return rc;
+    if (c->E == 0 || c->no_auto_partition || (c->opt_partitions < 0 && c->avg_deg() < c->opt_part_min_deg) || c->opt_partitions == 0) return GNNAGG_OK;
+    {   // neighbors ascending in every row?
+        std::vector<int> h_idx((size_t)c->E);
+        HIP_TRY(hipMemcpy(h_idx.data(), c->d_idx, (size_t)c->E * sizeof(int), hipMemcpyDeviceToHost));
+        int unsorted = 0;
+#pragma omp parallel for schedule(static) reduction(| : unsorted)
+        for (int r = 0; r < c->V; ++r)
+            for (int e = c->h_ptr[r] + 1; e < c->h_ptr[r + 1]; ++e) unsorted |= h_idx[e] < h_idx[e - 1];
+        if (unsorted) return GNNAGG_OK;
+    }
+    Schedule &s = rb.sched;
+    c->keep_h_eperm = true;
+    rc = build_locality(c, s, c->opt_partitions > 0 ? c->opt_partitions : -1, 0, -1, GNNAGG_SCHED_LOCALITY, true);
+    c->keep_h_eperm = false;
+    if (rc) return rc;
+    if (s.num_target == 0 || s.par_num < 2 || s.total_cols >= (1 << 24)) return GNNAGG_OK;
+    {   // A sub-row is walked by ONE lane group, a few edges per microsecond: rows with a sub-row of more than hub_edges edges would
+        // set the duration of their range's launch.  They go to the workgroup-per-row kernel of the rows mode (k_gcn_rows_long:
+        // parallel gathers, one consuming wavefront; the same canonical chain) after the other rows' chains, whole.
+        // The threshold follows the duration of a launch, i.e. the number of column tiles of the first run that builds the plan
+        // (reddit-shaped, ms per step at 512 / 1024 / 2048 / 4096 edges: F = 128 5.6 / 5.7 / 7.1 / 7.5, F = 256 10.5 / 10.1 / 10.3 /
+        // 10.3, F = 602 -- 10 tiles -- 23.9 / 20.2 / 19.7 at 1024 / 2048 / 4096).
+        static const int hub_env = getenv("GNNAGG_RB_HUB_EDGES") ? std::max(1, atoi(getenv("GNNAGG_RB_HUB_EDGES"))) : 0;
+        const int hub_edges = hub_env ? hub_env : std::min(4096, std::max(512, 256 * std::max(1, ntiles_hint)));
+        const int G0 = s.num_target;
+        std::vector<char> is_hub((size_t)c->V, 0);
+        int n_hub = 0;
+        for (int g = 0; g < G0; ++g)
+            if (s.h_ptr_s[g + 1] - s.h_ptr_s[g] > hub_edges && !is_hub[s.h_target[g]]) { is_hub[s.h_target[g]] = 1; ++n_hub; }
+        {   // the groups that stay, range by range, the longest sub-rows of a range first (they are walked by one lane group each: started
+            // first they do not form the tail of their launch); any order of the rows inside a range gives the same chains
+            const int P0 = s.par_num, w0 = s.total_cols / P0;
+            auto part0 = [&](int col) { const int p = col / w0; return p >= P0 ? P0 - 1 : p; };
+            std::vector<int> order;
+            order.reserve((size_t)G0);
+            for (int g = 0; g < G0; ++g)
+                if (!is_hub[s.h_target[g]]) order.push_back(g);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                const int pa = part0(s.h_idx_s[s.h_ptr_s[a]]), pb = part0(s.h_idx_s[s.h_ptr_s[b]]);
+                if (pa != pb) return pa < pb;
+                return s.h_ptr_s[a + 1] - s.h_ptr_s[a] > s.h_ptr_s[b + 1] - s.h_ptr_s[b];
+            });
+            std::vector<int> np(1, 0), nt, ni, ne;
+            nt.reserve(order.size()); ni.reserve(s.h_idx_s.size()); ne.reserve(s.h_idx_s.size());
+            for (int g : order) {
+                nt.push_back(s.h_target[g]);
+                ni.insert(ni.end(), s.h_idx_s.begin() + s.h_ptr_s[g], s.h_idx_s.begin() + s.h_ptr_s[g + 1]);
+                ne.insert(ne.end(), s.h_eperm.begin() + s.h_ptr_s[g], s.h_eperm.begin() + s.h_ptr_s[g + 1]);
+                np.push_back((int)ni.size());
+            }
+            const int par = s.par_num, cols = s.total_cols, kind = s.kind;
+            s.reset();
+            s.par_num = par; s.total_cols = cols; s.kind = kind; s.permuted = true;
+            s.h_ptr_s.swap(np); s.h_target.swap(nt); s.h_idx_s.swap(ni); s.h_eperm.swap(ne);
+            if ((rc = finalize_schedule(c, s)) || (rc = s.eperm.upload(s.h_eperm))) return rc;
+        }
+        if (n_hub > 0) {
+            struct Long { int beg, end, row; };
+            std::vector<Long> longs;
+            for (int r = 0; r < c->V; ++r)
+                if (is_hub[r]) longs.push_back({c->h_ptr[r], c->h_ptr[r + 1], r});
+            std::stable_sort(longs.begin(), longs.end(), [](const Long &a, const Long &b) { return a.end - a.beg > b.end - b.beg; });
+            std::vector<int> r1;
+            for (const Long &l : longs) r1.insert(r1.end(), {l.beg, l.end, l.row, 0});
+            if ((rc = rb.r1.upload(r1))) return rc;
+            std::vector<unsigned char> mask(is_hub.begin(), is_hub.end());
+            if ((rc = rb.hub_mask.upload(mask))) return rc;
+            rb.n1 = n_hub;
+        }
+        s.h_eperm.clear();
+        s.h_eperm.shrink_to_fit();
+    }
+    const int G = s.num_target, P = s.par_num;
+    if (G == 0) return GNNAGG_OK;
+    const int width = s.total_cols / P;
+    auto part_of = [&](int col) { const int p = col / width; return p >= P ? P - 1 : p; };
+    std::vector<int> idx_f(s.h_idx_s);
+    for (int g = 0; g < G; ++g) idx_f[s.h_ptr_s[g + 1] - 1] = (int)((unsigned)idx_f[s.h_ptr_s[g + 1] - 1] | 0x80000000u);
+    std::vector<int> span_g(1, 0);
+    rb.span0.assign(1, 0);
+    rb.cost.assign((size_t)P, std::vector<long>());
+    int g = 0;
+    for (int p = 0; p < P; ++p) {
+        std::vector<long> &cost = rb.cost[(size_t)p];
+        cost.assign(1, 0);
+        const long base = g < G ? s.h_ptr_s[g] : 0;
+        while (g < G && part_of(s.h_idx_s[s.h_ptr_s[g]]) == p) {
+            const int e0 = s.h_ptr_s[g];
+            int h = g + 1;
+            while (h < G && s.h_ptr_s[h] - e0 < kSpanEdges && part_of(s.h_idx_s[s.h_ptr_s[h]]) == p) ++h;
+            span_g.push_back(h);
+            cost.push_back((long)s.h_ptr_s[h] - base);
+            g = h;
+        }
+        rb.span0.push_back((int)span_g.size() - 1);
+    }
+    if (g != G) return GNNAGG_OK;   // (a source outside every range: not this path)
+    if ((rc = rb.idx_f.upload(idx_f)) || (rc = rb.span_g.upload(span_g))) return rc;
+    rb.ok = true;
+    return GNNAGG_OK;
+}
+
+static int run_rows_blocked(Ctx *c, const float *x, float *y, int feat, int reduce, int flags, const NnRequest *nn, bool *used)
+{
+    *used = false;
+    Ctx::RowsBlocked &rb = c->rb;
+    int rc;
+    if (!rb.tried && (rc = build_rows_blocked(c, (feat + 63) / 64))) return rc;
+    if (!rb.ok) return GNNAGG_OK;
+    Schedule &s = rb.sched;
+    TiledRun tr = plan_tiles(c, s, x, y, feat, 4);
+    if (!tr.spec.on || tr.spec.tile_w != 64 || (size_t)s.total_cols * tr.spec.xpitch * sizeof(float) >= 0xffffffffULL) return GNNAGG_OK;
+    const size_t yt_floats = (size_t)c->V * tr.spec.tile_w * tr.ntiles;
+    if ((size_t)c->V * tr.spec.tile_w * sizeof(float) >= 0x7fffffffULL) return GNNAGG_OK;
+    if (yt_floats > c->yt.n || tr.xt_floats > c->xt.n) {   // first use (or a wider feature matrix): the scratch, or not this path
+        size_t free_b = 0, total_b = 0;
+        const size_t want = (yt_floats + tr.xt_floats) * sizeof(float);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || want > free_b / 2 || c->yt.reserve(yt_floats) != GNNAGG_OK ||
+            c->xt.reserve(tr.xt_floats) != GNNAGG_OK) {
+            (void)hipGetLastError();
+            rb.ok = false;
+            return GNNAGG_OK;
+        }
+    }
+    if ((rc = refresh_partitioned_val(c, &s))) return rc;
+    // the rows left out of the chained launches, whole, on the workgroup-per-row kernel: beside the launches on the auxiliary stream
+    // (disjoint rows of y), or behind them on this stream ("aux_stream" = 0)
+    const bool fork = rb.n1 > 0 && c->use_aux_stream;
+    auto hub_rows = [&](hipStream_t st) -> int {
+        GcnRowsLongLaunch R;
+        R.r1 = rb.r1.p; R.n1 = rb.n1; R.idx = c->d_idx; R.val = c->d_val; R.x = x; R.y = y; R.feat = feat; R.reduce = reduce;
+        R.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
+        return launch_gcn_rows_long(R, st);
+    };
+    if (fork) {
+        if (!c->aux_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        if ((rc = hub_rows(c->aux_stream))) return rc;
+        HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
+    }
+    const float *xin = x;
+    if (tr.retile) {
+        if ((rc = launch_tile_x(x, c->xt.p, s.total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
+        xin = c->xt.p;
+    }
+    HIP_TRY(hipMemsetAsync(c->yt.p, 0, yt_floats * sizeof(float), c->stream));
+    SpanLaunch S;
+    S.chain = 1;
+    S.ptr_s = s.ptr_s.p; S.idx_f = rb.idx_f.p; S.val_s = c->d_val ? s.val_s.p : nullptr; S.target = s.target.p;
+    S.n_groups = c->V;   // rows of the Yt image (the launcher sizes the partial window from it)
+    S.row_ptr = c->d_ptr; S.x = xin; S.x_rows = s.total_cols; S.y = y; S.partial = c->yt.p; S.feat = feat; S.reduce = GNNAGG_REDUCE_SUM;
+    S.tile = tr.spec;
+    S.tile.p_tile_stride = (long)c->V * tr.spec.tile_w;
+    for (int p = 0; p < s.par_num; ++p) {
+        const int s0 = rb.span0[(size_t)p], s1 = rb.span0[(size_t)p + 1];
+        if (s1 == s0) continue;
+        S.span_g = rb.span_g.p + s0; S.n_spans = s1 - s0; S.span_cost_prefix = rb.cost[(size_t)p].data();
+        if ((rc = launch_gcn_span(S, c->stream))) return rc;
+    }
+    if ((rc = launch_untile_y(c->yt.p, y, c->d_ptr, rb.n1 > 0 ? rb.hub_mask.p : nullptr, c->V, feat, tr.spec.tile_w, reduce == GNNAGG_REDUCE_MEAN,
+                              (flags & GNNAGG_FLAG_RELU) ? 1 : 0, c->stream)))
+        return rc;
+    if (fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    else if (rb.n1 > 0 && (rc = hub_rows(c->stream))) return rc;
+    *used = true;
+    if (nn) return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
+    return GNNAGG_OK;
+}
+
 static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0, const NnRequest *nn = nullptr,
                    int probe = 0)
 {
@@ -1033,6 +1236,11 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
     if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
     if (mode == GNNAGG_MODE_SCHEDULED && c->fast_scheduled && c->sched[0].valid) mode = GNNAGG_MODE_BALANCED;
+    if (mode == GNNAGG_MODE_ROWS && c->opt_rows_blocked && c->tiled && c->use_plan && reduce != GNNAGG_REDUCE_MAX && !probe) {
+        bool used = false;   // canonical chains on the blocked order where the graph allows it (sorted rows, high degree)
+        const int rcb = run_rows_blocked(c, x, y, feat, reduce, flags, nn, &used);
+        if (rcb || used) return rcb;
+    }
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
@@ -1491,6 +1699,7 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     if (const char *e = getenv("GNNAGG_DEST_STATIONARY")) c->opt_ds = atoi(e);
     if (const char *e = getenv("GNNAGG_DS_SLACK")) c->opt_ds_slack = atoi(e);
     if (const char *e = getenv("GNNAGG_DS_HUB_EDGES")) c->opt_ds_hub_edges = std::max(1, atoi(e));
+    if (const char *e = getenv("GNNAGG_ROWS_BLOCKED")) c->opt_rows_blocked = atoi(e);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);
@@ -1566,6 +1775,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "ds_slack") c->opt_ds_slack = value;
     else if (n == "ds_hub_edges") { c->opt_ds_hub_edges = std::max(1, value); replan = true; }
     else if (n == "inkernel_combine") c->inkernel_combine = value;
+    else if (n == "rows_blocked") c->opt_rows_blocked = value;
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
     if (replan) {
         c->partitions = 0;
@@ -1574,6 +1784,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
         c->plan.reset();
         c->ds.reset();
         c->sched_hub.reset();
+        c->rb.reset();
     }
     return GNNAGG_OK;
 }
@@ -1649,6 +1860,18 @@ int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions, int *total_cols
     if (rc) return rc;
     *partitions = c->partitions;
     if (total_cols) *total_cols = c->partitions > 0 ? c->sched[1].total_cols : 0;
+    return GNNAGG_OK;
+}
+
+int gnnagg_rows_blocked_ranges(gnnagg_handle h, int *ranges)
+{
+    GET_CTX(h);
+    if (!ranges) return fail(GNNAGG_ERR_ARG, "null output");
+    *ranges = 0;
+    if (c->kind != Ctx::GCN || !c->opt_rows_blocked || !c->tiled || !c->use_plan || c->fast_rows) return GNNAGG_OK;
+    int rc;
+    if (!c->rb.tried && (rc = build_rows_blocked(c, 4))) return rc;
+    if (c->rb.ok) *ranges = c->rb.sched.par_num;
     return GNNAGG_OK;
 }
 

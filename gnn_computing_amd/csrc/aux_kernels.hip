@@ -821,6 +821,56 @@ int launch_tile_x(const float *x, float *xt, int rows, int feat, int tile_w, voi
     return GNNAGG_OK;
 }
 
+// The inverse for the canonical rows mode on the blocked order: Yt[tile][row][tile_w] -> y[row][feat], finishing the row on the way
+// (mean: / degree as finish_gcn_row does; ReLU).  One thread per (row, 4-column quad); the caller's rows may be 4-byte aligned only.
+__global__ __launch_bounds__(256) void k_untile_y(const float *__restrict__ yt, float *__restrict__ y, const int *__restrict__ row_ptr,
+                                                  const unsigned char *__restrict__ skip, int rows, int feat, int tile_w, int quads_per_row, int mean,
+                                                  int relu)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)rows * quads_per_row;
+    if (i >= total) return;
+    const int r = (int)(i / quads_per_row), q = (int)(i - (long)r * quads_per_row);
+    if (skip && skip[r]) return;   // (rows another kernel writes)
+    const int c = q * 4;
+    const int t = c / tile_w, ct = c - t * tile_w;
+    const float4 v4 = *reinterpret_cast<const float4 *>(yt + ((size_t)t * rows + r) * tile_w + ct);
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    if (mean) {
+        const float dg = (float)(row_ptr[r + 1] - row_ptr[r]);
+        if (dg > 0.0f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] / dg;
+        }
+    }
+    if (relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
+    }
+    float *dst = y + (size_t)r * feat + c;
+    if (c + 3 < feat && (((uintptr_t)dst) & 15) == 0) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    else if (c + 3 < feat && (((uintptr_t)dst) & 7) == 0) {
+        *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[1]);
+        *reinterpret_cast<float2 *>(dst + 2) = make_float2(v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c + k < feat) dst[k] = v[k];
+    }
+}
+
+int launch_untile_y(const float *yt, float *y, const int *row_ptr, const unsigned char *skip, int rows, int feat, int tile_w, int mean, int relu,
+                    void *stream_v)
+{
+    if (rows <= 0 || feat <= 0) return GNNAGG_OK;
+    const int quads = (feat + 3) / 4;
+    const long total = (long)rows * quads;
+    hipLaunchKernelGGL(k_untile_y, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, yt, y, row_ptr, skip, rows, feat,
+                       tile_w, quads, mean, relu);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
 // ------------------------------------------------------------------ compact attention terms (2-D blocked GAT)
 // att is [V, H, 2] (centre term, source term interleaved per head): a tile of the span kernel needs the source terms of its
 // HT heads per EDGE -- HT four-byte loads that each touch a different 64-byte att row per lane.  The compact image keeps

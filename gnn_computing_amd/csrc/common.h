@@ -153,6 +153,9 @@ struct SpanLaunch {
     int n_events = 0;
     void *join_event = nullptr;
     int overlap_chunks = 0;   // >= 2: that many launches of consecutive tiles instead of one per tile
+    // chain = 1 (canonical rows mode on the blocked order): the spans of ONE source range; every group's chain starts from and
+    // returns to partial = Yt[ntiles][n_groups = V rows][tile_w]; no combine, no zero-fill (launch_untile_y finishes)
+    int chain = 0;
 };
 int launch_gcn_span(const SpanLaunch &a, void *stream);
 // Destination-stationary form of the same order (agg_ds.hip; option "dest_stationary"): units of RB output rows per column tile
@@ -173,6 +176,10 @@ struct DsLaunch {
     long x_tile_stride = 0;
 };
 int launch_gcn_ds(const DsLaunch &a, void *stream);
+// y[r, :] = finish(Yt[tile][r][:]) -- the tiled image back into the caller's rows, mean (/ degree) and ReLU applied
+// (skip: optional [rows] bytes, 1 = leave the row of y alone)
+int launch_untile_y(const float *yt, float *y, const int *row_ptr, const unsigned char *skip, int rows, int feat, int tile_w, int mean, int relu,
+                    void *stream);
 struct GatSpanLaunch {
     SpanLaunch s;                   // val_s unused
     const float *att = nullptr;     // [V, H, 2]

@@ -131,6 +131,9 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *                                         graph measured ("Measured (round 3)"): default 0, kept for A/B.
  *   "ds_slack" [GNNAGG_DS_SLACK]          phases a workgroup may run ahead of the slowest one of its XCD (0)
  *   "ds_hub_edges" [GNNAGG_DS_HUB_EDGES]  rows with a (row, range) group above this many edges stay on the streaming form (4096)
+ *   "rows_blocked" [GNNAGG_ROWS_BLOCKED]  1 (default): GNNAGG_MODE_ROWS of a GCN handle runs its canonical chains on the 2-D blocked
+ *                                         order where the graph allows it (gnnagg_rows_blocked_ranges); 0: always the row kernels.
+ *                                         The results are the same bits either way
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
 int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
 /* Aggregator_GCN::updateval, aggr_gcn.h:540-544: re-aliases the edge values (borrowed; read at run time). */
@@ -172,6 +175,11 @@ int gnnagg_mode_params(gnnagg_handle h, int mode, int *chunk, int *seg_chunks);
  * them.  *total_cols (may be NULL) = largest neighbor id + 1: the column count the ranges are cut from (the CSR need not be
  * square). */
 int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions, int *total_cols);
+/* GNNAGG_MODE_ROWS of a GCN handle: *ranges = the number of source ranges when the canonical chains run on the 2-D blocked order
+ * (option "rows_blocked", default 1: graphs of average degree >= "partition_min_degree" whose rows list their neighbors in ascending
+ * order -- range after range is then the CSR order, and every (row, column) stays the reference's one sequential chain,
+ * aggr_gcn.h:13-35, with the gathers served by the L2; sum / mean, feature widths above 32), 0 when the row kernels run. */
+int gnnagg_rows_blocked_ranges(gnnagg_handle h, int *ranges);
 /* Aggregator::num_target (aggregator.h:126), and the scheduled arrays copied to host buffers
  * (any may be NULL): ptr_s[num_target+1], idx_s[ptr_s[num_target]], target[num_target], val_s. */
 int gnnagg_num_target(gnnagg_handle h, int mode, int *out);

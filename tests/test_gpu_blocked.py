@@ -655,3 +655,50 @@ def test_overlap_combine_chunks_keep_every_bit(n):
     gb.run(dev(x), dev(att), y2, 128, "balanced", heads=H)
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("F", [602, 100, 64, 256, 33])
+@pytest.mark.parametrize("slice_kb", [16, 4])
+def test_rows_mode_on_the_blocked_order_is_the_canonical_chain(F, slice_kb):
+    """GNNAGG_MODE_ROWS (`scheduled = 0`) of a GCN handle on a graph the blocked order applies to (average degree >= 96, neighbors
+    ascending in every row): the reference's locality_schedule groups (one per (row, source range)) walked one range per launch, every
+    chain carried from range to range through a tiled image of Y -- range after range is the CSR order, so the result is the
+    reference's one sequential chain per (row, column) (aggr_gcn.h:13-35): bit-equal to the oracle's gcn_seq / gcn_mean and to the row
+    kernels, explicit and implicit weights, ReLU, updateval, hub rows, rows without edges.  Unsorted rows and max keep the row kernels."""
+    V, E = 900, 260000
+    ptr, idx = hub_graph(V, E, seed=5)
+    assert all(np.all(np.diff(idx[ptr[r]:ptr[r + 1]]) >= 0) for r in range(V))   # the generator sorts the rows
+    x, val = rand((V, F), 1), rand(E, 2)
+    for v in (val, None):
+        a = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if v is None else dev(v), F, F)
+        a.set_option("slice_kb", slice_kb)
+        k = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if v is None else dev(v), F, F)
+        k.set_option("rows_blocked", 0)
+        assert a.rows_blocked_ranges() > 1 and k.rows_blocked_ranges() == 0
+        y, y2 = torch.full((V, F), 7.0, device=DEV), torch.full((V, F), 7.0, device=DEV)
+        a.run(dev(x), y, 128, 0)
+        ref = orc.gcn_seq(ptr, idx, v, x)
+        assert np.array_equal(y.cpu().numpy(), ref)
+        assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0)
+        a.run(dev(x), y, 128, 0, reduce="mean")
+        assert np.array_equal(y.cpu().numpy(), orc.gcn_mean(ptr, idx, v, x))
+        for kw in ({}, {"reduce": "mean"}, {"relu": True}, {"reduce": "max"}):
+            a.run(dev(x), y, 128, 0, **kw)
+            k.run(dev(x), y2, 128, 0, **kw)
+            assert torch.equal(y, y2), kw
+        if v is not None:
+            v2 = rand(E, 9)
+            a.updateval(dev(v2))
+            a.run(dev(x), y, 128, 0)
+            assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx, v2, x))
+    # rows that do not list their neighbors in ascending order: range after range is not the CSR order -- the row kernels run
+    rng = np.random.default_rng(3)
+    idx_u = idx.copy()
+    for r in range(0, V, 7):
+        rng.shuffle(idx_u[ptr[r]:ptr[r + 1]])
+    u = gnc.Aggregator_GCN(dev(ptr), dev(idx_u), dev(val), F, F)
+    u.set_option("slice_kb", slice_kb)
+    assert u.rows_blocked_ranges() == 0
+    y = torch.full((V, F), 7.0, device=DEV)
+    u.run(dev(x), y, 128, 0)
+    assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx_u, val, x))
