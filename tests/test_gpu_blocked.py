@@ -686,6 +686,12 @@ def test_rows_mode_on_the_blocked_order_is_the_canonical_chain(F, slice_kb):
             a.run(dev(x), y, 128, 0, **kw)
             k.run(dev(x), y2, 128, 0, **kw)
             assert torch.equal(y, y2), kw
+        one = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if v is None else dev(v), F, F)   # hub rows behind the launches, one stream
+        one.set_option("slice_kb", slice_kb)
+        one.set_option("aux_stream", 0)
+        one.run(dev(x), y2, 128, 0, reduce="mean")
+        a.run(dev(x), y, 128, 0, reduce="mean")
+        assert torch.equal(y, y2)
         if v is not None:
             v2 = rand(E, 9)
             a.updateval(dev(v2))
