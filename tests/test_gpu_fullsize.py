@@ -74,6 +74,35 @@ def test_reddit_sage_mean_f602(reddit):
     assert bool(torch.all(y[:, 0] == degs.to(torch.float32))) and bool(torch.all(y[:, 601] == degs.to(torch.float32)))
 
 
+def test_reddit_sage_mean_f602_canonical_rows_mode(reddit):
+    """BASELINE's SAGE case in the canonical order (`scheduled = 0`): on this graph (average degree 492, sorted rows) the chains run
+    on the 2-D blocked order, one source range per launch.  Sampled rows bit-equal to the oracle's sequential chain (the reference's
+    aggr_gcn order, aggr_gcn.h:13-35) -- hub rows included --, the whole output bit-equal to the row kernels, and the
+    size-independent identities of the balanced test."""
+    ptr, idx = reddit
+    V, E, F = ptr.numel() - 1, idx.numel(), 602
+    agg = gnc.Aggregator_GCN(ptr, idx, None, F, F)
+    assert agg.rows_blocked_ranges() >= 8
+    x = torch.randn((V, F), device=DEV)
+    y = torch.empty((V, F), device=DEV)
+    agg.run(x, y, 512, 0, reduce="mean")
+    degs = (ptr[1:] - ptr[:-1])
+    rows = np.unique(np.concatenate([pick_rows(ptr, 40, 1), torch.argsort(degs, descending=True)[:3].cpu().numpy()]))   # + the three largest hubs
+    sp, si, _ = sample_rows(ptr, idx, rows)
+    got = y[torch.from_numpy(rows).to(DEV)].cpu().numpy()
+    assert np.array_equal(got, orc.gcn_mean(sp, si, None, x.cpu().numpy()))
+    kern = gnc.Aggregator_GCN(ptr, idx, None, F, F)
+    kern.set_option("rows_blocked", 0)
+    y2 = torch.empty((V, F), device=DEV)
+    kern.run(x, y2, 512, 0, reduce="mean")
+    assert torch.equal(y, y2)
+    ones = torch.full((V, F), 3.0, device=DEV)
+    agg.run(ones, y, 512, 0, reduce="mean")
+    assert bool(torch.all(y[degs > 0] == 3.0)) and bool(torch.all(y[degs == 0] == 0.0))
+    agg.run(ones.fill_(1.0), y, 512, 0, reduce="sum")
+    assert bool(torch.all(y[:, 0] == degs.to(torch.float32))) and bool(torch.all(y[:, 601] == degs.to(torch.float32)))
+
+
 def test_reddit_gat_8x32(reddit):
     ptr, idx = reddit
     V, E, H, D = ptr.numel() - 1, idx.numel(), 8, 32
