@@ -219,7 +219,7 @@ int launch_gcn_ds(const DsLaunch &L, void *stream_v)
     const long chunks = ((long)a.n_jobs + a.WPX - 1) / a.WPX;
     a.n_waves = (int)((chunks + 7) / 8);
     if ((size_t)8 * a.n_waves * a.P > L.cnt_capacity) return fail(GNNAGG_ERR_STATE, "internal: phase counters too small");
-    HIP_TRY(hipMemsetAsync(a.cnt, 0, (size_t)8 * a.n_waves * a.P * sizeof(unsigned), stream));
+    { const int rcz = launch_zero_words(a.cnt, (size_t)8 * a.n_waves * a.P, stream); if (rcz) return rcz; }   // (not a memset: graph replays)
     const size_t lds = ((size_t)L.RB * 64 + (size_t)(NT / 16) * kDsStage * 64) * sizeof(float) + (size_t)(NT / 16) * kDsStage * sizeof(int);
     static bool attr = false;
     if (!attr) {

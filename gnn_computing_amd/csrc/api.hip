@@ -1195,7 +1195,7 @@ static int run_rows_blocked(Ctx *c, const float *x, float *y, int feat, int redu
         if ((rc = launch_tile_x(x, c->xt.p, s.total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
         xin = c->xt.p;
     }
-    HIP_TRY(hipMemsetAsync(c->yt.p, 0, yt_floats * sizeof(float), c->stream));
+    if ((rc = launch_zero_words(c->yt.p, yt_floats, c->stream))) return rc;
     SpanLaunch S;
     S.chain = 1;
     S.ptr_s = s.ptr_s.p; S.idx_f = rb.idx_f.p; S.val_s = c->d_val ? s.val_s.p : nullptr; S.target = s.target.p;

@@ -239,7 +239,7 @@ int launch_edgewise(const int *edgelist, const float *val, const float *x, float
                     void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
-    HIP_TRY(hipMemsetAsync(y, 0, (size_t)V * feat * sizeof(float), stream));  // aggr_gcn.h:448
+    { const int rcz = launch_zero_words(y, (size_t)V * feat, stream); if (rcz) return rcz; }  // aggr_gcn.h:448
     if (E <= 0) return GNNAGG_OK;
     hipLaunchKernelGGL(k_edgewise, dim3(ceil_div(E, kBlock / 64)), dim3(kBlock), 0, stream,
                        reinterpret_cast<const int2 *>(edgelist), val, x, y, E, feat);
@@ -637,8 +637,7 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
         }
     }
     if (K <= 0) {
-        HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream));
-        return GNNAGG_OK;
+        return launch_zero_words(C, (size_t)M * N, stream);
     }
     {
         static const int big = getenv("GNNAGG_GEMM_BIG") ? atoi(getenv("GNNAGG_GEMM_BIG")) : 1;
@@ -817,6 +816,35 @@ int launch_tile_x(const float *x, float *xt, int rows, int feat, int tile_w, voi
     const int quads = ntiles * tile_w / 4;
     const long total = (long)rows * quads;
     hipLaunchKernelGGL(k_tile_x, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, x, xt, rows, feat, tile_w, quads);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+// n 4-byte words at p = 0.  A kernel rather than hipMemsetAsync: a memset NODE of a captured HIP graph did its work on the first
+// replay only (ROCm 7.2: replays 2 and 3 of the chained rows mode started from the previous replay's Yt;
+// tests/test_gpu_blocked.py::test_rows_mode_on_the_blocked_order_with_the_dense_combine_behind_it).  Every fill on a path that a
+// caller may capture goes through here.
+__global__ __launch_bounds__(256) void k_zero_f32x4(float4 *__restrict__ p, long n4)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ __launch_bounds__(256) void k_zero_u32(unsigned *__restrict__ p, long n)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+int launch_zero_words(void *p, size_t n, void *stream_v)
+{
+    if (n == 0) return GNNAGG_OK;
+    if (((uintptr_t)p & 3) != 0) return fail(GNNAGG_ERR_STATE, "internal: zero fill of an unaligned range");
+    if ((n & 3) == 0 && ((uintptr_t)p & 15) == 0) {
+        const long n4 = (long)(n / 4);
+        hipLaunchKernelGGL(k_zero_f32x4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, reinterpret_cast<float4 *>(p), n4);
+    } else {
+        hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)(((long)n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, reinterpret_cast<unsigned *>(p), (long)n);
+    }
     HIP_TRY(hipGetLastError());
     return GNNAGG_OK;
 }

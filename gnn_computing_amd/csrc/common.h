@@ -177,6 +177,7 @@ struct DsLaunch {
 };
 int launch_gcn_ds(const DsLaunch &a, void *stream);
 // y[r, :] = finish(Yt[tile][r][:]) -- the tiled image back into the caller's rows, mean (/ degree) and ReLU applied
+int launch_zero_words(void *p, size_t n_words, void *stream);   // 4-byte words; a kernel, not a memset (graph replays: aux_kernels.hip)
 // (skip: optional [rows] bytes, 1 = leave the row of y alone)
 int launch_untile_y(const float *yt, float *y, const int *row_ptr, const unsigned char *skip, int rows, int feat, int tile_w, int mean, int relu,
                     void *stream);

@@ -708,3 +708,34 @@ def test_rows_mode_on_the_blocked_order_is_the_canonical_chain(F, slice_kb):
     y = torch.full((V, F), 7.0, device=DEV)
     u.run(dev(x), y, 128, 0)
     assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx_u, val, x))
+
+
+def test_rows_mode_on_the_blocked_order_with_the_dense_combine_behind_it():
+    """run_with_nn in the canonical order on a graph whose chains run on the blocked order: vout is the sequential chain, transformed
+    the oracle's ascending-k GEMM of it, both bit for bit; and the whole run replays from a captured HIP graph (memset, one launch per
+    range, the hub rows forked to the auxiliary stream and joined)."""
+    V, E, F, OUT = 900, 260000, 128, 32
+    ptr, idx = hub_graph(V, E, seed=5)
+    x, val, W = rand((V, F), 1), rand(E, 2), rand((F, OUT), 3) * 0.3
+    a = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, OUT)
+    a.set_option("slice_kb", 16)
+    assert a.rows_blocked_ranges() > 1
+    y, tr = torch.full((V, F), 7.0, device=DEV), torch.full((V, OUT), 7.0, device=DEV)
+    a.run_with_nn(dev(x), y, dev(W), tr, 128, 0)
+    ref = orc.gcn_seq(ptr, idx, val, x)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    assert np.array_equal(tr.cpu().numpy(), orc.matmul_nn(ref, W))
+    dx = dev(x)
+    a.run(dx, y, 128, 0)           # warm: plan, scratch, streams and events exist
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    y.fill_(7.0)
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            a.run(dx, y, 128, 0, reduce="mean")
+    for _ in range(2):
+        y.fill_(7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(y.cpu().numpy(), orc.gcn_mean(ptr, idx, val, x))
