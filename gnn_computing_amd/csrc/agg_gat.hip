@@ -491,8 +491,7 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
 #define CALL_GP                                                                                              \
         if (a.heads == 1) hipLaunchKernelGGL((k_gat_plan<VEC, GROUP, true>), dim3(grid), dim3(blk), 0, stream, a);   \
         else              hipLaunchKernelGGL((k_gat_plan<VEC, GROUP, false>), dim3(grid), dim3(blk), 0, stream, a);
-        static const int u4_env = getenv("GNNAGG_PLAN_UNROLL4") ? atoi(getenv("GNNAGG_PLAN_UNROLL4")) : 1;
-        const bool u4 = u4_env && L.unroll == 4 && g.vec == 4 && !L.tile.on;
+        const bool u4 = L.unroll == 4 && g.vec == 4 && !L.tile.on;
         if (u4 && g.group == 32) {
             if (a.heads == 1) hipLaunchKernelGGL((k_gat_plan<4, 32, true, 4>), dim3(grid), dim3(blk), 0, stream, a);
             else              hipLaunchKernelGGL((k_gat_plan<4, 32, false, 4>), dim3(grid), dim3(blk), 0, stream, a);

@@ -790,12 +790,6 @@ static int launch_combine_gcn(const GcnLaunch &L, const Geometry &g, bool is_max
 
 int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int K, void *stream_v);
 
-static bool nn_fusion_enabled()
-{
-    static const int on = getenv("GNNAGG_FUSE_NN") ? atoi(getenv("GNNAGG_FUSE_NN")) : 1;
-    return on != 0;
-}
-
 int launch_dense_rows(const int *rows, int n_rows, const float *Y, const float *W, float *out, int K, int N, void *stream_v)
 {
     hipStream_t stream = (hipStream_t)stream_v;
@@ -839,18 +833,16 @@ int launch_gcn_plan(const GcnPlanLaunch &L, void *stream_v)
     }
     const bool hubs_in_kernel = a.hub_count != nullptr;
     {
-        static const int wt_env = getenv("GNNAGG_WT_STORES") ? atoi(getenv("GNNAGG_WT_STORES")) : 1;
         const size_t ybytes = (size_t)L.num_rows * L.feat * sizeof(float);
-        a.wt = (wt_env && !L.accumulate && ybytes < 0x7fffffffULL) ? 1 : 0;
+        a.wt = (!L.accumulate && ybytes < 0x7fffffffULL) ? 1 : 0;
         a.ybytes = (unsigned)ybytes;
     }
     // dense combine fused as the epilogue when one lane group spans the row and the [32][K] tile fits LDS
     const bool want_nn = L.nn_weight != nullptr;
     // (8-lane groups, F <= 32: the GEMM is ~11 us on the arxiv-shaped input and the epilogue costs as much -- not fused)
-    const bool fuse_nn = want_nn && !L.tile.on && !L.probe && g.ntiles == 1 && g.group >= 16 && !L.accumulate && !L.relu && !L.t0_partials && nn_fusion_enabled();
+    const bool fuse_nn = want_nn && !L.tile.on && !L.probe && g.ntiles == 1 && g.group >= 16 && !L.accumulate && !L.relu && !L.t0_partials;
     // 4 gathers per batch on the 32-lane float4 geometry when the caller asks for it (see k_gcn_plan)
-    static const int u4_env = getenv("GNNAGG_PLAN_UNROLL4") ? atoi(getenv("GNNAGG_PLAN_UNROLL4")) : 1;
-    const bool u4 = u4_env && L.unroll == 4 && g.vec == 4 && (g.group == 32 || g.group == 64) && !L.tile.on && !fuse_nn;
+    const bool u4 = L.unroll == 4 && g.vec == 4 && (g.group == 32 || g.group == 64) && !L.tile.on && !fuse_nn;
     const int blk = block_for(g.group);
     const int gpb = fuse_nn ? std::max(kNnRows, blk / g.group) : blk / g.group;
     const int item_blocks = ceil_div(a.n0, gpb);
@@ -943,10 +935,10 @@ int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)
     }
 #define LAUNCH_LONG_K(K)                                                                                             \
     {                                                                                                                \
-        static bool big_lds_ok = false; /* > 64 KB of dynamic LDS needs the attribute, once per instantiation */    \
-        if (!big_lds_ok) {                                                                                           \
+        static OncePerDevice big_lds_ok; /* > 64 KB of dynamic LDS needs the attribute: once per instantiation AND device */ \
+        if (big_lds_ok.first()) {                                                                                    \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            big_lds_ok = true;                                                                                       \
+            big_lds_ok.done();                                                                                       \
         }                                                                                                            \
         hipLaunchKernelGGL(K, dim3(grid), dim3(kLongBlock), lds, stream, a);                                         \
     }

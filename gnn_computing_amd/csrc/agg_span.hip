@@ -634,31 +634,13 @@ __global__ __launch_bounds__(256) void k_combine_groups_gat(const CombineGroupsG
     store_pack_any<VEC>(a.y + (size_t)row * F + col, acc, F - col, a.yvec);
 }
 
-// Launch plan shared by the GCN and GAT launchers: either ONE span launch over all tiles followed by one combine, or (with
-// an auxiliary stream) one span launch per tile on `stream`, each followed by its combine on the auxiliary stream.
+// Launch plan shared by the GCN and GAT launchers: ONE span launch over all tiles, one ordered combine, the rows without groups.
+// (Per-tile / per-chunk launches with the combine on a second stream were measured and lost: scripts/attic/, profiles/r03/overlap_chunks.txt.)
 template <class SpanFn, class CombineFn>
 static int run_span_plan(const SpanLaunch &L, int ntiles, hipStream_t stream, SpanFn span, CombineFn combine)
 {
-    hipStream_t aux = (hipStream_t)L.aux_stream;
-    const bool overlap = aux != nullptr && ntiles > 1 && L.n_events >= ntiles && L.join_event != nullptr && L.n_crows > 0 && !L.probe;
-    if (!overlap) {
-        if (L.n_spans > 0) { const int rc = span(0, ntiles, stream); if (rc) return rc; }
-        if (!L.probe && L.n_crows > 0) { const int rc = combine(0, ntiles, stream); if (rc) return rc; }
-    } else {
-        // overlap_chunks >= 2: that many launches of consecutive tiles instead of one per tile (fewer breaks of the tile-major walk)
-        const int step = L.overlap_chunks >= 2 ? (ntiles + L.overlap_chunks - 1) / L.overlap_chunks : 1;
-        for (int t = 0; t < ntiles; t += step) {
-            const int nt = t + step <= ntiles ? step : ntiles - t;
-            if (L.n_spans > 0) { const int rc = span(t, nt, stream); if (rc) return rc; }
-            hipEvent_t ev = (hipEvent_t)L.events[t];
-            HIP_TRY(hipEventRecord(ev, stream));
-            HIP_TRY(hipStreamWaitEvent(aux, ev, 0));
-            const int rc = combine(t, nt, aux);
-            if (rc) return rc;
-        }
-        HIP_TRY(hipEventRecord((hipEvent_t)L.join_event, aux));
-        HIP_TRY(hipStreamWaitEvent(stream, (hipEvent_t)L.join_event, 0));
-    }
+    if (L.n_spans > 0) { const int rc = span(0, ntiles, stream); if (rc) return rc; }
+    if (!L.probe && L.n_crows > 0) { const int rc = combine(0, ntiles, stream); if (rc) return rc; }
     if (!L.probe && L.n_empty > 0) {
         const long total = (long)L.n_empty * L.feat;
         hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, L.empty_rows, L.n_empty, L.y, L.feat);
@@ -669,14 +651,13 @@ static int run_span_plan(const SpanLaunch &L, int ntiles, hipStream_t stream, Sp
 
 static void fill_span_args(SpanArgs &a, const SpanLaunch &L, int ntiles_total, int group)
 {
-    static const int wt_env = getenv("GNNAGG_PARTIAL_WT") ? atoi(getenv("GNNAGG_PARTIAL_WT")) : 1;
     a.span_g = L.span_g; a.ptr_s = L.ptr_s; a.idx_f = L.idx_f; a.val_s = L.val_s; a.target = L.target;
     a.x = L.x; a.y = L.y; a.partial = L.partial;
     a.n_spans = L.n_spans; a.feat = L.feat; a.ntiles = ntiles_total; a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.relu = L.relu;
     a.yvec = L.tile.yvec; a.xpitch = L.tile.xpitch; a.ppitch = L.tile.ppitch;
     a.x_tile_stride = L.tile.x_tile_stride; a.p_tile_stride = L.tile.p_tile_stride;
     const size_t tb = (size_t)L.n_groups * L.tile.ppitch * sizeof(float);
-    a.ptile_bytes = (wt_env && tb < 0x7fffffffULL) ? (unsigned)tb : 0u;
+    a.ptile_bytes = (tb < 0x7fffffffULL) ? (unsigned)tb : 0u;
     a.probe_sink = nullptr;
     a.tile0 = 0;
     a.span_blocks = ceil_div(L.n_spans, 256 / group);

@@ -73,7 +73,7 @@ struct Schedule {
     int total_cols = 0;     // locality schedules: the column count the ranges were cut from
     int par_num = 0;        // locality schedules: the number of column ranges
     std::vector<int> h_ptr_s, h_target, h_idx_s, h_slot, h_empty;
-    std::vector<int> h_eperm;  // library-built permuted schedules: host copy of eperm (the destination-stationary plan is cut from it)
+    std::vector<int> h_eperm;  // library-built permuted schedules: host copy of eperm while a plan is being cut from it (build_rows_blocked)
     std::vector<float> h_val_s;
     DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s, big_rows;
     DevBuf<int> eperm;      // library-built permuted schedules: original edge of every permuted position (val follows its edges)
@@ -138,22 +138,6 @@ struct RowsPlan {
     std::vector<long> r0_cost_prefix;
 };
 
-// Destination-stationary plan of the 2-D blocked order (agg_ds.hip; option "dest_stationary"): cut from sched[1]
-struct DsPlan {
-    bool valid = false, failed = false;
-    int U = 0, RB = 208, P = 0, WPX = 64, width = 0;
-    size_t n_edges = 0;
-    DevBuf<unsigned> idw, cnt;
-    DevBuf<float> val;
-    DevBuf<int> dsp, dstage, urows, eperm;
-    void reset()
-    {
-        valid = failed = false;
-        idw.release(); cnt.release(); val.release(); dsp.release(); dstage.release(); urows.release(); eperm.release();
-        U = P = width = 0; n_edges = 0;
-    }
-};
-
 static constexpr int kItemCost = 2;  // fixed per-item overhead in edge-equivalents (XCD range balancing)
 
 struct Ctx {
@@ -170,9 +154,6 @@ struct Ctx {
     BalancedPlan plan;       // balanced mode
     BalancedPlan plan_sched; // `scheduled = 1` with a neighbor-grouping schedule, when the plan kernel suits that NG
     BalancedPlan plan_part;  // source-partitioned balanced mode: one short-row descriptor per group of sched[1]
-    DsPlan ds;               // destination-stationary form of that order (option "dest_stationary")
-    Schedule sched_hub;      // ... and the rows it leaves to the streaming form (sub-rows of thousands of edges): their groups of sched[1]
-    int opt_ds = 0, opt_ds_slack = 0, opt_ds_hub_edges = 4096;
     // canonical rows mode on the blocked order (option "rows_blocked"; build_rows_blocked / run_rows_blocked)
     struct RowsBlocked {
         bool tried = false, ok = false;
@@ -191,8 +172,6 @@ struct Ctx {
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> tile_events;  // blocked mode: tile t's span kernel done (its combine waits on the aux stream)
-    int overlap_combine = 0;              // blocked mode, A/B: per-tile launches with tile t's combine on the aux stream beside tile t + 1 (measured slower: reddit-shaped F=602 15.4 -> 16.9 ms, GAT 8x32 9.8 -> 10.7 ms)
     Schedule sched_edges;    // chunked work items of the edge kernels (run_att, u_add_v, add_to_center, div_each)
     DevBuf<float> den;       // [V,heads] row sums of run_att
     DevBuf<float> partial, partial_den;
@@ -377,7 +356,7 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
         eid.resize((size_t)kept);
         int rc2 = s.eperm.upload(eid);
         if (rc2) return rc2;
-        if (c->opt_ds || c->keep_h_eperm) s.h_eperm = eid;
+        if (c->keep_h_eperm) s.h_eperm = eid;
     }
     s.h_idx_s.resize((size_t)kept);
     if (!s.h_val_s.empty()) s.h_val_s.resize((size_t)kept);
@@ -504,10 +483,8 @@ static int build_rows_plan(Ctx *c)
     // holds one such workgroup while it could hold dozens of lane groups walking their own rows, so it only takes rows far
     // above the average degree: max(1024, 16 * avg).  Measured (rows mode, ms): reddit-shaped SAGE F=602 56.3 with every
     // row on lane groups, 45.8 at 4 * avg, 41.0 at 16 * avg, 40.0 at 32 * avg; reddit-shaped GAT 47.2 / 19.8 / 16.8 / 16.5;
-    // products-shaped 9.8 at 1024 but 89 at 256 (the short rows starve).  GNNAGG_LONG_DEG / GNNAGG_LONG_MULT override.
-    static const int long_min = getenv("GNNAGG_LONG_DEG") ? atoi(getenv("GNNAGG_LONG_DEG")) : 1024;
-    static const int long_mult = getenv("GNNAGG_LONG_MULT") ? atoi(getenv("GNNAGG_LONG_MULT")) : 16;
-    p.long_deg = std::max(long_min, long_mult * c->avg_deg());
+    // products-shaped 9.8 at 1024 but 89 at 256 (the short rows starve).
+    p.long_deg = std::max(1024, 16 * c->avg_deg());
     std::vector<int> r0;
     struct Long { int beg, end, row; };
     std::vector<Long> longs;
@@ -580,37 +557,13 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
 
 static int build_spans(Ctx *c, Schedule &s);
 
-// aux stream + events of the per-tile overlap (created on first use: never inside a capture of a warm handle)
-static int span_overlap(Ctx *c, int ntiles, SpanLaunch &S)
-{
-    if (!c->overlap_combine || ntiles < 2) return GNNAGG_OK;
-    if (!c->aux_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
-    while ((int)c->tile_events.size() < ntiles) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->tile_events.push_back(e);
-    }
-    S.aux_stream = c->aux_stream;
-    S.overlap_chunks = c->overlap_combine >= 2 ? c->overlap_combine : 0;
-    S.events = reinterpret_cast<void **>(c->tile_events.data());
-    S.n_events = (int)c->tile_events.size();
-    S.join_event = c->ev_join;
-    return GNNAGG_OK;
-}
-
 static int build_partitioned(Ctx *c, int parts)
 {
     c->plan.reset();
     c->plan_part.reset();
-    c->ds.reset();
-    c->sched_hub.reset();
     Schedule &s = c->sched[1];
     // the segmented-stream kernel wants several groups per span: groups of at most 128 edges there
-    static const int span_chunk = getenv("GNNAGG_SPAN_CHUNK") ? std::max(1, atoi(getenv("GNNAGG_SPAN_CHUNK"))) : 128;
+    constexpr int span_chunk = 128;
     const bool spans = c->tiled && c->use_spans;
     int rc = build_locality(c, s, parts, spans ? std::min(pick_chunk(c), span_chunk) : pick_chunk(c), -1,
                             GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING, true);
@@ -647,8 +600,7 @@ static int build_spans(Ctx *c, Schedule &s)
     int mx = 0;
     for (int v : s.h_idx_s) mx = std::max(mx, v);
     if ((unsigned)mx > 0x3fffffffu) return GNNAGG_OK;  // the two flag bits are not free: stay on the descriptor kernels
-    static const int span_env = getenv("GNNAGG_SPAN_EDGES") ? atoi(getenv("GNNAGG_SPAN_EDGES")) : kSpanEdges;
-    const int span_edges = std::max(1, span_env);
+    const int span_edges = kSpanEdges;
     std::vector<int> groups_of((size_t)V, 0);
     for (int g = 0; g < G; ++g) groups_of[s.h_target[g]]++;
     // flagged ids
@@ -690,216 +642,6 @@ static int build_spans(Ctx *c, Schedule &s)
     return GNNAGG_OK;
 }
 
-// Destination-stationary plan: units of RB output rows (dealt so that every unit sees about the same number of edges in every
-// source range: rows are bucketed by their heaviest range, sorted by degree inside a bucket and dealt to the units in snake
-// order), and per (unit, range) the unit's groups of sched[1] in LDS-row order, cut into at most 32 spans of whole groups.  A
-// sub-row that continues into the next span has its continuation groups flagged for the staging slots (at most kDsStage at the
-// head of a span); the words carry the group-end flag, the LDS row and the source row inside the range.
-static int build_ds_plan(Ctx *c, Schedule &s, DsPlan &d)
-{
-    constexpr int LG = 32;
-    d.reset();
-    const int V = c->V, G = s.num_target, P = s.par_num;
-    const int width = P > 0 ? s.total_cols / P : 0;
-    if (G == 0 || P < 2 || width <= 0 || s.h_eperm.size() != s.h_idx_s.size() || (long)s.total_cols - (long)(P - 1) * width > (1L << 21)) {
-        if (getenv("GNNAGG_DS_DEBUG")) fprintf(stderr, "dest-stationary plan: not applicable (G %d P %d width %d eperm %zu idx %zu)\n", G, P, width, s.h_eperm.size(), s.h_idx_s.size());
-        d.failed = true;
-        return GNNAGG_OK;
-    }
-    auto part_of = [&](int col) { const int p = col / width; return p >= P ? P - 1 : p; };
-    std::vector<int> gp((size_t)G);
-#pragma omp parallel for schedule(static)
-    for (int g = 0; g < G; ++g) gp[g] = part_of(s.h_idx_s[s.h_ptr_s[g]]);
-    // heaviest range of every row
-    std::vector<int> dom((size_t)V, P), best((size_t)V, 0);
-    for (int g = 0; g < G;) {
-        const int r = s.h_target[g], p = gp[g];
-        int e = 0, h = g;
-        while (h < G && s.h_target[h] == r && gp[h] == p) { e += s.h_ptr_s[h + 1] - s.h_ptr_s[h]; ++h; }
-        if (e > best[r]) { best[r] = e; dom[r] = p; }
-        g = h;
-    }
-    // Rows with a sub-row of more than kDsHubEdges edges (a hub's home range: thousands of edges, hundreds of groups) would need
-    // hundreds of staged continuation groups per phase: they stay on the streaming form (their groups of sched[1], compacted
-    // into sched_hub; a few hundred rows, a few percent of the edges on the reddit-shaped graph).
-    const int hub_edges = c->opt_ds_hub_edges;
-    std::vector<char> is_hub((size_t)V, 0);
-    int n_hub = 0;
-    for (int r = 0; r < V; ++r)
-        if (best[r] > hub_edges) { is_hub[r] = 1; ++n_hub; }
-    Schedule &sh = c->sched_hub;
-    sh.reset();
-    if (n_hub > 0) {
-        sh.kind = s.kind; sh.permuted = true; sh.total_cols = s.total_cols; sh.par_num = s.par_num;
-        sh.h_ptr_s.push_back(0);
-        for (int g = 0; g < G; ++g) {
-            if (!is_hub[s.h_target[g]]) continue;
-            sh.h_target.push_back(s.h_target[g]);
-            sh.h_idx_s.insert(sh.h_idx_s.end(), s.h_idx_s.begin() + s.h_ptr_s[g], s.h_idx_s.begin() + s.h_ptr_s[g + 1]);
-            sh.h_eperm.insert(sh.h_eperm.end(), s.h_eperm.begin() + s.h_ptr_s[g], s.h_eperm.begin() + s.h_ptr_s[g + 1]);
-            sh.h_ptr_s.push_back((int)sh.h_idx_s.size());
-        }
-        int rc0 = finalize_schedule(c, sh);
-        if (rc0) return rc0;
-        if ((rc0 = sh.eperm.upload(sh.h_eperm))) return rc0;
-        if ((rc0 = build_spans(c, sh))) return rc0;
-        if (sh.n_spans == 0) { d.failed = true; return GNNAGG_OK; }
-    }
-    d.RB = 208;
-    const int U = (V - n_hub + (d.RB - 8) - 1) / (d.RB - 8) + 1;
-    // Rows -> units.  The ranges are swept in lock step, so a phase lasts as long as its heaviest unit: every unit should see about
-    // the same number of edges in EVERY range.  Longest-processing-time dealing on the total degree (a heap of units by edges so
-    // far) settles the totals; among the eight lightest units that still have room the row goes where the resulting heaviest range
-    // stays lightest (per-row edge counts per range from the groups) -- which spreads the rows of one community, whose edges
-    // concentrate in their home range, over different units.
-    std::vector<int> rp_ptr((size_t)V + 1, 0);
-    for (int g = 0; g < G;) {   // (row, range) pairs per row: count, then fill
-        const int r = s.h_target[g], pp = gp[g];
-        int h = g;
-        while (h < G && s.h_target[h] == r && gp[h] == pp) ++h;
-        ++rp_ptr[(size_t)r + 1];
-        g = h;
-    }
-    for (int r = 0; r < V; ++r) rp_ptr[r + 1] += rp_ptr[r];
-    std::vector<int> rp_p((size_t)rp_ptr[V]), rp_e((size_t)rp_ptr[V]);
-    {
-        std::vector<int> cur(rp_ptr.begin(), rp_ptr.end() - 1);
-        for (int g = 0; g < G;) {
-            const int r = s.h_target[g], pp = gp[g];
-            int e = 0, h = g;
-            while (h < G && s.h_target[h] == r && gp[h] == pp) { e += s.h_ptr_s[h + 1] - s.h_ptr_s[h]; ++h; }
-            rp_p[cur[r]] = pp;
-            rp_e[cur[r]++] = e;
-            g = h;
-        }
-    }
-    std::vector<int> order;
-    order.reserve((size_t)V - n_hub);
-    for (int r = 0; r < V; ++r)
-        if (!is_hub[r]) order.push_back(r);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return c->h_ptr[x + 1] - c->h_ptr[x] > c->h_ptr[y + 1] - c->h_ptr[y]; });
-    std::vector<int> unit_of((size_t)V, -1), lrow((size_t)V, 0), fill((size_t)U, 0);
-    std::vector<long> load((size_t)U * P, 0);
-    const int cap = d.RB - 2;
-    typedef std::pair<long, int> HeapEnt;
-    std::priority_queue<HeapEnt, std::vector<HeapEnt>, std::greater<HeapEnt>> pq;
-    for (int u = 0; u < U; ++u) pq.push({0L, u});
-    for (int r : order) {
-        HeapEnt cand[8];
-        int nc = 0;
-        while (nc < 8 && !pq.empty()) { cand[nc++] = pq.top(); pq.pop(); }
-        if (nc == 0) { d.failed = true; return GNNAGG_OK; }
-        int pick = 0;
-        long pick_score = -1;
-        for (int q = 0; q < nc; ++q) {
-            const long *L = &load[(size_t)cand[q].second * P];
-            long worst = 0;
-            for (int k2 = rp_ptr[r]; k2 < rp_ptr[r + 1]; ++k2) worst = std::max(worst, L[rp_p[k2]] + rp_e[k2]);
-            if (pick_score < 0 || worst < pick_score) { pick_score = worst; pick = q; }
-        }
-        const int u = cand[pick].second;
-        unit_of[r] = u;
-        lrow[r] = fill[u]++;
-        long *L = &load[(size_t)u * P];
-        for (int k2 = rp_ptr[r]; k2 < rp_ptr[r + 1]; ++k2) L[rp_p[k2]] += rp_e[k2];
-        for (int q = 0; q < nc; ++q) {
-            if (q == pick) { if (fill[u] < cap) pq.push({cand[q].first + (c->h_ptr[r + 1] - c->h_ptr[r]), u}); }
-            else pq.push(cand[q]);
-        }
-    }
-    for (int u = 0; u < U; ++u)
-        if (fill[u] > d.RB) { if (getenv("GNNAGG_DS_DEBUG")) fprintf(stderr, "dest-stationary plan: unit %d holds %d rows\n", u, fill[u]); d.failed = true; return GNNAGG_OK; }
-    // groups per (unit, range), in (LDS row, group) order
-    const size_t NK = (size_t)U * P;
-    std::vector<int> kcnt(NK + 1, 0);
-    for (int g = 0; g < G; ++g)
-        if (!is_hub[s.h_target[g]]) ++kcnt[(size_t)unit_of[s.h_target[g]] * P + gp[g] + 1];
-    for (size_t k = 0; k < NK; ++k) kcnt[k + 1] += kcnt[k];
-    std::vector<int> kg((size_t)kcnt[NK]);
-    {
-        std::vector<int> cur(kcnt.begin(), kcnt.end() - 1);
-        for (int g = 0; g < G; ++g)
-            if (!is_hub[s.h_target[g]]) kg[cur[(size_t)unit_of[s.h_target[g]] * P + gp[g]]++] = g;   // ascending g inside a key
-    }
-    const size_t NE = s.h_idx_s.size() - sh.h_idx_s.size();
-    std::vector<unsigned> idw(NE);
-    std::vector<int> eperm(NE), dsp(NK * (LG + 1), 0), dstage(NK * (LG + 1), 0);
-    // edge offsets of the keys
-    std::vector<long> koff(NK + 1, 0);
-    for (size_t k = 0; k < NK; ++k) {
-        long e = 0;
-        for (int q = kcnt[k]; q < kcnt[k + 1]; ++q) e += s.h_ptr_s[kg[q] + 1] - s.h_ptr_s[kg[q]];
-        koff[k + 1] = koff[k] + e;
-    }
-    bool overflow = false;
-    long worst = 0, total = 0;
-#pragma omp parallel for schedule(dynamic, 64) reduction(|| : overflow) reduction(max : worst) reduction(+ : total)
-    for (long k = 0; k < (long)NK; ++k) {
-        std::vector<int> gl(kg.begin() + kcnt[k], kg.begin() + kcnt[k + 1]);
-        std::stable_sort(gl.begin(), gl.end(), [&](int x, int y) { return lrow[s.h_target[x]] < lrow[s.h_target[y]]; });
-        const int p = (int)(k % P);
-        const long tot = koff[k + 1] - koff[k];
-        worst = std::max(worst, tot);
-        total += tot;
-        const long target = std::max<long>(64, (tot + LG - 1) / LG);
-        long pos = koff[k], span_edges = 0;
-        int span = 0, in_span = 0, prev_row = -1, pool = 0;
-        bool prev_staged = false;
-        int *sp = &dsp[(size_t)k * (LG + 1)];
-        int *sb = &dstage[(size_t)k * (LG + 1)];
-        sp[0] = (int)pos;
-        sb[0] = 0;
-        for (size_t q = 0; q < gl.size(); ++q) {
-            const int g = gl[q], r = s.h_target[g];
-            const bool is_cont = r == prev_row;
-            // a continuation group at the head of a span (its sub-row began in an earlier span), and the continuation groups
-            // right behind it, are staged: they take the next slot of the workgroup's pool, in group order
-            const bool staged = is_cont && (in_span == 0 || prev_staged);
-            if (staged && ++pool > LG * kDsStage) {
-                if (!overflow && getenv("GNNAGG_DS_DEBUG"))
-                    fprintf(stderr, "dest-stationary plan: staging pool overflow in unit %ld range %d: %ld edges in %zu groups, target %ld, row %d (%d edges in its heaviest range)\n",
-                            k / P, p, tot, gl.size(), target, r, best[r]);
-                overflow = true;
-            }
-            const int b0 = s.h_ptr_s[g], b1 = s.h_ptr_s[g + 1];
-            for (int e = b0; e < b1; ++e) {
-                unsigned w = (unsigned)(s.h_idx_s[e] - p * width) | ((unsigned)lrow[r] << 21);
-                if (e == b1 - 1) w |= 0x80000000u | (staged ? 0x40000000u : 0u);
-                idw[pos] = w;
-                eperm[pos] = s.h_eperm[e];
-                ++pos;
-            }
-            span_edges += b1 - b0;
-            ++in_span;
-            prev_row = r;
-            prev_staged = staged;
-            if (span_edges >= target && span < LG - 1 && q + 1 < gl.size()) { sp[++span] = (int)pos; sb[span] = pool; in_span = 0; span_edges = 0; }
-        }
-        for (int j = span + 1; j <= LG; ++j) sb[j] = pool;   // sb[LG] = staged groups of this (unit, range)
-        for (int j = span + 1; j <= LG; ++j) sp[j] = (int)pos;
-    }
-    if (overflow || koff[NK] > 0x7fffffffL) {
-        if (getenv("GNNAGG_DS_DEBUG")) fprintf(stderr, "dest-stationary plan: span overflow %d, edges %ld\n", (int)overflow, koff[NK]);
-        d.failed = true;
-        return GNNAGG_OK;
-    }
-    std::vector<int> urows((size_t)U * d.RB, -1);
-    for (int r = 0; r < V; ++r)
-        if (!is_hub[r]) urows[(size_t)unit_of[r] * d.RB + lrow[r]] = r;
-    d.U = U; d.P = P; d.width = width; d.n_edges = NE;
-    if (getenv("GNNAGG_DS_DEBUG"))
-        fprintf(stderr, "dest-stationary plan: %d units x %d ranges, %zu edges, heaviest (unit, range) %ld edges vs mean %.0f; %d hub rows "
-                        "(%zu edges, %d groups) stay on the streaming form\n", U, P, NE, worst, (double)total / (double)NK, n_hub,
-                sh.h_idx_s.size(), sh.num_target);
-    int rc;
-    if ((rc = d.idw.upload(idw)) || (rc = d.dsp.upload(dsp)) || (rc = d.dstage.upload(dstage)) || (rc = d.urows.upload(urows)) ||
-        (rc = d.eperm.upload(eperm)))
-        return rc;
-    if ((rc = d.cnt.reserve((size_t)8 * 4096 * 8))) return rc;
-    d.valid = true;
-    return GNNAGG_OK;
-}
-
 // The source-partitioned order was chosen by the library, not by the caller, so the aliasing contract of updateval
 // (aggr_gcn.h:540-544: the aggregator reads the caller's array at run time) has to survive the permutation: the permuted
 // copy of the edge values is re-gathered from the caller's array before every run (E floats; 0.13 ms at 115 M edges).
@@ -922,8 +664,6 @@ static int demote_partitioned(Ctx *c)
     c->no_auto_partition = 1;
     c->sched[1].reset();
     c->plan_part.reset();
-    c->ds.reset();
-    c->sched_hub.reset();
     c->xt.release();
     return build_balanced_plan(c, pick_chunk(c));
 }
@@ -1072,8 +812,7 @@ static int build_rows_blocked(Ctx *c, int ntiles_hint)
         // The threshold follows the duration of a launch, i.e. the number of column tiles of the first run that builds the plan
         // (reddit-shaped, ms per step at 512 / 1024 / 2048 / 4096 edges: F = 128 5.6 / 5.7 / 7.1 / 7.5, F = 256 10.5 / 10.1 / 10.3 /
         // 10.3, F = 602 -- 10 tiles -- 23.9 / 20.2 / 19.7 at 1024 / 2048 / 4096).
-        static const int hub_env = getenv("GNNAGG_RB_HUB_EDGES") ? std::max(1, atoi(getenv("GNNAGG_RB_HUB_EDGES"))) : 0;
-        const int hub_edges = hub_env ? hub_env : std::min(4096, std::max(512, 256 * std::max(1, ntiles_hint)));
+        const int hub_edges = std::min(4096, std::max(512, 256 * std::max(1, ntiles_hint)));
         const int G0 = s.num_target;
         std::vector<char> is_hub((size_t)c->V, 0);
         int n_hub = 0;
@@ -1224,6 +963,15 @@ static int run_rows_blocked(Ctx *c, const float *x, float *y, int feat, int redu
     return GNNAGG_OK;
 }
 
+// "fast_scheduled" may replace the user's groups by the balanced order only when both cover the same edges: a locality schedule cut
+// with total_num_v below the largest column id + 1 DROPS the edges beyond it (graph_schedule.h:23-44 keeps idx < total_num_v only),
+// and the balanced order would put them back.
+static bool sched_keeps_every_edge(const Ctx *c)
+{
+    const Schedule &s = c->sched[0];
+    return !s.permuted || (long)s.h_idx_s.size() == (long)c->E;
+}
+
 static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0, const NnRequest *nn = nullptr,
                    int probe = 0)
 {
@@ -1240,7 +988,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
     if (reduce < GNNAGG_REDUCE_SUM || reduce > GNNAGG_REDUCE_MAX) return fail(GNNAGG_ERR_ARG, "bad reduce");
     if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
     if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
-    if (mode == GNNAGG_MODE_SCHEDULED && c->fast_scheduled && c->sched[0].valid) mode = GNNAGG_MODE_BALANCED;
+    if (mode == GNNAGG_MODE_SCHEDULED && c->fast_scheduled && c->sched[0].valid && sched_keeps_every_edge(c)) mode = GNNAGG_MODE_BALANCED;
     if (mode == GNNAGG_MODE_ROWS && c->opt_rows_blocked && c->tiled && c->use_plan && reduce != GNNAGG_REDUCE_MAX && !probe) {
         bool used = false;   // canonical chains on the blocked order where the graph allows it (sorted rows, high degree)
         const int rcb = run_rows_blocked(c, x, y, feat, reduce, flags, nn, &used);
@@ -1293,15 +1041,10 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             tr.spec.p_tile_stride = (long)s->num_target * tr.spec.tile_w;
             tr.partial_floats = (size_t)s->num_target * tr.spec.tile_w * tr.ntiles;
         }
-        // option "dest_stationary": accumulators in LDS instead of partial rows -- no partial scratch, no permuted value copy
-        const bool ds_run = span_run && c->opt_ds && tr.retile && tr.spec.tile_w == 64 && reduce != GNNAGG_REDUCE_MAX && !probe;
-        if (ds_run && !c->ds.valid && !c->ds.failed && (rc = build_ds_plan(c, *s, c->ds))) return rc;
-        const bool ds_ok = ds_run && c->ds.valid;
-        if (ds_ok) tr.partial_floats = (size_t)c->sched_hub.num_target * tr.spec.tile_w * tr.ntiles;   // the hub rows' partial rows only
         bool demoted = false;
         if ((rc = reserve_partitioned_scratch(c, tr.partial_floats, 0, tr.xt_floats, &demoted))) return rc;
         if (demoted) return gcn_run(c, x, y, feat, mode, reduce, flags, nn, probe);
-        if (!ds_ok && (rc = refresh_partitioned_val(c, s))) return rc;
+        if ((rc = refresh_partitioned_val(c, s))) return rc;
         if (span_run) {
             SpanLaunch S;
             S.span_g = s->span_g.p; S.n_spans = s->n_spans; S.span_cost_prefix = s->span_cost_prefix.data();
@@ -1310,40 +1053,9 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             S.empty_rows = s->empty_rows.p; S.n_empty = s->n_empty; S.row_ptr = c->d_ptr;
             S.x = x; S.x_rows = s->total_cols; S.y = y; S.partial = c->partial.p; S.feat = feat; S.reduce = reduce; S.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
             S.tile = tr.spec; S.probe = probe;
-            if ((rc = span_overlap(c, tr.ntiles, S))) return rc;
             if (tr.retile) {
                 if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
                 S.x = c->xt.p;
-            }
-            // option "dest_stationary": the same groups with LDS-resident accumulators instead of partial rows (agg_ds.hip)
-            if (ds_ok) {
-                {
-                    DsPlan &d = c->ds;
-                    DsLaunch D;
-                    if (c->d_val) {
-                        if ((rc = d.val.reserve(d.n_edges))) return rc;
-                        if ((rc = launch_permute_val(d.eperm.p, c->d_val, d.val.p, (int)d.n_edges, c->stream))) return rc;
-                        D.val = d.val.p;
-                    }
-                    D.idw = d.idw.p; D.dsp = d.dsp.p; D.dstage = d.dstage.p; D.urows = d.urows.p; D.row_ptr = c->d_ptr; D.xt = c->xt.p; D.y = y;
-                    D.cnt = d.cnt.p; D.cnt_capacity = d.cnt.n; D.U = d.U; D.P = d.P; D.T = tr.ntiles; D.RB = d.RB; D.WPX = d.WPX; D.feat = feat;
-                    D.reduce = reduce; D.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0; D.yvec = tr.spec.yvec; D.width = d.width;
-                    D.slack = c->opt_ds_slack; D.x_tile_stride = tr.spec.x_tile_stride;
-                    Schedule &sh = c->sched_hub;
-                    if (sh.valid && sh.n_spans > 0) {   // the hub rows: streaming form on their own groups, ahead of the units
-                        if ((rc = refresh_partitioned_val(c, &sh))) return rc;
-                        SpanLaunch H = S;
-                        H.span_g = sh.span_g.p; H.n_spans = sh.n_spans; H.span_cost_prefix = sh.span_cost_prefix.data();
-                        H.ptr_s = sh.ptr_s.p; H.idx_f = sh.idx_f.p; H.val_s = c->d_val ? sh.val_s.p : nullptr; H.target = sh.target.p;
-                        H.n_groups = sh.num_target; H.crows = sh.crows.p; H.n_crows = sh.n_crows; H.rg_ptr = sh.rg_ptr.p; H.rg_idx = sh.rg_idx.p;
-                        H.empty_rows = nullptr; H.n_empty = 0;
-                        H.tile.p_tile_stride = (long)sh.num_target * tr.spec.tile_w;
-                        H.aux_stream = nullptr; H.events = nullptr; H.n_events = 0; H.join_event = nullptr;
-                        if ((rc = launch_gcn_span(H, c->stream))) return rc;
-                    }
-                    if ((rc = launch_gcn_ds(D, c->stream)) || !nn) return rc;
-                    return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
-                }
             }
             if ((rc = launch_gcn_span(S, c->stream)) || !nn || probe) return rc;
             return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
@@ -1441,7 +1153,7 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     if (!x || !y || !att) return fail(GNNAGG_ERR_ARG, "null feature/attention pointer");
     if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
     if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
-    if (mode == GNNAGG_MODE_SCHEDULED && c->fast_scheduled && c->sched[0].valid && !newval) mode = GNNAGG_MODE_BALANCED;
+    if (mode == GNNAGG_MODE_SCHEDULED && c->fast_scheduled && c->sched[0].valid && !newval && sched_keeps_every_edge(c)) mode = GNNAGG_MODE_BALANCED;
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
@@ -1503,7 +1215,6 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
             S.empty_rows = s->empty_rows.p; S.n_empty = s->n_empty; S.row_ptr = c->d_ptr;
             S.x = x; S.x_rows = s->total_cols; S.y = y; S.partial = c->partial.p; S.feat = feat; S.tile = tr.spec;
             G.att = att; G.partial_den = c->partial_den.p; G.newval = newval; G.eperm = s->eperm.p; G.heads = heads; G.slope = slope;
-            if ((rc = span_overlap(c, tr.ntiles, S))) return rc;
             if (tr.retile) {
                 if ((rc = launch_tile_x(x, c->xt.p, s->total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
                 S.x = c->xt.p;
@@ -1687,24 +1398,10 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     c->kind = kind; c->V = V; c->E = E; c->d_ptr = d_ptr; c->d_idx = d_idx; c->d_val = d_val;
     if (const char *e = getenv("GNNAGG_XCD_REMAP")) c->xcd_remap = atoi(e);
     if (const char *e = getenv("GNNAGG_PLAN")) c->use_plan = atoi(e);
-    if (const char *e = getenv("GNNAGG_SORT_WINDOW")) c->sort_window = atoi(e);
-    if (const char *e = getenv("GNNAGG_INKERNEL_COMBINE")) c->inkernel_combine = atoi(e);
-    if (const char *e = getenv("GNNAGG_PART_DESC")) c->part_descriptors = atoi(e);
-    if (const char *e = getenv("GNNAGG_TILED")) c->tiled = atoi(e);
     if (const char *e = getenv("GNNAGG_PARTITIONS")) c->opt_partitions = atoi(e);
-    if (const char *e = getenv("GNNAGG_PART_MIN_DEG")) c->opt_part_min_deg = atoi(e);
-    if (const char *e = getenv("GNNAGG_TILE_W")) { const int w = atoi(e); if (w == 32 || w == 64 || w == 128 || w == 256) c->opt_tile_w = w; }
-    if (const char *e = getenv("GNNAGG_SLICE_KB")) c->opt_slice_kb = std::max(1, atoi(e));
-    if (const char *e = getenv("GNNAGG_RETILE")) c->opt_retile = atoi(e);
     if (const char *e = getenv("GNNAGG_FAST_ROWS")) { c->fast_rows = atoi(e); c->fast_rows_from_env = true; }
     if (const char *e = getenv("GNNAGG_FAST_SCHEDULED")) c->fast_scheduled = atoi(e);
     if (const char *e = getenv("GNNAGG_AUX_STREAM")) c->use_aux_stream = atoi(e);
-    if (const char *e = getenv("GNNAGG_SPANS")) c->use_spans = atoi(e);
-    if (const char *e = getenv("GNNAGG_OVERLAP_COMBINE")) c->overlap_combine = atoi(e);
-    if (const char *e = getenv("GNNAGG_DEST_STATIONARY")) c->opt_ds = atoi(e);
-    if (const char *e = getenv("GNNAGG_DS_SLACK")) c->opt_ds_slack = atoi(e);
-    if (const char *e = getenv("GNNAGG_DS_HUB_EDGES")) c->opt_ds_hub_edges = std::max(1, atoi(e));
-    if (const char *e = getenv("GNNAGG_ROWS_BLOCKED")) c->opt_rows_blocked = atoi(e);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live.insert(c);
@@ -1740,7 +1437,6 @@ int gnnagg_destroy(gnnagg_handle h)
         (void)hipStreamDestroy(c->aux_stream);
         (void)hipEventDestroy(c->ev_fork);
         (void)hipEventDestroy(c->ev_join);
-        for (hipEvent_t e : c->tile_events) (void)hipEventDestroy(e);
     }
     delete c;
     return GNNAGG_OK;
@@ -1775,10 +1471,6 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "fast_scheduled") c->fast_scheduled = value;
     else if (n == "aux_stream") c->use_aux_stream = value;
     else if (n == "spans") { c->use_spans = value; replan = true; }
-    else if (n == "overlap_combine") c->overlap_combine = value;
-    else if (n == "dest_stationary") { c->opt_ds = value; replan = true; }
-    else if (n == "ds_slack") c->opt_ds_slack = value;
-    else if (n == "ds_hub_edges") { c->opt_ds_hub_edges = std::max(1, value); replan = true; }
     else if (n == "inkernel_combine") c->inkernel_combine = value;
     else if (n == "rows_blocked") c->opt_rows_blocked = value;
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
@@ -1787,8 +1479,6 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
         c->sched[1].reset();
         c->plan_part.reset();
         c->plan.reset();
-        c->ds.reset();
-        c->sched_hub.reset();
         c->rb.reset();
     }
     return GNNAGG_OK;

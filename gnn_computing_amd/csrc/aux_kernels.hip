@@ -623,10 +623,9 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
     hipStream_t stream = (hipStream_t)stream_v;
     if (M <= 0 || N <= 0) return GNNAGG_OK;
     {
-        static const int tall = getenv("GNNAGG_GEMM_TALL") ? atoi(getenv("GNNAGG_GEMM_TALL")) : 1;
         // measured against k_dense_nn (N = 32): K = 128: M = 300 k 48.2 vs 46.4 us, 600 k 92.4 vs 99.9, 1.2 M 169 vs 184,
         // 2.45 M 307 vs 352; K = 100, M = 2.45 M: 268 vs 363 (torch.mm 427); K = 64 loses at every M -> large M, wide K only
-        if (tall && K > 64 && K <= 128 && (K & 3) == 0 && M >= 500000 && ((uintptr_t)A & 15) == 0) {
+        if (K > 64 && K <= 128 && (K & 3) == 0 && M >= 500000 && ((uintptr_t)A & 15) == 0) {
             const int ntiles = ceil_div(M, 32);
             const size_t lds = (size_t)kTallWaves * 32 * (K + 4) * sizeof(float);
             const int wgs = std::min(ceil_div(ntiles, kTallWaves), 256 * 4);
@@ -640,28 +639,25 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
         return launch_zero_words(C, (size_t)M * N, stream);
     }
     {
-        static const int big = getenv("GNNAGG_GEMM_BIG") ? atoi(getenv("GNNAGG_GEMM_BIG")) : 1;
-        if (big && N > 64 && M >= 1024) {   // wide outputs: 128 x 128 tiles, A read once (k_dense_nn_big)
+        if (N > 64 && M >= 1024) {   // wide outputs: 128 x 128 tiles, A read once (k_dense_nn_big)
             const size_t lds = (size_t)(2 * kBigT * kBigPA + 2 * kBigKC * kBigT) * sizeof(float);
             const bool bvec = (N & 3) == 0 && N >= 4 && ((uintptr_t)B & 15) == 0;
             const int av = !bvec ? 1 : ((K & 3) == 0 && K >= 4 && ((uintptr_t)A & 15) == 0) ? 4 : ((K & 1) == 0 && K >= 2 && ((uintptr_t)A & 7) == 0) ? 2 : 1;
             // tiles the chip runs at a time: kBigWgs workgroups per CU, shared by the column tiles
-            static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
+            const int cus = device_cu_count();
             const int ncol = ceil_div(N, kBigT), slots = std::max(1, kBigWgs * cus / ncol);
             const int n_main = (int)(((long)M / kBigT) / slots) * slots;   // whole rounds of full 128-row tiles
             const int rem = M - n_main * kBigT;
             int tmt = kBigT;
-            static const int tail_env = getenv("GNNAGG_GEMM_TAIL") ? atoi(getenv("GNNAGG_GEMM_TAIL")) : 1;
-            if (tail_env)
-                for (int t = 32; t < kBigT; t += 32)
+            for (int t = 32; t < kBigT; t += 32)
                     if (ceil_div(rem, t) <= slots) { tmt = t; break; }
             const dim3 grid(n_main + ceil_div(rem, tmt), ncol);
 #define BIG_CALL(T_, V_)                                                                                                               \
             {                                                                                                                           \
-                static bool attr_ok = false;                                                                                            \
-                if (!attr_ok) {                                                                                                         \
+                static OncePerDevice attr_ok;                                                                                           \
+                if (attr_ok.first()) {                                                                                                  \
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_big<T_, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                    attr_ok = true;                                                                                                     \
+                    attr_ok.done();                                                                                                     \
                 }                                                                                                                       \
                 hipLaunchKernelGGL((k_dense_nn_big<T_, V_>), grid, dim3(256), lds, stream, A, B, C, M, N, K, n_main);                   \
             }

@@ -145,37 +145,11 @@ struct SpanLaunch {
     int feat = 0, reduce = GNNAGG_REDUCE_SUM, relu = 0;
     TileSpec tile;
     int probe = 0;
-    // Overlap of the ordered combine with the aggregation: one launch per column tile, tile t's combine (HBM-bound: it
-    // streams the partial rows) runs on aux_stream beside tile t + 1's span kernel (bound by L1 / address processing).
-    // events: ntiles hipEvent_t (tile t's span kernel done), join_event: the last combine done.  All null: one launch.
-    void *aux_stream = nullptr;
-    void **events = nullptr;
-    int n_events = 0;
-    void *join_event = nullptr;
-    int overlap_chunks = 0;   // >= 2: that many launches of consecutive tiles instead of one per tile
     // chain = 1 (canonical rows mode on the blocked order): the spans of ONE source range; every group's chain starts from and
     // returns to partial = Yt[ntiles][n_groups = V rows][tile_w]; no combine, no zero-fill (launch_untile_y finishes)
     int chain = 0;
 };
 int launch_gcn_span(const SpanLaunch &a, void *stream);
-// Destination-stationary form of the same order (agg_ds.hip; option "dest_stationary"): units of RB output rows per column tile
-// with LDS accumulators, phases = source ranges, per-XCD arrival counters.
-static constexpr int kDsStage = 3;   // staging pool of a workgroup = 32 lane groups x kDsStage slots, handed out in group order
-struct DsLaunch {
-    const unsigned *idw = nullptr;   // edge words: last / staged flags, LDS row, row inside the range
-    const float *val = nullptr;      // edge values in stream order, nullptr => implicit 1
-    const int *dsp = nullptr;        // [(U * P) * (LG + 1)] span bounds, LG = 32 lane groups
-    const int *dstage = nullptr;     // [(U * P) * (LG + 1)] first staging-pool slot of every span, then the total
-    const int *urows = nullptr;      // [U * RB]
-    const int *row_ptr = nullptr;
-    const float *xt = nullptr;       // tiled image of X
-    float *y = nullptr;
-    unsigned *cnt = nullptr;         // phase counters
-    size_t cnt_capacity = 0;
-    int U = 0, P = 0, T = 0, RB = 0, WPX = 64, feat = 0, reduce = GNNAGG_REDUCE_SUM, relu = 0, yvec = 1, width = 0, slack = 0;
-    long x_tile_stride = 0;
-};
-int launch_gcn_ds(const DsLaunch &a, void *stream);
 // y[r, :] = finish(Yt[tile][r][:]) -- the tiled image back into the caller's rows, mean (/ degree) and ReLU applied
 int launch_zero_words(void *p, size_t n_words, void *stream);   // 4-byte words; a kernel, not a memset (graph replays: aux_kernels.hip)
 // (skip: optional [rows] bytes, 1 = leave the row of y alone)

@@ -357,6 +357,15 @@ static int step_fork(DistStep *st, hipStream_t stream)
     HIPD_TRY(hipStreamWaitEvent(st->comm_stream, st->ev_fork, 0));
     return GNNAGG_OK;
 }
+// An error between fork and join: the caller's stream still joins the communication stream (whatever was enqueued there before the
+// failure), so a stream capture is never left with an unjoined fork and the buffers are not reused under an exchange in flight.
+// `recorded`: ev_join already stands behind the exchange.  The error message of `rc` is kept.
+static int step_abandon(DistStep *st, hipStream_t stream, int rc, bool recorded = false)
+{
+    const std::string msg = gnnagg_last_error();
+    if (recorded || hipEventRecord(st->ev_join, st->comm_stream) == hipSuccess) (void)hipStreamWaitEvent(stream, st->ev_join, 0);
+    return fail(rc, msg);
+}
 }  // namespace gnnagg
 
 int gnnagg_dist_step_create(gnnagg_comm comm, gnnagg_handle agg_local, gnnagg_handle agg_remote, const int *d_send_ids,
@@ -420,14 +429,15 @@ int gnnagg_dist_step_gcn(gnnagg_dist_step_t h, const float *d_x_local, float *d_
     if (ex) {
         if ((st->n_send > 0 && !d_send_buf) || (st->n_recv > 0 && !d_x_halo)) return fail(GNNAGG_ERR_ARG, "dist_step: null exchange buffer");
         if ((rc = step_fork(st, stream))) return rc;
-        if ((rc = gnnagg_dist_halo_exchange(st->comm, d_x_local, st->d_send_ids, st->send_rows.data(), st->recv_rows.data(), feat, d_send_buf,
-                                            d_x_halo, st->comm_stream)))
-            return rc;
+        rc = gnnagg_dist_halo_exchange(st->comm, d_x_local, st->d_send_ids, st->send_rows.data(), st->recv_rows.data(), feat, d_send_buf,
+                                       d_x_halo, st->comm_stream);
+        if (rc) return step_abandon(st, stream, rc);
         HIPD_TRY(hipEventRecord(st->ev_join, st->comm_stream));
     }
-    if ((rc = gnnagg_set_stream(st->agg_local, stream))) return rc;
-    if ((rc = gnnagg_gcn_run_ex(st->agg_local, d_x_local, d_y, feat, GNNAGG_MODE_BALANCED, reduce, 0))) return rc;   // overlaps the exchange
-    if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));
+    if ((rc = gnnagg_set_stream(st->agg_local, stream))) return ex ? step_abandon(st, stream, rc, true) : rc;
+    rc = gnnagg_gcn_run_ex(st->agg_local, d_x_local, d_y, feat, GNNAGG_MODE_BALANCED, reduce, 0);   // overlaps the exchange
+    if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));   // joined on the error path too
+    if (rc) return rc;
     if (st->agg_remote && st->n_recv > 0) {
         if ((rc = gnnagg_set_stream(st->agg_remote, stream))) return rc;
         if ((rc = gnnagg_gcn_run_ex(st->agg_remote, d_x_halo, d_y, feat, GNNAGG_MODE_BALANCED, reduce, GNNAGG_FLAG_ACCUMULATE))) return rc;
@@ -449,21 +459,28 @@ int gnnagg_dist_step_gat(gnnagg_dist_step_t h, float *d_x_ext, float *d_att_ext,
         if ((st->n_send > 0 && !d_send_buf) || (st->n_recv > 0 && !d_recv_buf)) return fail(GNNAGG_ERR_ARG, "dist_step: null exchange buffer");
         if ((rc = step_fork(st, stream))) return rc;
         // ONE exchange carries [feature row | attention terms] of every requested row
-        if ((rc = launch_pack_rows2(d_x_ext, d_att_ext, st->d_send_ids, (int)st->n_send, feat, aw, d_send_buf, st->comm_stream))) return rc;
+        if ((rc = launch_pack_rows2(d_x_ext, d_att_ext, st->d_send_ids, (int)st->n_send, feat, aw, d_send_buf, st->comm_stream)))
+            return step_abandon(st, stream, rc);
         if ((rc = gnnagg_dist_alltoallv(st->comm, d_send_buf, st->send_rows.data(), d_recv_buf, st->recv_rows.data(), w * (int)sizeof(float),
                                         st->comm_stream)))
-            return rc;
+            return step_abandon(st, stream, rc);
         if ((rc = launch_unpack_rows2(d_recv_buf, (int)st->n_recv, feat, aw, d_x_ext + (size_t)n_local * feat, d_att_ext + (size_t)n_local * aw,
                                       st->comm_stream)))
-            return rc;
+            return step_abandon(st, stream, rc);
         HIPD_TRY(hipEventRecord(st->ev_join, st->comm_stream));
     }
     // numerators and denominators of the local-source edges while the exchange is in flight; the halo-source pass adds its own
     // and divides (it runs for every row: a row without halo sources is divided all the same)
     if ((rc = gnnagg_set_stream(st->agg_local, stream))) return rc;
-    if (!st->agg_remote) return gnnagg_gat_run(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, GNNAGG_MODE_BALANCED, nullptr);
-    if ((rc = gnnagg_gat_run_part(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, 1, d_den))) return rc;
-    if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));
+    if (!st->agg_remote) {
+        // (a step made without a halo-source aggregator: one pass over X_ext.  It reads the halo tail, so it runs BEHIND the
+        // exchange -- and the caller's stream is joined whatever happens: send_buf / the tail are free again when it is)
+        if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));
+        return gnnagg_gat_run(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, GNNAGG_MODE_BALANCED, nullptr);
+    }
+    rc = gnnagg_gat_run_part(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, 1, d_den);
+    if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));   // joined on the error path too: a fork is never left dangling
+    if (rc) return rc;
     if ((rc = gnnagg_set_stream(st->agg_remote, stream))) return rc;
     return gnnagg_gat_run_part(st->agg_remote, d_x_ext, d_att_ext, d_y, feat, heads, slope, 2, d_den);
 }

@@ -479,6 +479,28 @@ static Geometry pick_geometry(int F, const void *p0, const void *p1, const void 
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Launch-site state that belongs to a DEVICE, not to the process (a process may drive several): "this function attribute has been
+// set here" flags and the CU count.  (A relaxed race sets an attribute twice, which is harmless.)
+struct OncePerDevice {
+    unsigned long long mask = 0;   // bit d: done on device d (devices >= 64: never cached)
+    int dev = -1;
+    bool first()
+    {
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { dev = -1; return true; }
+        return ((__atomic_load_n(&mask, __ATOMIC_RELAXED) >> dev) & 1ull) == 0;
+    }
+    void done() { if (dev >= 0) __atomic_fetch_or(&mask, 1ull << dev, __ATOMIC_RELAXED); }
+};
+static int device_cu_count()
+{
+    static int cus[64] = {};
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] > 0) return cus[dev];
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return cus[dev] = n;
+}
+
 // One word of device memory per DEVICE for the probe instantiations' never-taken store (a process-wide pointer allocated on
 // the first device would be dereferenced by kernels of handles that live on another one).
 static unsigned *device_probe_sink()

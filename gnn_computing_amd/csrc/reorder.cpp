@@ -81,7 +81,7 @@ static constexpr int kLongRow = 64;
 // Source rows gathered by more than kHubCut clusters do not vote: they are in the cache whatever the order is (or thrash
 // it whatever the order is), and scanning their long gatherer lists on every (re)entry is what makes the pass quadratic
 // on power-law graphs (products-shaped: hours -> minutes).  They still occupy cache capacity in the model.
-static const long kHubCut = getenv("GNNAGG_HUB_CUT") ? atol(getenv("GNNAGG_HUB_CUT")) : 4096;
+static const long kHubCut = 4096;
 
 static void emit_cache_greedy(const int *ptr, const int *idx, int V, const std::vector<std::vector<int>> &members,
                               int cache_rows, int *rows_out)
@@ -432,7 +432,6 @@ static void emit_cache_greedy_parallel(const int *ptr, const int *idx, int V, co
             ++left;
             for (int v : members[c]) rows_out[pos++] = v;
         }
-    if (getenv("GNNAGG_REORDER_DEBUG")) fprintf(stderr, "parallel greedy: %d walkers, %d clusters, %ld left for the tail\n", walkers, NC, left);
 }
 
 int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int num_perm, int cap, uint64_t seed,

@@ -95,18 +95,17 @@ int gnnagg_gat_create(const int *d_ptr, const int *d_idx, int num_v, int num_e, 
 int gnnagg_destroy(gnnagg_handle h);
 /* hipStream_t as void*; NULL = default stream.  Work of later calls is enqueued there. */
 int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
-/* Per-handle knobs (defaults come from the environment variables in brackets; DESIGN.md section 4 "A/B knobs"):
+/* Per-handle knobs.  Every knob is an option; the SIX a C++ driver linked against the class shim cannot reach through code also
+ * read an environment variable (in brackets) when the handle is made.  INTEGRATION.md section 5 is the table of all of them.
  *   "partitions" [GNNAGG_PARTITIONS]      -1 the library decides, 0 never, N > 0: N source ranges for the balanced mode
- *   "partition_min_degree" [GNNAGG_PART_MIN_DEG]  average degree from which the library partitions (96)
- *   "tile_width" [GNNAGG_TILE_W]          floats per column tile of the 2-D blocked balanced mode: 32 / 64 / 128 / 256
- *   "slice_kb" [GNNAGG_SLICE_KB]          target size of the X slice an XCD's L2 holds (4096)
+ *   "partition_min_degree"                average degree from which the library partitions (96)
+ *   "tile_width"                          floats per column tile of the 2-D blocked balanced mode: 32 / 64 / 128 / 256 (64)
+ *   "slice_kb"                            target size of the X slice an XCD's L2 holds (4096)
  *   "scratch_limit_mb"                    > 0: cap on the scratch (partial rows + tiled image of X) the blocked order may take;
  *                                         a handle that would need more -- or more than half of the free device memory, or
  *                                         whose allocation fails -- moves to the chunked plan for good
- *   "retile" [GNNAGG_RETILE], "tiled" [GNNAGG_TILED], "spans" [GNNAGG_SPANS], "inkernel_combine"   A/B switches
- *   "overlap_combine" [GNNAGG_OVERLAP_COMBINE]  2-D blocked order: 1: one launch per column tile, tile t's ordered combine on an
- *                                         auxiliary stream beside tile t + 1's aggregation; N >= 2: N launches of consecutive tiles.
- *                                         Measured slower or within noise: default 0
+ *   "retile", "tiled", "spans", "inkernel_combine"   older forms of the blocked order / the hub fold, kept because parity tests
+ *                                         compare them bit for bit with the default form (tests/test_gpu_blocked.py)
  *   "fast_rows" [GNNAGG_FAST_ROWS]        1: GNNAGG_MODE_ROWS (`scheduled = 0`) runs the balanced order -- results within the
  *                                         1e-5 bound instead of bit-exact CSR-order chains; 0: canonical order.  Default 0 for
  *                                         handles made through this section, 1 for the reference-facing surfaces (see
@@ -120,20 +119,17 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *                                         aggr_gat.h:196-203): every association is one of its legal results.  A schedule must
  *                                         still have been made; num_target / get_schedule / mode_params of GNNAGG_MODE_SCHEDULED
  *                                         keep describing the user's groups, the order that RUNS is the one GNNAGG_MODE_BALANCED's
- *                                         queries describe; GAT calls that ask for newval keep the scheduled order.  0: the user's
- *                                         groups, folded in the restated order (bit-exact against the oracle)
+ *                                         queries describe; GAT calls that ask for newval keep the scheduled order -- and so does a
+ *                                         locality schedule that DROPPED edges (total_num_v below the largest column id + 1,
+ *                                         graph_schedule.h:23-44): the balanced order covers every edge.  0: the user's groups,
+ *                                         folded in the restated order (bit-exact against the oracle)
  *   "aux_stream" [GNNAGG_AUX_STREAM]      0: GNNAGG_MODE_ROWS runs its hub rows on the handle's stream, before the short rows, instead of
  *                                         beside them on an auxiliary stream (slower by the hub rows' duration, but the process keeps
  *                                         a single queue); 1 (default)
- *   "dest_stationary" [GNNAGG_DEST_STATIONARY]  1: GCN / SAGE runs of the 2-D blocked balanced order keep the output rows of a unit in
- *                                         LDS and sweep the source ranges in phase (agg_ds.hip) instead of streaming partial rows to a
- *                                         combine pass.  Same groups, same fold: bit-equal to the streaming form.  Slower on every
- *                                         graph measured ("Measured (round 3)"): default 0, kept for A/B.
- *   "ds_slack" [GNNAGG_DS_SLACK]          phases a workgroup may run ahead of the slowest one of its XCD (0)
- *   "ds_hub_edges" [GNNAGG_DS_HUB_EDGES]  rows with a (row, range) group above this many edges stay on the streaming form (4096)
- *   "rows_blocked" [GNNAGG_ROWS_BLOCKED]  1 (default): GNNAGG_MODE_ROWS of a GCN handle runs its canonical chains on the 2-D blocked
- *                                         order where the graph allows it (gnnagg_rows_blocked_ranges); 0: always the row kernels.
- *                                         The results are the same bits either way
+ *   "rows_blocked"                        1 (default): GNNAGG_MODE_ROWS runs its canonical chains on the 2-D blocked order where the
+ *                                         graph allows it (gnnagg_rows_blocked_ranges); 0: always the row kernels.  Same bits either way
+ * [GNNAGG_XCD_REMAP] 0 / 1 / 2 (workgroup -> XCD mapping: identity / equal-count / work-balanced ranges, default 2) and [GNNAGG_PLAN] 0
+ * (the round-1 item kernels + k_combine instead of the plan kernels) are environment-only measurement switches (scripts/tune_gcn.py).
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
 int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
 /* Aggregator_GCN::updateval, aggr_gcn.h:540-544: re-aliases the edge values (borrowed; read at run time). */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Figure 10b on the arxiv-shaped input: aggregation + separate GEMM vs run_with_nn (GEMM as the epilogue).
-GNNAGG_FUSE_NN=0 in the environment turns the fusion off (run_with_nn = the two kernels back to back)."""
+(The back-to-back arm calls run + matmul_nn itself; the GNNAGG_FUSE_NN switch of rounds 1-3 is gone.)"""
 import os
 import sys
 

@@ -36,12 +36,6 @@ elif what == "rows_self":
     agg.run(x, y, 512, 0)
 elif what == "mean_self":
     agg.run(x, y, 512, "balanced", reduce="mean")
-elif what == "aux_only":   # blocked order with the per-tile combine overlap: auxiliary stream + events, no > 64 KB LDS kernel
-    dp, di = gnc.graph.powerlaw_csr(700, 220000, seed=6, alpha=0.9)
-    o = gnc.Aggregator_GCN(dp.to(dev), di.to(dev), None, 256, 256)
-    o.set_option("partitions", 8); o.set_option("overlap_combine", 1)
-    xs, ys = torch.randn((700, 256), device=dev), torch.empty((700, 256), device=dev)
-    o.run(xs, ys, 512, "balanced")
 elif what == "torch_fork_join":   # no library stream at all: a fork / join between torch's current stream and a side stream
     main = torch.cuda.current_stream()
     s2 = torch.cuda.Stream()
