@@ -101,6 +101,8 @@ SIGNATURES = {
     "gnnagg_pack_rows2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gnnagg_unpack_rows2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gnnagg_dist_step_create": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64)]),
+    "gnnagg_dist_step_create_staged": (c_int, [c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64)]),
+    "gnnagg_dist_step_info": (c_int, [c_int64, P_INT, P_INT]),
     "gnnagg_dist_step_destroy": (c_int, [c_int64]),
     "gnnagg_dist_step_gcn": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gnnagg_dist_step_gat": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,

@@ -196,7 +196,8 @@ struct GatPlanArgs {
     unsigned ptile_bytes;
     const int *eperm;
     // two-pass form (gnnagg_gat_run_part; the row-partitioned step): 1 = first pass, y receives the NUMERATOR and den_io[row, h]
-    // the denominator, no division; 2 = last pass, both are added to what the first pass left and the row is divided
+    // the denominator, no division; 2 = last pass, both are added to what the first pass left and the row is divided; 3 = a pass
+    // in between (staged halo exchange): both are added, nothing is divided
     int part_mode;
     float *den_io;
     XcdRanges xr;
@@ -211,11 +212,15 @@ __device__ __forceinline__ void finish_gat_row(const GatPlanArgs &a, float (&acc
         if (head_leader) a.den_io[(size_t)row * a.heads + h] = den;
         return;
     }
-    if (a.part_mode == 2) {
+    if (a.part_mode >= 2) {
         const Pack<VEC> old = load_pack<VEC>(yold);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = old.v[k] + acc[k];
         den = a.den_io[(size_t)row * a.heads + h] + den;
+        if (a.part_mode == 3) {   // (every lane of the head has read the old value: one wavefront, program order)
+            if (head_leader) a.den_io[(size_t)row * a.heads + h] = den;
+            return;
+        }
     }
     if (den != 0.0f || always_divide) {
 #pragma unroll

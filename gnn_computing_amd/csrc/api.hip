@@ -1158,8 +1158,8 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
     if (part != 0) {  // two-pass form: the chunked plan kernel implements it (a handle on the 2-D blocked order gets a plan beside it)
-        if (mode != GNNAGG_MODE_BALANCED || !c->use_plan || newval || probe || !den_io || (part != 1 && part != 2))
-            return fail(GNNAGG_ERR_ARG, "gat_run_part: GNNAGG_MODE_BALANCED, part 1 or 2, a denominator array, no newval");
+        if (mode != GNNAGG_MODE_BALANCED || !c->use_plan || newval || probe || !den_io || part < 1 || part > 3)
+            return fail(GNNAGG_ERR_ARG, "gat_run_part: GNNAGG_MODE_BALANCED, part 1, 2 or 3, a denominator array, no newval");
         if (!c->plan.valid && (rc = build_balanced_plan_keep(c))) return rc;
     }
     if (probe && !(mode == GNNAGG_MODE_BALANCED && c->partitions > 0 && c->plan_part.valid && c->part_descriptors))

@@ -321,17 +321,29 @@ int gnnagg_unpack_rows2(const float *d_in, int n, int feat, int att_width, float
 // halo-source pass, which adds to what the local pass wrote.  Everything is enqueued asynchronously -- stream operations only,
 // so a warm step can be captured into a HIP graph like any fork / join of two streams -- and nothing is allocated per step.
 // A rank without peers (world 1) or without halo rows never creates the second stream: its step is the local pass alone.
+//
+// Staged form (round 4): the halo arrives in S stages, every stage one grouped send / recv with an event behind it, and the
+// halo-source edges are split by the stage their source row arrives in: the pass over stage s's edges runs while stage s + 1 is
+// on the links.  Buffers are stage-major, so a stage's rows are contiguous on both sides and every stage is a plain
+// all-to-all-v on a sub-range.  On the point-to-point xGMI mesh every peer pair has its own link: a stage that talks to ONE
+// peer uses one link of seven, so the default plan (dist.py, "stripe") gives every stage a slice of EVERY peer's rows.
 namespace gnnagg {
 struct DistStep {
     gnnagg_comm comm = 0;
-    int world = 1, rank = 0;
-    gnnagg_handle agg_local = 0, agg_remote = 0;
+    int world = 1, rank = 0, n_stages = 1;
+    gnnagg_handle agg_local = 0;
+    std::vector<gnnagg_handle> agg_remote;                 // [n_stages], 0 = no halo-source edges in that stage
     const int *d_send_ids = nullptr;
-    std::vector<long long> send_rows, recv_rows, send_el, recv_el;
+    std::vector<long long> send_rows, recv_rows;           // [n_stages * world]
+    std::vector<long long> stage_send0, stage_recv0;       // [n_stages + 1] first row of every stage in the send buffer / halo tail
     long long n_send = 0, n_recv = 0;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool exchanging() const { return world > 1 && (n_send > 0 || n_recv > 0); }
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_stage;                      // [n_stages]: stage s has landed (the last one is the join)
+    // (world 1 with rows addressed to itself -- the self part of an all-to-all-v is a stream-ordered copy -- still takes the staged path:
+    // tests/test_gpu_dist.py drives every stage of it on one GPU that way)
+    bool exchanging() const { return comm != 0 && (n_send > 0 || n_recv > 0); }
+    bool any_remote() const { for (gnnagg_handle h : agg_remote) if (h) return true; return false; }
 };
 static std::mutex g_step_mu;
 static std::set<DistStep *> g_steps;
@@ -351,7 +363,8 @@ static int step_fork(DistStep *st, hipStream_t stream)
     if (!st->comm_stream) {  // first exchanging step: never inside a capture of a warm step
         HIPD_TRY(hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking));
         HIPD_TRY(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
-        HIPD_TRY(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
+        st->ev_stage.assign((size_t)st->n_stages, nullptr);
+        for (int s = 0; s < st->n_stages; ++s) HIPD_TRY(hipEventCreateWithFlags(&st->ev_stage[(size_t)s], hipEventDisableTiming));
     }
     HIPD_TRY(hipEventRecord(st->ev_fork, stream));            // x_local is ready where the caller's stream stands now
     HIPD_TRY(hipStreamWaitEvent(st->comm_stream, st->ev_fork, 0));
@@ -359,33 +372,55 @@ static int step_fork(DistStep *st, hipStream_t stream)
 }
 // An error between fork and join: the caller's stream still joins the communication stream (whatever was enqueued there before the
 // failure), so a stream capture is never left with an unjoined fork and the buffers are not reused under an exchange in flight.
-// `recorded`: ev_join already stands behind the exchange.  The error message of `rc` is kept.
-static int step_abandon(DistStep *st, hipStream_t stream, int rc, bool recorded = false)
+// The error message of `rc` is kept.
+static int step_abandon(DistStep *st, hipStream_t stream, int rc)
 {
     const std::string msg = gnnagg_last_error();
-    if (recorded || hipEventRecord(st->ev_join, st->comm_stream) == hipSuccess) (void)hipStreamWaitEvent(stream, st->ev_join, 0);
+    hipEvent_t ev = st->ev_stage.empty() ? nullptr : st->ev_stage.back();
+    if (ev && hipEventRecord(ev, st->comm_stream) == hipSuccess) (void)hipStreamWaitEvent(stream, ev, 0);
     return fail(rc, msg);
+}
+// stage s of the exchange on the communication stream, rows of `row_floats` floats, then its event
+static int step_exchange_stage(DistStep *st, int s, const float *d_send_buf, float *d_recv, int row_floats)
+{
+    const size_t w = (size_t)st->world;
+    const int rc = gnnagg_dist_alltoallv(st->comm, d_send_buf + (size_t)st->stage_send0[(size_t)s] * row_floats, &st->send_rows[(size_t)s * w],
+                                         d_recv + (size_t)st->stage_recv0[(size_t)s] * row_floats, &st->recv_rows[(size_t)s * w],
+                                         row_floats * (int)sizeof(float), st->comm_stream);
+    return rc;
 }
 }  // namespace gnnagg
 
-int gnnagg_dist_step_create(gnnagg_comm comm, gnnagg_handle agg_local, gnnagg_handle agg_remote, const int *d_send_ids,
-                            const long long *h_send_rows, const long long *h_recv_rows, gnnagg_dist_step_t *out)
+int gnnagg_dist_step_create_staged(gnnagg_comm comm, gnnagg_handle agg_local, int n_stages, const gnnagg_handle *agg_remote,
+                                   const int *d_send_ids, const long long *h_send_rows, const long long *h_recv_rows,
+                                   gnnagg_dist_step_t *out)
 {
     if (!out) return fail(GNNAGG_ERR_ARG, "null output step");
     *out = 0;
     if (!agg_local) return fail(GNNAGG_ERR_ARG, "dist_step: no local aggregator");
+    if (n_stages < 1 || n_stages > 64) return fail(GNNAGG_ERR_ARG, "dist_step: 1 .. 64 stages");
     DistStep *st = new DistStep;
-    st->comm = comm; st->agg_local = agg_local; st->agg_remote = agg_remote; st->d_send_ids = d_send_ids;
+    st->comm = comm; st->agg_local = agg_local; st->d_send_ids = d_send_ids; st->n_stages = n_stages;
+    st->agg_remote.assign((size_t)n_stages, 0);
+    if (agg_remote) st->agg_remote.assign(agg_remote, agg_remote + n_stages);
+    st->stage_send0.assign((size_t)n_stages + 1, 0);
+    st->stage_recv0.assign((size_t)n_stages + 1, 0);
     if (comm) {
         int rc = gnnagg_dist_comm_info(comm, &st->rank, &st->world);
         if (rc) { delete st; return rc; }
         if (!h_send_rows || !h_recv_rows) { delete st; return fail(GNNAGG_ERR_ARG, "dist_step: null row counts"); }
-        st->send_rows.assign(h_send_rows, h_send_rows + st->world);
-        st->recv_rows.assign(h_recv_rows, h_recv_rows + st->world);
-        for (int p = 0; p < st->world; ++p) {
-            if (st->send_rows[p] < 0 || st->recv_rows[p] < 0) { delete st; return fail(GNNAGG_ERR_ARG, "dist_step: negative row count"); }
-            st->n_send += st->send_rows[p];
-            st->n_recv += st->recv_rows[p];
+        const size_t n = (size_t)n_stages * st->world;
+        st->send_rows.assign(h_send_rows, h_send_rows + n);
+        st->recv_rows.assign(h_recv_rows, h_recv_rows + n);
+        for (int s = 0; s < n_stages; ++s) {
+            for (int p = 0; p < st->world; ++p) {
+                const long long a = st->send_rows[(size_t)s * st->world + p], b = st->recv_rows[(size_t)s * st->world + p];
+                if (a < 0 || b < 0) { delete st; return fail(GNNAGG_ERR_ARG, "dist_step: negative row count"); }
+                st->n_send += a;
+                st->n_recv += b;
+            }
+            st->stage_send0[(size_t)s + 1] = st->n_send;
+            st->stage_recv0[(size_t)s + 1] = st->n_recv;
         }
         if (st->n_send > 0x7fffffffLL || st->n_recv > 0x7fffffffLL) { delete st; return fail(GNNAGG_ERR_ARG, "dist_step: too many halo rows"); }
         if (st->n_send > 0 && !d_send_ids) { delete st; return fail(GNNAGG_ERR_ARG, "dist_step: null send ids"); }
@@ -395,6 +430,21 @@ int gnnagg_dist_step_create(gnnagg_comm comm, gnnagg_handle agg_local, gnnagg_ha
         g_steps.insert(st);
     }
     *out = reinterpret_cast<gnnagg_dist_step_t>(st);
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_step_create(gnnagg_comm comm, gnnagg_handle agg_local, gnnagg_handle agg_remote, const int *d_send_ids,
+                            const long long *h_send_rows, const long long *h_recv_rows, gnnagg_dist_step_t *out)
+{
+    return gnnagg_dist_step_create_staged(comm, agg_local, 1, &agg_remote, d_send_ids, h_send_rows, h_recv_rows, out);
+}
+
+int gnnagg_dist_step_info(gnnagg_dist_step_t h, int *n_stages, int *world)
+{
+    DistStep *st = lookup_step(h);
+    if (!st) return fail(GNNAGG_ERR_ARG, "invalid or destroyed step");
+    if (n_stages) *n_stages = st->n_stages;
+    if (world) *world = st->world;
     return GNNAGG_OK;
 }
 
@@ -411,7 +461,7 @@ int gnnagg_dist_step_destroy(gnnagg_dist_step_t h)
         (void)hipStreamSynchronize(st->comm_stream);
         (void)hipStreamDestroy(st->comm_stream);
         (void)hipEventDestroy(st->ev_fork);
-        (void)hipEventDestroy(st->ev_join);
+        for (hipEvent_t e : st->ev_stage) if (e) (void)hipEventDestroy(e);
     }
     delete st;
     return GNNAGG_OK;
@@ -426,23 +476,28 @@ int gnnagg_dist_step_gcn(gnnagg_dist_step_t h, const float *d_x_local, float *d_
     hipStream_t stream = (hipStream_t)hip_stream;
     int rc;
     const bool ex = st->exchanging();
+    const int S = st->n_stages;
     if (ex) {
         if ((st->n_send > 0 && !d_send_buf) || (st->n_recv > 0 && !d_x_halo)) return fail(GNNAGG_ERR_ARG, "dist_step: null exchange buffer");
         if ((rc = step_fork(st, stream))) return rc;
-        rc = gnnagg_dist_halo_exchange(st->comm, d_x_local, st->d_send_ids, st->send_rows.data(), st->recv_rows.data(), feat, d_send_buf,
-                                       d_x_halo, st->comm_stream);
-        if (rc) return step_abandon(st, stream, rc);
-        HIPD_TRY(hipEventRecord(st->ev_join, st->comm_stream));
+        // ONE pack kernel for all stages (the send buffer is stage-major), then a grouped send / recv and an event per stage
+        if (st->n_send > 0 && (rc = launch_pack_rows(d_x_local, st->d_send_ids, (int)st->n_send, feat, d_send_buf, st->comm_stream)))
+            return step_abandon(st, stream, rc);
+        for (int s = 0; s < S; ++s) {
+            if ((rc = step_exchange_stage(st, s, d_send_buf, d_x_halo, feat))) return step_abandon(st, stream, rc);
+            HIPD_TRY(hipEventRecord(st->ev_stage[(size_t)s], st->comm_stream));
+        }
     }
-    if ((rc = gnnagg_set_stream(st->agg_local, stream))) return ex ? step_abandon(st, stream, rc, true) : rc;
-    rc = gnnagg_gcn_run_ex(st->agg_local, d_x_local, d_y, feat, GNNAGG_MODE_BALANCED, reduce, 0);   // overlaps the exchange
-    if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));   // joined on the error path too
-    if (rc) return rc;
-    if (st->agg_remote && st->n_recv > 0) {
-        if ((rc = gnnagg_set_stream(st->agg_remote, stream))) return rc;
-        if ((rc = gnnagg_gcn_run_ex(st->agg_remote, d_x_halo, d_y, feat, GNNAGG_MODE_BALANCED, reduce, GNNAGG_FLAG_ACCUMULATE))) return rc;
+    rc = gnnagg_set_stream(st->agg_local, stream);
+    if (!rc) rc = gnnagg_gcn_run_ex(st->agg_local, d_x_local, d_y, feat, GNNAGG_MODE_BALANCED, reduce, 0);   // overlaps the exchange
+    for (int s = 0; s < S; ++s) {
+        // the caller's stream joins every stage (the last one is the join of the fork), on the error path too
+        if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_stage[(size_t)s], 0));
+        if (rc || !st->agg_remote[(size_t)s] || st->stage_recv0[(size_t)s + 1] == st->stage_recv0[(size_t)s]) continue;
+        if (!(rc = gnnagg_set_stream(st->agg_remote[(size_t)s], stream)))
+            rc = gnnagg_gcn_run_ex(st->agg_remote[(size_t)s], d_x_halo, d_y, feat, GNNAGG_MODE_BALANCED, reduce, GNNAGG_FLAG_ACCUMULATE);
     }
-    return GNNAGG_OK;
+    return rc;
 }
 
 int gnnagg_dist_step_gat(gnnagg_dist_step_t h, float *d_x_ext, float *d_att_ext, int n_local, float *d_send_buf, float *d_recv_buf,
@@ -455,34 +510,41 @@ int gnnagg_dist_step_gat(gnnagg_dist_step_t h, float *d_x_ext, float *d_att_ext,
     const int aw = 2 * heads, w = feat + aw;
     int rc;
     const bool ex = st->exchanging();
+    const int S = st->n_stages;
     if (ex) {
         if ((st->n_send > 0 && !d_send_buf) || (st->n_recv > 0 && !d_recv_buf)) return fail(GNNAGG_ERR_ARG, "dist_step: null exchange buffer");
         if ((rc = step_fork(st, stream))) return rc;
-        // ONE exchange carries [feature row | attention terms] of every requested row
-        if ((rc = launch_pack_rows2(d_x_ext, d_att_ext, st->d_send_ids, (int)st->n_send, feat, aw, d_send_buf, st->comm_stream)))
+        // ONE exchange per stage carries [feature row | attention terms] of every requested row; the received rows are split into
+        // the halo tails of x_ext / att_ext stage by stage (same row order on both sides)
+        if (st->n_send > 0 && (rc = launch_pack_rows2(d_x_ext, d_att_ext, st->d_send_ids, (int)st->n_send, feat, aw, d_send_buf, st->comm_stream)))
             return step_abandon(st, stream, rc);
-        if ((rc = gnnagg_dist_alltoallv(st->comm, d_send_buf, st->send_rows.data(), d_recv_buf, st->recv_rows.data(), w * (int)sizeof(float),
-                                        st->comm_stream)))
-            return step_abandon(st, stream, rc);
-        if ((rc = launch_unpack_rows2(d_recv_buf, (int)st->n_recv, feat, aw, d_x_ext + (size_t)n_local * feat, d_att_ext + (size_t)n_local * aw,
-                                      st->comm_stream)))
-            return step_abandon(st, stream, rc);
-        HIPD_TRY(hipEventRecord(st->ev_join, st->comm_stream));
+        for (int s = 0; s < S; ++s) {
+            if ((rc = step_exchange_stage(st, s, d_send_buf, d_recv_buf, w))) return step_abandon(st, stream, rc);
+            const long long r0 = st->stage_recv0[(size_t)s], nr = st->stage_recv0[(size_t)s + 1] - r0;
+            if (nr > 0 && (rc = launch_unpack_rows2(d_recv_buf + (size_t)r0 * w, (int)nr, feat, aw, d_x_ext + ((size_t)n_local + r0) * feat,
+                                                    d_att_ext + ((size_t)n_local + r0) * aw, st->comm_stream)))
+                return step_abandon(st, stream, rc);
+            HIPD_TRY(hipEventRecord(st->ev_stage[(size_t)s], st->comm_stream));
+        }
     }
-    // numerators and denominators of the local-source edges while the exchange is in flight; the halo-source pass adds its own
-    // and divides (it runs for every row: a row without halo sources is divided all the same)
-    if ((rc = gnnagg_set_stream(st->agg_local, stream))) return rc;
-    if (!st->agg_remote) {
-        // (a step made without a halo-source aggregator: one pass over X_ext.  It reads the halo tail, so it runs BEHIND the
-        // exchange -- and the caller's stream is joined whatever happens: send_buf / the tail are free again when it is)
-        if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));
+    // numerators and denominators of the local-source edges while the exchange is in flight; every halo-source pass adds its own,
+    // the last one divides (it runs for every row: a row without halo sources is divided all the same)
+    if ((rc = gnnagg_set_stream(st->agg_local, stream))) return ex ? step_abandon(st, stream, rc) : rc;
+    if (!st->any_remote()) {
+        // (a step made without halo-source aggregators: one pass over X_ext.  It reads the halo tail, so it runs BEHIND the exchange)
+        for (int s = 0; ex && s < S; ++s) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_stage[(size_t)s], 0));
         return gnnagg_gat_run(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, GNNAGG_MODE_BALANCED, nullptr);
     }
+    int last = -1;
+    for (int s = 0; s < S; ++s) if (st->agg_remote[(size_t)s]) last = s;
     rc = gnnagg_gat_run_part(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, 1, d_den);
-    if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_join, 0));   // joined on the error path too: a fork is never left dangling
-    if (rc) return rc;
-    if ((rc = gnnagg_set_stream(st->agg_remote, stream))) return rc;
-    return gnnagg_gat_run_part(st->agg_remote, d_x_ext, d_att_ext, d_y, feat, heads, slope, 2, d_den);
+    for (int s = 0; s < S; ++s) {
+        if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_stage[(size_t)s], 0));   // joined on the error path too
+        if (rc || !st->agg_remote[(size_t)s]) continue;
+        if (!(rc = gnnagg_set_stream(st->agg_remote[(size_t)s], stream)))
+            rc = gnnagg_gat_run_part(st->agg_remote[(size_t)s], d_x_ext, d_att_ext, d_y, feat, heads, slope, s == last ? 2 : 3, d_den);
+    }
+    return rc;
 }
 
 }  // extern "C"

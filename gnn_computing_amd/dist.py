@@ -17,6 +17,14 @@ Two execution plans share the same communication plan:
   (GNNAGG_FLAG_ACCUMULATE).  Deterministic; equals the single-GPU result up to the one extra fp32
   add per row that joins the two parts.
 
+Staged exchange (round 4; ``stages=``): the halo rows arrive in S stages, stage s with its own all-to-all-v, and the halo-source
+edges are split by the stage their source arrives in -- the pass over stage s's edges runs while stage s + 1 is on the links.
+Buffers are stage-major (send buffer, halo tail: stage 0's rows in rank order, then stage 1's ...), so every stage is a plain
+all-to-all-v on a contiguous sub-range.  ``("stripe", K)``: every stage takes 1/K of EVERY peer's rows -- on the point-to-point
+xGMI mesh each peer pair has its own link, so a stage must talk to all peers to keep all links busy (the default for
+``stages="auto"``: K from the halo bytes); ``"owner"``: stage s exchanges with the peers at ring distance s + 1 only (one link per
+stage: for switched fabrics and for tests).  Result: y = local pass, += stage 0's pass, += stage 1's ... in that fixed order.
+
 Transports (same plan, same buffers): "torch" = torch.distributed.all_to_all_single (backend "nccl" = RCCL on ROCm,
 "gloo" in the CPU tests); "rccl" = the C-ABI's own grouped ncclSend / ncclRecv (gnnagg_dist_halo_exchange)
 -- what a C++ driver uses (drivers/dist_step.cpp); torch.distributed then only carries the 128-byte unique id.  The
@@ -50,6 +58,31 @@ class _StreamWork:
 
     def wait(self):
         torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class _EventWork:
+    """one stage of a staged exchange on the C-ABI transport: wait() orders the current stream behind the stage's event"""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+class _StagedWork:
+    """the stages' work handles in order; wait() waits for all of them, stage(s).wait() for one"""
+
+    def __init__(self, works):
+        self.works = works
+
+    def stage(self, s):
+        return self.works[s]
+
+    def wait(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()
 
 
 class RcclTransport:
@@ -112,7 +145,7 @@ class HaloExchange:
     """
 
     def __init__(self, ptr, idx, rank=None, world=None, group=None, device="cpu", bounds=None, pack_fn=None,
-                 offline=False, row_slice=False, num_cols=None, transport="torch"):
+                 offline=False, row_slice=False, num_cols=None, transport="torch", stages=1):
         """row_slice=False: (ptr, idx) is the global CSR (every rank holds it at plan time).  row_slice=True: (ptr, idx) are
         THIS rank's rows only -- ptr[0 .. n_local] with any base offset, idx with global column ids -- and `bounds`
         (partition_rows of the global ptr, e.g. computed by rank 0 and broadcast) and `num_cols` are required.
@@ -148,12 +181,93 @@ class HaloExchange:
         self.recv_counts = plan["halo_counts"].astype(np.int64)  # rows received from each rank
         self.n_halo = int(len(self.halo_ids))
         self.row0 = int(self.bounds[self.rank])
+        self._plan_stages(stages)
         if offline:
             self.send_counts = np.zeros(self.world, np.int64)
+            self.stage_send = np.zeros((self.n_stages, self.world), np.int64)
+            self.stage_send0 = np.zeros(self.n_stages + 1, np.int64)
             self.send_ids = torch.zeros(0, dtype=torch.int32, device=self.device)
             self.n_send = 0
         else:
             self._exchange_requests()  # one-time: tell every owner which of its rows this rank needs
+
+    @staticmethod
+    def stage_counts(n_rows, rank, world, mode, k):
+        """[S][world] rows of the (reader <- owner) lists `n_rows[owner]` that travel in each stage, for reader `rank`.  Both ends
+        of a pair call this with the same list length, so they cut it the same way: "stripe": slice j of K of every owner's list;
+        "owner": stage s = the owner at ring distance s + 1 behind the reader (its whole list)."""
+        n_rows = [int(v) for v in n_rows]
+        if mode == "owner":
+            out = np.zeros((max(world - 1, 1), world), np.int64)
+            for s in range(world - 1):
+                o = (rank - s - 1) % world
+                out[s, o] = n_rows[o]
+            return out
+        out = np.zeros((k, world), np.int64)
+        for o in range(world):
+            for j in range(k):
+                out[j, o] = n_rows[o] * (j + 1) // k - n_rows[o] * j // k
+        return out
+
+    def _plan_stages(self, stages):
+        """Chooses the stages and renumbers the halo slots stage-major: halo_ids, the halo columns of local_idx and (later) the
+        send list follow.  stages: 1 | K | ("stripe", K) | "owner" | "auto" (stripes, K from the halo rows: about 64 k rows per
+        stage, at most 4)."""
+        w = self.world
+        if stages == "auto":
+            stages = ("stripe", int(min(4, max(1, self.n_halo // 65536))))
+        if isinstance(stages, int):
+            stages = ("stripe", stages)
+        if stages == "owner":
+            stages = ("owner", 0)
+        mode, k = stages
+        if mode not in ("stripe", "owner") or (mode == "stripe" and k < 1):
+            raise ValueError("stages: 1, K, ('stripe', K), 'owner' or 'auto'")
+        if w == 1 or (mode == "stripe" and k == 1):
+            mode, k = "stripe", 1
+        self.stage_mode, self.stage_k = mode, k
+        self.stage_recv = self.stage_counts(self.recv_counts, self.rank, w, mode, k)       # [S][owner]
+        self.n_stages = int(self.stage_recv.shape[0])
+        self.stage_recv0 = np.concatenate([[0], np.cumsum(self.stage_recv.sum(axis=1))]).astype(np.int64)   # first halo slot of a stage
+        if self.n_stages == 1:
+            self.stage_of_slot = np.zeros(self.n_halo, np.int32)
+            return
+        # old slot order: owner-major, ascending id.  new: stage-major, then owner, then ascending id
+        owner0 = np.concatenate([[0], np.cumsum(self.recv_counts)]).astype(np.int64)
+        new_of_old = np.empty(self.n_halo, np.int64)
+        stage_of_new = np.empty(self.n_halo, np.int32)
+        pos = 0
+        taken = np.zeros(w, np.int64)
+        for s in range(self.n_stages):
+            for o in range(w):
+                c = int(self.stage_recv[s, o])
+                if c:
+                    new_of_old[owner0[o] + taken[o]: owner0[o] + taken[o] + c] = np.arange(pos, pos + c)
+                    stage_of_new[pos: pos + c] = s
+                    taken[o] += c
+                    pos += c
+        assert pos == self.n_halo
+        ids = np.empty_like(self.halo_ids)
+        ids[new_of_old] = self.halo_ids
+        self.halo_ids = ids
+        is_halo = self.local_idx >= self.n_local
+        li = self.local_idx.copy()
+        li[is_halo] = (new_of_old[self.local_idx[is_halo] - self.n_local] + self.n_local).astype(li.dtype)
+        self.local_idx = li
+        self.stage_of_slot = stage_of_new
+        # the request lists go out owner-major (one all-to-all), each owner's list in the order its rows will arrive: stage by stage
+        self._req_order = np.argsort(self._owner_of_new(), kind="stable")
+
+    def _owner_of_new(self):
+        """owner of every (stage-major) halo slot"""
+        out = np.empty(self.n_halo, np.int64)
+        pos = 0
+        for s in range(self.n_stages):
+            for o in range(self.world):
+                c = int(self.stage_recv[s, o])
+                out[pos: pos + c] = o
+                pos += c
+        return out
 
     def _exchange_requests(self):
         w = self.world
@@ -165,22 +279,59 @@ class HaloExchange:
         else:
             send_counts.copy_(recv_counts)
         self.send_counts = send_counts.cpu().numpy().astype(np.int64)
-        req = torch.from_numpy(self.halo_ids.astype(np.int32)).to(cpu_like)
+        req_ids = self.halo_ids if self.n_stages == 1 else self.halo_ids[self._req_order]   # owner-major, arrival order inside
+        req = torch.from_numpy(req_ids.astype(np.int32)).to(cpu_like)
         serve = torch.empty(int(self.send_counts.sum()), dtype=torch.int32, device=cpu_like)
         if w > 1:
             dist.all_to_all_single(serve, req, output_split_sizes=self.send_counts.tolist(),
                                    input_split_sizes=self.recv_counts.tolist(), group=self.group)
-        # rows of the LOCAL x to pack, in the order the peers expect them
+        # rows of the LOCAL x to pack, in the order the peers expect them: stage-major, reader by reader inside a stage.  What
+        # reader q receives from this rank in stage s is what stage_counts says for q's list of this rank's rows
+        self.stage_send = np.zeros((self.n_stages, w), np.int64)
+        for q in range(w):
+            n_q = np.zeros(w, np.int64)
+            n_q[self.rank] = self.send_counts[q]
+            self.stage_send[:, q] = self.stage_counts(n_q, q, w, self.stage_mode, self.stage_k)[:self.n_stages, self.rank] if w > 1 else 0
+        if self.n_stages > 1:
+            reader0 = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
+            taken = np.zeros(w, np.int64)
+            order = []
+            for st in range(self.n_stages):
+                for q in range(w):
+                    c = int(self.stage_send[st, q])
+                    order.append(np.arange(reader0[q] + taken[q], reader0[q] + taken[q] + c))
+                    taken[q] += c
+            order = np.concatenate(order) if order else np.zeros(0, np.int64)
+            serve = serve[torch.from_numpy(order).to(serve.device)]
+        self.stage_send0 = np.concatenate([[0], np.cumsum(self.stage_send.sum(axis=1))]).astype(np.int64)
         self.send_ids = (serve - self.row0).to(self.device)
         self.n_send = int(self.send_ids.numel())
         self._split_lists = None
         assert self.n_send == 0 or (int(self.send_ids.min()) >= 0 and int(self.send_ids.max()) < self.n_local)
 
-    def split_lists(self):
-        """(rows received from, rows sent to) every rank as Python lists -- what all_to_all_single wants; made once, not per step."""
+    def split_lists(self, stage=None):
+        """(rows received from, rows sent to) every rank as Python lists -- what all_to_all_single wants; made once, not per step.
+        stage=None: the whole exchange (one stage); else that stage's share."""
         if getattr(self, "_split_lists", None) is None:
-            self._split_lists = ([int(v) for v in self.recv_counts], [int(v) for v in self.send_counts])
-        return self._split_lists
+            self._split_lists = {None: ([int(v) for v in self.recv_counts], [int(v) for v in self.send_counts])}
+            for st in range(self.n_stages):
+                self._split_lists[st] = ([int(v) for v in self.stage_recv[st]], [int(v) for v in self.stage_send[st]])
+        return self._split_lists[stage]
+
+    def split_remote_stages(self):
+        """The halo-source edges per stage: [(ptr_s, idx_s, mask_s)] -- CSR over this rank's rows of the edges whose source arrives
+        in stage s (column ids = halo slots, 0-based, over the WHOLE halo tail), mask_s over the rank's edge list; in-row order kept."""
+        rows = np.repeat(np.arange(self.n_local), np.diff(self.local_ptr))
+        is_rem = self.local_idx >= self.n_local
+        slot = np.where(is_rem, self.local_idx - self.n_local, 0)
+        st_of_edge = np.where(is_rem, self.stage_of_slot[slot] if self.n_halo else 0, -1)
+        out = []
+        for st in range(self.n_stages):
+            m = st_of_edge == st
+            p = np.zeros(self.n_local + 1, np.int32)
+            p[1:] = np.cumsum(np.bincount(rows[m], minlength=self.n_local))
+            out.append((p, slot[m].astype(np.int32), m))
+        return out
 
     def halo_bytes(self, feat):
         return self.n_halo * feat * 4
@@ -212,13 +363,35 @@ class HaloExchange:
         feat = x_local.shape[1]
         if send_buf is None or send_buf.shape[0] < self.n_send:
             send_buf = torch.empty((max(self.n_send, 1), feat), dtype=x_local.dtype, device=x_local.device)
-        if self.rccl is not None:
+        if self.rccl is not None and self.n_stages == 1:
             return self.rccl.halo_exchange(x_local, self.send_ids, self.send_counts, self.recv_counts, send_buf, x_halo, async_op)
         if self.n_send:
             self.pack_fn(x_local, self.send_ids, send_buf)
-        return dist.all_to_all_single(x_halo, send_buf[:self.n_send],
-                                      output_split_sizes=self.split_lists()[0],
-                                      input_split_sizes=self.split_lists()[1], group=self.group, async_op=async_op)
+        if self.n_stages == 1:
+            return dist.all_to_all_single(x_halo, send_buf[:self.n_send],
+                                          output_split_sizes=self.split_lists()[0],
+                                          input_split_sizes=self.split_lists()[1], group=self.group, async_op=async_op)
+        works = [self.exchange_stage(st, send_buf, x_halo, async_op) for st in range(self.n_stages)]
+        return _StagedWork(works) if async_op else None
+
+    def exchange_stage(self, st, send_buf, recv_rows, async_op):
+        """Stage st of a staged exchange: rows [stage_send0[st], stage_send0[st + 1]) of the (packed, stage-major) send buffer to the
+        peers, rows [stage_recv0[st], stage_recv0[st + 1]) of `recv_rows` from them."""
+        s0, s1 = int(self.stage_send0[st]), int(self.stage_send0[st + 1])
+        r0, r1 = int(self.stage_recv0[st]), int(self.stage_recv0[st + 1])
+        if self.rccl is not None:
+            stream = self.rccl.stream if async_op else torch.cuda.current_stream()
+            if async_op and st == 0:
+                stream.wait_stream(torch.cuda.current_stream())
+            w = send_buf.shape[1]
+            with torch.cuda.stream(stream):
+                self.rccl.alltoallv(send_buf[s0:s1], [int(v) * w for v in self.stage_send[st]], recv_rows[r0:r1],
+                                    [int(v) * w for v in self.stage_recv[st]])
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            return _EventWork(ev) if async_op else None
+        return dist.all_to_all_single(recv_rows[r0:r1], send_buf[s0:s1], output_split_sizes=self.split_lists(st)[0],
+                                      input_split_sizes=self.split_lists(st)[1], group=self.group, async_op=async_op)
 
 
 class PartitionedGCN:
@@ -231,11 +404,14 @@ class PartitionedGCN:
     local pass, event wait, halo pass)."""
 
     def __init__(self, ptr, idx, val=None, feat=128, group=None, device=None, mode="balanced", rank=None, world=None,
-                 overlap=True, offline=False, row_slice=False, bounds=None, num_cols=None, transport="torch"):
-        """row_slice=True: ptr / idx / val hold this rank's rows only (see HaloExchange)."""
+                 overlap=True, offline=False, row_slice=False, bounds=None, num_cols=None, transport="torch", stages=1):
+        """row_slice=True: ptr / idx / val hold this rank's rows only (see HaloExchange).  stages: the staged exchange of the
+        module docstring (overlap plan only): 1, K, ("stripe", K), "owner", "auto"."""
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if not (bool(overlap) and mode == "balanced"):
+            stages = 1
         self.hx = HaloExchange(ptr, idx, rank=rank, world=world, group=group, device=device, offline=offline,
-                               row_slice=row_slice, bounds=bounds, num_cols=num_cols, transport=transport)
+                               row_slice=row_slice, bounds=bounds, num_cols=num_cols, transport=transport, stages=stages)
         hx = self.hx
         self.feat, self.mode = feat, mode
         self.overlap = bool(overlap) and mode == "balanced"
@@ -256,20 +432,32 @@ class PartitionedGCN:
         if self.overlap:
             pl, il, pr, ir, is_loc = hx.split_local_remote()
             self.agg_loc = Aggregator_GCN(t(pl), t(il), None if val_loc is None else t(val_loc[is_loc]), feat, feat)
-            self.agg_rem = Aggregator_GCN(t(pr), t(ir), None if val_loc is None else t(val_loc[~is_loc]), feat, feat)
             self.agg_loc.schedule_balanced(0)
-            self.agg_rem.schedule_balanced(0)
             self.num_e_remote = int(len(ir))
             self.deg_total = t(np.diff(hx.local_ptr).astype(np.int32))   # the row's degree in the whole graph (mean divisor)
-            self.deg_local = t(np.diff(pl).astype(np.int32))             # edges the first pass folds (max join)
+            # one aggregator per stage over the halo-source edges whose source arrives in that stage (None: no such edges);
+            # deg_before[s] = edges of a row folded before stage s's pass (the guarded max join, gnnagg_set_row_aux)
+            self.agg_rem_stages, self.deg_before = [], []
+            folded = np.diff(pl).astype(np.int64)
+            for ps_, is_, m_ in hx.split_remote_stages():
+                self.deg_before.append(t(folded.astype(np.int32)))
+                folded = folded + np.diff(ps_)
+                if len(is_) == 0:
+                    self.agg_rem_stages.append(None)
+                    continue
+                a = Aggregator_GCN(t(ps_), t(is_), None if val_loc is None else t(val_loc[m_]), feat, feat)
+                a.schedule_balanced(0)
+                self.agg_rem_stages.append(a)
+            self.agg_rem = self.agg_rem_stages[0] if hx.n_stages == 1 else None   # (the one-stage name, kept for callers)
+            self.deg_local = self.deg_before[0]
             if device.type == "cuda" and not offline and (hx.rccl is not None or hx.world == 1):
-                n = hx.world
-                sc = (ctypes.c_longlong * n)(*[int(v) for v in hx.send_counts])
-                rc = (ctypes.c_longlong * n)(*[int(v) for v in hx.recv_counts])
-                check(lib().gnnagg_dist_step_create(hx.rccl._h if hx.rccl is not None else ctypes.c_int64(0), self.agg_loc._h,
-                                                    self.agg_rem._h if hx.n_halo else ctypes.c_int64(0),
-                                                    ctypes.c_void_p(hx.send_ids.data_ptr()) if hx.n_send else None, sc, rc,
-                                                    ctypes.byref(self._step)))
+                n, S = hx.world, hx.n_stages
+                sc = (ctypes.c_longlong * (n * S))(*[int(v) for v in hx.stage_send.reshape(-1)])
+                rc = (ctypes.c_longlong * (n * S))(*[int(v) for v in hx.stage_recv.reshape(-1)])
+                hs = (ctypes.c_int64 * S)(*[(a._h.value if a is not None else 0) for a in self.agg_rem_stages])
+                check(lib().gnnagg_dist_step_create_staged(hx.rccl._h if hx.rccl is not None else ctypes.c_int64(0), self.agg_loc._h, S,
+                                                           hs, ctypes.c_void_p(hx.send_ids.data_ptr()) if hx.n_send else None, sc, rc,
+                                                           ctypes.byref(self._step)))
         else:
             self.agg = Aggregator_GCN(t(hx.local_ptr), t(hx.local_idx), None if val_loc is None else t(val_loc), feat, feat)
             if mode == "balanced":
@@ -295,25 +483,23 @@ class PartitionedGCN:
         if getattr(self, "_aux_kind", None) == kind:
             return            # (two host calls saved per step: the step is a handful of launches)
         self._aux_kind = kind
-        if reduce == "mean":
-            self.agg_loc.set_row_aux(self.deg_total)
-            self.agg_rem.set_row_aux(self.deg_total)
-        elif reduce == "max":
-            self.agg_loc.set_row_aux(None)
-            self.agg_rem.set_row_aux(self.deg_local)
-        else:
-            self.agg_loc.set_row_aux(None)
-            self.agg_rem.set_row_aux(None)
+        self.agg_loc.set_row_aux(self.deg_total if reduce == "mean" else None)
+        for a, before in zip(self.agg_rem_stages, self.deg_before):
+            if a is not None:
+                a.set_row_aux(self.deg_total if reduce == "mean" else before if reduce == "max" else None)
 
     def compute(self, reduce="sum", work=None):
         """The aggregation kernels of one step, given that the exchange `work` (or None) fills x_halo."""
         if self.overlap:
             self._set_aux(reduce)
             self.agg_loc.run(self.x_local, self.y, 512, "balanced", reduce=reduce)   # overlaps the all-to-all
-            if work is not None:
-                work.wait()                                                            # current stream waits for the halo
-            if self.hx.n_halo:
-                self.agg_rem.run(self.x_halo, self.y, 512, "balanced", reduce=reduce, accumulate=True)
+            for st, a in enumerate(self.agg_rem_stages):
+                if work is not None:                                                   # current stream waits for stage st of the halo
+                    (work.stage(st) if isinstance(work, _StagedWork) else work).wait()
+                    if not isinstance(work, _StagedWork):
+                        work = None
+                if a is not None:
+                    a.run(self.x_halo, self.y, 512, "balanced", reduce=reduce, accumulate=True)
         else:
             if work is not None:
                 work.wait()
@@ -355,18 +541,19 @@ class PartitionedGAT:
 
     def __init__(self, ptr, idx, feat=256, heads=8, group=None, device=None, mode="balanced", rank=None, world=None,
                  offline=False, row_slice=False, bounds=None, num_cols=None, transport="torch", overlap=True, pack_fn2=None,
-                 unpack_fn2=None, build_aggregators=True):
+                 unpack_fn2=None, build_aggregators=True, stages=1):
         """pack_fn2 / unpack_fn2 / build_aggregators=False: test doubles for the CPU tests of the exchange (the product's pack,
         unpack and aggregation are HIP kernels without a CPU fallback)."""
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.hx = HaloExchange(ptr, idx, rank=rank, world=world, group=group, device=device, offline=offline,
-                               row_slice=row_slice, bounds=bounds, num_cols=num_cols, transport=transport)
-        hx = self.hx
-        self.feat, self.heads, self.mode = feat, heads, mode
-        self.pack_fn2, self.unpack_fn2 = pack_fn2 or _hip_pack_rows2, unpack_fn2 or _hip_unpack_rows2
         aw = 2 * heads
         # the two-pass form runs on 16-byte lanes over one column tile (gnnagg_gat_run_part)
         self.overlap = bool(overlap) and mode == "balanced" and feat % 4 == 0 and (feat // heads) % 4 == 0 and feat <= 256
+        self.hx = HaloExchange(ptr, idx, rank=rank, world=world, group=group, device=device, offline=offline,
+                               row_slice=row_slice, bounds=bounds, num_cols=num_cols, transport=transport,
+                               stages=stages if self.overlap else 1)
+        hx = self.hx
+        self.feat, self.heads, self.mode = feat, heads, mode
+        self.pack_fn2, self.unpack_fn2 = pack_fn2 or _hip_pack_rows2, unpack_fn2 or _hip_unpack_rows2
         self.x_ext = hx.alloc_x_ext(feat)
         self.att_ext = hx.alloc_x_ext(aw)
         self.y = torch.empty((hx.n_local, feat), dtype=torch.float32, device=device)
@@ -380,14 +567,23 @@ class PartitionedGAT:
         if self.overlap:
             pl, il, pr, ir, _ = hx.split_local_remote()
             self.agg_loc = Aggregator_GAT(t(pl), t(il), feat, feat)
-            self.agg_rem = Aggregator_GAT(t(pr), t((ir + hx.n_local).astype(np.int32)), feat, feat)   # X_ext slots, like agg_loc
+            # one aggregator per stage (X_ext slots, like agg_loc); the LAST stage's pass divides every row, so it always exists
+            self.agg_rem_stages = []
+            stage_csr = hx.split_remote_stages()
+            for st, (ps_, is_, _) in enumerate(stage_csr):
+                if len(is_) == 0 and st + 1 < len(stage_csr):
+                    self.agg_rem_stages.append(None)
+                else:
+                    self.agg_rem_stages.append(Aggregator_GAT(t(ps_), t((is_ + hx.n_local).astype(np.int32)), feat, feat))
+            self.agg_rem = self.agg_rem_stages[0] if hx.n_stages == 1 else None
             if device.type == "cuda" and not offline and (hx.rccl is not None or hx.world == 1):
-                n = hx.world
-                sc = (ctypes.c_longlong * n)(*[int(v) for v in hx.send_counts])
-                rc = (ctypes.c_longlong * n)(*[int(v) for v in hx.recv_counts])
-                check(lib().gnnagg_dist_step_create(hx.rccl._h if hx.rccl is not None else ctypes.c_int64(0), self.agg_loc._h,
-                                                    self.agg_rem._h, ctypes.c_void_p(hx.send_ids.data_ptr()) if hx.n_send else None,
-                                                    sc, rc, ctypes.byref(self._step)))
+                n, S = hx.world, hx.n_stages
+                sc = (ctypes.c_longlong * (n * S))(*[int(v) for v in hx.stage_send.reshape(-1)])
+                rc = (ctypes.c_longlong * (n * S))(*[int(v) for v in hx.stage_recv.reshape(-1)])
+                hs = (ctypes.c_int64 * S)(*[(a._h.value if a is not None else 0) for a in self.agg_rem_stages])
+                check(lib().gnnagg_dist_step_create_staged(hx.rccl._h if hx.rccl is not None else ctypes.c_int64(0), self.agg_loc._h, S,
+                                                           hs, ctypes.c_void_p(hx.send_ids.data_ptr()) if hx.n_send else None, sc, rc,
+                                                           ctypes.byref(self._step)))
         else:
             self.d_ptr = t(hx.local_ptr)
             self.d_idx = t(hx.local_idx)
@@ -412,40 +608,38 @@ class PartitionedGAT:
         self.att_ext[:n].copy_(att_local.reshape(n, -1))
 
     def exchange(self, async_op=False):
-        """ONE all-to-all of [x | att] rows into recv_buf; returns the work handle (None: nothing to wait for).  The received
-        rows still have to be split into the halo tails (finish_exchange)."""
+        """The all-to-all(s) of [x | att] rows into recv_buf -- one per stage; returns the work handle (None: nothing to wait for).
+        The received rows still have to be split into the halo tails (finish_exchange)."""
         hx = self.hx
         if hx.offline or (hx.world == 1 and not (dist.is_available() and dist.is_initialized())):
             return None
         n = hx.n_local
         if hx.n_send:
             self.pack_fn2(self.x_ext[:n], self.att_ext[:n], hx.send_ids, self.send_buf)
-        if hx.rccl is not None:
-            st = hx.rccl.stream if async_op else torch.cuda.current_stream()
-            if async_op:
-                st.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(st):
-                hx.rccl.alltoallv(self.send_buf, [int(v) * self.send_buf.shape[1] for v in hx.send_counts], self.recv_buf,
-                                  [int(v) * self.recv_buf.shape[1] for v in hx.recv_counts])
-            return _StreamWork(st) if async_op else None
-        return dist.all_to_all_single(self.recv_buf[:hx.n_halo], self.send_buf[:hx.n_send],
-                                      output_split_sizes=hx.split_lists()[0], input_split_sizes=hx.split_lists()[1],
-                                      group=hx.group, async_op=async_op)
+        works = [hx.exchange_stage(st, self.send_buf[:max(hx.n_send, 1)], self.recv_buf[:max(hx.n_halo, 1)], async_op) for st in range(hx.n_stages)]
+        return _StagedWork(works) if async_op else None
 
-    def finish_exchange(self):
+    def finish_exchange(self, stage=None):
+        """recv_buf rows -> the halo tails of x_ext / att_ext (all stages, or one)"""
         hx = self.hx
-        if hx.n_halo and not hx.offline:
-            self.unpack_fn2(self.recv_buf, hx.n_halo, self.x_ext[hx.n_local:], self.att_ext[hx.n_local:])
+        if not hx.n_halo or hx.offline:
+            return
+        r0, r1 = (0, hx.n_halo) if stage is None else (int(hx.stage_recv0[stage]), int(hx.stage_recv0[stage + 1]))
+        if r1 > r0:
+            self.unpack_fn2(self.recv_buf[r0:r1], r1 - r0, self.x_ext[hx.n_local + r0:hx.n_local + r1], self.att_ext[hx.n_local + r0:hx.n_local + r1])
 
     def compute(self, slope=0.2, work=None):
         """The aggregation kernels of one step (the halo tails of x_ext / att_ext are filled by `work` + finish_exchange, or by
         hand in the single-process tests)."""
         if self.overlap:
             self.agg_loc.run_part(self.x_ext, self.att_ext, self.y, self.den, 1, self.heads, slope)   # overlaps the all-to-all
-            if work is not None:
-                work.wait()
-                self.finish_exchange()
-            self.agg_rem.run_part(self.x_ext, self.att_ext, self.y, self.den, 2, self.heads, slope)
+            last = max(st for st, a in enumerate(self.agg_rem_stages) if a is not None)
+            for st, a in enumerate(self.agg_rem_stages):
+                if work is not None:
+                    work.stage(st).wait()
+                    self.finish_exchange(st)
+                if a is not None:
+                    a.run_part(self.x_ext, self.att_ext, self.y, self.den, 2 if st == last else 3, self.heads, slope)
         else:
             if work is not None:
                 work.wait()

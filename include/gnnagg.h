@@ -241,7 +241,8 @@ int gnnagg_gat_run(gnnagg_handle h, const float *d_x, const float *d_att, float 
  * the chunked plan; 16-byte aligned rows of at most 256 columns.
  *   part = 1  d_y[row, :] receives the NUMERATOR sum_e w_e x_e and d_den_io[row, h] the denominator sum_e w_e; no division
  *   part = 2  both are added to what part 1 left (old + new, one fp32 add per element), then the row is divided
- *             (scaleArray, aggr_gat.h:207-213); rows this handle has no edges for are divided all the same */
+ *             (scaleArray, aggr_gat.h:207-213); rows this handle has no edges for are divided all the same
+ *   part = 3  a pass in between (staged halo exchange, gnnagg_dist_step_create_staged): both are added, nothing is divided */
 int gnnagg_gat_run_part(gnnagg_handle h, const float *d_x, const float *d_att, float *d_y, int feat, int heads, float slope, int part,
                         float *d_den_io);
 /* Aggregator_GAT::run_att, aggr_gat.h:395-401 (attGat :5-31): out_val[E,heads] = softmax weights */
@@ -377,10 +378,26 @@ int gnnagg_unpack_rows2(const float *d_in, int n, int feat, int att_width, float
  *   gnnagg_dist_step_gat      x_ext = [X_local ; X_halo], att_ext likewise ([., heads, 2]); ONE exchange carries [x | att] rows
  *                             (d_send_buf [n_send, feat + 2 heads], d_recv_buf [n_halo, feat + 2 heads]); both aggregators index
  *                             X_ext slots; d_den [n_local, heads] carries the denominators between the two passes
- *                             (gnnagg_gat_run_part) */
+ *                             (gnnagg_gat_run_part)
+ *   gnnagg_dist_step_create_staged  the exchange PIPELINED against the halo-source pass: the halo rows arrive in n_stages stages,
+ *                             stage s with its own grouped send / recv (h_send_rows / h_recv_rows: [n_stages][world], rows) and its
+ *                             own event, and agg_remote[s] (0: no edges) -- an aggregator over the halo-source edges whose source
+ *                             arrives in stage s -- runs as soon as stage s has landed, while stage s + 1 is in flight.  Buffers are
+ *                             STAGE-MAJOR: d_send_ids, d_send_buf, the halo tail and d_recv_buf list stage 0's rows in rank order,
+ *                             then stage 1's ...; agg_remote[s] indexes the whole halo tail (GCN: 0-based halo slots; GAT: X_ext
+ *                             slots).  How the rows are dealt to stages is the caller's plan (gnn_computing_amd/dist.py:
+ *                             "stripe" -- every stage takes 1/K of EVERY peer's rows, so each stage keeps all xGMI links of the
+ *                             mesh busy; "owner" -- stage s exchanges with the peers at ring distance s + 1 only).  The result
+ *                             is y = local pass, then += stage 0's pass, += stage 1's ... in this fixed order: deterministic.
+ *                             mean: total degrees on every aggregator; max: agg_remote[s] gets the edges folded BEFORE stage s */
 typedef int64_t gnnagg_dist_step_t;
 int gnnagg_dist_step_create(gnnagg_comm comm, gnnagg_handle agg_local, gnnagg_handle agg_remote, const int *d_send_ids,
                             const long long *h_send_rows, const long long *h_recv_rows, gnnagg_dist_step_t *out);
+int gnnagg_dist_step_create_staged(gnnagg_comm comm, gnnagg_handle agg_local, int n_stages, const gnnagg_handle *agg_remote,
+                                   const int *d_send_ids, const long long *h_send_rows, const long long *h_recv_rows,
+                                   gnnagg_dist_step_t *out);
+/* (n_stages, the world size of the step's communicator -- 1 without one) */
+int gnnagg_dist_step_info(gnnagg_dist_step_t step, int *n_stages, int *world);
 int gnnagg_dist_step_destroy(gnnagg_dist_step_t step);
 int gnnagg_dist_step_gcn(gnnagg_dist_step_t step, const float *d_x_local, float *d_x_halo, float *d_send_buf, float *d_y, int feat, int reduce,
                          void *hip_stream);

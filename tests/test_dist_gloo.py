@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, F, q):
+def _worker(rank, world, port, F, q, stages=1):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,7 +41,7 @@ def _worker(rank, world, port, F, q):
         rng = np.random.default_rng(7)
         x = rng.standard_normal((V, F), dtype=np.float32)
         val = rng.standard_normal(E, dtype=np.float32)
-        hx = HaloExchange(ptr, idx, device="cpu",
+        hx = HaloExchange(ptr, idx, device="cpu", stages=stages,
                           pack_fn=lambda xs, ids, out: out[:ids.numel()].copy_(xs.index_select(0, ids.long())))
         r0, r1 = int(hx.bounds[rank]), int(hx.bounds[rank + 1])
         x_ext = hx.alloc_x_ext(F)
@@ -63,8 +63,27 @@ def _worker(rank, world, port, F, q):
         scale = orc.gcn_abs_scale(ptr, idx, val, x)[r0:r1]
         ok_y = ok_y and bool(np.all(np.abs(y_split - y_global[r0:r1]) <= 1e-5 * scale + 1e-30))
         ok_y = ok_y and len(il) + len(ir) == hx.e1 - hx.e0 and (ir.max(initial=-1) < hx.n_halo)
+        # staged exchange: the halo tail is stage-major, every stage's edges name slots of that stage only, the stages' CSRs
+        # partition the halo-source edges, and local + stage 0 + stage 1 + ... (the order the step adds them in) is the row
+        parts = hx.split_remote_stages()
+        y_st = orc.gcn_seq(pl, il, vl[is_loc], x_ext[:hx.n_local].numpy())
+        n_rem = 0
+        for st, (ps_, is_, m_) in enumerate(parts):
+            lo, hi = int(hx.stage_recv0[st]), int(hx.stage_recv0[st + 1])
+            ok_y = ok_y and (len(is_) == 0 or (is_.min() >= lo and is_.max() < hi)) and int(m_.sum()) == len(is_)
+            y_st = y_st + orc.gcn_seq(ps_, is_, vl[m_], x_ext[hx.n_local:].numpy())
+            n_rem += len(is_)
+        ok_y = ok_y and n_rem == len(ir) and len(parts) == hx.n_stages and int(hx.stage_recv0[-1]) == hx.n_halo
+        ok_y = ok_y and bool(np.all(np.abs(y_st - y_global[r0:r1]) <= 1e-5 * scale + 1e-30))
+        if hx.n_stages == 1:
+            ok_y = ok_y and np.array_equal(y_st, y_split)
+        # what this rank sends in a stage is what its peers expect to receive in it
+        mine = torch.from_numpy(np.ascontiguousarray(hx.stage_send.T)).contiguous()     # [peer][stage]
+        theirs = torch.empty_like(mine)
+        dist.all_to_all_single(theirs, mine)
+        ok_y = ok_y and np.array_equal(theirs.numpy().T, hx.stage_recv)
         # the same plan built from THIS rank's rows only (row slice + partition bounds): nothing of the global CSR needed
-        hs = HaloExchange(ptr[r0:r1 + 1], idx[ptr[r0]:ptr[r1]], device="cpu", row_slice=True, bounds=hx.bounds, num_cols=V,
+        hs = HaloExchange(ptr[r0:r1 + 1], idx[ptr[r0]:ptr[r1]], device="cpu", row_slice=True, bounds=hx.bounds, num_cols=V, stages=stages,
                           pack_fn=lambda xs, ids, out: out[:ids.numel()].copy_(xs.index_select(0, ids.long())))
         ok_slice = (np.array_equal(hs.local_ptr, hx.local_ptr) and np.array_equal(hs.local_idx, hx.local_idx) and
                     np.array_equal(hs.halo_ids, hx.halo_ids) and np.array_equal(hs.recv_counts, hx.recv_counts) and
@@ -73,7 +92,7 @@ def _worker(rank, world, port, F, q):
         ok_y = ok_y and ok_slice
         # GAT: ONE exchange carries [x | att] rows (PartitionedGAT.exchange / finish_exchange; pack / unpack test doubles)
         from gnn_computing_amd.dist import PartitionedGAT
-        H = 4
+        H = 4 if stages == 1 else 2    # (staged: the overlap plan needs (F / H) % 4 == 0)
         att = rng.standard_normal((V, 2 * H), dtype=np.float32)
 
         def pack2(xs, at, ids, out):
@@ -82,7 +101,8 @@ def _worker(rank, world, port, F, q):
         def unpack2(buf, n, x_out, att_out):
             x_out.copy_(buf[:n, :x_out.shape[1]])
             att_out.copy_(buf[:n, x_out.shape[1]:])
-        pgat = PartitionedGAT(ptr, idx, F, H, device="cpu", pack_fn2=pack2, unpack_fn2=unpack2, build_aggregators=False)
+        pgat = PartitionedGAT(ptr, idx, F, H, device="cpu", pack_fn2=pack2, unpack_fn2=unpack2, build_aggregators=False, stages=stages)
+        ok_y = ok_y and pgat.hx.n_stages == hx.n_stages and np.array_equal(pgat.hx.halo_ids, hx.halo_ids)
         pgat.set_local(torch.from_numpy(x[r0:r1]), torch.from_numpy(att[r0:r1]))
         pgat.x_ext[hx.n_local:] = float("nan")
         pgat.att_ext[hx.n_local:] = float("nan")
@@ -118,6 +138,28 @@ def test_halo_exchange_gloo(world, F):
         assert ok_e and ok_v
         assert n_halo > 0 and n_send > 0
     assert sum(r[5] for r in res) == sum(r[6] for r in res)  # every requested row is served exactly once
+
+
+@pytest.mark.parametrize("world,stages", [(2, ("stripe", 3)), (3, "owner"), (4, ("stripe", 2)), (4, "owner"), (3, ("stripe", 5))])
+def test_staged_halo_exchange_gloo(world, stages):
+    """The staged exchange (one all-to-all-v and one halo-source pass per stage; dist.py): stripes of every peer's rows, or one
+    ring distance per stage.  Same checks as above plus the stage plan's own: stage-major halo tail, per-stage edge sets, the
+    fixed summation order local + stage 0 + stage 1 + ..., both ends of every pair cutting their list the same way."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 8, q, stages)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_halo, ok_y, ok_e, ok_v, n_halo, n_send in res:
+        assert ok_halo, "rank %d: halo rows differ" % rank
+        assert ok_y, "rank %d: staged plan inconsistent" % rank
+        assert ok_e and ok_v and n_halo > 0 and n_send > 0
+    assert sum(r[5] for r in res) == sum(r[6] for r in res)
 
 
 def test_pack_has_no_cpu_fallback():

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, overlap, q):
+def _worker(rank, world, port, overlap, q, stages=1):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +39,7 @@ def _worker(rank, world, port, overlap, q):
         ptr, idx = ptr_t.numpy(), idx_t.numpy()
         rng = np.random.default_rng(3)
         x, val = rng.standard_normal((V, F), dtype=np.float32), rng.standard_normal(E, dtype=np.float32)
-        pg = PartitionedGCN(ptr, idx, val, F, device="cuda:0", overlap=overlap)
+        pg = PartitionedGCN(ptr, idx, val, F, device="cuda:0", overlap=overlap, stages=stages)
         r0, r1 = int(pg.hx.bounds[rank]), int(pg.hx.bounds[rank + 1])
         pg.set_local_x(torch.from_numpy(x[r0:r1]).cuda())
         ok = True
@@ -60,7 +60,7 @@ def _worker(rank, world, port, overlap, q):
         H, FG = 8, 256
         xg = rng.standard_normal((V, FG), dtype=np.float32)
         att = (rng.standard_normal((V, H, 2), dtype=np.float32) * 0.4).astype(np.float32)
-        gat = PartitionedGAT(ptr, idx, FG, H, device="cuda:0", overlap=overlap)
+        gat = PartitionedGAT(ptr, idx, FG, H, device="cuda:0", overlap=overlap, stages=stages)
         gat.set_local(torch.from_numpy(xg[r0:r1]).cuda(), torch.from_numpy(att[r0:r1]).cuda())
         y_ref = orc.gat_fused(ptr, idx, att, xg, H)[r0:r1]
         wn = orc.gat_att(ptr, idx, att, H, 0.2)                       # normalised weights [E, H]
@@ -77,12 +77,14 @@ def _worker(rank, world, port, overlap, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_ranks_one_gpu(overlap):
+@pytest.mark.parametrize("overlap,stages", [(True, 1), (False, 1), (True, ("stripe", 3))])
+def test_two_ranks_one_gpu(overlap, stages):
+    """stages = ("stripe", 3): the staged exchange end to end -- three all-to-all-v's per step, the halo-source pass of a stage
+    behind its own work handle while the next stage is in flight (GCN sum / mean / max and the GAT numerator / denominator form)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q, stages)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(2)]
@@ -228,3 +230,107 @@ def test_single_call_step_at_world_one_costs_what_a_launch_costs():
     one.run(gat.x_ext, gat.att_ext, y2, 128, "balanced", heads=H)
     yg = gat.step()
     assert torch.allclose(yg, y2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("S", [1, 3])
+def test_staged_step_behind_the_cabi_on_one_gpu(S):
+    """gnnagg_dist_step_create_staged + gnnagg_dist_step_gcn / _gat with S stages, driven on ONE GPU: a world-1 communicator whose
+    "halo" rows are addressed to the rank itself (the self part of an all-to-all-v is a stream-ordered device copy), so the pack
+    kernel, every stage's exchange and event, the per-stage accumulate passes and the final join all run for real.  The result must
+    equal the same passes issued by hand (bit for bit), eagerly and from a captured HIP graph."""
+    import ctypes
+    import sys
+    sys.path.insert(0, ROOT)
+    import gnn_computing_amd as gnc
+    from gnn_computing_amd import _lib
+    L = gnc.lib()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    V, E, F, NH = 3000, 60000, 128, 600
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=21)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((V, F), dtype=np.float32)).to(dev)
+    send_ids = torch.from_numpy(rng.integers(0, V, NH).astype(np.int32)).to(dev)          # stage-major: stage s = rows [cut[s], cut[s + 1])
+    cut = [NH * s // S for s in range(S + 1)]
+    buf = ctypes.create_string_buffer(128)
+    _lib.check(L.gnnagg_dist_unique_id(buf))
+    comm = ctypes.c_int64(0)
+    _lib.check(L.gnnagg_dist_comm_create(buf, 0, 1, ctypes.byref(comm)))
+    loc = gnc.Aggregator_GCN(ptr_t.to(dev), idx_t.to(dev), None, F, F)
+    loc.schedule_balanced(0)
+    rem = []
+    for s in range(S):   # halo-source edges of stage s: every third row gets a few, all naming slots of that stage
+        deg = np.where(np.arange(V) % 3 == s % 3, rng.integers(1, 9, V), 0)
+        p = np.zeros(V + 1, np.int32)
+        p[1:] = np.cumsum(deg)
+        i = rng.integers(cut[s], cut[s + 1], int(p[-1])).astype(np.int32)
+        a = gnc.Aggregator_GCN(torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev), None, F, F)
+        a.schedule_balanced(0)
+        rem.append(a)
+    rows = (ctypes.c_longlong * S)(*[cut[s + 1] - cut[s] for s in range(S)])
+    hs = (ctypes.c_int64 * S)(*[a._h.value for a in rem])
+    step = ctypes.c_int64(0)
+    _lib.check(L.gnnagg_dist_step_create_staged(comm, loc._h, S, hs, send_ids.data_ptr(), rows, rows, ctypes.byref(step)))
+    ns, w = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(L.gnnagg_dist_step_info(step, ctypes.byref(ns), ctypes.byref(w)))
+    assert (ns.value, w.value) == (S, 1)
+    x_halo = torch.full((NH, F), float("nan"), device=dev)
+    send_buf = torch.empty((NH, F), device=dev)
+    y = torch.empty((V, F), device=dev)
+
+    def run_step():
+        _lib.check(L.gnnagg_dist_step_gcn(step, x.data_ptr(), x_halo.data_ptr(), send_buf.data_ptr(), y.data_ptr(), F, 0,
+                                          torch.cuda.current_stream().cuda_stream))
+    run_step()
+    torch.cuda.synchronize()
+    assert torch.equal(x_halo, x[send_ids.long()])
+    ref = torch.empty((V, F), device=dev)
+    loc.run(x, ref, 512, "balanced")
+    for a in rem:
+        a.run(x_halo, ref, 512, "balanced", accumulate=True)
+    assert torch.equal(y, ref)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        run_step()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            run_step()
+    for _ in range(3):
+        y.zero_()
+        x_halo.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+    # GAT: [x | att] rows, unpacked stage by stage; the last stage's pass divides
+    H, aw = 4, 8
+    n_ext = V + NH
+    x_ext = torch.full((n_ext, F), float("nan"), device=dev)
+    x_ext[:V] = x
+    att_ext = torch.full((n_ext, aw), float("nan"), device=dev)
+    att_ext[:V] = torch.from_numpy((rng.standard_normal((V, aw)) * 0.4).astype(np.float32)).to(dev)
+    gl = gnc.Aggregator_GAT(ptr_t.to(dev), idx_t.to(dev), F, F)
+    gr = []
+    for s in range(S):
+        deg = np.where(np.arange(V) % 3 == s % 3, rng.integers(1, 9, V), 0)
+        p = np.zeros(V + 1, np.int32)
+        p[1:] = np.cumsum(deg)
+        i = (rng.integers(cut[s], cut[s + 1], int(p[-1])) + V).astype(np.int32)      # X_ext slots
+        gr.append(gnc.Aggregator_GAT(torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev), F, F))
+    hg = (ctypes.c_int64 * S)(*[a._h.value for a in gr])
+    gstep = ctypes.c_int64(0)
+    _lib.check(L.gnnagg_dist_step_create_staged(comm, gl._h, S, hg, send_ids.data_ptr(), rows, rows, ctypes.byref(gstep)))
+    sb, rb = torch.empty((NH, F + aw), device=dev), torch.empty((NH, F + aw), device=dev)
+    den, yg = torch.empty((V, H), device=dev), torch.empty((V, F), device=dev)
+    _lib.check(L.gnnagg_dist_step_gat(gstep, x_ext.data_ptr(), att_ext.data_ptr(), V, sb.data_ptr(), rb.data_ptr(), den.data_ptr(), yg.data_ptr(),
+                                      F, H, ctypes.c_float(0.2), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(x_ext[V:], x[send_ids.long()]) and torch.equal(att_ext[V:], att_ext[:V][send_ids.long()])
+    ref_g, den2 = torch.empty((V, F), device=dev), torch.empty((V, H), device=dev)
+    gl.run_part(x_ext, att_ext, ref_g, den2, 1, H, 0.2)
+    for s, a in enumerate(gr):
+        a.run_part(x_ext, att_ext, ref_g, den2, 2 if s == S - 1 else 3, H, 0.2)
+    assert torch.equal(yg, ref_g) and bool(torch.isfinite(yg).all())
+    _lib.check(L.gnnagg_dist_step_destroy(step))
+    _lib.check(L.gnnagg_dist_step_destroy(gstep))
+    _lib.check(L.gnnagg_dist_comm_destroy(comm))

@@ -713,10 +713,11 @@ def test_run_with_nn_mean_empty_rows():
 
 
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("overlap", [False, True])
-def test_partitioned_gcn_single_gpu_emulation(world, overlap):
+@pytest.mark.parametrize("overlap,stages", [(False, 1), (True, 1), (True, ("stripe", 3)), (True, "owner")])
+def test_partitioned_gcn_single_gpu_emulation(world, overlap, stages):
     """The row-partitioned plan of every rank, run one rank at a time on this GPU with the halo filled by hand
-    (offline plan: the collective itself is covered by tests/test_dist_gloo.py)."""
+    (offline plan: the collective itself is covered by tests/test_dist_gloo.py).  stages: the staged exchange's plan -- the
+    halo-source edges split by the stage their source arrives in, one accumulate pass per stage in stage order."""
     from gnn_computing_amd.dist import PartitionedGCN
     V, E, F = 4000, 90000, 128
     ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=11)
@@ -726,8 +727,9 @@ def test_partitioned_gcn_single_gpu_emulation(world, overlap):
     scale = orc.gcn_abs_scale(ptr, idx, val, x)
     seen = 0
     for r in range(world):
-        pg = PartitionedGCN(ptr, idx, val, F, device=DEV, rank=r, world=world, overlap=overlap, offline=True)
+        pg = PartitionedGCN(ptr, idx, val, F, device=DEV, rank=r, world=world, overlap=overlap, offline=True, stages=stages)
         hx = pg.hx
+        assert hx.n_stages == (1 if stages == 1 else 3 if stages != "owner" else world - 1)
         r0, r1 = int(hx.bounds[r]), int(hx.bounds[r + 1])
         pg.set_local_x(dev(x[r0:r1]))
         pg.x_halo.copy_(dev(x[hx.halo_ids]))
@@ -739,16 +741,22 @@ def test_partitioned_gcn_single_gpu_emulation(world, overlap):
             pl, il, pr, ir, is_loc = hx.split_local_remote()
             vl = val[hx.e0:hx.e1]
             cl, sl = pg.agg_loc.balanced_params()
-            cr, sr = pg.agg_rem.balanced_params()
             a = orc.gcn_grouped(*orc.neighbor_grouping(pl, cl), il, vl[is_loc], x[r0:r1], r1 - r0, seg=sl)
-            b = orc.gcn_grouped(*orc.neighbor_grouping(pr, cr), ir, vl[~is_loc], x[hx.halo_ids], r1 - r0, seg=sr)
-            has_rem = (np.diff(pr) > 0)[:, None]
-            assert np.array_equal(y, np.where(has_rem, a + b, a))
-            # mean and max on the overlap plan: the total degree divides both passes; the halo pass joins a maximum
-            # only where the local pass folded an edge (gnnagg_set_row_aux)
             deg = np.maximum(np.diff(hx.local_ptr), 1)[:, None].astype(np.float32)
+            acc, acc_mean = a, a / deg
+            for ag, (ps_, is_, m_) in zip(pg.agg_rem_stages, hx.split_remote_stages()):     # += stage 0, += stage 1, ... in order
+                assert (ag is None) == (len(is_) == 0)
+                if ag is None:
+                    continue
+                cr, sr = ag.balanced_params()
+                b = orc.gcn_grouped(*orc.neighbor_grouping(ps_, cr), is_, vl[m_], x[hx.halo_ids], r1 - r0, seg=sr)
+                has = (np.diff(ps_) > 0)[:, None]
+                acc, acc_mean = np.where(has, acc + b, acc), np.where(has, acc_mean + b / deg, acc_mean)
+            assert np.array_equal(y, acc)
+            # mean and max on the overlap plan: the total degree divides every pass; a halo pass joins a maximum
+            # only where the passes before it folded an edge (gnnagg_set_row_aux)
             ym = pg.step(reduce="mean").cpu().numpy()
-            assert np.array_equal(ym, np.where(has_rem, a / deg + b / deg, a / deg))
+            assert np.array_equal(ym, acc_mean)
             assert_within(ym, y_ref[r0:r1] / deg, scale[r0:r1] / deg, "mean, rank %d/%d" % (r, world))
             yx = pg.step(reduce="max").cpu().numpy()
             assert np.array_equal(yx, orc.gcn_max(ptr, idx, val, x)[r0:r1])
@@ -764,8 +772,8 @@ def test_partitioned_gcn_single_gpu_emulation(world, overlap):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("F,H", [(64, 1), (256, 8)])
-@pytest.mark.parametrize("overlap", [False, True])
-def test_partitioned_gat_single_gpu_emulation(world, F, H, overlap):
+@pytest.mark.parametrize("overlap,stages", [(False, 1), (True, 1), (True, ("stripe", 3)), (True, "owner")])
+def test_partitioned_gat_single_gpu_emulation(world, F, H, overlap, stages):
     """PartitionedGAT (att rows travel with the feature rows): every rank's plan run on this GPU with the halo filled by
     hand, against the single-GPU fused result and against the rank-local order restated exactly.  overlap: numerators and
     denominators of the local-source edges first, the halo-source pass adds its own and divides (gnnagg_gat_run_part)."""
@@ -778,8 +786,8 @@ def test_partitioned_gat_single_gpu_emulation(world, F, H, overlap):
     scale = gat_scale(ptr, idx, att, x, H) + np.abs(y_ref)
     seen = 0
     for r in range(world):
-        pg = PartitionedGAT(ptr, idx, F, H, device=DEV, rank=r, world=world, offline=True, overlap=overlap)
-        assert pg.overlap == overlap
+        pg = PartitionedGAT(ptr, idx, F, H, device=DEV, rank=r, world=world, offline=True, overlap=overlap, stages=stages)
+        assert pg.overlap == overlap and pg.hx.n_stages == (1 if stages == 1 else 3 if stages != "owner" else world - 1)
         hx = pg.hx
         r0, r1 = int(hx.bounds[r]), int(hx.bounds[r + 1])
         n = r1 - r0
@@ -794,11 +802,16 @@ def test_partitioned_gat_single_gpu_emulation(world, F, H, overlap):
             # restated: (numerator, denominator) of the local-source edges + those of the halo-source edges, one division
             pl, il, pr, ir, _ = hx.split_local_remote()
             cl, sl = pg.agg_loc.balanced_params()
-            cr, sr = pg.agg_rem.balanced_params()
-            _, _, (na, da) = orc.gat_grouped(*orc.neighbor_grouping(pl, cl), il, att_ext, x_ext, n, H, seg=sl, parts=True)
-            _, _, (nb, db) = orc.gat_grouped(*orc.neighbor_grouping(pr, cr), (ir + n).astype(np.int32), att_ext, x_ext, n, H, seg=sr, parts=True)
-            den = np.repeat(da + db, F // H, axis=1)
-            ref = np.where(den != 0, (na + nb) / np.where(den != 0, den, 1), 0).astype(np.float32)
+            _, _, (num, dn) = orc.gat_grouped(*orc.neighbor_grouping(pl, cl), il, att_ext, x_ext, n, H, seg=sl, parts=True)
+            for ag, (ps_, is_, _) in zip(pg.agg_rem_stages, hx.split_remote_stages()):   # every stage's pass adds its own, the last divides
+                if ag is None:
+                    continue
+                cr, sr = ag.balanced_params()
+                _, _, (nb, db) = orc.gat_grouped(*orc.neighbor_grouping(ps_, cr), (is_ + n).astype(np.int32), att_ext, x_ext, n, H, seg=sr, parts=True)
+                num, dn = num + nb, dn + db
+            assert pg.agg_rem_stages[-1] is not None
+            den = np.repeat(dn, F // H, axis=1)
+            ref = np.where(den != 0, num / np.where(den != 0, den, 1), 0).astype(np.float32)
         else:
             ch, sg = pg.agg.balanced_params()
             assert pg.agg.balanced_partitions() == 0
