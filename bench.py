@@ -5,6 +5,12 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks itself (fresh child processes through
+torch.distributed.run, before anything touches the GPU) and relays their one line.  Under a launcher every rank process is a thin
+supervisor that never touches the GPU either: it runs the real rank in a fresh child on the C-ABI RCCL step and, if that child fails
+(oracle check of its first step, a watchdog on a hung exchange, a crash), runs it again in another fresh child on
+torch.distributed's all_to_all_single -- the stated fallback; the line says which transport produced the number.
+
 A step = one pass of the hot path (one aggregation Y = A.X) over the whole synthetic input, inputs
 resident in HBM.  N = 1: BASELINE.json configs[1], arxiv-shaped CSR (169 343 x 1 166 243, seed 123),
 GCN sum with explicit unit weights (Figure7/our.py:78), fp32, loaded with the locality reorder
@@ -19,8 +25,7 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+np = torch = None   # imported in main(), after the decision to launch / supervise ranks (those paths stay off the GPU stack)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -370,18 +375,45 @@ def run_other_config(args, dev):
                                  "the dominant kernel's fabric-side bytes per launch, `traffic_step` all kernels of a step"}}
 
 
-def run_multi(args, dev, rank, world):
+class Watchdog:
+    """N > 1 only: a hung exchange (an RCCL kernel waiting for a peer that never posts) cannot be cancelled from inside the process.
+    arm(seconds, what) starts a deadline; when it passes the process exits with code 18 and the supervising parent starts the
+    fallback transport in fresh processes.  disarm() when the guarded phase is over."""
+
+    def __init__(self):
+        import threading
+        self.deadline, self.what = None, ""
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            d = self.deadline
+            if d is not None and time.monotonic() > d:
+                log("bench.py watchdog: '%s' did not finish in time; exiting 18 (the supervisor falls back to the other transport)" % self.what)
+                os._exit(18)
+
+    def arm(self, seconds, what):
+        self.what, self.deadline = what, time.monotonic() + seconds
+
+    def disarm(self):
+        self.deadline = None
+
+
+def partitioned_run(args, dev, rank, world, strong, steps, warmup, transport, dog):
+    """One row-partitioned configuration over the `world` ranks: weak (N x arxiv-shaped, feat 128) or strong (ONE products-shaped
+    graph, feat 100).  Returns the measurements on rank 0 (None elsewhere)."""
     import torch.distributed as dist
     import gnn_computing_amd as gnc
     from gnn_computing_amd.dist import PartitionedGCN
-    strong = args.config == "P"  # BASELINE configs[4]: ONE products-shaped graph row-partitioned over the N GPUs
     feat = 100 if strong else FEAT
     V1, E1 = gnc.graph.SHAPES["products" if strong else "arxiv"]
     Vg, Eg = (V1, E1) if strong else (V1 * world, E1 * world)
     # rank 0 generates the global graph on its GPU (seeded, community order = "locality reorder applied on load"); every
     # rank receives the row offsets (to cut the same nnz-balanced partition) and ONLY ITS OWN rows' neighbor ids
     if rank == 0:
-        ptr_t, idx_t = gnc.graph.powerlaw_csr(Vg, Eg, seed=123, device=dev, community_order=True)
+        ptr_t, idx_t = gnc.graph.powerlaw_csr(Vg, Eg, seed=123, device=dev, community_order=True, p_local=1.0 - args.global_share)
     else:
         ptr_t = torch.empty(Vg + 1, dtype=torch.int32, device=dev)
     dist.broadcast(ptr_t, src=0)
@@ -402,19 +434,33 @@ def run_multi(args, dev, rank, world):
         del buf
     del ptr_t
     val_slice = np.ones(e1 - e0, np.float32)
-    transport = os.environ.get("BENCH_TRANSPORT", "torch")   # "rccl": the C-ABI's grouped ncclSend / ncclRecv
+    stages = os.environ.get("BENCH_STAGES", "auto")
+    stages = int(stages) if stages.lstrip("-").isdigit() else stages
+    t_plan = time.perf_counter()
+    dog.arm(240, "communicator + plan exchange (%s transport)" % transport)
     pg = PartitionedGCN(ptr[r0:r1 + 1], idx_slice, val_slice, feat, device=dev, mode=os.environ.get("BENCH_MODE", "balanced"),
-                        row_slice=True, bounds=bounds, num_cols=Vg, transport=transport)
+                        row_slice=True, bounds=bounds, num_cols=Vg, transport=transport, stages=stages)
+    t_plan = time.perf_counter() - t_plan
     hx = pg.hx
+    rccl_ranks = None
+    if hx.rccl is not None:   # what the C-ABI's communicator itself says (gnnagg_dist_comm_info)
+        import ctypes
+        rr, ww = ctypes.c_int(-1), ctypes.c_int(-1)
+        gnc._lib.check(gnc.lib().gnnagg_dist_comm_info(hx.rccl._h, ctypes.byref(rr), ctypes.byref(ww)))
+        assert rr.value == rank
+        rccl_ranks = ww.value
     # correctness outside the timed region: features that are a closed form of the GLOBAL row id, so every rank can check
     # the halo rows it pulled and (on its first rows) the aggregation against the oracle without any further exchange
+
     def closed_form(ids):
         r = torch.as_tensor(ids, dtype=torch.int64, device=dev)[:, None]
         c = torch.arange(feat, dtype=torch.int64, device=dev)[None, :]
         return (((r * 131 + c * 71) % 1013).to(torch.float32) / 1013.0 - 0.5)
     pg.set_local_x(closed_form(np.arange(r0, r1)))
+    dog.arm(120, "first step over the %s transport" % transport)
     y_chk = pg.step().clone()
     torch.cuda.synchronize()
+    dog.disarm()
     ok = bool(torch.equal(pg.x_halo, closed_form(hx.halo_ids))) if hx.n_halo else True
     from oracle import oracle as orc
     nchk = min(hx.n_local, 2000)
@@ -425,42 +471,87 @@ def run_multi(args, dev, rank, world):
     ok = ok and bool(np.all(np.abs(y_chk[:nchk].cpu().numpy() - ref) <= 1e-5 * scale + 1e-30))
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    assert int(flag.item()) == 1, "row-partitioned step differs from the oracle / halo rows differ from their owners' rows"
+    if int(flag.item()) != 1:
+        log("rank %d: row-partitioned step over the %s transport differs from the oracle / halo rows differ from their owners' rows (this rank ok: %s)"
+            % (rank, transport, ok))
+        dist.barrier()
+        os._exit(17)   # every rank takes this exit together; the supervisor starts the fallback transport in fresh processes
     g = torch.Generator(device=dev)
     g.manual_seed(123 + rank)
     pg.set_local_x(torch.randn((hx.n_local, feat), generator=g, device=dev))
-    wall, dev_s, med_s = time_steps(pg.step, args.steps, args.warmup, dist.barrier)
+    dog.arm(120 + 0.5 * (steps + warmup) * 3, "timed steps over the %s transport" % transport)
+    wall, dev_s, med_s = time_steps(pg.step, steps, warmup, dist.barrier)
+    dog.disarm()
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    halo = torch.tensor([hx.halo_bytes(feat), pg.num_e_local], dtype=torch.float64, device=dev)
+    halo = torch.tensor([hx.halo_bytes(feat), pg.num_e_local, pg.num_e_remote if pg.overlap else 0], dtype=torch.float64, device=dev)
+    halo_max = halo.clone()
     dist.all_reduce(halo, op=dist.ReduceOp.SUM)
+    dist.all_reduce(halo_max, op=dist.ReduceOp.MAX)
     wall = float(t.item())
     # Context, reported beside the line and never as `value`: the same kernels with the halo rows already resident (static
     # input features, i.e. the exchange hoisted out of the step) -- what the step costs when the xGMI exchange is free.
-    wall_nx, _, _ = time_steps(lambda: pg.compute("sum", None), args.steps, args.warmup, dist.barrier)
+    wall_nx, _, _ = time_steps(lambda: pg.compute("sum", None), steps, warmup, dist.barrier)
     t_nx = torch.tensor([wall_nx], dtype=torch.float64, device=dev)
     dist.all_reduce(t_nx, op=dist.ReduceOp.MAX)
     wall_nx = float(t_nx.item())
+    tp = torch.tensor([t_plan], dtype=torch.float64, device=dev)
+    dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+    n_stages, stage_mode = hx.n_stages, "%s x %d" % (hx.stage_mode, hx.n_stages)
+    pg.close()
+    if hx.rccl is not None:
+        hx.rccl.close()
+    del pg
+    torch.cuda.empty_cache()
     if rank != 0:
         return None
+    return {"Vg": Vg, "Eg": Eg, "feat": feat, "step_s": wall / steps, "step_nx_s": wall_nx / steps, "steps": steps, "warmup": warmup,
+            "halo_bytes_all": float(halo[0].item()), "halo_bytes_max_rank": float(halo_max[0].item()),
+            "remote_edge_share": float(halo[2].item()) / max(float(halo[1].item()), 1.0),
+            "rccl_ranks": rccl_ranks, "plan_s": float(tp.item()), "n_stages": n_stages, "stage_mode": stage_mode}
+
+
+TRANSPORT_NAMES = {"rccl": "C-ABI step (gnnagg_dist_step_gcn: pack kernel + grouped ncclSend/ncclRecv per stage on the step's own stream)",
+                   "torch": "torch.distributed all_to_all_single per stage + the aggregation launches from Python"}
+
+
+def run_multi(args, dev, rank, world):
+    import torch.distributed as dist
+    backend = dist.get_backend()
+    transport = os.environ.get("BENCH_TRANSPORT") or ("rccl" if backend == "nccl" else "torch")
+    dog = Watchdog()
+    strong = args.config == "P"  # BASELINE configs[4]: ONE products-shaped graph row-partitioned over the N GPUs
+    m = partitioned_run(args, dev, rank, world, strong, args.steps, args.warmup, transport, dog)
+    # one driver pass yields both: the N > 1 headline line (weak scaling, feat 128) carries BASELINE configs[4] -- the products-shaped
+    # graph strong-scaled over the same ranks -- as a sub-record (fewer steps: a step is milliseconds there)
+    ps = None
+    if not strong and os.environ.get("BENCH_PRODUCTS", "1") != "0":
+        ps = partitioned_run(args, dev, rank, world, True, max(2, min(args.steps, 10)), min(args.warmup, 2), transport, dog)
+    if rank != 0:
+        return None
+    feat, Vg, Eg, step_s = m["feat"], m["Vg"], m["Eg"], m["step_s"]
     B = algorithmic_bytes(Vg, Eg, feat)
-    step_s = wall / args.steps
-    return {
+    out = {
         "metric": "aggregated edges/sec, GCN SpMM feat=%d" % feat, "value": Eg / step_s, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%s power-law CSR (%dx%d, seed 123, community order), GCN sum, feat=%d, 1-D row "
-                               "partition + RCCL halo pull per step (%s; overlapped with the local-source edges)" % (
-                                   "products-shaped" if strong else "%d x arxiv-shaped" % world, Vg, Eg, feat,
-                                   "all_to_all_single" if transport == "torch" else "grouped ncclSend/ncclRecv behind the C-ABI"),
-                   "num_v": Vg, "num_e": Eg, "feat": feat, "halo_bytes_per_step_all_ranks": float(halo[0].item()),
-                   "verified_against_oracle": True},
+        "config": {"workload": "%s power-law CSR (%dx%d, seed 123, community order, %d %% of a row's sources are global-popularity picks: "
+                               "--global-share), GCN sum, feat=%d, 1-D row partition + halo pull per step over xGMI (%s; %s; local-source "
+                               "edges overlap the exchange, stage s's halo-source edges overlap stage s + 1)" % (
+                                   "products-shaped" if strong else "%d x arxiv-shaped" % world, Vg, Eg, round(args.global_share * 100), feat,
+                                   TRANSPORT_NAMES[transport], "stages: " + m["stage_mode"]),
+                   "num_v": Vg, "num_e": Eg, "feat": feat, "halo_bytes_per_step_all_ranks": m["halo_bytes_all"],
+                   "global_share": args.global_share, "verified_against_oracle": True},
+        "transport": transport, "transport_is": TRANSPORT_NAMES[transport], "backend": backend, "rccl_ranks": m["rccl_ranks"],
+        "transport_fallback": os.environ.get("BENCH_FALLBACK_REASON"),
+        "halo_stages": m["n_stages"], "plan_s": m["plan_s"],
         "achieved_gbps": B / step_s / 1e9,
         # halo bytes (config.halo_bytes_per_step_all_ranks) and the exposed communication time = what the step costs
         # beyond the same kernels with the halo rows already resident
-        "exposed_comm_ms_per_step": max(0.0, (wall - wall_nx) / args.steps * 1e3),
-        "no_exchange_upper_bound": {"value": Eg / (wall_nx / args.steps), "ms_per_step": wall_nx / args.steps * 1e3,
+        "exposed_comm_ms_per_step": max(0.0, (m["step_s"] - m["step_nx_s"]) * 1e3),
+        "remote_edge_share": m["remote_edge_share"],
+        "no_exchange_upper_bound": {"value": Eg / m["step_nx_s"], "ms_per_step": m["step_nx_s"] * 1e3,
                                     "note": "the same aggregation kernels with the halo rows already resident (static features: the "
                                             "exchange hoisted out of the step); NOT the reported value -- it bounds what overlap can hide"},
         # per-GPU share of the step, halo exchange included: the bound is whichever of the xGMI links and the memory system
@@ -472,8 +563,77 @@ def run_multi(args, dev, rank, world):
                                 "count, so this is not an HBM utilisation",
                      "kernel": "per-GPU share of the step (halo exchange over xGMI included; gather-model bytes, cache-served "
                                "gathers count: see the N = 1 line for the measured ceiling)", "algorithmic_bytes": B,
-                     "halo_bytes_per_rank": float(halo[0].item()) / world},
+                     "halo_bytes_per_rank": m["halo_bytes_all"] / world, "halo_bytes_max_rank": m["halo_bytes_max_rank"]},
     }
+    if ps is not None:
+        out["products_strong"] = {
+            "what": "BASELINE configs[4]: ONE products-shaped CSR (%dx%d, feat=100, GCN sum) row-partitioned over the same %d ranks, same "
+                    "transport; strong scaling: divide by the 1-GPU P1 line (bench.py --config P1)" % (ps["Vg"], ps["Eg"], world),
+            "value": ps["Eg"] / ps["step_s"], "unit": "edges/s", "ms_per_step": ps["step_s"] * 1e3, "steps": ps["steps"], "warmup": ps["warmup"],
+            "scaling": "strong", "halo_bytes_per_step_all_ranks": ps["halo_bytes_all"], "halo_bytes_max_rank": ps["halo_bytes_max_rank"],
+            "exposed_comm_ms_per_step": max(0.0, (ps["step_s"] - ps["step_nx_s"]) * 1e3),
+            "no_exchange_ms_per_step": ps["step_nx_s"] * 1e3, "remote_edge_share": ps["remote_edge_share"], "halo_stages": ps["n_stages"],
+            "plan_s": ps["plan_s"], "rccl_ranks": ps["rccl_ranks"], "verified_against_oracle": True}
+    return out
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relay_json(stdout_bytes, json_fd):
+    """writes the child's JSON line(s) to the real stdout; returns how many there were"""
+    n = 0
+    for line in stdout_bytes.decode(errors="replace").splitlines():
+        if line.strip().startswith("{"):
+            os.write(json_fd, (line.strip() + "\n").encode())
+            n += 1
+    return n
+
+
+def launch_ranks(args, json_fd):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes through torch.distributed.run.  This process has not
+    imported torch, let alone touched a GPU."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: no launcher environment, starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE)
+    n = relay_json(r.stdout, json_fd)
+    return r.returncode if r.returncode != 0 else (0 if n == 1 else 1)
+
+
+def supervise_rank(args, json_fd):
+    """A rank process under a launcher (WORLD_SIZE > 1): runs the real rank in a FRESH child -- first on the C-ABI RCCL step, and
+    if that child exits non-zero (oracle mismatch: 17, watchdog: 18, a crash) once more in another fresh child on
+    torch.distributed's all_to_all_single.  Never touches the GPU itself; nothing is restarted in place."""
+    import subprocess
+    rank = int(os.environ.get("RANK", "0"))
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    first = os.environ.get("BENCH_TRANSPORT") or ("rccl" if backend == "nccl" else "torch")
+    attempts = [first] + (["torch"] if first == "rccl" and os.environ.get("BENCH_NO_FALLBACK") != "1" else [])
+    rc = 1
+    for i, tr in enumerate(attempts):
+        env = dict(os.environ, BENCH_CHILD="1", BENCH_TRANSPORT=tr)
+        if i > 0:
+            # a fresh rendezvous for the fresh processes: rank 0's child hosts the store itself on the next port
+            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + 1)
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+            env["BENCH_FALLBACK_REASON"] = "the %s transport's ranks exited with code %d (17: first step failed the oracle check, 18: watchdog on a hung exchange); " \
+                                           "this line was measured on the fallback transport in fresh processes" % (attempts[0], rc)
+            log("bench.py rank %d: %s" % (rank, env["BENCH_FALLBACK_REASON"]))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)
+        rc = r.returncode
+        if rc == 0:
+            if rank == 0:
+                return 0 if relay_json(r.stdout, json_fd) == 1 else 1
+            return 0
+    return rc
 
 
 def main():
@@ -484,15 +644,36 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     ap.add_argument("--config", default="A", choices=["A", "R", "G", "P1", "P"],
-                    help="A (default): arxiv-shaped GCN sum feat=128, the headline line (weak scaling for N > 1); "
-                         "R/G/P1: the other 1-GPU configs; P (N > 1): products-shaped GCN feat=100, strong scaling")
+                    help="A (default): arxiv-shaped GCN sum feat=128, the headline line (weak scaling for N > 1, with the products-shaped "
+                         "strong-scaling sub-record); R/G/P1: the other 1-GPU configs; P (N > 1): products-shaped GCN feat=100, strong scaling")
+    ap.add_argument("--global-share", type=float, default=0.5,
+                    help="N > 1: share of a row's sources the generator draws from the global popularity distribution (the rest come from a "
+                         "window around the row: what a row partition can keep local).  Default 0.5 = the generator every other line uses")
     args = ap.parse_args()
+    if not 0.0 <= args.global_share <= 1.0:
+        raise SystemExit("--global-share must be in [0, 1]")
 
     # stdout carries exactly ONE JSON line.  RCCL prints a version banner through C stdio that is flushed at
     # process exit, so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved descriptor.
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    # N > 1: the processes that touch GPUs are always FRESH children (see the module docstring); none of the two functions below
+    # imports torch or loads the HIP library
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        rc = launch_ranks(args, json_fd)
+        os.close(json_fd)
+        sys.exit(rc)
+    if launched and int(os.environ["WORLD_SIZE"]) > 1 and os.environ.get("BENCH_CHILD") != "1":
+        rc = supervise_rank(args, json_fd)
+        os.close(json_fd)
+        sys.exit(rc)
+
+    global np, torch
+    import numpy as np
+    import torch
 
     import __graft_entry__ as ge
     if not os.path.exists(os.path.join(ROOT, "gnn_computing_amd", "libgnnagg.so")):
@@ -525,7 +706,7 @@ def main():
         dist.destroy_process_group()
     else:
         if args.gpus != 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many processes" % args.gpus)
+            raise SystemExit("--gpus %d: WORLD_SIZE is 1 in the environment" % args.gpus)
         if args.config == "P":
             args.config = "P1"
         out = run_single(args, dev) if args.config == "A" else run_other_config(args, dev)

@@ -43,6 +43,8 @@ SIGNATURES = {
     "gnnagg_destroy": (c_int, [c_int64]),
     "gnnagg_set_stream": (c_int, [c_int64, c_void_p]),
     "gnnagg_set_option": (c_int, [c_int64, c_char_p, c_int]),
+    "gnnagg_plan_info": (c_int, [c_int64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
+                                 ctypes.POINTER(ctypes.c_longlong)]),
     "gnnagg_update_val": (c_int, [c_int64, c_void_p]),
     "gnnagg_set_row_aux": (c_int, [c_int64, c_void_p]),
     "gnnagg_schedule": (c_int, [c_int64, c_int, P_INT, c_int]),

@@ -88,6 +88,12 @@ class Aggregator:
         arr = (ctypes.c_int * 2)(*(list(param) + [0])[:2])
         check(lib().gnnagg_schedule(self._h, int(s), arr, self.num_v if total_num_v is None else int(total_num_v)))
 
+    def plan_info(self):
+        """{plan_s, rows_plan_s, plan_bytes, scratch_bytes} of the library-chosen blocked order (gnnagg_plan_info)."""
+        a, b, pb, sb = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+        check(lib().gnnagg_plan_info(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(pb), ctypes.byref(sb)))
+        return {"plan_s": a.value, "rows_plan_s": b.value, "plan_bytes": pb.value, "scratch_bytes": sb.value}
+
     def schedule_balanced(self, chunk=0):
         check(lib().gnnagg_schedule_balanced(self._h, int(chunk)))
 

@@ -8,12 +8,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <queue>
 #include <set>
 #include <vector>
 
 #include "common.h"
+#include "devbuf.h"
 
 namespace gnnagg {
 
@@ -26,43 +28,6 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                      \
-    do {                                                                                   \
-        hipError_t _e = (expr);                                                            \
-        if (_e != hipSuccess)                                                              \
-            return fail(GNNAGG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-    } while (0)
-
-template <class T>
-struct DevBuf {  // owning device array
-    T *p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { release(); }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    int upload(const std::vector<T> &h)
-    {
-        release();
-        n = h.size();
-        if (n == 0) return GNNAGG_OK;
-        HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
-        HIP_TRY(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
-        return GNNAGG_OK;
-    }
-    int reserve(size_t want)  // grow-only scratch
-    {
-        if (want <= n) return GNNAGG_OK;
-        release();
-        HIP_TRY(hipMalloc((void **)&p, want * sizeof(T)));
-        n = want;
-        return GNNAGG_OK;
-    }
-};
-
 // One schedule = the reference's (d_ptr_scheduled, d_idx_scheduled, d_target_scheduled,
 // d_val_scheduled, num_target) of aggregator.h:130-133 plus what the deterministic combine needs.
 struct Schedule {
@@ -70,6 +35,9 @@ struct Schedule {
     int kind = GNNAGG_SCHED_NOP;
     int num_target = 0;
     bool permuted = false;  // locality schedules permute idx/val; neighbor grouping aliases them
+    bool gpu_built = false; // library-built blocked order made on the device (plan_gpu.hip): per-edge arrays exist on the device only
+                            // (idx_f, eperm), the descriptor form (slot, mrow_*, idx_s) does not exist at all
+    int n_edges_perm = 0;   // ... and its edge count
     int total_cols = 0;     // locality schedules: the column count the ranges were cut from
     int par_num = 0;        // locality schedules: the number of column ranges
     std::vector<int> h_ptr_s, h_target, h_idx_s, h_slot, h_empty;
@@ -96,7 +64,8 @@ struct Schedule {
         h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear(); h_slot.clear(); h_empty.clear(); h_eperm.clear();
         cost_prefix.clear();
         num_target = n_empty = n_mrows = n_slots = 0;
-        permuted = false;
+        permuted = gpu_built = false;
+        n_edges_perm = 0;
     }
     WorkList worklist() const
     {
@@ -207,6 +176,11 @@ struct Ctx {
     int partitions = 0;        // > 0: the balanced mode is SOURCE-PARTITIONED (high-degree graphs, see auto_partitions)
     int part_descriptors = 1;  // run it on the plan kernels' descriptor path (GNNAGG_PART_DESC=0: item kernels)
     int no_auto_partition = 0; // set when a run found the partial-row scratch too large: the handle stays on the chunked plan
+    int force_host_plan = 0;   // set when a run needed the descriptor form of the blocked order (GAT head widths the span kernel does not tile,
+                               // "spans" / "tiled" = 0): the order is then built by the host builder, which makes both forms
+    double rb_plan_seconds = 0.0;   // ... of the chain plan of the rows mode (build_rows_blocked)
+    double plan_seconds = 0.0; // wall time of the last library-chosen plan construction (gnnagg_plan_info)
+    size_t plan_bytes = 0;     // device bytes the plan's arrays hold
     std::vector<long> row_cost_prefix;  // MODE_ROWS work items
     // GAT backward (run_bwd): the transposed graph -- row s of A^T lists the destination rows of the edges whose source is
     // s, in ascending original edge order; perm[e'] = original edge id -- and a GCN aggregator over it
@@ -312,6 +286,13 @@ static int build_grouping(Ctx *c, Schedule &s, int ng, int kind)
 }
 
 static int parts_for_cols(const Ctx *c, long cols);
+static int pick_chunk(const Ctx *c);
+static double wall_seconds()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 // par_num == -1 (library-chosen order only): the range count follows from the column count (parts_for_cols)
 static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v, int kind, bool keep_eid)
@@ -557,7 +538,66 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
 
 static int build_spans(Ctx *c, Schedule &s);
 
+static constexpr int kSpanEdges = 512;
+
+// The blocked order built on the device (plan_gpu.hip): only what the segmented-stream kernels read.  `parts` as in build_locality
+// (-1: from the column count).  *done = false: not applicable here (the caller builds on the host).
+static int build_partitioned_gpu(Ctx *c, int parts, int ng, bool *done)
+{
+    *done = false;
+    if (c->E <= 0 || c->V <= 0 || c->force_host_plan) return GNNAGG_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)c->E * 72 > free_b / 2) return GNNAGG_OK;   // ~ 50 B / edge of temporaries
+    int rc = fetch_host_ptr(c);
+    if (rc) return rc;
+    int mx = 0;
+    if ((rc = gpu_max_col(c->d_idx, c->E, c->stream, &mx))) return rc;
+    if ((unsigned)mx > 0x3fffffffu) return GNNAGG_OK;   // the two flag bits are not free
+    int par_num = parts == -1 ? parts_for_cols(c, (long)mx + 1) : parts;
+    par_num = std::max(1, std::min(par_num, mx + 1));
+    GpuBlockedPlan g;
+    if ((rc = gpu_build_blocked_plan(c->d_ptr, c->d_idx, c->V, c->E, par_num, mx + 1, ng, kSpanEdges, c->stream, g))) return rc;
+    Schedule &s = c->sched[1];
+    s.reset();
+    s.kind = GNNAGG_SCHED_LOCALITY_NEIGHBOR_GROUPING;
+    s.permuted = true; s.gpu_built = true;
+    s.total_cols = g.total_cols; s.par_num = g.par_num; s.num_target = g.G; s.n_edges_perm = g.n_edges;
+    s.n_slots = g.G; s.n_empty = g.n_empty; s.n_spans = g.n_spans; s.n_crows = g.n_crows;
+    s.ptr_s.swap(g.ptr_s); s.target.swap(g.target); s.eperm.swap(g.eperm); s.idx_f.swap(g.idx_f); s.span_g.swap(g.span_g);
+    s.rg_ptr.swap(g.rg_ptr); s.rg_idx.swap(g.rg_idx); s.crows.swap(g.crows); s.empty_rows.swap(g.empty_rows);
+    s.h_ptr_s.swap(g.h_ptr_s); s.h_target.swap(g.h_target); s.h_empty.swap(g.h_empty); s.span_cost_prefix.swap(g.span_cost_prefix);
+    s.valid = true;
+    c->partitions = s.par_num;
+    c->plan_part.chunk = ng;
+    c->plan_part.valid = true;   // (no descriptors: a run that needs them rebuilds on the host, see force_host_plan)
+    *done = true;
+    return GNNAGG_OK;
+}
+
+static size_t sched_device_bytes(const Schedule &s)
+{
+    return (s.ptr_s.n + s.target.n + s.slot.n + s.empty_rows.n + s.mrow_id.n + s.mrow_ptr.n + s.idx_s.n + s.big_rows.n + s.eperm.n + s.idx_f.n +
+            s.span_g.n + s.crows.n + s.rg_ptr.n + s.rg_idx.n + s.val_s.n) * sizeof(int);
+}
+
+static int build_partitioned_host(Ctx *c, int parts);
+
 static int build_partitioned(Ctx *c, int parts)
+{
+    const double t0 = wall_seconds();
+    c->plan.reset();
+    c->plan_part.reset();
+    constexpr int span_chunk_gpu = 128;
+    bool done = false;
+    int rc = GNNAGG_OK;
+    if (c->tiled && c->use_spans && c->use_plan) rc = build_partitioned_gpu(c, parts, std::min(pick_chunk(c), span_chunk_gpu), &done);
+    if (!rc && !done) rc = build_partitioned_host(c, parts);
+    c->plan_seconds = wall_seconds() - t0;
+    c->plan_bytes = sched_device_bytes(c->sched[1]) + c->plan_part.t0.n * sizeof(int);
+    return rc;
+}
+
+static int build_partitioned_host(Ctx *c, int parts)
 {
     c->plan.reset();
     c->plan_part.reset();
@@ -591,8 +631,6 @@ static int build_partitioned(Ctx *c, int parts)
 
 // Segmented-stream form of the partitioned order: spans of whole groups with about kSpanEdges edges each, the ids with
 // the group-end flags, and the row -> groups lists of the ordered combine.
-static constexpr int kSpanEdges = 512;
-
 static int build_spans(Ctx *c, Schedule &s)
 {
     const int G = s.num_target, V = c->V;
@@ -778,14 +816,62 @@ struct NnRequest {  // run_with_nn: transformed[V, cols] = y . weight[feat, cols
 // and returning there (k_gcn_span<..., CHAIN>), give exactly the canonical chains -- with the gathers served by the L2 instead of
 // the fabric (reddit-shaped SAGE F = 602: 41 ms on the row kernels).  Applies to graphs the balanced mode would block as well
 // (average degree >= partition_min_degree), sum / mean, 64-float tiles; everything else stays on the row kernels.
+static int build_rows_blocked_host(Ctx *c, int ntiles_hint);
+
+// the chain plan on the device (plan_gpu.hip); *done = false: not applicable (the host builder decides)
+static int build_rows_blocked_gpu(Ctx *c, int ntiles_hint, bool *done)
+{
+    *done = false;
+    Ctx::RowsBlocked &rb = c->rb;
+    size_t free_b = 0, total_b = 0;
+    if (c->force_host_plan || hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)c->E * 80 > free_b / 2) return GNNAGG_OK;
+    int mx = 0, rc;
+    if ((rc = gpu_max_col(c->d_idx, c->E, c->stream, &mx))) return rc;
+    if (mx + 1 >= (1 << 24)) { *done = true; return GNNAGG_OK; }   // (24-bit ids in the chained kernel: the row kernels keep such graphs)
+    const int slice_kb = c->opt_slice_kb;
+    if (ntiles_hint <= 4 && c->opt_partitions < 0) c->opt_slice_kb = 2 * slice_kb;   // see build_rows_blocked_host
+    int par_num = c->opt_partitions > 0 ? c->opt_partitions : parts_for_cols(c, (long)mx + 1);
+    c->opt_slice_kb = slice_kb;
+    par_num = std::max(1, std::min(par_num, mx + 1));
+    *done = true;
+    if (par_num < 2) return GNNAGG_OK;
+    const int hub_edges = std::min(4096, std::max(512, 256 * std::max(1, ntiles_hint)));
+    GpuChainPlan g;
+    if ((rc = gpu_build_chain_plan(c->d_ptr, c->d_idx, c->h_ptr.data(), c->V, c->E, par_num, mx + 1, hub_edges, kSpanEdges, c->stream, g))) return rc;
+    if (!g.sorted_rows || g.G == 0) return GNNAGG_OK;
+    Schedule &s = rb.sched;
+    s.reset();
+    s.kind = GNNAGG_SCHED_LOCALITY; s.permuted = true; s.gpu_built = true;
+    s.total_cols = g.total_cols; s.par_num = g.par_num; s.num_target = g.G; s.n_edges_perm = g.n_edges; s.n_slots = 0;
+    s.ptr_s.swap(g.ptr_s); s.target.swap(g.target); s.eperm.swap(g.eperm);
+    s.h_ptr_s.swap(g.h_ptr_s); s.h_target.swap(g.h_target);
+    s.valid = true;
+    rb.idx_f.swap(g.idx_f); rb.span_g.swap(g.span_g); rb.r1.swap(g.r1); rb.hub_mask.swap(g.hub_mask);
+    rb.n1 = g.n_hub; rb.span0.swap(g.span0); rb.cost.swap(g.cost);
+    rb.ok = true;
+    return GNNAGG_OK;
+}
+
 static int build_rows_blocked(Ctx *c, int ntiles_hint)
 {
+    const double t0 = wall_seconds();
     Ctx::RowsBlocked &rb = c->rb;
     rb.reset();
     rb.tried = true;
     int rc = fetch_host_ptr(c);
     if (rc) return rc;
     if (c->E == 0 || c->no_auto_partition || (c->opt_partitions < 0 && c->avg_deg() < c->opt_part_min_deg) || c->opt_partitions == 0) return GNNAGG_OK;
+    bool done = false;
+    rc = build_rows_blocked_gpu(c, ntiles_hint, &done);
+    if (!rc && !done) rc = build_rows_blocked_host(c, ntiles_hint);
+    c->rb_plan_seconds = wall_seconds() - t0;
+    return rc;
+}
+
+static int build_rows_blocked_host(Ctx *c, int ntiles_hint)
+{
+    Ctx::RowsBlocked &rb = c->rb;
+    int rc;
     {   // neighbors ascending in every row?
         std::vector<int> h_idx((size_t)c->E);
         HIP_TRY(hipMemcpy(h_idx.data(), c->d_idx, (size_t)c->E * sizeof(int), hipMemcpyDeviceToHost));
@@ -1037,6 +1123,11 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         BalancedPlan &p = c->plan_part;
         TiledRun tr = plan_tiles(c, *s, x, y, feat, 4);
         const bool span_run = tr.spec.on && s->n_spans > 0;
+        if (!span_run && s->gpu_built) {   // the descriptor form is needed after all: the host builder makes both
+            c->force_host_plan = 1;
+            if ((rc = build_partitioned(c, c->partitions))) return rc;
+            return gcn_run(c, x, y, feat, mode, reduce, flags, nn, probe);
+        }
         if (span_run) {  // every group owns a partial row (slot = group index): sequential flushes
             tr.spec.p_tile_stride = (long)s->num_target * tr.spec.tile_w;
             tr.partial_floats = (size_t)s->num_target * tr.spec.tile_w * tr.ntiles;
@@ -1195,6 +1286,11 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
         if (heads <= 0 || feat % heads != 0) return fail(GNNAGG_ERR_ARG, "GAT needs feat % heads == 0");
         TiledRun tr = plan_tiles(c, *s, x, y, feat, feat / heads);
         const bool span_run = tr.spec.on && s->n_spans > 0 && gat_span_tiles(feat, heads, tr.spec.tile_w);
+        if (!span_run && s->gpu_built) {   // head widths the span kernel does not tile: the descriptor form, from the host builder
+            c->force_host_plan = 1;
+            if ((rc = build_partitioned(c, c->partitions))) return rc;
+            return gat_run(c, x, att, y, feat, heads, slope, mode, newval, probe, part, den_io);
+        }
         size_t den_floats = (size_t)s->n_slots * heads;
         if (span_run) {
             tr.spec.p_tile_stride = (long)s->num_target * tr.spec.tile_w;
@@ -1473,8 +1569,10 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "spans") { c->use_spans = value; replan = true; }
     else if (n == "inkernel_combine") c->inkernel_combine = value;
     else if (n == "rows_blocked") c->opt_rows_blocked = value;
+    else if (n == "host_plan") replan = true;
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
     if (replan) {
+        c->force_host_plan = (n == "host_plan") ? (value != 0) : 0;
         c->partitions = 0;
         c->sched[1].reset();
         c->plan_part.reset();
@@ -1558,6 +1656,17 @@ int gnnagg_balanced_partitions(gnnagg_handle h, int *partitions, int *total_cols
     return GNNAGG_OK;
 }
 
+int gnnagg_plan_info(gnnagg_handle h, double *plan_seconds, double *rows_plan_seconds, long long *plan_bytes, long long *scratch_bytes)
+{
+    GET_CTX(h);
+    if (plan_seconds) *plan_seconds = c->plan_seconds;
+    if (rows_plan_seconds) *rows_plan_seconds = c->rb_plan_seconds;
+    if (plan_bytes)
+        *plan_bytes = (long long)(c->plan_bytes + sched_device_bytes(c->rb.sched) + (c->rb.span_g.n + c->rb.idx_f.n + c->rb.r1.n) * sizeof(int) + c->rb.hub_mask.n);
+    if (scratch_bytes) *scratch_bytes = (long long)((c->partial.n + c->partial_den.n + c->xt.n + c->yt.n + c->att_t.n + c->den.n) * sizeof(float));
+    return GNNAGG_OK;
+}
+
 int gnnagg_rows_blocked_ranges(gnnagg_handle h, int *ranges)
 {
     GET_CTX(h);
@@ -1596,10 +1705,17 @@ int gnnagg_get_schedule(gnnagg_handle h, int mode, int *h_ptr_s, int *h_idx_s, i
     const int G = s->num_target;
     if (h_ptr_s) memcpy(h_ptr_s, s->h_ptr_s.data(), ((size_t)G + 1) * sizeof(int));
     if (h_target && G > 0) memcpy(h_target, s->h_target.data(), (size_t)G * sizeof(int));
-    const size_t ne = s->permuted ? s->h_idx_s.size() : (size_t)c->E;
-    if (h_idx_s && ne > 0)
-        HIP_TRY(hipMemcpy(h_idx_s, s->permuted ? s->idx_s.p : c->d_idx, ne * sizeof(int), hipMemcpyDeviceToHost));
+    const size_t ne = s->gpu_built ? (size_t)s->n_edges_perm : s->permuted ? s->h_idx_s.size() : (size_t)c->E;
+    if (h_idx_s && ne > 0) {
+        HIP_TRY(hipMemcpy(h_idx_s, s->gpu_built ? s->idx_f.p : s->permuted ? s->idx_s.p : c->d_idx, ne * sizeof(int), hipMemcpyDeviceToHost));
+        if (s->gpu_built)   // the device holds the ids with the span kernel's two flag bits
+            for (size_t e = 0; e < ne; ++e) h_idx_s[e] &= 0x3fffffff;
+    }
     if (h_val_s && ne > 0) {
+        if (s->permuted && s->eperm.p && c->d_val) {   // library-built orders gather their copy of the values before every run
+            if ((rc = refresh_partitioned_val(c, s))) return rc;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
         const float *src = s->permuted ? s->val_s.p : c->d_val;
         if (!src) return fail(GNNAGG_ERR_STATE, "aggregator has no edge values");
         HIP_TRY(hipMemcpy(h_val_s, src, ne * sizeof(float), hipMemcpyDeviceToHost));

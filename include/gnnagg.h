@@ -126,12 +126,20 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *   "aux_stream" [GNNAGG_AUX_STREAM]      0: GNNAGG_MODE_ROWS runs its hub rows on the handle's stream, before the short rows, instead of
  *                                         beside them on an auxiliary stream (slower by the hub rows' duration, but the process keeps
  *                                         a single queue); 1 (default)
+ *   "host_plan"                           1: the blocked orders are built by the host builders of rounds 2-3 (host_graph.cpp: D2H copy of the
+ *                                         CSR, 2-3 GB of uploads) instead of on the device (plan_gpu.hip); the same arrays either way (tests
+ *                                         compare them), 5-10 x the construction time.  0 (default)
  *   "rows_blocked"                        1 (default): GNNAGG_MODE_ROWS runs its canonical chains on the 2-D blocked order where the
  *                                         graph allows it (gnnagg_rows_blocked_ranges); 0: always the row kernels.  Same bits either way
  * [GNNAGG_XCD_REMAP] 0 / 1 / 2 (workgroup -> XCD mapping: identity / equal-count / work-balanced ranges, default 2) and [GNNAGG_PLAN] 0
  * (the round-1 item kernels + k_combine instead of the plan kernels) are environment-only measurement switches (scripts/tune_gcn.py).
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
 int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
+/* What the library-chosen blocked order cost to build and holds (the reference prints its schedule time, graph_schedule.h:125-127):
+ * wall seconds of the last construction of the balanced mode's 2-D blocked order (0: the handle runs the chunked plan, built in O(V))
+ * and of the rows mode's chain plan; device bytes of the plans' arrays; device bytes of the scratch the runs so far have reserved
+ * (partial rows, tiled images of X / Y, compact attention terms).  Any output pointer may be NULL. */
+int gnnagg_plan_info(gnnagg_handle h, double *plan_seconds, double *rows_plan_seconds, long long *plan_bytes, long long *scratch_bytes);
 /* Aggregator_GCN::updateval, aggr_gcn.h:540-544: re-aliases the edge values (borrowed; read at run time). */
 int gnnagg_update_val(gnnagg_handle h, const float *d_val);
 

@@ -62,13 +62,50 @@ def test_other_config_line():
     assert d["config"]["feat"] == 100 and d["roofline"]["ceiling_probe_us"] > 0
 
 
+def check_multi(d):
+    assert d["scaling"] == "weak" and d["config"]["verified_against_oracle"] is True and d["config"]["num_e"] == 2 * 1166243
+    assert d["no_exchange_upper_bound"]["value"] >= d["value"] * 0.9
+    assert d["transport"] in ("rccl", "torch") and "rccl_ranks" in d and d["halo_stages"] >= 1 and d["config"]["global_share"] == 0.5
+    p = d["products_strong"]      # ONE pass yields the feat-128 line and BASELINE configs[4] over the same ranks
+    assert p["scaling"] == "strong" and p["value"] > 0 and p["verified_against_oracle"] is True and p["halo_bytes_per_step_all_ranks"] > 0
+    assert "123718280" in p["what"] and p["exposed_comm_ms_per_step"] >= 0
+
+
 def test_two_ranks_on_one_gpu_over_gloo():
+    """the driver's N > 1 command: torch.distributed.run starts the ranks (each a supervisor + a fresh child)"""
     d = run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu"], env={"BENCH_ONE_GPU": "1", "BENCH_BACKEND": "gloo"},
             launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                       "--master-port", "29571"])
     check_common(d, 2, 3, 1)
-    assert d["scaling"] == "weak" and d["config"]["verified_against_oracle"] is True and d["config"]["num_e"] == 2 * 1166243
-    assert d["no_exchange_upper_bound"]["value"] >= d["value"] * 0.9
+    check_multi(d)
+    assert d["transport"] == "torch" and d["rccl_ranks"] is None and d["transport_fallback"] is None
+
+
+def test_two_ranks_without_a_launcher():
+    """`python3 bench.py --gpus 2` the way the driver launches N = 1: no launcher, WORLD_SIZE unset.  bench.py starts the ranks
+    itself in fresh child processes (before anything touches the GPU) and relays their one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_ONE_GPU="1", BENCH_BACKEND="gloo", BENCH_PRODUCTS="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu", "--global-share", "0.25"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    check_common(d, 2, 3, 1)
+    assert d["config"]["global_share"] == 0.25 and "products_strong" not in d and d["remote_edge_share"] < 0.2   # the locality knob
+
+
+def test_failed_rccl_ranks_fall_back_to_torch_transport_in_fresh_processes():
+    """The C-ABI RCCL step is the default transport with the nccl backend; when its ranks fail -- here: two ranks on ONE GPU, which
+    RCCL refuses -- every supervisor starts the rank again in a fresh child on all_to_all_single, with a fresh rendezvous, and the
+    line says so.  The same path catches a failed oracle check (exit 17) and a hung exchange (watchdog, 18)."""
+    d = run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"],
+            env={"BENCH_ONE_GPU": "1", "BENCH_BACKEND": "gloo", "BENCH_TRANSPORT": "rccl", "BENCH_PRODUCTS": "0"},
+            launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", "29575"])
+    check_common(d, 2, 2, 1)
+    assert d["transport"] == "torch" and d["transport_fallback"] and "rccl" in d["transport_fallback"]
 
 
 def test_products_strong_scaling_two_ranks_on_one_gpu_over_gloo():

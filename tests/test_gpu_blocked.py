@@ -613,8 +613,16 @@ def test_two_pass_gat_on_hub_rows(F, H):
     ref = orc.gat_fused(ptr, idx, att, x, H)
     assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "two-pass gat")
     assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0)
+    # part 3 (a pass in between: both added, nothing divided -- the staged halo exchange): a (1), b (3), then a third handle
+    # without edges (2) divides; the same sums in the same order as a (1), b (2): the same bits
+    y2, den2 = torch.full((V, F), 7.0, device=DEV), torch.full((V, H), 7.0, device=DEV)
+    none = gnc.Aggregator_GAT(dev(np.zeros(V + 1, np.int32)), dev(np.zeros(0, np.int32)), F, F)
+    a.run_part(dev(x), dev(att), y2, den2, 1, heads=H)
+    b.run_part(dev(x), dev(att), y2, den2, 3, heads=H)
+    none.run_part(dev(x), dev(att), y2, den2, 2, heads=H)
+    assert torch.equal(y, y2)
     with pytest.raises(Exception):
-        a.run_part(dev(x), dev(att), y, den, 3, heads=H)
+        a.run_part(dev(x), dev(att), y, den, 4, heads=H)
 
 
 @pytest.mark.parametrize("F", [602, 100, 64, 256, 33])
