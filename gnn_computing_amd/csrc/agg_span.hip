@@ -345,6 +345,10 @@ struct GatSpanArgs {
     const int *eperm;     // permuted position -> CSR edge
     int heads, dhead, att_rows;
     float slope;
+    // CHAIN (canonical rows mode on the blocked order): per-tile denominator image den_t[tile][den_rows][HT] carried from range to
+    // range beside the numerator image Yt (s.partial)
+    float *den_t;
+    int den_rows;
 };
 
 // HT consecutive floats with one load
@@ -383,7 +387,13 @@ __device__ __forceinline__ float row_bcast_banks(float old, float v)
 #ifndef GAT_SPAN_WAVES
 #define GAT_SPAN_WAVES 4
 #endif
-template <int GROUP, int HT, bool SHIFT, bool PROBE>
+// CHAIN (gnnagg "rows_blocked", GAT): one launch per source range, a group = a whole (row, range) sub-row; its numerator chain starts
+// from what the row's earlier ranges left in Yt[tile][row] and its denominator chain from den_t[tile][row][head] -- both go back
+// there at the group's end, the next group's carries are requested while the current one is walked.  For rows whose neighbors are
+// sorted, range after range IS the CSR order: every (row, column) numerator and every (row, head) denominator is the one sequential
+// chain of aggr_gat (aggr_gat.h:125-163); k_untile_y divides.  A head wider than the tile keeps one denominator copy per tile (the
+// tiles of a row run in different workgroups of the same launch: a shared copy would be read after another tile had updated it).
+template <int GROUP, int HT, bool SHIFT, bool PROBE, bool CHAIN = false>
 __global__ __launch_bounds__(256, (HT <= 2 ? GAT_SPAN_WAVES : 2)) void k_gat_span(const GatSpanArgs A)
 {
     const SpanArgs &a = A.s;
@@ -455,6 +465,31 @@ __global__ __launch_bounds__(256, (HT <= 2 ? GAT_SPAN_WAVES : 2)) void k_gat_spa
     float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
     float den = 0.0f;
     unsigned sig = 0;
+    // CHAIN: the current group's row, the next one's row and carries (numerator pack, this lane's head's denominator)
+    int row_cur = 0, row_n = 0;
+    Pack<VEC> cn;
+    float dn = 0.0f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) cn.v[k] = 0.0f;
+    float *__restrict__ dtile = nullptr;
+    const bool den_leader = col_ok && (HT > 1 ? (col % A.dhead) == 0 : lane == 0);
+    if constexpr (CHAIN) {
+        dtile = A.den_t + (size_t)tile * A.den_rows * HT + hl;
+        row_cur = __shfl(tw_c, 0, GROUP);
+        if (col_ok) {
+            const Pack<VEC> c0 = load_pack<VEC>(ptile + (size_t)row_cur * a.ppitch + lane * VEC);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = c0.v[k];
+            den = dtile[(size_t)row_cur * HT];
+        }
+        if (g + 1 < g1) {
+            row_n = GROUP > 1 ? __shfl(tw_c, 1, GROUP) : a.target[g + 1];
+            if (col_ok) {
+                cn = load_pack<VEC>(ptile + (size_t)row_n * a.ppitch + lane * VEC);
+                dn = dtile[(size_t)row_n * HT];
+            }
+        }
+    }
     for (int cb = e0; cb < e_end; cb += GROUP) {
         unsigned nx_s = 0;
         int nx_e = 0;
@@ -544,7 +579,27 @@ __global__ __launch_bounds__(256, (HT <= 2 ? GAT_SPAN_WAVES : 2)) void k_gat_spa
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = __builtin_fmaf(xv[u].v[k], w, acc[k]);
                 den += w;
-                if (sru & kLastFlag) {  // lane-group uniform: the group ends here
+                if (CHAIN && (sru & kLastFlag)) {  // the sub-row ends: its chains go back to Yt / den_t, the next row's carries take over
+                    if (col_ok) {
+                        if (a.ptile_bytes) store_pack_wt<VEC, kPartialAux>(ptile, a.ptile_bytes, (size_t)row_cur * a.ppitch + lane * VEC, acc);
+                        else store_pack<VEC>(ptile + (size_t)row_cur * a.ppitch + lane * VEC, acc);
+                        if (den_leader) dtile[(size_t)row_cur * HT] = den;
+                    }
+                    ++g;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = cn.v[k];
+                    den = dn;
+                    row_cur = row_n;
+                    if (g + 1 < g1) {
+                        const int gi = g + 1 - gw0;  // <= 2 * GROUP (the windows shift between edge windows only)
+                        const int r0 = __shfl(tw_c, gi & (GROUP - 1), GROUP), r1 = __shfl(tw_n, gi & (GROUP - 1), GROUP);
+                        row_n = gi < GROUP ? r0 : gi < 2 * GROUP ? r1 : a.target[g + 1];
+                        if (col_ok) {
+                            cn = load_pack<VEC>(ptile + (size_t)row_n * a.ppitch + lane * VEC);
+                            dn = dtile[(size_t)row_n * HT];
+                        }
+                    }
+                } else if (sru & kLastFlag) {  // lane-group uniform: the group ends here
                     if (sru & kDirectFlag) {
                         const int gi = g - gw0;  // < 2 * GROUP
                         const int r0 = __shfl(tw_c, gi & (GROUP - 1), GROUP), r1 = __shfl(tw_n, gi & (GROUP - 1), GROUP);
@@ -779,12 +834,29 @@ int launch_gat_span(const GatSpanLaunch &G, void *stream_v)
         if (!A0.s.probe_sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
     }
     A0.as_t = G.as_t; A0.ac_t = G.ac_t; A0.att_rows = G.att_rows; A0.partial_den = G.partial_den; A0.newval = G.newval; A0.eperm = G.eperm; A0.heads = G.heads; A0.dhead = dhead;
-    A0.slope = G.slope;
+    A0.slope = G.slope; A0.den_t = G.den_t; A0.den_rows = G.den_rows;
+    if (L.chain && (group != 16 || L.probe || G.newval || !G.den_t)) return fail(GNNAGG_ERR_STATE, "internal: chained GAT span launch on a geometry without that kernel");
     auto span = [&](int tile0, int nt, hipStream_t st) -> int {
         GatSpanArgs A = A0;
         A.s.tile0 = tile0;
         const int gpb = 256 / group;
         const int grid = 8 * fill_xcd_ranges_tile_major(L.span_cost_prefix, L.n_spans, gpb, A.s.span_blocks, nt, A.s.xr);
+#define GAT_CHAIN_HT(HT_)                                                                                                      \
+        {                                                                                                                      \
+            if (A.s.xshift_bytes >= 0) hipLaunchKernelGGL((k_gat_span<16, HT_, true, false, true>), dim3(grid), dim3(256), 0, st, A);  \
+            else                       hipLaunchKernelGGL((k_gat_span<16, HT_, false, false, true>), dim3(grid), dim3(256), 0, st, A); \
+        }
+        if (L.chain) {   // canonical rows mode on the blocked order: one source range per launch, carries through Yt / den_t
+            switch (ht) {
+                case 1: GAT_CHAIN_HT(1); break;
+                case 2: GAT_CHAIN_HT(2); break;
+                case 4: GAT_CHAIN_HT(4); break;
+                default: GAT_CHAIN_HT(8); break;
+            }
+            HIP_TRY(hipGetLastError());
+            return GNNAGG_OK;
+        }
+#undef GAT_CHAIN_HT
 #define GAT_SPAN_HT(G_, HT_)                                                                                                   \
         {                                                                                                                      \
             if (L.probe) {                                                                                                     \

@@ -137,6 +137,7 @@ struct Ctx {
     } rb;
     bool keep_h_eperm = false;   // build_locality keeps the host copy of eperm (the plan being built filters its groups)
     DevBuf<float> yt;        // tiled image of Y the chains of that mode pass through
+    DevBuf<float> den_t;     // ... and, GAT, the per-tile image of the softmax denominators
     int opt_rows_blocked = 1;
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
@@ -1058,6 +1059,85 @@ static bool sched_keeps_every_edge(const Ctx *c)
     return !s.permuted || (long)s.h_idx_s.size() == (long)c->E;
 }
 
+// The same for GAT (`scheduled = 0` = aggr_gat, aggr_gat.h:116-164: one numerator chain per (row, column) and one denominator chain
+// per (row, head) in CSR order, one division): k_gat_span<..., CHAIN> carries both through tiled images from range to range,
+// k_untile_y divides.  Rows with a sub-row too long for one lane group go whole to the workgroup-per-row kernel's GAT flavour (head
+// width % 32 == 0); graphs where that does not hold, head widths the span kernel does not tile, and callers that ask for newval stay
+// on the row kernels.
+static int run_rows_blocked_gat(Ctx *c, const float *x, const float *att, float *y, int feat, int heads, float slope, bool *used)
+{
+    *used = false;
+    if (heads <= 0 || feat % heads != 0) return GNNAGG_OK;
+    const int dhead = feat / heads;
+    Ctx::RowsBlocked &rb = c->rb;
+    int rc;
+    if (!rb.tried && (rc = build_rows_blocked(c, (feat + 63) / 64))) return rc;
+    if (!rb.ok) return GNNAGG_OK;
+    Schedule &s = rb.sched;
+    TiledRun tr = plan_tiles(c, s, x, y, feat, dhead);
+    if (!tr.spec.on || tr.spec.tile_w != 64 || !gat_span_tiles(feat, heads, 64) || (rb.n1 > 0 && (dhead % 32) != 0) ||
+        (size_t)s.total_cols * tr.spec.xpitch * sizeof(float) >= 0xffffffffULL || (size_t)c->V * tr.spec.tile_w * sizeof(float) >= 0x7fffffffULL)
+        return GNNAGG_OK;
+    const int ht = 64 >= dhead ? 64 / dhead : 1;
+    const int n_hg = (heads + ht - 1) / ht, arows = c->V > s.total_cols ? c->V : s.total_cols;
+    const size_t yt_floats = (size_t)c->V * tr.spec.tile_w * tr.ntiles, den_floats = (size_t)c->V * ht * tr.ntiles, half = (size_t)n_hg * arows * ht;
+    if (yt_floats > c->yt.n || tr.xt_floats > c->xt.n || den_floats > c->den_t.n || 2 * half > c->att_t.n) {   // first use: the scratch, or not this path
+        size_t free_b = 0, total_b = 0;
+        const size_t want = (yt_floats + tr.xt_floats + den_floats + 2 * half) * sizeof(float);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || want > free_b / 2 || c->yt.reserve(yt_floats) != GNNAGG_OK ||
+            c->xt.reserve(tr.xt_floats) != GNNAGG_OK || c->den_t.reserve(den_floats) != GNNAGG_OK || c->att_t.reserve(2 * half) != GNNAGG_OK) {
+            (void)hipGetLastError();
+            rb.ok = false;
+            return GNNAGG_OK;
+        }
+    }
+    const bool fork = rb.n1 > 0 && c->use_aux_stream;
+    auto hub_rows = [&](hipStream_t st) -> int {
+        GcnRowsLongLaunch R;
+        R.r1 = rb.r1.p; R.n1 = rb.n1; R.idx = c->d_idx; R.x = x; R.y = y; R.feat = feat; R.att = att; R.heads = heads; R.slope = slope;
+        return launch_gcn_rows_long(R, st);
+    };
+    if (fork) {
+        if (!c->aux_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        if ((rc = hub_rows(c->aux_stream))) return rc;
+        HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
+    }
+    GatSpanLaunch G;
+    SpanLaunch &S = G.s;
+    S.chain = 1;
+    S.x = x;
+    if (tr.retile) {
+        if ((rc = launch_tile_x(x, c->xt.p, s.total_cols, feat, tr.spec.tile_w, c->stream))) return rc;
+        S.x = c->xt.p;
+    }
+    if ((rc = launch_tile_att(att, c->att_t.p, c->att_t.p + half, arows, heads, ht, c->stream))) return rc;
+    if ((rc = launch_zero_words(c->yt.p, yt_floats, c->stream)) || (rc = launch_zero_words(c->den_t.p, den_floats, c->stream))) return rc;
+    S.ptr_s = s.ptr_s.p; S.idx_f = rb.idx_f.p; S.target = s.target.p;
+    S.n_groups = c->V;   // rows of the Yt image
+    S.row_ptr = c->d_ptr; S.x_rows = s.total_cols; S.y = y; S.partial = c->yt.p; S.feat = feat;
+    S.tile = tr.spec;
+    S.tile.p_tile_stride = (long)c->V * tr.spec.tile_w;
+    G.att = att; G.as_t = c->att_t.p; G.ac_t = c->att_t.p + half; G.att_rows = arows; G.heads = heads; G.slope = slope;
+    G.den_t = c->den_t.p; G.den_rows = c->V;
+    for (int p = 0; p < s.par_num; ++p) {
+        const int s0 = rb.span0[(size_t)p], s1 = rb.span0[(size_t)p + 1];
+        if (s1 == s0) continue;
+        S.span_g = rb.span_g.p + s0; S.n_spans = s1 - s0; S.span_cost_prefix = rb.cost[(size_t)p].data();
+        if ((rc = launch_gat_span(G, c->stream))) return rc;
+    }
+    if ((rc = launch_untile_y_gat(c->yt.p, c->den_t.p, y, rb.n1 > 0 ? rb.hub_mask.p : nullptr, c->V, feat, tr.spec.tile_w, ht, dhead, c->stream))) return rc;
+    if (fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    else if (rb.n1 > 0 && (rc = hub_rows(c->stream))) return rc;
+    *used = true;
+    return GNNAGG_OK;
+}
+
 static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0, const NnRequest *nn = nullptr,
                    int probe = 0)
 {
@@ -1245,6 +1325,11 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     if (mode < GNNAGG_MODE_ROWS || mode > GNNAGG_MODE_BALANCED) return fail(GNNAGG_ERR_ARG, "bad mode");
     if (mode == GNNAGG_MODE_ROWS && c->fast_rows) mode = GNNAGG_MODE_BALANCED;
     if (mode == GNNAGG_MODE_SCHEDULED && c->fast_scheduled && c->sched[0].valid && !newval && sched_keeps_every_edge(c)) mode = GNNAGG_MODE_BALANCED;
+    if (mode == GNNAGG_MODE_ROWS && c->opt_rows_blocked && c->tiled && c->use_plan && !newval && !probe && part == 0) {
+        bool used = false;   // canonical chains on the blocked order where the graph allows it (sorted rows, high degree)
+        const int rcb = run_rows_blocked_gat(c, x, att, y, feat, heads, slope, &used);
+        if (rcb || used) return rcb;
+    }
     Schedule *s = nullptr;
     int rc = get_sched(c, mode, &s);
     if (rc) return rc;
@@ -1663,7 +1748,7 @@ int gnnagg_plan_info(gnnagg_handle h, double *plan_seconds, double *rows_plan_se
     if (rows_plan_seconds) *rows_plan_seconds = c->rb_plan_seconds;
     if (plan_bytes)
         *plan_bytes = (long long)(c->plan_bytes + sched_device_bytes(c->rb.sched) + (c->rb.span_g.n + c->rb.idx_f.n + c->rb.r1.n) * sizeof(int) + c->rb.hub_mask.n);
-    if (scratch_bytes) *scratch_bytes = (long long)((c->partial.n + c->partial_den.n + c->xt.n + c->yt.n + c->att_t.n + c->den.n) * sizeof(float));
+    if (scratch_bytes) *scratch_bytes = (long long)((c->partial.n + c->partial_den.n + c->xt.n + c->yt.n + c->den_t.n + c->att_t.n + c->den.n) * sizeof(float));
     return GNNAGG_OK;
 }
 
@@ -1672,7 +1757,7 @@ int gnnagg_rows_blocked_ranges(gnnagg_handle h, int *ranges)
     GET_CTX(h);
     if (!ranges) return fail(GNNAGG_ERR_ARG, "null output");
     *ranges = 0;
-    if (c->kind != Ctx::GCN || !c->opt_rows_blocked || !c->tiled || !c->use_plan || c->fast_rows) return GNNAGG_OK;
+    if (!c->opt_rows_blocked || !c->tiled || !c->use_plan || c->fast_rows) return GNNAGG_OK;
     int rc;
     if (!c->rb.tried && (rc = build_rows_blocked(c, 4))) return rc;
     if (c->rb.ok) *ranges = c->rb.sched.par_num;

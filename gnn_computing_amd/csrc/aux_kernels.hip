@@ -849,7 +849,7 @@ int launch_zero_words(void *p, size_t n, void *stream_v)
 // (mean: / degree as finish_gcn_row does; ReLU).  One thread per (row, 4-column quad); the caller's rows may be 4-byte aligned only.
 __global__ __launch_bounds__(256) void k_untile_y(const float *__restrict__ yt, float *__restrict__ y, const int *__restrict__ row_ptr,
                                                   const unsigned char *__restrict__ skip, int rows, int feat, int tile_w, int quads_per_row, int mean,
-                                                  int relu)
+                                                  int relu, const float *__restrict__ den_t = nullptr, int ht = 1, int dhead = 1)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)rows * quads_per_row;
@@ -860,6 +860,11 @@ __global__ __launch_bounds__(256) void k_untile_y(const float *__restrict__ yt, 
     const int t = c / tile_w, ct = c - t * tile_w;
     const float4 v4 = *reinterpret_cast<const float4 *>(yt + ((size_t)t * rows + r) * tile_w + ct);
     float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    if (den_t) {   // GAT: the softmax division (scaleArray, aggr_gat.h:207-213); a quad lies inside one head (head width % 4 == 0)
+        const float d = den_t[((size_t)t * rows + r) * ht + (ht > 1 ? ct / dhead : 0)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = d != 0.0f ? v[k] / d : 0.0f;
+    }
     if (mean) {
         const float dg = (float)(row_ptr[r + 1] - row_ptr[r]);
         if (dg > 0.0f) {
@@ -891,6 +896,18 @@ int launch_untile_y(const float *yt, float *y, const int *row_ptr, const unsigne
     const long total = (long)rows * quads;
     hipLaunchKernelGGL(k_untile_y, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, yt, y, row_ptr, skip, rows, feat,
                        tile_w, quads, mean, relu);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+int launch_untile_y_gat(const float *yt, const float *den_t, float *y, const unsigned char *skip, int rows, int feat, int tile_w, int ht, int dhead,
+                        void *stream_v)
+{
+    if (rows <= 0 || feat <= 0) return GNNAGG_OK;
+    const int quads = (feat + 3) / 4;
+    const long total = (long)rows * quads;
+    hipLaunchKernelGGL(k_untile_y, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, yt, y, (const int *)nullptr, skip, rows,
+                       feat, tile_w, quads, 0, 0, den_t, ht, dhead);
     HIP_TRY(hipGetLastError());
     return GNNAGG_OK;
 }

@@ -155,6 +155,9 @@ int launch_zero_words(void *p, size_t n_words, void *stream);   // 4-byte words;
 // (skip: optional [rows] bytes, 1 = leave the row of y alone)
 int launch_untile_y(const float *yt, float *y, const int *row_ptr, const unsigned char *skip, int rows, int feat, int tile_w, int mean, int relu,
                     void *stream);
+// GAT flavour: y[r, c] = Yt[tile][r][c] / den_t[tile][r][head of c inside the tile] (0 where the denominator is 0: rows without edges)
+int launch_untile_y_gat(const float *yt, const float *den_t, float *y, const unsigned char *skip, int rows, int feat, int tile_w, int ht, int dhead,
+                        void *stream);
 struct GatSpanLaunch {
     SpanLaunch s;                   // val_s unused
     const float *att = nullptr;     // [V, H, 2]
@@ -166,6 +169,8 @@ struct GatSpanLaunch {
     const int *eperm = nullptr;
     int heads = 1;
     float slope = 0.2f;
+    float *den_t = nullptr;         // s.chain = 1: per-tile denominator image [ntiles][den_rows][HT] (the numerator image is s.partial)
+    int den_rows = 0;
 };
 int launch_gat_span(const GatSpanLaunch &a, void *stream);
 // whether the GAT span kernel covers (feat, heads) at this tile width

@@ -678,6 +678,42 @@ def test_rows_mode_on_the_blocked_order_is_the_canonical_chain(F, slice_kb):
     assert np.array_equal(y.cpu().numpy(), orc.gcn_seq(ptr, idx_u, val, x))
 
 
+@pytest.mark.parametrize("F,H", [(256, 8), (64, 1), (128, 2), (128, 1), (96, 3), (192, 2), (512, 16)])
+@pytest.mark.parametrize("slice_kb", [16, 4])
+def test_gat_rows_mode_on_the_blocked_order_is_the_canonical_chain(F, H, slice_kb):
+    """GNNAGG_MODE_ROWS of a GAT handle (`scheduled = 0` = aggr_gat, aggr_gat.h:116-164) on a graph the blocked order applies to: the
+    numerator chain of every (row, column) and the denominator chain of every (row, head) carried from source range to source range
+    through tiled images (k_gat_span<..., CHAIN>), one division at the end.  Range after range is the CSR order,
+    so it is the same chain the row kernels run: bit-equal to them ("rows_blocked" = 0), within the 1e-5 bound of the oracle's fused
+    result; heads narrower than, equal to and wider than the 64-float tile, a ragged last tile, hub rows on the workgroup-per-row
+    kernel beside the launches or behind them, rows without edges 0; callers that ask for newval keep the row kernels."""
+    V, E = 900, 260000
+    ptr, idx = hub_graph(V, E, seed=5)
+    x, att = rand((V, F), 1), rand((V, H, 2), 2) * 0.4
+    a = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    a.set_option("slice_kb", slice_kb)
+    k = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    k.set_option("rows_blocked", 0)
+    y, y2 = torch.full((V, F), 7.0, device=DEV), torch.full((V, F), 7.0, device=DEV)
+    for _ in range(2):   # (the second call reuses the images: they are zeroed by every run)
+        a.run(dev(x), dev(att), y, 128, 0, heads=H)
+    k.run(dev(x), dev(att), y2, 128, 0, heads=H)
+    assert a.rows_blocked_ranges() > 1 and k.rows_blocked_ranges() == 0
+    ref = orc.gat_fused(ptr, idx, att, x, H)
+    assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "gat chains on the blocked order")
+    assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0)
+    assert torch.equal(y, y2), "the chained form and the row kernels run the same chains"
+    one = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+    one.set_option("slice_kb", slice_kb)
+    one.set_option("aux_stream", 0)
+    one.run(dev(x), dev(att), y2, 128, 0, heads=H)
+    assert torch.equal(y, y2)
+    nv, nv2 = torch.full((E, H), 7.0, device=DEV), torch.full((E, H), 7.0, device=DEV)
+    a.run(dev(x), dev(att), y2, 128, 0, heads=H, newval=nv)
+    k.run(dev(x), dev(att), y, 128, 0, heads=H, newval=nv2)
+    assert torch.equal(nv, nv2) and torch.equal(y, y2)
+
+
 def test_rows_mode_on_the_blocked_order_with_the_dense_combine_behind_it():
     """run_with_nn in the canonical order on a graph whose chains run on the blocked order: vout is the sequential chain, transformed
     the oracle's ascending-k GEMM of it, both bit for bit; and the whole run replays from a captured HIP graph (memset, one launch per
