@@ -139,6 +139,7 @@ struct Ctx {
     DevBuf<float> yt;        // tiled image of Y the chains of that mode pass through
     DevBuf<float> den_t;     // ... and, GAT, the per-tile image of the softmax denominators
     int opt_rows_blocked = 1;
+    int opt_rb_hub_edges = 0;   // "rows_hub_edges": rows with a (row, range) sub-row above this many edges leave the chained launches (0: library rule)
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -836,7 +837,11 @@ static int build_rows_blocked_gpu(Ctx *c, int ntiles_hint, bool *done)
     par_num = std::max(1, std::min(par_num, mx + 1));
     *done = true;
     if (par_num < 2) return GNNAGG_OK;
-    const int hub_edges = std::min(4096, std::max(512, 256 * std::max(1, ntiles_hint)));
+    // (GAT: the workgroup-per-row kernel pays an exp per edge and 32-column tile -- 8.9 ms beside 9.5 ms of chained launches on the
+    // reddit-shaped 8 x 32 case at 1024 -- so only sub-rows a lane group cannot finish inside a launch leave the chains:
+    // 12.05 / 10.89 / 10.40 / 10.23 ms at 1024 / 2048 / 4096 / 8192, 13.65 ms without hub rows; profiles/r04/rows_gat_sweep.txt)
+    const int hub_edges = c->opt_rb_hub_edges > 0 ? c->opt_rb_hub_edges
+                          : c->kind == Ctx::GAT ? 8192 : std::min(4096, std::max(512, 256 * std::max(1, ntiles_hint)));
     GpuChainPlan g;
     if ((rc = gpu_build_chain_plan(c->d_ptr, c->d_idx, c->h_ptr.data(), c->V, c->E, par_num, mx + 1, hub_edges, kSpanEdges, c->stream, g))) return rc;
     if (!g.sorted_rows || g.G == 0) return GNNAGG_OK;
@@ -899,7 +904,8 @@ static int build_rows_blocked_host(Ctx *c, int ntiles_hint)
         // The threshold follows the duration of a launch, i.e. the number of column tiles of the first run that builds the plan
         // (reddit-shaped, ms per step at 512 / 1024 / 2048 / 4096 edges: F = 128 5.6 / 5.7 / 7.1 / 7.5, F = 256 10.5 / 10.1 / 10.3 /
         // 10.3, F = 602 -- 10 tiles -- 23.9 / 20.2 / 19.7 at 1024 / 2048 / 4096).
-        const int hub_edges = std::min(4096, std::max(512, 256 * std::max(1, ntiles_hint)));
+        const int hub_edges = c->opt_rb_hub_edges > 0 ? c->opt_rb_hub_edges
+                              : c->kind == Ctx::GAT ? 8192 : std::min(4096, std::max(512, 256 * std::max(1, ntiles_hint)));
         const int G0 = s.num_target;
         std::vector<char> is_hub((size_t)c->V, 0);
         int n_hub = 0;
@@ -1655,6 +1661,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "inkernel_combine") c->inkernel_combine = value;
     else if (n == "rows_blocked") c->opt_rows_blocked = value;
     else if (n == "host_plan") replan = true;
+    else if (n == "rows_hub_edges") { c->opt_rb_hub_edges = std::max(0, value); replan = true; }
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
     if (replan) {
         c->force_host_plan = (n == "host_plan") ? (value != 0) : 0;
