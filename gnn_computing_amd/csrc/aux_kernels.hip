@@ -436,58 +436,68 @@ __device__ __forceinline__ void dense_tile(const float *__restrict__ A, const fl
     // [KC k][128 cols]: thread t k-rows t/32 + 8 j, floats (t % 32) * 4.  Branch-free: out-of-range pieces are loaded from a
     // clamped (valid) address and replaced by zeros, so the loads of a chunk are issued back to back (with per-piece branches
     // the compiler put a wait behind every load and the fetch, not the matrix pipe, set the pace)
-    auto piece = [&](auto vtag, const float *base, long pitch, int r, int rmax, int c, int cmax) -> float4 {
+    // The loads of a chunk are issued with CLAMPED (always valid) addresses and nothing else: what is out of range is zeroed when
+    // the registers are written to LDS, one chunk of MFMAs later.  (Round 3 masked the values right behind the loads: the
+    // compiler then waits for every load of the next chunk BEFORE the current chunk's first MFMA -- s_waitcnt vmcnt(7..0) at the
+    // head of the loop -- and the whole fetch latency was exposed once per chunk: the matrix pipe 61 % busy whatever the occupancy.)
+    auto piece_load = [&](auto vtag, const float *base, long pitch, int r, int rmax, int c, int cmax) -> float4 {
         constexpr int V = decltype(vtag)::value;
         const int rc = r < rmax ? r : rmax - 1;
         const float *src = base + (size_t)rc * pitch;
-        const bool rok = r < rmax;
-        float4 v;
-        // (bit masks, not selects: the compiler turns `cond ? 0 : load` into a branch around the load)
         if constexpr (V == 4) {
             const int cc = c < cmax ? c : cmax - 4;
-            v = *reinterpret_cast<const float4 *>(src + cc);
-            const unsigned keep = (rok && c < cmax) ? 0xffffffffu : 0u;
-            v.x = __uint_as_float(__float_as_uint(v.x) & keep); v.y = __uint_as_float(__float_as_uint(v.y) & keep);
-            v.z = __uint_as_float(__float_as_uint(v.z) & keep); v.w = __uint_as_float(__float_as_uint(v.w) & keep);
+            return *reinterpret_cast<const float4 *>(src + cc);
         } else if constexpr (V == 2) {
             const int ca = c < cmax ? c : cmax - 2, cb = c + 2 < cmax ? c + 2 : cmax - 2;
             const float2 lo = *reinterpret_cast<const float2 *>(src + ca), hi = *reinterpret_cast<const float2 *>(src + cb);
-            const unsigned k0 = (rok && c < cmax) ? 0xffffffffu : 0u, k1 = (rok && c + 2 < cmax) ? 0xffffffffu : 0u;
-            v.x = __uint_as_float(__float_as_uint(lo.x) & k0); v.y = __uint_as_float(__float_as_uint(lo.y) & k0);
-            v.z = __uint_as_float(__float_as_uint(hi.x) & k1); v.w = __uint_as_float(__float_as_uint(hi.y) & k1);
+            return make_float4(lo.x, lo.y, hi.x, hi.y);
         } else {
             const int c0 = c < cmax ? c : cmax - 1, c1 = c + 1 < cmax ? c + 1 : cmax - 1, c2 = c + 2 < cmax ? c + 2 : cmax - 1,
                       c3 = c + 3 < cmax ? c + 3 : cmax - 1;
-            v = make_float4(src[c0], src[c1], src[c2], src[c3]);
-            v.x = __uint_as_float(__float_as_uint(v.x) & ((rok && c < cmax) ? 0xffffffffu : 0u));
-            v.y = __uint_as_float(__float_as_uint(v.y) & ((rok && c + 1 < cmax) ? 0xffffffffu : 0u));
-            v.z = __uint_as_float(__float_as_uint(v.z) & ((rok && c + 2 < cmax) ? 0xffffffffu : 0u));
-            v.w = __uint_as_float(__float_as_uint(v.w) & ((rok && c + 3 < cmax) ? 0xffffffffu : 0u));
+            return make_float4(src[c0], src[c1], src[c2], src[c3]);
         }
+    };
+    // (bit masks, not selects; V == 4: the whole piece is in or out -- K % 4 == 0 / N % 4 == 0)
+    auto piece_mask = [&](auto vtag, float4 v, int r, int rmax, int c, int cmax) -> float4 {
+        constexpr int V = decltype(vtag)::value;
+        const bool rok = r < rmax;
+        unsigned k0, k1, k2, k3;
+        if constexpr (V == 4) k0 = k1 = k2 = k3 = (rok && c < cmax) ? 0xffffffffu : 0u;
+        else if constexpr (V == 2) { k0 = k1 = (rok && c < cmax) ? 0xffffffffu : 0u; k2 = k3 = (rok && c + 2 < cmax) ? 0xffffffffu : 0u; }
+        else {
+            k0 = (rok && c < cmax) ? 0xffffffffu : 0u; k1 = (rok && c + 1 < cmax) ? 0xffffffffu : 0u;
+            k2 = (rok && c + 2 < cmax) ? 0xffffffffu : 0u; k3 = (rok && c + 3 < cmax) ? 0xffffffffu : 0u;
+        }
+        v.x = __uint_as_float(__float_as_uint(v.x) & k0); v.y = __uint_as_float(__float_as_uint(v.y) & k1);
+        v.z = __uint_as_float(__float_as_uint(v.z) & k2); v.w = __uint_as_float(__float_as_uint(v.w) & k3);
         return v;
     };
+    constexpr int BV = AV > 1 ? 4 : 1;
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int p = (int)threadIdx.x + 256 * j;
-            ra[j] = piece(std::integral_constant<int, AV>{}, A, K, row0 + p / KQ, M, k0 + (p % KQ) * 4, K);
+            ra[j] = piece_load(std::integral_constant<int, AV>{}, A, K, row0 + p / KQ, M, k0 + (p % KQ) * 4, K);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            rb[j] = piece(std::integral_constant<int, (AV > 1 ? 4 : 1)>{}, B, N, k0 + (threadIdx.x >> 5) + 8 * j, K, col0 + (threadIdx.x & 31) * 4, N);
+            rb[j] = piece_load(std::integral_constant<int, BV>{}, B, N, k0 + (threadIdx.x >> 5) + 8 * j, K, col0 + (threadIdx.x & 31) * 4, N);
     };
-    auto stash = [&](float *As, float *Bs) {
+    auto stash = [&](float *As, float *Bs, int k0) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int p = (int)threadIdx.x + 256 * j;   // p / KQ < 128: inside the image whatever TM is
+            const float4 v = piece_mask(std::integral_constant<int, AV>{}, ra[j], row0 + p / KQ, M, k0 + (p % KQ) * 4, K);
             float *da = As + (p / KQ) * kBigPA + (p % KQ) * 4;
-            da[0] = ra[j].x; da[1] = ra[j].y; da[2] = ra[j].z; da[3] = ra[j].w;
+            da[0] = v.x; da[1] = v.y; da[2] = v.z; da[3] = v.w;
         }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) *reinterpret_cast<float4 *>(Bs + ((threadIdx.x >> 5) + 8 * j) * kBigT + (threadIdx.x & 31) * 4) = rb[j];
+        for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<float4 *>(Bs + ((threadIdx.x >> 5) + 8 * j) * kBigT + (threadIdx.x & 31) * 4) =
+                piece_mask(std::integral_constant<int, BV>{}, rb[j], k0 + (threadIdx.x >> 5) + 8 * j, K, col0 + (threadIdx.x & 31) * 4, N);
     };
     fetch(0);
-    stash(As0, Bs0);
+    stash(As0, Bs0, 0);
     __syncthreads();
     const int nchunks = (K + kBigKC - 1) / kBigKC;
     for (int c = 0; c < nchunks; ++c) {
@@ -506,7 +516,7 @@ __device__ __forceinline__ void dense_tile(const float *__restrict__ A, const fl
         for (int t = 0; t < kBigKC / 2; ++t)
 #pragma unroll
             for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
-        if (c + 1 < nchunks) stash((c & 1) ? As0 : As1, (c & 1) ? Bs0 : Bs1);   // the other buffer: last read in chunk c - 1
+        if (c + 1 < nchunks) stash((c & 1) ? As0 : As1, (c & 1) ? Bs0 : Bs1, (c + 1) * kBigKC);   // the other buffer: last read in chunk c - 1
         __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -531,6 +541,153 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_big(const float *__re
     const int col0 = blockIdx.y * kBigT;
     if (TMT == kBigT || (int)blockIdx.x < n_main) dense_tile<kBigT, AV>(A, B, C, M, N, K, blockIdx.x * kBigT, col0, big_lds);
     else dense_tile<TMT, AV>(A, B, C, M, N, K, n_main * kBigT + ((int)blockIdx.x - n_main) * TMT, col0, big_lds);
+}
+
+// Round 4: the same tile arithmetic as dense_tile, organised as PERSISTENT STRIPS.  The grid is what the chip holds at a time
+// (kBigWgs workgroups per CU); the 32-row blocks of the matrix are dealt evenly to the workgroups (strips differ by at most one block:
+// no partial last round -- 169 343 rows are 2.58 rounds of 512 tiles, and a round costs what a full one costs), a workgroup walks its
+// strip in tiles of up to 128 rows (the last one 32 / 64 / 96), and the chunk pipeline runs ACROSS tiles: the first K chunk of the
+// next tile is fetched during the last chunk of the current one, so the fetch latency at the head of a tile and the C stores at its
+// end are hidden too.  Per output the same ascending-k chain: bit-exact as before.
+template <int AV>
+__global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_strip(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                                 int M, int N, int K, int nb32, int nstrips)
+{
+    extern __shared__ float lds[];
+    constexpr int KQ = kBigKC / 4, NA = kBigT * KQ / 256, NB = kBigKC * (kBigT / 4) / 256, BV = AV > 1 ? 4 : 1;
+    const int col0 = blockIdx.y * kBigT;
+    const int q = nb32 / nstrips, extra = nb32 - q * nstrips, sidx = blockIdx.x;
+    const int blk0 = sidx * q + (sidx < extra ? sidx : extra), nblk = q + (sidx < extra ? 1 : 0);
+    if (nblk == 0) return;
+    float *As0 = lds, *As1 = lds + kBigT * kBigPA, *Bs0 = lds + 2 * kBigT * kBigPA, *Bs1 = Bs0 + kBigKC * kBigT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float4 ra[NA], rb[NB];
+    auto load_a = [&](int r, int c) -> float4 {   // clamped (always valid) addresses; zeroing happens at the stash
+        const int rc = r < M ? r : M - 1;
+        const float *src = A + (size_t)rc * K;
+        if constexpr (AV == 4) return *reinterpret_cast<const float4 *>(src + (c < K ? c : K - 4));
+        else if constexpr (AV == 2) {
+            const float2 lo = *reinterpret_cast<const float2 *>(src + (c < K ? c : K - 2)), hi = *reinterpret_cast<const float2 *>(src + (c + 2 < K ? c + 2 : K - 2));
+            return make_float4(lo.x, lo.y, hi.x, hi.y);
+        } else return make_float4(src[c < K ? c : K - 1], src[c + 1 < K ? c + 1 : K - 1], src[c + 2 < K ? c + 2 : K - 1], src[c + 3 < K ? c + 3 : K - 1]);
+    };
+    auto load_b = [&](int r, int c) -> float4 {
+        const int rc = r < K ? r : K - 1;
+        const float *src = B + (size_t)rc * N;
+        if constexpr (BV == 4) return *reinterpret_cast<const float4 *>(src + (c < N ? c : N - 4));
+        else return make_float4(src[c < N ? c : N - 1], src[c + 1 < N ? c + 1 : N - 1], src[c + 2 < N ? c + 2 : N - 1], src[c + 3 < N ? c + 3 : N - 1]);
+    };
+    auto keep4 = [](float4 v, bool k0, bool k1, bool k2, bool k3) -> float4 {   // bit masks, not selects
+        v.x = __uint_as_float(__float_as_uint(v.x) & (k0 ? 0xffffffffu : 0u)); v.y = __uint_as_float(__float_as_uint(v.y) & (k1 ? 0xffffffffu : 0u));
+        v.z = __uint_as_float(__float_as_uint(v.z) & (k2 ? 0xffffffffu : 0u)); v.w = __uint_as_float(__float_as_uint(v.w) & (k3 ? 0xffffffffu : 0u));
+        return v;
+    };
+    auto fetch = [&](int row0, int k0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int p = (int)threadIdx.x + 256 * j;
+            ra[j] = load_a(row0 + p / KQ, k0 + (p % KQ) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) rb[j] = load_b(k0 + (threadIdx.x >> 5) + 8 * j, col0 + (threadIdx.x & 31) * 4);
+    };
+    auto stash = [&](float *As, float *Bs, int row0, int k0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int p = (int)threadIdx.x + 256 * j;
+            const int r = row0 + p / KQ, c = k0 + (p % KQ) * 4;
+            const bool rok = r < M;
+            const float4 v = AV == 4 ? keep4(ra[j], rok && c < K, rok && c < K, rok && c < K, rok && c < K)
+                             : AV == 2 ? keep4(ra[j], rok && c < K, rok && c < K, rok && c + 2 < K, rok && c + 2 < K)
+                                       : keep4(ra[j], rok && c < K, rok && c + 1 < K, rok && c + 2 < K, rok && c + 3 < K);
+            float *da = As + (p / KQ) * kBigPA + (p % KQ) * 4;
+            da[0] = v.x; da[1] = v.y; da[2] = v.z; da[3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int r = k0 + (threadIdx.x >> 5) + 8 * j, c = col0 + (threadIdx.x & 31) * 4;
+            const bool rok = r < K;
+            *reinterpret_cast<float4 *>(Bs + ((threadIdx.x >> 5) + 8 * j) * kBigT + (threadIdx.x & 31) * 4) =
+                BV == 4 ? keep4(rb[j], rok && c < N, rok && c < N, rok && c < N, rok && c < N)
+                        : keep4(rb[j], rok && c < N, rok && c + 1 < N, rok && c + 2 < N, rok && c + 3 < N);
+        }
+    };
+    // rbk: 32-row blocks of the tile (workgroup-uniform): the blocks beyond it are skipped by scalar branches (one code path: four
+    // unrolled variants of the chunk keep four operand sets alive and spill)
+    auto mma = [&](int rbk, const float *As, const float *Bs) {
+        const float *ap = As + (lane & 31) * kBigPA + (lane >> 5);
+        const float *bp = Bs + (lane >> 5) * kBigT + 32 * wave + (lane & 31);
+        // operands of k-step t + 1 are requested before the MFMAs of k-step t (4 x 64 pipe cycles cover the LDS latency); rows of the
+        // image that belong to no block of the tile are read and never used
+        float a_cur[4], a_nxt[4], b_cur, b_nxt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_cur[i] = ap[i * 32 * kBigPA];
+        b_cur = bp[0];
+        // (s_setprio around the burst -- so that the two wavefronts that share a SIMD's matrix pipe fall out of phase -- measured:
+        // 201.1 against 202.2 us, nothing)
+#pragma unroll
+        for (int t = 0; t < kBigKC / 2; ++t) {
+            if (t + 1 < kBigKC / 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a_nxt[i] = ap[i * 32 * kBigPA + 2 * (t + 1)];
+                b_nxt = bp[2 * (t + 1) * kBigT];
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b_cur, acc[0], 0, 0, 0);
+            if (rbk > 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b_cur, acc[1], 0, 0, 0);
+            if (rbk > 2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b_cur, acc[2], 0, 0, 0);
+            if (rbk > 3) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b_cur, acc[3], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
+            b_cur = b_nxt;
+        }
+    };
+    const int nchunks = (K + kBigKC - 1) / kBigKC;
+    const int ntiles = (nblk + 3) >> 2, total = ntiles * nchunks;   // the strip as ONE sequence of chunks g = tile * nchunks + c
+    const int col = col0 + 32 * wave + (lane & 31);
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)((size_t)M * N * sizeof(float)), 0x00020000);   // (host-checked: < 2 GB)
+    auto row_of = [&](int g) { return (blk0 + 4 * (g / nchunks)) * 32; };
+    auto k_of = [&](int g) { return (g % nchunks) * kBigKC; };
+    // While chunk g is multiplied out of LDS buffer g & 1, chunk g + 1 travels to registers; after the MFMAs it goes to the other LDS
+    // buffer.  (A second register set -- chunk g + 2 requested during chunk g -- was built and measured: 206.7 against 201-205 us on the
+    // 512 -> 128 layer; the loads are not what the matrix pipe waits for.  profiles/r04/gemm.txt)
+    fetch(row_of(0), 0);
+    stash(As0, Bs0, row_of(0), 0);
+    __syncthreads();
+    for (int g = 0; g < total; ++g) {
+        const float *As = (g & 1) ? As1 : As0, *Bs = (g & 1) ? Bs1 : Bs0;
+        const int tile = g / nchunks, c = g - tile * nchunks;
+        const int row0 = (blk0 + 4 * tile) * 32;
+        const int rbk = nblk - 4 * tile < 4 ? nblk - 4 * tile : 4;   // 32-row blocks of this tile (workgroup-uniform)
+        // (unconditional: the last step re-requests the last chunk -- behind a branch the fetch registers meet in phi copies, and the
+        // copies wait for the loads that were just issued)
+        const int gn = g + 1 < total ? g + 1 : total - 1;
+        fetch(row_of(gn), k_of(gn));
+        mma(rbk, As, Bs);
+        if (c + 1 == nchunks) {
+            // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Buffer stores: ONE
+            // lane offset + a scalar offset per store (64 global addresses computed up front cost 128 registers while the next
+            // tile's fetch is in flight), and rows beyond M fall off the end of the buffer -- the hardware drops them
+            const unsigned voff = (unsigned)(((size_t)(row0 + 4 * (lane >> 5)) * N + col) * sizeof(float));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < rbk && col < N) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][reg]), crsrc, voff,
+                                                              (unsigned)((32 * i + (reg & 3) + 8 * (reg >> 2)) * N) * (unsigned)sizeof(float), 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) acc[i][reg] = 0.0f;
+            }
+        }
+        if (g + 1 < total) stash((g & 1) ? As0 : As1, (g & 1) ? Bs0 : Bs1, row_of(g + 1), k_of(g + 1));   // the other buffer: last read one chunk ago
+        __syncthreads();
+    }
 }
 
 // Tall-skinny variant for the aggregation widths (K <= 128, K % 4 == 0): every wavefront keeps its B operands -- the
@@ -646,6 +803,23 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
             // tiles the chip runs at a time: kBigWgs workgroups per CU, shared by the column tiles
             const int cus = device_cu_count();
             const int ncol = ceil_div(N, kBigT), slots = std::max(1, kBigWgs * cus / ncol);
+            if ((size_t)M * N * sizeof(float) < 0x7fffffffULL) {   // persistent strips (buffer stores into C: 2 GB); else the tile grid below
+                const int nb32 = ceil_div(M, 32), nstrips = std::min(slots, ceil_div(nb32, 2));
+                const dim3 sgrid(nstrips, ncol);
+#define STRIP_CALL(V_)                                                                                                                  \
+                {                                                                                                                       \
+                    static OncePerDevice attr_ok;                                                                                       \
+                    if (attr_ok.first()) {                                                                                              \
+                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_strip<V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        attr_ok.done();                                                                                                 \
+                    }                                                                                                                   \
+                    hipLaunchKernelGGL((k_dense_nn_strip<V_>), sgrid, dim3(256), lds, stream, A, B, C, M, N, K, nb32, nstrips);         \
+                }
+                if (av == 4) STRIP_CALL(4) else if (av == 2) STRIP_CALL(2) else STRIP_CALL(1)
+#undef STRIP_CALL
+                HIP_TRY(hipGetLastError());
+                return GNNAGG_OK;
+            }
             const int n_main = (int)(((long)M / kBigT) / slots) * slots;   // whole rounds of full 128-row tiles
             const int rem = M - n_main * kBigT;
             int tmt = kBigT;

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../gnn_computing_amd/csrc"
 make -s -j4
 mkdir -p build/ab
 objs=""
-for f in agg_gcn agg_gat agg_span aux_kernels; do
+for f in agg_gcn agg_gat agg_span aux_kernels plan_gpu; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form $2 -c $f.hip -o build/ab/${f}_$1.o &
   objs="$objs build/ab/${f}_$1.o"
 done

@@ -703,11 +703,14 @@ def test_gat_rows_mode_on_the_blocked_order_is_the_canonical_chain(F, H, slice_k
     assert_within(y.cpu().numpy(), ref, gat_scale(ptr, idx, att, x, H) + np.abs(ref), "gat chains on the blocked order")
     assert np.all(y.cpu().numpy()[np.diff(ptr) == 0] == 0)
     assert torch.equal(y, y2), "the chained form and the row kernels run the same chains"
-    one = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
-    one.set_option("slice_kb", slice_kb)
-    one.set_option("aux_stream", 0)
-    one.run(dev(x), dev(att), y2, 128, 0, heads=H)
-    assert torch.equal(y, y2)
+    for aux in (0, 1):   # rows with a sub-row above the threshold leave the chains: whole, on the workgroup-per-row kernel (head widths % 32 == 0)
+        one = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+        one.set_option("slice_kb", slice_kb)
+        one.set_option("rows_hub_edges", 150)
+        one.set_option("aux_stream", aux)
+        y2.fill_(7.0)
+        one.run(dev(x), dev(att), y2, 128, 0, heads=H)
+        assert one.rows_blocked_ranges() > 1 and torch.equal(y, y2), aux
     nv, nv2 = torch.full((E, H), 7.0, device=DEV), torch.full((E, H), 7.0, device=DEV)
     a.run(dev(x), dev(att), y2, 128, 0, heads=H, newval=nv)
     k.run(dev(x), dev(att), y, 128, 0, heads=H, newval=nv2)
