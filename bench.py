@@ -34,7 +34,7 @@ FEAT = 128
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 L2_PEAK_GBPS = 34500.0  # same guide, "L2": 4 MiB per XCD, ~34.5 TB/s aggregate (the 2-D blocked order gathers from L2)
 L2_GATHER_MEASURED_GBPS = 24500.0  # measured here: 256-byte row gathers from an XCD's own L2 (profiles/r02/gather_ceiling.txt)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def algorithmic_bytes(V, E, F, explicit_val=True):
@@ -64,7 +64,7 @@ def pmc_traffic(tag):
     -> scripts/prof_config.sh -> profiles/<round>/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, the
     gfx950 correction of MI355X_MICROARCH.md).  Returns (dominant kernel's bytes, all kernels' bytes per step, label, stale):
     `stale` is True when the build the counters were collected on is not the library running now."""
-    for rnd in (PROFILE_ROUND, "r02"):
+    for rnd in (PROFILE_ROUND, "r03", "r02"):
         f = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if os.path.exists(f):
             d = json.load(open(f)).get(tag)
@@ -268,8 +268,9 @@ def run_single(args, dev):
         "achieved_gbps": achieved,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (traffic_gbps / HBM_PEAK_GBPS) if traffic_gbps else achieved / HBM_PEAK_GBPS,
-                     "frac_is": ("counter traffic (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel, per launch) / average launch "
-                                 "time / 8 TB/s" if traffic_gbps else
+                     "frac_is": ("counter traffic (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel, per launch; the x 2 calibrated on this "
+                                 "kernel's own 512-byte row gathers: known bytes / counter = 1.986, profiles/r04/fetch_calibration.txt) / average "
+                                 "launch time / 8 TB/s" if traffic_gbps else
                                  "algorithmic bytes / average launch time / 8 TB/s (no counter file found)"),
                      "traffic": traffic, "traffic_source": traffic_label, "traffic_stale": traffic_stale,
                      "traffic_gbps": traffic_gbps,
@@ -334,6 +335,14 @@ def run_other_config(args, dev):
         B = algorithmic_bytes(V, E, F)
         kernel = "k_gcn_plan"
     steps, warm = min(args.steps, 20), min(args.warmup, 3)
+    # the first call builds the library-chosen order (on the device: plan_gpu.hip) and reserves the scratch; reported separately, like
+    # the reference's neighbor_grouping_schedule_time (graph_schedule.h:125-127)
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t_first
+    plan = agg.plan_info()
     wall, dev_s, med_s = time_steps(step, steps, warm, lambda: None)
     achieved = B / dev_s / 1e9
     # the gather probe of the same launch sequence (same id / value / attention-term loads and row gathers, no chains, no stores)
@@ -362,6 +371,10 @@ def run_other_config(args, dev):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "num_v": V, "num_e": E, "feat": F, "source_partitions": agg.balanced_partitions()},
             "achieved_gbps": achieved,
+            "schedule_prep_s": plan["plan_s"], "first_call_s": t_first, "plan_bytes": plan["plan_bytes"], "scratch_bytes": plan["scratch_bytes"],
+            "schedule_prep_is": "wall seconds the library-chosen order took to build inside the first call (0: the chunked plan, built on the host in "
+                                "O(V)); first_call_s = plan + scratch allocation + one step; plan_bytes / scratch_bytes = device memory the plan's "
+                                "arrays / the partial rows and tiled images hold",
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": frac, "frac_is": frac_is,
                          "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_label,
                          "traffic_stale": traffic_stale, "kernel": kernel, "algorithmic_bytes": B,

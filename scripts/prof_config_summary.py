@@ -27,10 +27,12 @@ try:
 except Exception:
     commit = os.environ.get("GNNAGG_BUILD_LABEL", "unknown")
 kernels = []
+PLAN_KERNELS = ("k_range_keys", "k_mark_row_starts", "k_rows_unsorted", "k_gather_sorted", "k_subrow_starts", "k_group_flags", "k_scatter_groups",
+                "k_count_groups", "k_iota", "k_flag_ids", "k_mark_hub_rows", "k_chain_", "k_gather_u32")
 print("# config %s %s -- per-launch averages; traffic = FETCH_SIZE*2*1024 + WRITE_SIZE*1024 (fabric side, Infinity-Cache hits included)" % (cfg, sys.argv[3] if len(sys.argv) > 3 else ""))
 tot = 0.0
 for k, (s, n) in sorted(dur.items(), key=lambda t: -t[1][0]):
-    if "gnnagg" not in k:
+    if "gnnagg" not in k or any(n in k for n in PLAN_KERNELS):   # (the plan builder's kernels run once per handle, not once per step)
         continue
     avg = s / n
     c = {name: v[0] / v[1] for name, v in pmc.get(k, {}).items()}
@@ -41,6 +43,12 @@ for k, (s, n) in sorted(dur.items(), key=lambda t: -t[1][0]):
         c.get("TCP_TCC_READ_REQ_sum", 0), c.get("TCC_EA0_RDREQ_sum", 0)))
     kernels.append({"kernel": k, "launches": n, "avg_us": avg, "traffic_bytes": traffic, "fetch_bytes": c.get("FETCH_SIZE", 0) * 2048,
                     "write_bytes": c.get("WRITE_SIZE", 0) * 1024, "l2_hit": hit})
+    if c.get("TCC_EA0_RDREQ_DRAM_sum") is not None and c.get("TCC_EA0_RDREQ_sum"):
+        # read requests that went on to DRAM (the rest of the fabric-side requests were served by the Infinity Cache); 128-B requests
+        print("      ea rd to DRAM %.4g of %.4g requests (%.3f) -> HBM fetch ~ %.2f GB of the %.2f GB fabric fetch; 128-B requests %.4g" % (
+            c["TCC_EA0_RDREQ_DRAM_sum"], c["TCC_EA0_RDREQ_sum"], c["TCC_EA0_RDREQ_DRAM_sum"] / c["TCC_EA0_RDREQ_sum"],
+            c.get("FETCH_SIZE", 0) * 2048 / 1e9 * c["TCC_EA0_RDREQ_DRAM_sum"] / c["TCC_EA0_RDREQ_sum"], c.get("FETCH_SIZE", 0) * 2048 / 1e9,
+            c.get("TCC_EA0_RDREQ_128B_sum", 0)))
     extra = {n: v for n, v in c.items() if n.startswith(("SQ_", "TA_", "GRBM", "TCP_TOTAL"))}
     if extra:
         print("      " + "  ".join("%s=%.4g" % (n, v) for n, v in sorted(extra.items())))
