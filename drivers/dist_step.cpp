@@ -52,6 +52,7 @@ static T *to_device(const std::vector<T> &h)
 int main(int argc, char **argv)
 {
     std::string dataset, datadir = "../data/", idfile = "/tmp/gnnagg_dist.id", plan = "overlap";
+    std::string stages = "1";   // staged exchange (overlap plan): K stripes of every peer's rows, or "owner" (one ring distance per stage)
     int feat = 128, iters = 20;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
@@ -61,9 +62,10 @@ int main(int argc, char **argv)
         else if (k == "--iters") iters = atoi(argv[i + 1]);
         else if (k == "--idfile") idfile = argv[i + 1];
         else if (k == "--plan") plan = argv[i + 1];
+        else if (k == "--stages") stages = argv[i + 1];
         else { fprintf(stderr, "unknown flag %s\n", k.c_str()); return 2; }
     }
-    if (dataset.empty()) { fprintf(stderr, "usage: dist_step.out --dataset D [--datadir DIR] [--feature-len F] [--iters K] [--idfile PATH] [--plan overlap|onepass]\n"); return 2; }
+    if (dataset.empty()) { fprintf(stderr, "usage: dist_step.out --dataset D [--datadir DIR] [--feature-len F] [--iters K] [--idfile PATH] [--plan overlap|onepass] [--stages K|owner]\n"); return 2; }
     const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), local_rank = env_int("LOCAL_RANK", 0);
     HCK(hipSetDevice(local_rank));
     gnnagg_set_abort_on_error(0);
@@ -102,11 +104,28 @@ int main(int argc, char **argv)
     HCK(hipMalloc((void **)&d_send_ids, sizeof(int) * std::max<long long>(n_send, 1)));
     CK(gnnagg_dist_alltoallv(comm, d_req, recv_rows.data(), d_send_ids, send_rows.data(), (int)sizeof(int), stream));
     HCK(hipStreamSynchronize(stream));
-    {   // global ids -> rows of the local X
-        std::vector<int> ids((size_t)n_send);
+    // staged exchange (gnnagg_halo_stage_plan): the halo tail and the send buffer become stage-major.  Requests went out owner-major
+    // in ascending id = the order the rows arrive in (a stage takes a contiguous slice of every list), so only the slots move.
+    const int stage_mode = stages == "owner" ? GNNAGG_STAGES_OWNER : GNNAGG_STAGES_STRIPE;
+    const int stage_k = stages == "owner" ? 1 : std::max(1, atoi(stages.c_str()));
+    int n_stages = 1;
+    CK(gnnagg_halo_stage_plan(nullptr, nullptr, world, rank, stage_mode, stage_k, &n_stages, nullptr, nullptr, nullptr, nullptr));
+    if (plan != "overlap") n_stages = 1;
+    std::vector<long long> stage_recv((size_t)n_stages * world), stage_send((size_t)n_stages * world);
+    std::vector<int> new_of_old((size_t)std::max(n_halo, 1)), send_order((size_t)std::max<long long>(n_send, 1));
+    if (n_stages > 1) {
+        CK(gnnagg_halo_stage_plan(recv_rows.data(), send_rows.data(), world, rank, stage_mode, stage_k, &n_stages, stage_recv.data(), new_of_old.data(),
+                                  stage_send.data(), send_order.data()));
+        for (auto &c : lidx)
+            if (c >= n_local) c = n_local + new_of_old[(size_t)(c - n_local)];
+    } else {
+        for (int p = 0; p < world; ++p) { stage_recv[p] = recv_rows[p]; stage_send[p] = send_rows[p]; }
+    }
+    {   // global ids -> rows of the local X, in the order the send buffer is packed in (stage-major)
+        std::vector<int> ids((size_t)n_send), staged((size_t)n_send);
         HCK(hipMemcpy(ids.data(), d_send_ids, sizeof(int) * n_send, hipMemcpyDeviceToHost));
-        for (auto &v : ids) v -= r0;
-        HCK(hipMemcpy(d_send_ids, ids.data(), sizeof(int) * n_send, hipMemcpyHostToDevice));
+        for (long long i = 0; i < n_send; ++i) staged[(size_t)i] = ids[(size_t)(n_stages > 1 ? send_order[(size_t)i] : i)] - r0;
+        HCK(hipMemcpy(d_send_ids, staged.data(), sizeof(int) * n_send, hipMemcpyHostToDevice));
     }
 
     // device state: local CSR (columns = X_ext slots), X_ext = [X_local ; X_halo], send buffer, Y
@@ -124,27 +143,41 @@ int main(int argc, char **argv)
     HCK(hipMemcpy(d_x_ext, hx.data(), sizeof(float) * hx.size(), hipMemcpyHostToDevice));
     float *d_x_halo = d_x_ext + (size_t)n_local * feat;
 
-    gnnagg_handle agg = 0, agg_loc = 0, agg_rem = 0;
+    gnnagg_handle agg = 0, agg_loc = 0;
+    std::vector<gnnagg_handle> agg_rem((size_t)n_stages, 0);
     gnnagg_dist_step_t dstep = 0;
-    int *d_pl = nullptr, *d_il = nullptr, *d_pr = nullptr, *d_ir = nullptr;
+    int *d_pl = nullptr, *d_il = nullptr;
+    std::vector<int *> d_stage_arrays;
     if (plan == "overlap") {
-        // the rank's CSR as two: edges whose source is an owned row (columns = local rows) and edges whose source is a halo
-        // row (columns = halo slots); in-row order kept
-        std::vector<int> pl((size_t)n_local + 1, 0), pr((size_t)n_local + 1, 0), il, ir;
+        // the rank's CSR as 1 + S: edges whose source is an owned row (columns = local rows) and, per stage, the edges whose source
+        // is a halo row that arrives in that stage (columns = halo slots); in-row order kept
+        std::vector<long long> stage0((size_t)n_stages + 1, 0);
+        for (int st = 0; st < n_stages; ++st) {
+            stage0[(size_t)st + 1] = stage0[(size_t)st];
+            for (int p = 0; p < world; ++p) stage0[(size_t)st + 1] += stage_recv[(size_t)st * world + p];
+        }
+        auto stage_of = [&](int slot) { int st = 0; while (st + 1 < n_stages && slot >= stage0[(size_t)st + 1]) ++st; return st; };
+        std::vector<int> pl((size_t)n_local + 1, 0), il;
+        std::vector<std::vector<int>> pr((size_t)n_stages, std::vector<int>((size_t)n_local + 1, 0)), ir((size_t)n_stages);
         for (int r = 0; r < n_local; ++r) {
             for (int e = lptr[r]; e < lptr[r + 1]; ++e) {
                 if (lidx[e] < n_local) il.push_back(lidx[e]);
-                else ir.push_back(lidx[e] - n_local);
+                else ir[(size_t)stage_of(lidx[e] - n_local)].push_back(lidx[e] - n_local);
             }
             pl[r + 1] = (int)il.size();
-            pr[r + 1] = (int)ir.size();
+            for (int st = 0; st < n_stages; ++st) pr[(size_t)st][r + 1] = (int)ir[(size_t)st].size();
         }
-        d_pl = to_device(pl); d_il = to_device(il); d_pr = to_device(pr); d_ir = to_device(ir);
+        d_pl = to_device(pl); d_il = to_device(il);
         CK(gnnagg_gcn_create(d_pl, d_il, nullptr, n_local, (int)il.size(), &agg_loc));
-        CK(gnnagg_gcn_create(d_pr, d_ir, nullptr, n_local, (int)ir.size(), &agg_rem));
         CK(gnnagg_schedule_balanced(agg_loc, 0));
-        CK(gnnagg_schedule_balanced(agg_rem, 0));
-        CK(gnnagg_dist_step_create(comm, agg_loc, n_halo > 0 ? agg_rem : 0, d_send_ids, send_rows.data(), recv_rows.data(), &dstep));
+        for (int st = 0; st < n_stages; ++st) {
+            if (ir[(size_t)st].empty()) continue;
+            int *dp = to_device(pr[(size_t)st]), *di = to_device(ir[(size_t)st]);
+            d_stage_arrays.push_back(dp); d_stage_arrays.push_back(di);
+            CK(gnnagg_gcn_create(dp, di, nullptr, n_local, (int)ir[(size_t)st].size(), &agg_rem[(size_t)st]));
+            CK(gnnagg_schedule_balanced(agg_rem[(size_t)st], 0));
+        }
+        CK(gnnagg_dist_step_create_staged(comm, agg_loc, n_stages, agg_rem.data(), d_send_ids, stage_send.data(), stage_recv.data(), &dstep));
     } else {
         CK(gnnagg_gcn_create(d_ptr, d_idx, nullptr, n_local, nnz, &agg));
         CK(gnnagg_set_stream(agg, stream));
@@ -171,9 +204,9 @@ int main(int argc, char **argv)
     const double sec = ms * 1e-3 / iters;
     // a checksum of the halo rows against what their owners hold is the launcher's job at world > 1; at world == 1 there is
     // no halo and the step is the single-GPU aggregation
-    fprintf(stderr, "{\"plan\": \"%s\", \"rank\": %d, \"world\": %d, \"n_local\": %d, \"nnz_local\": %d, \"n_halo\": %d, \"n_send\": %lld, \"seconds\": %.9f, "
+    fprintf(stderr, "{\"plan\": \"%s\", \"stages\": %d, \"rank\": %d, \"world\": %d, \"n_local\": %d, \"nnz_local\": %d, \"n_halo\": %d, \"n_send\": %lld, \"seconds\": %.9f, "
                     "\"edges_per_s\": %.6e, \"halo_bytes\": %.0f}\n",
-            plan.c_str(), rank, world, n_local, nnz, n_halo, n_send, sec, (double)nnz / sec, (double)n_halo * feat * 4.0);
+            plan.c_str(), n_stages, rank, world, n_local, nnz, n_halo, n_send, sec, (double)nnz / sec, (double)n_halo * feat * 4.0);
     // the slowest rank bounds the step: gather the times on rank 0
     {
         std::vector<double> mine(1, sec), all((size_t)world, 0.0);
@@ -193,7 +226,8 @@ int main(int argc, char **argv)
     if (dstep) CK(gnnagg_dist_step_destroy(dstep));
     if (agg) CK(gnnagg_destroy(agg));
     if (agg_loc) CK(gnnagg_destroy(agg_loc));
-    if (agg_rem) CK(gnnagg_destroy(agg_rem));
+    for (gnnagg_handle hr : agg_rem)
+        if (hr) CK(gnnagg_destroy(hr));
     CK(gnnagg_dist_comm_destroy(comm));
     gnnagg_free_host(halo_ids); gnnagg_free_host(h_ptr); gnnagg_free_host(h_idx);
     if (rank == 0) remove(idfile.c_str());

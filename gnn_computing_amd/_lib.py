@@ -90,6 +90,7 @@ SIGNATURES = {
     "gnnagg_partition_rows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "gnnagg_halo_plan": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, PP_INT,
                                  c_void_p, P_INT]),
+    "gnnagg_halo_stage_plan": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, P_INT, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gnnagg_pack_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "gnnagg_halo_plan_slice": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, PP_INT,
                                        c_void_p, P_INT]),

@@ -2266,6 +2266,24 @@ int gnnagg_halo_plan_slice(const int *h_ptr_slice, const int *h_idx_slice, int n
                            h_halo_counts, num_halo);
 }
 
+int gnnagg_halo_stage_plan(const long long *h_recv_rows, const long long *h_send_rows, int world, int rank, int mode, int k, int *n_stages,
+                           long long *h_stage_recv, int *h_new_of_old, long long *h_stage_send, int *h_send_order)
+{
+    if (world <= 0 || rank < 0 || rank >= world || (mode != GNNAGG_STAGES_STRIPE && mode != GNNAGG_STAGES_OWNER) || (mode == GNNAGG_STAGES_STRIPE && (k < 1 || k > 64)) ||
+        (mode == GNNAGG_STAGES_OWNER && world > 65) || !n_stages)
+        return fail(GNNAGG_ERR_ARG, "bad halo_stage_plan arguments (stripe: 1 <= k <= 64; owner: world <= 65)");
+    *n_stages = halo_stage_count(world, mode, k);
+    if (h_recv_rows) {
+        if (!h_stage_recv) return fail(GNNAGG_ERR_ARG, "halo_stage_plan: null stage_recv");
+        halo_stage_plan_recv(h_recv_rows, world, rank, mode, k, h_stage_recv, h_new_of_old);
+    }
+    if (h_send_rows) {
+        if (!h_stage_send) return fail(GNNAGG_ERR_ARG, "halo_stage_plan: null stage_send");
+        halo_stage_plan_send(h_send_rows, world, rank, mode, k, h_stage_send, h_send_order);
+    }
+    return GNNAGG_OK;
+}
+
 int gnnagg_pack_rows(const float *d_x, const int *d_ids, int n, int feat, float *d_out, void *hip_stream)
 {
     if (n < 0 || feat <= 0 || (n > 0 && (!d_x || !d_ids || !d_out))) return fail(GNNAGG_ERR_ARG, "bad pack_rows arguments");

@@ -23,6 +23,9 @@ int halo_plan_slice(const int *ptr_slice, const int *idx_slice, int num_cols, co
                     int *lidx, int **halo_ids_o, int *halo_counts, int *num_halo);
 int halo_plan(const int *ptr, const int *idx, int V, const int *bounds, int nparts, int rank, int *lptr, int *lidx,
               int **halo_ids_o, int *halo_counts, int *num_halo);
+int halo_stage_count(int world, int mode, int k);
+void halo_stage_plan_recv(const long long *recv_rows, int world, int rank, int mode, int k, long long *stage_recv, int *new_of_old);
+void halo_stage_plan_send(const long long *send_rows, int world, int rank, int mode, int k, long long *stage_send, int *order);
 
 // ---- reorder.cpp
 int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int num_perm, int cap, uint64_t seed,

@@ -339,6 +339,55 @@ int halo_plan_slice(const int *ptr_slice, const int *idx_slice, int num_cols, co
     return GNNAGG_OK;
 }
 
+// ---- staged exchange: how one (reader <- owner) list of n rows is cut into stages.  Both ends of a pair call this with the same n,
+// so they cut the list the same way.  mode 0 ("stripe"): slice j of k of every list; mode 1 ("owner"): the whole list in the stage
+// of the pair's ring distance (reader - owner) mod world - 1.
+static long long stage_share(long long n, int reader, int owner, int world, int mode, int k, int stage)
+{
+    if (mode == 1) return ((reader - owner - 1 + 2 * world) % world) == stage ? n : 0;
+    return n * (stage + 1) / k - n * stage / k;
+}
+
+int halo_stage_count(int world, int mode, int k) { return world <= 1 ? 1 : mode == 1 ? std::max(world - 1, 1) : std::max(k, 1); }
+
+// Receiving side: recv_rows[owner] rows in owner-major order -> stage_recv[S][world] and, for every owner-major halo slot, its
+// stage-major slot (stage, then owner, then the list's own order).
+void halo_stage_plan_recv(const long long *recv_rows, int world, int rank, int mode, int k, long long *stage_recv, int *new_of_old)
+{
+    const int S = halo_stage_count(world, mode, k);
+    std::vector<long long> owner0((size_t)world + 1, 0), taken((size_t)world, 0);
+    for (int o = 0; o < world; ++o) owner0[o + 1] = owner0[o] + recv_rows[o];
+    long long pos = 0;
+    for (int s = 0; s < S; ++s)
+        for (int o = 0; o < world; ++o) {
+            const long long c = (world <= 1 || S == 1) ? recv_rows[o] : stage_share(recv_rows[o], rank, o, world, mode, k, s);
+            stage_recv[(size_t)s * world + o] = c;
+            if (new_of_old)
+                for (long long i = 0; i < c; ++i) new_of_old[owner0[o] + taken[o] + i] = (int)(pos + i);
+            taken[o] += c;
+            pos += c;
+        }
+}
+
+// Sending side: send_rows[reader] rows in reader-major order (every reader's list in ITS arrival order: stage by stage) ->
+// stage_send[S][world] and order[stage-major position] = index into the reader-major list.
+void halo_stage_plan_send(const long long *send_rows, int world, int rank, int mode, int k, long long *stage_send, int *order)
+{
+    const int S = halo_stage_count(world, mode, k);
+    std::vector<long long> reader0((size_t)world + 1, 0), taken((size_t)world, 0);
+    for (int q = 0; q < world; ++q) reader0[q + 1] = reader0[q] + send_rows[q];
+    long long pos = 0;
+    for (int s = 0; s < S; ++s)
+        for (int q = 0; q < world; ++q) {
+            const long long c = (world <= 1 || S == 1) ? send_rows[q] : stage_share(send_rows[q], q, rank, world, mode, k, s);
+            stage_send[(size_t)s * world + q] = c;
+            if (order)
+                for (long long i = 0; i < c; ++i) order[pos + i] = (int)(reader0[q] + taken[q] + i);
+            taken[q] += c;
+            pos += c;
+        }
+}
+
 int halo_plan(const int *ptr, const int *idx, int V, const int *bounds, int nparts, int rank, int *lptr,
               int *lidx, int **halo_ids_o, int *halo_counts, int *num_halo)
 {

@@ -191,22 +191,27 @@ class HaloExchange:
         else:
             self._exchange_requests()  # one-time: tell every owner which of its rows this rank needs
 
-    @staticmethod
-    def stage_counts(n_rows, rank, world, mode, k):
-        """[S][world] rows of the (reader <- owner) lists `n_rows[owner]` that travel in each stage, for reader `rank`.  Both ends
-        of a pair call this with the same list length, so they cut it the same way: "stripe": slice j of K of every owner's list;
-        "owner": stage s = the owner at ring distance s + 1 behind the reader (its whole list)."""
-        n_rows = [int(v) for v in n_rows]
-        if mode == "owner":
-            out = np.zeros((max(world - 1, 1), world), np.int64)
-            for s in range(world - 1):
-                o = (rank - s - 1) % world
-                out[s, o] = n_rows[o]
-            return out
-        out = np.zeros((k, world), np.int64)
-        for o in range(world):
-            for j in range(k):
-                out[j, o] = n_rows[o] * (j + 1) // k - n_rows[o] * j // k
+    def _stage_plan(self, recv_rows=None, send_rows=None):
+        """gnnagg_halo_stage_plan (host C++, host_graph.cpp): the stage counts and slot / send-order permutations of this rank"""
+        w = self.world
+        mode = 1 if self.stage_mode == "owner" else 0
+        ns = ctypes.c_int(0)
+        check(lib().gnnagg_halo_stage_plan(None, None, w, self.rank, mode, max(self.stage_k, 1), ctypes.byref(ns), None, None, None, None))
+        S = ns.value
+        out = {"n_stages": S}
+        ll = lambda a: np.ascontiguousarray(a, dtype=np.int64)   # noqa: E731
+        if recv_rows is not None:
+            rr = ll(recv_rows)
+            st, perm = np.zeros((S, w), np.int64), np.zeros(max(int(rr.sum()), 1), np.int32)
+            check(lib().gnnagg_halo_stage_plan(rr.ctypes.data, None, w, self.rank, mode, max(self.stage_k, 1), ctypes.byref(ns), st.ctypes.data,
+                                               perm.ctypes.data, None, None))
+            out["stage_recv"], out["new_of_old"] = st, perm[:int(rr.sum())]
+        if send_rows is not None:
+            sr = ll(send_rows)
+            st, order = np.zeros((S, w), np.int64), np.zeros(max(int(sr.sum()), 1), np.int32)
+            check(lib().gnnagg_halo_stage_plan(None, sr.ctypes.data, w, self.rank, mode, max(self.stage_k, 1), ctypes.byref(ns), None, None,
+                                               st.ctypes.data, order.ctypes.data))
+            out["stage_send"], out["send_order"] = st, order[:int(sr.sum())]
         return out
 
     def _plan_stages(self, stages):
@@ -226,27 +231,14 @@ class HaloExchange:
         if w == 1 or (mode == "stripe" and k == 1):
             mode, k = "stripe", 1
         self.stage_mode, self.stage_k = mode, k
-        self.stage_recv = self.stage_counts(self.recv_counts, self.rank, w, mode, k)       # [S][owner]
-        self.n_stages = int(self.stage_recv.shape[0])
+        plan = self._stage_plan(recv_rows=self.recv_counts)
+        self.stage_recv, self.n_stages = plan["stage_recv"], plan["n_stages"]        # [S][owner]
         self.stage_recv0 = np.concatenate([[0], np.cumsum(self.stage_recv.sum(axis=1))]).astype(np.int64)   # first halo slot of a stage
+        self.stage_of_slot = np.repeat(np.arange(self.n_stages, dtype=np.int32), self.stage_recv.sum(axis=1))
         if self.n_stages == 1:
-            self.stage_of_slot = np.zeros(self.n_halo, np.int32)
             return
         # old slot order: owner-major, ascending id.  new: stage-major, then owner, then ascending id
-        owner0 = np.concatenate([[0], np.cumsum(self.recv_counts)]).astype(np.int64)
-        new_of_old = np.empty(self.n_halo, np.int64)
-        stage_of_new = np.empty(self.n_halo, np.int32)
-        pos = 0
-        taken = np.zeros(w, np.int64)
-        for s in range(self.n_stages):
-            for o in range(w):
-                c = int(self.stage_recv[s, o])
-                if c:
-                    new_of_old[owner0[o] + taken[o]: owner0[o] + taken[o] + c] = np.arange(pos, pos + c)
-                    stage_of_new[pos: pos + c] = s
-                    taken[o] += c
-                    pos += c
-        assert pos == self.n_halo
+        new_of_old = plan["new_of_old"].astype(np.int64)
         ids = np.empty_like(self.halo_ids)
         ids[new_of_old] = self.halo_ids
         self.halo_ids = ids
@@ -254,20 +246,11 @@ class HaloExchange:
         li = self.local_idx.copy()
         li[is_halo] = (new_of_old[self.local_idx[is_halo] - self.n_local] + self.n_local).astype(li.dtype)
         self.local_idx = li
-        self.stage_of_slot = stage_of_new
-        # the request lists go out owner-major (one all-to-all), each owner's list in the order its rows will arrive: stage by stage
-        self._req_order = np.argsort(self._owner_of_new(), kind="stable")
-
-    def _owner_of_new(self):
-        """owner of every (stage-major) halo slot"""
-        out = np.empty(self.n_halo, np.int64)
-        pos = 0
-        for s in range(self.n_stages):
-            for o in range(self.world):
-                c = int(self.stage_recv[s, o])
-                out[pos: pos + c] = o
-                pos += c
-        return out
+        # the request lists go out owner-major (one all-to-all), each owner's list in the order its rows will arrive (stage by stage):
+        # the owner-major slots sorted by their new slot inside every owner = argsort of new_of_old per owner = its inverse restricted
+        owner_of_old = np.repeat(np.arange(w), self.recv_counts)
+        self._req_order = np.lexsort((new_of_old, owner_of_old))      # positions in the OLD (owner-major) list ...
+        self._req_order = new_of_old[self._req_order]                 # ... as indices into the renumbered halo_ids
 
     def _exchange_requests(self):
         w = self.world
@@ -287,22 +270,10 @@ class HaloExchange:
                                    input_split_sizes=self.recv_counts.tolist(), group=self.group)
         # rows of the LOCAL x to pack, in the order the peers expect them: stage-major, reader by reader inside a stage.  What
         # reader q receives from this rank in stage s is what stage_counts says for q's list of this rank's rows
-        self.stage_send = np.zeros((self.n_stages, w), np.int64)
-        for q in range(w):
-            n_q = np.zeros(w, np.int64)
-            n_q[self.rank] = self.send_counts[q]
-            self.stage_send[:, q] = self.stage_counts(n_q, q, w, self.stage_mode, self.stage_k)[:self.n_stages, self.rank] if w > 1 else 0
+        plan = self._stage_plan(send_rows=self.send_counts)
+        self.stage_send = plan["stage_send"]
         if self.n_stages > 1:
-            reader0 = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
-            taken = np.zeros(w, np.int64)
-            order = []
-            for st in range(self.n_stages):
-                for q in range(w):
-                    c = int(self.stage_send[st, q])
-                    order.append(np.arange(reader0[q] + taken[q], reader0[q] + taken[q] + c))
-                    taken[q] += c
-            order = np.concatenate(order) if order else np.zeros(0, np.int64)
-            serve = serve[torch.from_numpy(order).to(serve.device)]
+            serve = serve[torch.from_numpy(plan["send_order"].astype(np.int64)).to(serve.device)]
         self.stage_send0 = np.concatenate([[0], np.cumsum(self.stage_send.sum(axis=1))]).astype(np.int64)
         self.send_ids = (serve - self.row0).to(self.device)
         self.n_send = int(self.send_ids.numel())

@@ -337,6 +337,22 @@ int gnnagg_halo_plan(const int *h_ptr, const int *h_idx, int num_v, const int *h
  * the other ranks' rows is needed (gnnagg_halo_plan reads the same data out of a global CSR). */
 int gnnagg_halo_plan_slice(const int *h_ptr_slice, const int *h_idx_slice, int num_cols, const int *h_bounds, int nparts, int rank,
                            int *h_local_ptr, int *h_local_idx, int **h_halo_ids, int *h_halo_counts, int *num_halo);
+/* The stage plan of a staged halo exchange (gnnagg_dist_step_create_staged): how the rows of every (reader <- owner) list are dealt
+ * to stages.  GNNAGG_STAGES_STRIPE: every stage takes slice j of k of EVERY list (each stage keeps all links of the xGMI mesh busy);
+ * GNNAGG_STAGES_OWNER: stage s carries the whole lists of the pairs at ring distance s + 1 (world - 1 stages, one peer per stage).
+ * Both ends of a pair cut their common list by the same rule, so no coordination is needed.
+ *   receiving side (h_recv_rows[world], rows per owner in gnnagg_halo_plan's owner-major slot order; NULL to skip):
+ *     h_stage_recv[n_stages][world], h_new_of_old[n_halo] (may be NULL) = the stage-major slot of every owner-major slot: renumber
+ *     the halo columns of the local CSR and the halo id list with it; requests still go out owner-major, every owner's list in
+ *     the order its rows will ARRIVE (stage by stage)
+ *   sending side (h_send_rows[world], rows per reader as served reader-major; NULL to skip):
+ *     h_stage_send[n_stages][world], h_send_order[n_send] (may be NULL) = for every stage-major position of the send buffer the index
+ *     into the reader-major serve list
+ * *n_stages is always written (call with both lists NULL to size the outputs). */
+#define GNNAGG_STAGES_STRIPE 0
+#define GNNAGG_STAGES_OWNER 1
+int gnnagg_halo_stage_plan(const long long *h_recv_rows, const long long *h_send_rows, int world, int rank, int mode, int k, int *n_stages,
+                           long long *h_stage_recv, int *h_new_of_old, long long *h_stage_send, int *h_send_order);
 /* out[i,:] = x[ids[i],:] for i < n  (send-buffer pack before the all-to-all) */
 int gnnagg_pack_rows(const float *d_x, const int *d_ids, int n, int feat, float *d_out, void *hip_stream);
 

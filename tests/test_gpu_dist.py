@@ -156,7 +156,7 @@ def test_dist_step_driver_single_rank(tmp_path):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")])
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     for plan in ("overlap", "onepass"):   # overlap: ONE host call per step (gnnagg_dist_step_gcn)
-        r = subprocess.run([exe, "--dataset", "tiny", "--datadir", d, "--feature-len", "64", "--iters", "5", "--idfile", d + "id", "--plan", plan],
+        r = subprocess.run([exe, "--dataset", "tiny", "--datadir", d, "--feature-len", "64", "--iters", "5", "--idfile", d + "id", "--plan", plan, "--stages", "3"],
                            capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")]

@@ -123,3 +123,40 @@ def test_partition_and_halo_plan(nparts):
         owners = np.searchsorted(b, p["halo_ids"], side="right") - 1
         assert np.array_equal(np.bincount(owners, minlength=nparts), p["halo_counts"])
     assert seen_rows == V
+
+
+@pytest.mark.parametrize("world,mode,k", [(4, 0, 3), (8, 0, 4), (5, 1, 1), (8, 1, 1), (3, 0, 1), (1, 0, 2)])
+def test_halo_stage_plan_both_ends_of_every_pair_agree(world, mode, k):
+    """gnnagg_halo_stage_plan (the staged halo exchange's plan, host C++): for every pair the sender's share of a stage is the
+    receiver's, every row travels in exactly one stage, the slot / send-order maps are permutations that keep a list's own order inside
+    a (stage, peer) cell; stripes give every stage a slice of EVERY peer's list, owner stages name one ring distance each."""
+    import ctypes
+    L = gnc.lib()
+    rng = np.random.default_rng(world * 10 + mode)
+    rows = rng.integers(0, 50, (world, world)).astype(np.int64)     # rows[reader][owner]
+    np.fill_diagonal(rows, 0)
+    ns = ctypes.c_int(0)
+    plans = []
+    for r in range(world):
+        recv, send = np.ascontiguousarray(rows[r]), np.ascontiguousarray(rows[:, r])
+        assert L.gnnagg_halo_stage_plan(None, None, world, r, mode, k, ctypes.byref(ns), None, None, None, None) == 0
+        S = ns.value
+        assert S == (1 if world == 1 else (world - 1 if mode == 1 else k))
+        st_r, st_s = np.zeros((S, world), np.int64), np.zeros((S, world), np.int64)
+        perm, order = np.zeros(max(int(recv.sum()), 1), np.int32), np.zeros(max(int(send.sum()), 1), np.int32)
+        assert L.gnnagg_halo_stage_plan(recv.ctypes.data, send.ctypes.data, world, r, mode, k, ctypes.byref(ns), st_r.ctypes.data, perm.ctypes.data,
+                                        st_s.ctypes.data, order.ctypes.data) == 0
+        assert np.array_equal(st_r.sum(axis=0), recv) and np.array_equal(st_s.sum(axis=0), send)
+        n_r, n_s = int(recv.sum()), int(send.sum())
+        assert sorted(perm[:n_r].tolist()) == list(range(n_r)) and sorted(order[:n_s].tolist()) == list(range(n_s))
+        # inside one owner's list the new slots ascend (the rows of a list arrive in the list's own order)
+        o0 = np.concatenate([[0], np.cumsum(recv)])
+        assert all(np.all(np.diff(perm[o0[o]:o0[o + 1]]) > 0) for o in range(world))
+        if mode == 1 and world > 1:
+            assert all(np.count_nonzero(st_r[s]) <= 1 and np.count_nonzero(st_s[s]) <= 1 for s in range(S))
+        plans.append((st_r, st_s))
+    for r in range(world):
+        for q in range(world):
+            assert np.array_equal(plans[r][1][:, q], plans[q][0][:, r])      # what r sends q in a stage is what q expects from r
+    assert L.gnnagg_halo_stage_plan(None, None, 0, 0, 0, 1, ctypes.byref(ns), None, None, None, None) != 0
+    assert L.gnnagg_halo_stage_plan(None, None, 2, 0, 0, 0, ctypes.byref(ns), None, None, None, None) != 0
