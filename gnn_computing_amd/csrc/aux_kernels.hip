@@ -549,6 +549,12 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_big(const float *__re
 // strip in tiles of up to 128 rows (the last one 32 / 64 / 96), and the chunk pipeline runs ACROSS tiles: the first K chunk of the
 // next tile is fetched during the last chunk of the current one, so the fetch latency at the head of a tile and the C stores at its
 // end are hidden too.  Per output the same ascending-k chain: bit-exact as before.
+#ifdef GNNAGG_GEMM_TIMELINE   // A/B builds only (scripts/exp_gemm_timeline.py): s_memtime stamps of wave 0 of every workgroup, six per chunk
+__device__ unsigned long long *g_gemm_tl = nullptr;
+#define TL_STAMP(slot) do { if (g_gemm_tl && threadIdx.x == 0 && g < 64) g_gemm_tl[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + g) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TL_STAMP(slot) do { } while (0)
+#endif
 template <int AV>
 __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_strip(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                                  int M, int N, int K, int nb32, int nstrips)
@@ -666,8 +672,11 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_strip(const float *__
         // (unconditional: the last step re-requests the last chunk -- behind a branch the fetch registers meet in phi copies, and the
         // copies wait for the loads that were just issued)
         const int gn = g + 1 < total ? g + 1 : total - 1;
+        TL_STAMP(0);
         fetch(row_of(gn), k_of(gn));
+        TL_STAMP(1);
         mma(rbk, As, Bs);
+        TL_STAMP(2);
         if (c + 1 == nchunks) {
             // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Buffer stores: ONE
             // lane offset + a scalar offset per store (64 global addresses computed up front cost 128 registers while the next
@@ -685,8 +694,174 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_strip(const float *__
                 for (int reg = 0; reg < 16; ++reg) acc[i][reg] = 0.0f;
             }
         }
+        TL_STAMP(3);
         if (g + 1 < total) stash((g & 1) ? As0 : As1, (g & 1) ? Bs0 : Bs1, row_of(g + 1), k_of(g + 1));   // the other buffer: last read one chunk ago
+        TL_STAMP(4);
         __syncthreads();
+        TL_STAMP(5);
+    }
+}
+
+// Round 4, second step: the LEAN form of the strip kernel.  A per-phase timeline (scripts/exp_gemm_timeline.py, s_memtime stamps) showed
+// where a chunk goes: issuing the 8 loads of the next chunk 20 % of the period, the 64 MFMAs 35 %, the stash 20 %, the barrier 12 % -- and the
+// MFMA phase runs at 80 ticks per MFMA, i.e. the two wavefronts of a SIMD ALTERNATE: while one bursts, every other instruction of its
+// neighbour (address arithmetic, clamps, masks, LDS writes: ~210 per chunk) trickles out between MFMAs at ~30 ticks apiece.  The matrix
+// pipe is busy 2 x 35 %.  So everything that is not an MFMA or an operand read is made cheap in INSTRUCTIONS:
+//   * A and B come through buffer descriptors REBASED per chunk in scalar registers (base = A + row0 * K + k0): the per-thread offsets are
+//     computed once per kernel, a fetch is 8 buffer loads and a handful of scalar instructions, and rows beyond M / k beyond K are
+//     out of range of the descriptor -- the hardware returns zeros, no clamps, no masks;
+//   * only the ragged last K chunk (K % 32 != 0: the 602-wide layer) masks, behind a workgroup-uniform branch;
+//   * the chunk / tile counters advance by addition (g / nchunks was an integer division per chunk).
+// Needs N % 128 == 0, K even and 8-byte aligned rows; other shapes keep k_dense_nn_strip.  Same arithmetic: bit-exact.
+template <int AV>
+__global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_lean(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                                int M, int N, int K, int nb32, int nstrips)
+{
+    static_assert(AV == 4 || AV == 2, "lean form: 16- or 8-byte loads of A");
+    extern __shared__ float lds[];
+    constexpr int KQ = kBigKC / 4, NA = kBigT * KQ / 256, NB = kBigKC * (kBigT / 4) / 256;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const int col0 = blockIdx.y * kBigT;
+    const int q = nb32 / nstrips, extra = nb32 - q * nstrips, sidx = blockIdx.x;
+    const int blk0 = sidx * q + (sidx < extra ? sidx : extra), nblk = q + (sidx < extra ? 1 : 0);
+    if (nblk == 0) return;
+    float *As0 = lds, *As1 = lds + kBigT * kBigPA, *Bs0 = lds + 2 * kBigT * kBigPA, *Bs1 = Bs0 + kBigKC * kBigT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    // per-thread constants: byte offsets of this thread's pieces inside a chunk (global) and inside the LDS images
+    int voa[NA], vob[NB], la[NA], lb[NB];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int p = (int)threadIdx.x + 256 * j;
+        voa[j] = ((p / KQ) * K + (p % KQ) * 4) * (int)sizeof(float);
+        la[j] = (p / KQ) * kBigPA + (p % KQ) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        vob[j] = (((int)(threadIdx.x >> 5) + 8 * j) * N + (int)(threadIdx.x & 31) * 4) * (int)sizeof(float);
+        lb[j] = ((int)(threadIdx.x >> 5) + 8 * j) * kBigT + (int)(threadIdx.x & 31) * 4;
+    }
+    const size_t a_bytes = (size_t)M * K * sizeof(float), b_bytes = (size_t)K * N * sizeof(float);
+    float4 ra[NA], rb[NB];
+    // chunk (row0, k0): descriptors whose first byte is A[row0][k0] / B[k0][col0] and whose size is what is left of the matrix (capped at
+    // 4 GB - 4: a tile is 128 rows, the cap is never what decides a row of it)
+    auto fetch = [&](int row0, int k0) {
+        const size_t ao = ((size_t)row0 * K + k0) * sizeof(float), bo = ((size_t)k0 * N + col0) * sizeof(float);
+        const size_t ar = ao < a_bytes ? a_bytes - ao : 0, br = bo < b_bytes ? b_bytes - bo : 0;
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A) + ((size_t)row0 * K + k0), 0,
+                                                                                (int)(unsigned)(ar < 0xfffffffcULL ? ar : 0xfffffffcULL), 0x00020000);
+        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B) + ((size_t)k0 * N + col0), 0,
+                                                                                (int)(unsigned)(br < 0xfffffffcULL ? br : 0xfffffffcULL), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            if constexpr (AV == 4) {
+                const u4 v = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voa[j], 0, 0);
+                ra[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            } else {
+                const u2 lo = __builtin_amdgcn_raw_buffer_load_b64(arsrc, voa[j], 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b64(arsrc, voa[j] + 8, 0, 0);
+                ra[j] = make_float4(__uint_as_float(lo[0]), __uint_as_float(lo[1]), __uint_as_float(hi[0]), __uint_as_float(hi[1]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(brsrc, vob[j], 0, 0);
+            rb[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto stash = [&](float *As, float *Bs, int k0) {
+        if (k0 + kBigKC > K) {   // the ragged last chunk (workgroup-uniform): A's k beyond K belongs to the next row, not to nothing
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int c = k0 + (((int)threadIdx.x + 256 * j) % KQ) * 4;
+                const unsigned m0 = c < K ? 0xffffffffu : 0u, m1 = c + 1 < K ? 0xffffffffu : 0u, m2 = c + 2 < K ? 0xffffffffu : 0u, m3 = c + 3 < K ? 0xffffffffu : 0u;
+                ra[j].x = __uint_as_float(__float_as_uint(ra[j].x) & m0); ra[j].y = __uint_as_float(__float_as_uint(ra[j].y) & m1);
+                ra[j].z = __uint_as_float(__float_as_uint(ra[j].z) & m2); ra[j].w = __uint_as_float(__float_as_uint(ra[j].w) & m3);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            float *da = As + la[j];
+            da[0] = ra[j].x; da[1] = ra[j].y; da[2] = ra[j].z; da[3] = ra[j].w;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<float4 *>(Bs + lb[j]) = rb[j];
+    };
+    auto mma = [&](int rbk, const float *As, const float *Bs) {
+        const float *ap = As + (lane & 31) * kBigPA + (lane >> 5);
+        const float *bp = Bs + (lane >> 5) * kBigT + 32 * wave + (lane & 31);
+        float a_cur[4], a_nxt[4], b_cur, b_nxt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_cur[i] = ap[i * 32 * kBigPA];
+        b_cur = bp[0];
+#pragma unroll
+        for (int t = 0; t < kBigKC / 2; ++t) {
+            if (t + 1 < kBigKC / 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a_nxt[i] = ap[i * 32 * kBigPA + 2 * (t + 1)];
+                b_nxt = bp[2 * (t + 1) * kBigT];
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b_cur, acc[0], 0, 0, 0);
+            if (rbk > 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b_cur, acc[1], 0, 0, 0);
+            if (rbk > 2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b_cur, acc[2], 0, 0, 0);
+            if (rbk > 3) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b_cur, acc[3], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
+            b_cur = b_nxt;
+        }
+    };
+    const int nchunks = (K + kBigKC - 1) / kBigKC;
+    const int ntiles = (nblk + 3) >> 2, total = ntiles * nchunks;
+    const int colc = (32 * wave + (lane & 31)) * (int)sizeof(float);
+    fetch(blk0 * 32, 0);
+    stash(As0, Bs0, 0);
+    __syncthreads();
+    int c = 0, row0 = blk0 * 32, left = nblk;   // chunk inside the tile, the tile's first row, 32-row blocks from this tile on
+    for (int g = 0; g < total; ++g) {
+        const float *As = (g & 1) ? As1 : As0, *Bs = (g & 1) ? Bs1 : Bs0;
+        const int rbk = left < 4 ? left : 4;
+        const bool last_c = c + 1 == nchunks;
+        // the next chunk (the last step re-requests its own: unconditional, see k_dense_nn_strip)
+        const int nrow0 = last_c && g + 1 < total ? row0 + kBigT : row0;
+        const int nk0 = g + 1 < total ? (last_c ? 0 : (c + 1) * kBigKC) : c * kBigKC;
+        TL_STAMP(0);
+        fetch(nrow0, nk0);
+        TL_STAMP(1);
+        // (measured on this form and not kept, profiles/r04/gemm.txt: s_setprio low inside the burst / high outside -- the stash and barrier
+        // phases shrink, the fetch phase grows, 191.8-205 against 194 us; a second register set with chunk g + 2 in flight -- 195.5; K chunks
+        // of 16 with 3 / 4 workgroups per CU -- 193.6 / 207.5)
+        mma(rbk, As, Bs);
+        TL_STAMP(2);
+        if (last_c) {
+            // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); a descriptor rebased to
+            // C[row0][col0]: one lane offset + a scalar offset per store, rows beyond M fall off its end
+            const size_t co = ((size_t)row0 * N + col0) * sizeof(float), c_bytes = (size_t)M * N * sizeof(float);
+            const size_t cr = co < c_bytes ? c_bytes - co : 0;
+            const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C + ((size_t)row0 * N + col0), 0,
+                                                                                    (int)(unsigned)(cr < 0xfffffffcULL ? cr : 0xfffffffcULL), 0x00020000);
+            const int voff = 4 * (lane >> 5) * N * (int)sizeof(float) + colc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < rbk) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][reg]), crsrc, voff,
+                                                              (32 * i + (reg & 3) + 8 * (reg >> 2)) * N * (int)sizeof(float), 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) acc[i][reg] = 0.0f;
+            }
+        }
+        TL_STAMP(3);
+        if (g + 1 < total) stash((g & 1) ? As0 : As1, (g & 1) ? Bs0 : Bs1, nk0);
+        TL_STAMP(4);
+        __syncthreads();
+        TL_STAMP(5);
+        if (last_c) { c = 0; row0 += kBigT; left -= 4; } else ++c;
     }
 }
 
@@ -815,7 +990,21 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
                     }                                                                                                                   \
                     hipLaunchKernelGGL((k_dense_nn_strip<V_>), sgrid, dim3(256), lds, stream, A, B, C, M, N, K, nb32, nstrips);         \
                 }
-                if (av == 4) STRIP_CALL(4) else if (av == 2) STRIP_CALL(2) else STRIP_CALL(1)
+#define LEAN_CALL(V_)                                                                                                                   \
+                {                                                                                                                       \
+                    static OncePerDevice attr_ok;                                                                                       \
+                    if (attr_ok.first()) {                                                                                              \
+                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_lean<V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                        attr_ok.done();                                                                                                 \
+                    }                                                                                                                   \
+                    hipLaunchKernelGGL((k_dense_nn_lean<V_>), sgrid, dim3(256), lds, stream, A, B, C, M, N, K, nb32, nstrips);          \
+                }
+                // lean form: whole 128-column tiles, 16-byte aligned B rows, A rows 16- or 8-byte aligned, row pitches inside 32-bit offsets
+                const bool lean = (N % kBigT) == 0 && bvec && av >= 2 && (size_t)kBigT * K * sizeof(float) < 0x7fffffffULL &&
+                                  (size_t)kBigKC * N * sizeof(float) < 0x7fffffffULL && (size_t)kBigT * N * sizeof(float) < 0x7fffffffULL;
+                if (lean && av == 4) LEAN_CALL(4) else if (lean) LEAN_CALL(2)
+                else if (av == 4) STRIP_CALL(4) else if (av == 2) STRIP_CALL(2) else STRIP_CALL(1)
+#undef LEAN_CALL
 #undef STRIP_CALL
                 HIP_TRY(hipGetLastError());
                 return GNNAGG_OK;
@@ -1085,6 +1274,13 @@ int launch_untile_y_gat(const float *yt, const float *den_t, float *y, const uns
     HIP_TRY(hipGetLastError());
     return GNNAGG_OK;
 }
+
+#ifdef GNNAGG_GEMM_TIMELINE
+extern "C" __attribute__((visibility("default"))) int gnnagg_debug_set_gemm_timeline(void *d_buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_tl), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : 2;
+}
+#endif
 
 // ------------------------------------------------------------------ compact attention terms (2-D blocked GAT)
 // att is [V, H, 2] (centre term, source term interleaved per head): a tile of the span kernel needs the source terms of its
