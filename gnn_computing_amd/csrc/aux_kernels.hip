@@ -415,140 +415,8 @@ static constexpr int kBigWgs = GNNAGG_GEMM_WGS;   // workgroups per CU (LDS: 33.
 
 // AV: floats per aligned load of A (4: K % 4 == 0 and A 16-byte aligned; 2: K even, A 8-byte aligned -- the 602-wide layer; 1: any).
 // AV > 1 also says N % 4 == 0 and B 16-byte aligned: every 4-float piece of B is one aligned load.
-template <int TM, int AV>
-__device__ __forceinline__ void dense_tile(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K,
-                                           int row0, int col0, float *lds)
-{
-    constexpr int RB = TM / 32;   // 32-row blocks = accumulators per wavefront
-    constexpr int KQ = kBigKC / 4;                      // 4-float pieces per row of an A chunk
-    constexpr int NA = (TM * KQ + 255) / 256;           // A pieces per thread
-    constexpr int NB = kBigKC * (kBigT / 4) / 256;      // B pieces per thread
-    float *As0 = lds, *As1 = lds + kBigT * kBigPA, *Bs0 = lds + 2 * kBigT * kBigPA, *Bs1 = Bs0 + kBigKC * kBigT;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    f32x16 acc[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    float4 ra[NA], rb[NB];
-    // global -> registers: A chunk [TM rows][KC k]: piece p = thread + 256 j is row p / KQ, floats (p % KQ) * 4 (pieces beyond the
-    // tile's rows are loaded from a clamped address, zeroed, and land in LDS rows the operand reads never touch); B chunk
-    // [KC k][128 cols]: thread t k-rows t/32 + 8 j, floats (t % 32) * 4.  Branch-free: out-of-range pieces are loaded from a
-    // clamped (valid) address and replaced by zeros, so the loads of a chunk are issued back to back (with per-piece branches
-    // the compiler put a wait behind every load and the fetch, not the matrix pipe, set the pace)
-    // The loads of a chunk are issued with CLAMPED (always valid) addresses and nothing else: what is out of range is zeroed when
-    // the registers are written to LDS, one chunk of MFMAs later.  (Round 3 masked the values right behind the loads: the
-    // compiler then waits for every load of the next chunk BEFORE the current chunk's first MFMA -- s_waitcnt vmcnt(7..0) at the
-    // head of the loop -- and the whole fetch latency was exposed once per chunk: the matrix pipe 61 % busy whatever the occupancy.)
-    auto piece_load = [&](auto vtag, const float *base, long pitch, int r, int rmax, int c, int cmax) -> float4 {
-        constexpr int V = decltype(vtag)::value;
-        const int rc = r < rmax ? r : rmax - 1;
-        const float *src = base + (size_t)rc * pitch;
-        if constexpr (V == 4) {
-            const int cc = c < cmax ? c : cmax - 4;
-            return *reinterpret_cast<const float4 *>(src + cc);
-        } else if constexpr (V == 2) {
-            const int ca = c < cmax ? c : cmax - 2, cb = c + 2 < cmax ? c + 2 : cmax - 2;
-            const float2 lo = *reinterpret_cast<const float2 *>(src + ca), hi = *reinterpret_cast<const float2 *>(src + cb);
-            return make_float4(lo.x, lo.y, hi.x, hi.y);
-        } else {
-            const int c0 = c < cmax ? c : cmax - 1, c1 = c + 1 < cmax ? c + 1 : cmax - 1, c2 = c + 2 < cmax ? c + 2 : cmax - 1,
-                      c3 = c + 3 < cmax ? c + 3 : cmax - 1;
-            return make_float4(src[c0], src[c1], src[c2], src[c3]);
-        }
-    };
-    // (bit masks, not selects; V == 4: the whole piece is in or out -- K % 4 == 0 / N % 4 == 0)
-    auto piece_mask = [&](auto vtag, float4 v, int r, int rmax, int c, int cmax) -> float4 {
-        constexpr int V = decltype(vtag)::value;
-        const bool rok = r < rmax;
-        unsigned k0, k1, k2, k3;
-        if constexpr (V == 4) k0 = k1 = k2 = k3 = (rok && c < cmax) ? 0xffffffffu : 0u;
-        else if constexpr (V == 2) { k0 = k1 = (rok && c < cmax) ? 0xffffffffu : 0u; k2 = k3 = (rok && c + 2 < cmax) ? 0xffffffffu : 0u; }
-        else {
-            k0 = (rok && c < cmax) ? 0xffffffffu : 0u; k1 = (rok && c + 1 < cmax) ? 0xffffffffu : 0u;
-            k2 = (rok && c + 2 < cmax) ? 0xffffffffu : 0u; k3 = (rok && c + 3 < cmax) ? 0xffffffffu : 0u;
-        }
-        v.x = __uint_as_float(__float_as_uint(v.x) & k0); v.y = __uint_as_float(__float_as_uint(v.y) & k1);
-        v.z = __uint_as_float(__float_as_uint(v.z) & k2); v.w = __uint_as_float(__float_as_uint(v.w) & k3);
-        return v;
-    };
-    constexpr int BV = AV > 1 ? 4 : 1;
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int p = (int)threadIdx.x + 256 * j;
-            ra[j] = piece_load(std::integral_constant<int, AV>{}, A, K, row0 + p / KQ, M, k0 + (p % KQ) * 4, K);
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            rb[j] = piece_load(std::integral_constant<int, BV>{}, B, N, k0 + (threadIdx.x >> 5) + 8 * j, K, col0 + (threadIdx.x & 31) * 4, N);
-    };
-    auto stash = [&](float *As, float *Bs, int k0) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int p = (int)threadIdx.x + 256 * j;   // p / KQ < 128: inside the image whatever TM is
-            const float4 v = piece_mask(std::integral_constant<int, AV>{}, ra[j], row0 + p / KQ, M, k0 + (p % KQ) * 4, K);
-            float *da = As + (p / KQ) * kBigPA + (p % KQ) * 4;
-            da[0] = v.x; da[1] = v.y; da[2] = v.z; da[3] = v.w;
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            *reinterpret_cast<float4 *>(Bs + ((threadIdx.x >> 5) + 8 * j) * kBigT + (threadIdx.x & 31) * 4) =
-                piece_mask(std::integral_constant<int, BV>{}, rb[j], k0 + (threadIdx.x >> 5) + 8 * j, K, col0 + (threadIdx.x & 31) * 4, N);
-    };
-    fetch(0);
-    stash(As0, Bs0, 0);
-    __syncthreads();
-    const int nchunks = (K + kBigKC - 1) / kBigKC;
-    for (int c = 0; c < nchunks; ++c) {
-        const float *As = (c & 1) ? As1 : As0, *Bs = (c & 1) ? Bs1 : Bs0;
-        if (c + 1 < nchunks) fetch((c + 1) * kBigKC);   // in flight during this chunk's MFMAs
-        const float *ap = As + (lane & 31) * kBigPA + (lane >> 5);
-        const float *bp = Bs + (lane >> 5) * kBigT + 32 * wave + (lane & 31);
-        float av[RB][kBigKC / 2], bv[kBigKC / 2];
-#pragma unroll
-        for (int t = 0; t < kBigKC / 2; ++t) {
-#pragma unroll
-            for (int i = 0; i < RB; ++i) av[i][t] = ap[i * 32 * kBigPA + 2 * t];
-            bv[t] = bp[2 * t * kBigT];
-        }
-#pragma unroll
-        for (int t = 0; t < kBigKC / 2; ++t)
-#pragma unroll
-            for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
-        if (c + 1 < nchunks) stash((c & 1) ? As0 : As1, (c & 1) ? Bs0 : Bs1, (c + 1) * kBigKC);   // the other buffer: last read in chunk c - 1
-        __syncthreads();
-    }
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int col = col0 + 32 * wave + (lane & 31);
-    if (col < N) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = row0 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                if (row < M) C[(size_t)row * N + col] = acc[i][reg];
-            }
-    }
-}
-
-// blocks [0, n_main): 128-row tiles from row 0; blocks beyond: TMT-row tiles from row n_main * 128
-template <int TMT, int AV>
-__global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_big(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
-                                                               int M, int N, int K, int n_main)
-{
-    extern __shared__ float big_lds[];
-    const int col0 = blockIdx.y * kBigT;
-    if (TMT == kBigT || (int)blockIdx.x < n_main) dense_tile<kBigT, AV>(A, B, C, M, N, K, blockIdx.x * kBigT, col0, big_lds);
-    else dense_tile<TMT, AV>(A, B, C, M, N, K, n_main * kBigT + ((int)blockIdx.x - n_main) * TMT, col0, big_lds);
-}
-
-// Round 4: the same tile arithmetic as dense_tile, organised as PERSISTENT STRIPS.  The grid is what the chip holds at a time
-// (kBigWgs workgroups per CU); the 32-row blocks of the matrix are dealt evenly to the workgroups (strips differ by at most one block:
-// no partial last round -- 169 343 rows are 2.58 rounds of 512 tiles, and a round costs what a full one costs), a workgroup walks its
-// strip in tiles of up to 128 rows (the last one 32 / 64 / 96), and the chunk pipeline runs ACROSS tiles: the first K chunk of the
-// next tile is fetched during the last chunk of the current one, so the fetch latency at the head of a tile and the C stores at its
-// end are hidden too.  Per output the same ascending-k chain: bit-exact as before.
+// (Round 3's k_dense_nn_big -- one 128-row tile per workgroup, a last round of smaller tiles -- is gone: the strips below do the same
+// arithmetic without a partial last round; its text is in git history, its numbers in profiles/r03/gemm.txt.)
 #ifdef GNNAGG_GEMM_TIMELINE   // A/B builds only (scripts/exp_gemm_timeline.py): s_memtime stamps of wave 0 of every workgroup, six per chunk
 __device__ unsigned long long *g_gemm_tl = nullptr;
 #define TL_STAMP(slot) do { if (g_gemm_tl && threadIdx.x == 0 && g < 64) g_gemm_tl[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + g) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -655,7 +523,6 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_strip(const float *__
     const int nchunks = (K + kBigKC - 1) / kBigKC;
     const int ntiles = (nblk + 3) >> 2, total = ntiles * nchunks;   // the strip as ONE sequence of chunks g = tile * nchunks + c
     const int col = col0 + 32 * wave + (lane & 31);
-    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)((size_t)M * N * sizeof(float)), 0x00020000);   // (host-checked: < 2 GB)
     auto row_of = [&](int g) { return (blk0 + 4 * (g / nchunks)) * 32; };
     auto k_of = [&](int g) { return (g % nchunks) * kBigKC; };
     // While chunk g is multiplied out of LDS buffer g & 1, chunk g + 1 travels to registers; after the MFMAs it goes to the other LDS
@@ -681,7 +548,10 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_strip(const float *__
             // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Buffer stores: ONE
             // lane offset + a scalar offset per store (64 global addresses computed up front cost 128 registers while the next
             // tile's fetch is in flight), and rows beyond M fall off the end of the buffer -- the hardware drops them
-            const unsigned voff = (unsigned)(((size_t)(row0 + 4 * (lane >> 5)) * N + col) * sizeof(float));
+            const size_t co = (size_t)row0 * N * sizeof(float), c_bytes = (size_t)M * N * sizeof(float);   // descriptor rebased to C[row0][0]
+            const size_t cr = co < c_bytes ? c_bytes - co : 0;
+            const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C + (size_t)row0 * N, 0, (int)(unsigned)(cr < 0xfffffffcULL ? cr : 0xfffffffcULL), 0x00020000);
+            const unsigned voff = (unsigned)(((size_t)(4 * (lane >> 5)) * N + col) * sizeof(float));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i < rbk && col < N) {
@@ -971,69 +841,32 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
         return launch_zero_words(C, (size_t)M * N, stream);
     }
     {
-        if (N > 64 && M >= 1024) {   // wide outputs: 128 x 128 tiles, A read once (k_dense_nn_big)
+        if (N > 64 && M >= 1024 && (size_t)kBigT * N * sizeof(float) < 0x7fffffffULL) {   // wide outputs: persistent strips of 128 x 128 tiles, A read once
             const size_t lds = (size_t)(2 * kBigT * kBigPA + 2 * kBigKC * kBigT) * sizeof(float);
             const bool bvec = (N & 3) == 0 && N >= 4 && ((uintptr_t)B & 15) == 0;
             const int av = !bvec ? 1 : ((K & 3) == 0 && K >= 4 && ((uintptr_t)A & 15) == 0) ? 4 : ((K & 1) == 0 && K >= 2 && ((uintptr_t)A & 7) == 0) ? 2 : 1;
-            // tiles the chip runs at a time: kBigWgs workgroups per CU, shared by the column tiles
-            const int cus = device_cu_count();
-            const int ncol = ceil_div(N, kBigT), slots = std::max(1, kBigWgs * cus / ncol);
-            if ((size_t)M * N * sizeof(float) < 0x7fffffffULL) {   // persistent strips (buffer stores into C: 2 GB); else the tile grid below
-                const int nb32 = ceil_div(M, 32), nstrips = std::min(slots, ceil_div(nb32, 2));
-                const dim3 sgrid(nstrips, ncol);
-#define STRIP_CALL(V_)                                                                                                                  \
-                {                                                                                                                       \
-                    static OncePerDevice attr_ok;                                                                                       \
-                    if (attr_ok.first()) {                                                                                              \
-                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_strip<V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                        attr_ok.done();                                                                                                 \
-                    }                                                                                                                   \
-                    hipLaunchKernelGGL((k_dense_nn_strip<V_>), sgrid, dim3(256), lds, stream, A, B, C, M, N, K, nb32, nstrips);         \
-                }
-#define LEAN_CALL(V_)                                                                                                                   \
-                {                                                                                                                       \
-                    static OncePerDevice attr_ok;                                                                                       \
-                    if (attr_ok.first()) {                                                                                              \
-                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_lean<V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                        attr_ok.done();                                                                                                 \
-                    }                                                                                                                   \
-                    hipLaunchKernelGGL((k_dense_nn_lean<V_>), sgrid, dim3(256), lds, stream, A, B, C, M, N, K, nb32, nstrips);          \
-                }
-                // lean form: whole 128-column tiles, 16-byte aligned B rows, A rows 16- or 8-byte aligned, row pitches inside 32-bit offsets
-                const bool lean = (N % kBigT) == 0 && bvec && av >= 2 && (size_t)kBigT * K * sizeof(float) < 0x7fffffffULL &&
-                                  (size_t)kBigKC * N * sizeof(float) < 0x7fffffffULL && (size_t)kBigT * N * sizeof(float) < 0x7fffffffULL;
-                if (lean && av == 4) LEAN_CALL(4) else if (lean) LEAN_CALL(2)
-                else if (av == 4) STRIP_CALL(4) else if (av == 2) STRIP_CALL(2) else STRIP_CALL(1)
-#undef LEAN_CALL
-#undef STRIP_CALL
-                HIP_TRY(hipGetLastError());
-                return GNNAGG_OK;
-            }
-            const int n_main = (int)(((long)M / kBigT) / slots) * slots;   // whole rounds of full 128-row tiles
-            const int rem = M - n_main * kBigT;
-            int tmt = kBigT;
-            for (int t = 32; t < kBigT; t += 32)
-                    if (ceil_div(rem, t) <= slots) { tmt = t; break; }
-            const dim3 grid(n_main + ceil_div(rem, tmt), ncol);
-#define BIG_CALL(T_, V_)                                                                                                               \
+            // the grid is what the chip holds at a time: kBigWgs workgroups per CU, shared by the column tiles
+            const int ncol = ceil_div(N, kBigT), slots = std::max(1, kBigWgs * device_cu_count() / ncol);
+            const int nb32 = ceil_div(M, 32), nstrips = std::min(slots, ceil_div(nb32, 2));
+            const dim3 sgrid(nstrips, ncol);
+#define WIDE_CALL(KERNEL_)                                                                                                              \
             {                                                                                                                           \
                 static OncePerDevice attr_ok;                                                                                           \
                 if (attr_ok.first()) {                                                                                                  \
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_nn_big<T_, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                     attr_ok.done();                                                                                                     \
                 }                                                                                                                       \
-                hipLaunchKernelGGL((k_dense_nn_big<T_, V_>), grid, dim3(256), lds, stream, A, B, C, M, N, K, n_main);                   \
+                hipLaunchKernelGGL(KERNEL_, sgrid, dim3(256), lds, stream, A, B, C, M, N, K, nb32, nstrips);                            \
             }
-#define BIG_TAIL(V_)                                                                    \
-            switch (tmt) {                                                              \
-                case 32: BIG_CALL(32, V_) break;                                        \
-                case 64: BIG_CALL(64, V_) break;                                        \
-                case 96: BIG_CALL(96, V_) break;                                        \
-                default: BIG_CALL(128, V_) break;                                       \
-            }
-            if (av == 4) BIG_TAIL(4) else if (av == 2) BIG_TAIL(2) else BIG_TAIL(1)
-#undef BIG_TAIL
-#undef BIG_CALL
+            // lean form: whole 128-column tiles, 16-byte aligned B rows, A rows 16- or 8-byte aligned, row pitches inside 32-bit offsets
+            const bool lean = (N % kBigT) == 0 && bvec && av >= 2 && (size_t)kBigT * K * sizeof(float) < 0x7fffffffULL &&
+                              (size_t)kBigKC * N * sizeof(float) < 0x7fffffffULL;
+            if (lean && av == 4) WIDE_CALL(k_dense_nn_lean<4>)
+            else if (lean) WIDE_CALL(k_dense_nn_lean<2>)
+            else if (av == 4) WIDE_CALL(k_dense_nn_strip<4>)
+            else if (av == 2) WIDE_CALL(k_dense_nn_strip<2>)
+            else WIDE_CALL(k_dense_nn_strip<1>)
+#undef WIDE_CALL
             HIP_TRY(hipGetLastError());
             return GNNAGG_OK;
         }

@@ -560,13 +560,14 @@ def test_matmul_nn_bit_exact(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(1500, 128, 512), (1100, 100, 70), (2049, 200, 33), (1024, 65, 1), (3000, 129, 602), (3000, 128, 602),
-                                   (20001, 128, 36), (40003, 132, 34), (60001, 128, 33), (70536, 128, 40), (131072, 128, 8), (9000, 300, 64)])
+                                   (20001, 128, 36), (40003, 132, 34), (60001, 128, 33), (70536, 128, 40), (131072, 128, 8), (9000, 300, 64),
+                                   (5000, 256, 602), (4099, 384, 128), (33000, 128, 30), (1025, 128, 2)])
 def test_matmul_nn_wide_kernel_bit_exact(M, N, K):
-    """The wide-output kernel (k_dense_nn_big: 128-row tiles of 128 columns, a 32-column strip per wavefront, double-buffered K
-    chunks; taken for N > 64, M >= 1024 -- the 512 -> 128 layer): ragged M / N / K, unaligned rows (scalar, 8-byte and 16-byte loads
-    of A), every tail tile height (the rows beyond the last full round of 2 x CUs tiles run as one round of 32- / 64- / 96-row
-    tiles: M = 3000 / 20 001 / 40 003; 60 001 keeps 128; 70 536 = one full round + a 32-row tail on 256 CUs), several column tiles
-    -- still the oracle's ascending-k chain bit for bit."""
+    """The wide-output kernels (taken for N > 64, M >= 1024 -- the 512 -> 128 layer): persistent strips of 32-row blocks walked in tiles
+    of up to 128 rows, the chunk pipeline running across tiles.  k_dense_nn_lean (N % 128 == 0, A rows 16- or 8-byte aligned: buffer
+    descriptors rebased per chunk, out-of-range rows / k zeroed by the hardware, masks on a ragged last K chunk only) and k_dense_nn_strip
+    (everything else: ragged N, odd K, scalar loads).  Ragged M / N / K, every last-tile height (32 / 64 / 96 / 128 rows), strips of one
+    and of several tiles, several column tiles, K smaller than a chunk -- still the oracle's ascending-k chain bit for bit."""
     A, B = rand((M, K), 1), rand((K, N), 2)
     C = gnc.matmul_NN(dev(A), dev(B))
     torch.cuda.synchronize()
