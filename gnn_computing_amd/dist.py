@@ -145,7 +145,7 @@ class HaloExchange:
     """
 
     def __init__(self, ptr, idx, rank=None, world=None, group=None, device="cpu", bounds=None, pack_fn=None,
-                 offline=False, row_slice=False, num_cols=None, transport="torch", stages=1):
+                 offline=False, row_slice=False, num_cols=None, transport="torch", stages=1, row_bytes=512):
         """row_slice=False: (ptr, idx) is the global CSR (every rank holds it at plan time).  row_slice=True: (ptr, idx) are
         THIS rank's rows only -- ptr[0 .. n_local] with any base offset, idx with global column ids -- and `bounds`
         (partition_rows of the global ptr, e.g. computed by rank 0 and broadcast) and `num_cols` are required.
@@ -181,6 +181,7 @@ class HaloExchange:
         self.recv_counts = plan["halo_counts"].astype(np.int64)  # rows received from each rank
         self.n_halo = int(len(self.halo_ids))
         self.row0 = int(self.bounds[self.rank])
+        self.row_bytes = int(row_bytes)
         self._plan_stages(stages)
         if offline:
             self.send_counts = np.zeros(self.world, np.int64)
@@ -216,11 +217,12 @@ class HaloExchange:
 
     def _plan_stages(self, stages):
         """Chooses the stages and renumbers the halo slots stage-major: halo_ids, the halo columns of local_idx and (later) the
-        send list follow.  stages: 1 | K | ("stripe", K) | "owner" | "auto" (stripes, K from the halo rows: about 64 k rows per
-        stage, at most 4)."""
+        send list follow.  stages: 1 | K | ("stripe", K) | "owner" | "auto" (stripes, one per 64 MB of halo rows -- `row_bytes` per row --
+        at most 4: a stage is one more collective launch and one more pass over the rows of y, worth it when the transfer it hides
+        under is long)."""
         w = self.world
         if stages == "auto":
-            stages = ("stripe", int(min(4, max(1, self.n_halo // 65536))))
+            stages = ("stripe", int(min(4, max(1, (self.n_halo * self.row_bytes) >> 26))))
         if isinstance(stages, int):
             stages = ("stripe", stages)
         if stages == "owner":
@@ -382,7 +384,7 @@ class PartitionedGCN:
         if not (bool(overlap) and mode == "balanced"):
             stages = 1
         self.hx = HaloExchange(ptr, idx, rank=rank, world=world, group=group, device=device, offline=offline,
-                               row_slice=row_slice, bounds=bounds, num_cols=num_cols, transport=transport, stages=stages)
+                               row_slice=row_slice, bounds=bounds, num_cols=num_cols, transport=transport, stages=stages, row_bytes=4 * feat)
         hx = self.hx
         self.feat, self.mode = feat, mode
         self.overlap = bool(overlap) and mode == "balanced"
@@ -521,7 +523,7 @@ class PartitionedGAT:
         self.overlap = bool(overlap) and mode == "balanced" and feat % 4 == 0 and (feat // heads) % 4 == 0 and feat <= 256
         self.hx = HaloExchange(ptr, idx, rank=rank, world=world, group=group, device=device, offline=offline,
                                row_slice=row_slice, bounds=bounds, num_cols=num_cols, transport=transport,
-                               stages=stages if self.overlap else 1)
+                               stages=stages if self.overlap else 1, row_bytes=4 * (feat + aw))
         hx = self.hx
         self.feat, self.heads, self.mode = feat, heads, mode
         self.pack_fn2, self.unpack_fn2 = pack_fn2 or _hip_pack_rows2, unpack_fn2 or _hip_unpack_rows2
