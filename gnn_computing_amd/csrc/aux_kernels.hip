@@ -703,7 +703,8 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_lean(const float *__r
         TL_STAMP(1);
         // (measured on this form and not kept, profiles/r04/gemm.txt: s_setprio low inside the burst / high outside -- the stash and barrier
         // phases shrink, the fetch phase grows, 191.8-205 against 194 us; a second register set with chunk g + 2 in flight -- 195.5; K chunks
-        // of 16 with 3 / 4 workgroups per CU -- 193.6 / 207.5)
+        // of 16 with 3 / 4 workgroups per CU -- 193.6 / 207.5; the next chunk's stash folded into the second half of the burst -- the stash
+        // phase goes from 19 % to 4 % of the period and the burst grows by as much: 200 against 194 us at the same ratio to rocBLAS)
         mma(rbk, As, Bs);
         TL_STAMP(2);
         if (last_c) {
