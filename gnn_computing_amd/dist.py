@@ -219,10 +219,17 @@ class HaloExchange:
         """Chooses the stages and renumbers the halo slots stage-major: halo_ids, the halo columns of local_idx and (later) the
         send list follow.  stages: 1 | K | ("stripe", K) | "owner" | "auto" (stripes, one per 64 MB of halo rows -- `row_bytes` per row --
         at most 4: a stage is one more collective launch and one more pass over the rows of y, worth it when the transfer it hides
-        under is long)."""
+        under is long; ("auto", bytes) sets another size) -- from the largest halo of the job, so that all ranks agree."""
         w = self.world
-        if stages == "auto":
-            stages = ("stripe", int(min(4, max(1, (self.n_halo * self.row_bytes) >> 26))))
+        if stages == "auto" or (isinstance(stages, tuple) and stages[0] == "auto"):
+            # every rank must cut the lists the same way: the stage count follows the LARGEST halo of the job, not this rank's
+            per_stage = (64 << 20) if stages == "auto" else int(stages[1])
+            n = self.n_halo
+            if not self.offline and w > 1:
+                t = torch.tensor([n], dtype=torch.int64, device=self.device if self.device.type == "cuda" and dist.get_backend(self.group) == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                n = int(t.item())
+            stages = ("stripe", int(min(4, max(1, (n * self.row_bytes) // per_stage))))
         if isinstance(stages, int):
             stages = ("stripe", stages)
         if stages == "owner":
