@@ -163,6 +163,46 @@ def test_reddit_gat_8x32(reddit):
     assert bool(torch.all((y1 - y2).abs() <= 2e-5 * scale + 1e-30))
 
 
+def test_reddit_gat_8x32_canonical_rows_mode(reddit):
+    """Config G in GNNAGG_MODE_ROWS (`scheduled = 0` = aggr_gat, aggr_gat.h:116-164) at full size: the chains run on the 2-D blocked order
+    (k_gat_span<..., CHAIN>) -- sampled rows against the oracle's CSR-order fused result within north_star's 1e-5
+    (condition-aware), every row bit-equal to the row kernels ("rows_blocked" = 0), constants reproduced, rows without edges 0."""
+    ptr, idx = reddit
+    V, H, D = ptr.numel() - 1, 8, 32
+    F = H * D
+    gat = gnc.Aggregator_GAT(ptr, idx, F, F)
+    x = torch.randn((V, F), device=DEV)
+    att = torch.randn((V, H, 2), device=DEV) * 0.5
+    y = torch.empty((V, F), device=DEV)
+    gat.run(x, att, y, 128, 0, heads=H)
+    assert gat.rows_blocked_ranges() >= 4
+    rows = pick_rows(ptr, 40, 3)
+    sp, si, _ = sample_rows(ptr, idx, rows)
+    xh, atth = x.cpu().numpy(), att.cpu().numpy()
+    att_mix = atth.copy()
+    att_mix[:len(rows), :, 0] = atth[rows, :, 0]
+    ref = orc.gat_fused(sp, si, att_mix, xh, H)
+    got = y[torch.from_numpy(rows).to(DEV)].cpu().numpy()
+    w = orc.gat_att(sp, si, att_mix, H)
+    scale = np.zeros((len(rows), F))
+    for k in range(len(rows)):
+        e0, e1 = int(sp[k]), int(sp[k + 1])
+        if e1 > e0:
+            scale[k] = np.einsum("eh,ehd->hd", w[e0:e1].astype(np.float64), np.abs(xh[si[e0:e1]]).reshape(e1 - e0, H, D)).reshape(F)
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    bound = 1e-5 * (scale + np.abs(ref)) + 1e-30
+    assert np.all(err <= bound), "GAT 8x32 rows mode: worst ratio %.3g" % float((err / bound).max())
+    kern = gnc.Aggregator_GAT(ptr, idx, F, F)
+    kern.set_option("rows_blocked", 0)
+    y2 = torch.empty((V, F), device=DEV)
+    kern.run(x, att, y2, 128, 0, heads=H)
+    assert torch.equal(y, y2), "the chained form and the row kernels run the same chains"
+    const = torch.full((V, F), 2.0, device=DEV)
+    gat.run(const, att, y, 128, 0, heads=H)
+    degs = (ptr[1:] - ptr[:-1])
+    assert float((y[degs > 0] - 2.0).abs().max()) <= 2.0 * 1e-5 and bool(torch.all(y[degs == 0] == 0.0))
+
+
 def test_products_gcn_f100():
     ptr, idx = gnc.graph.dataset("products", device=DEV)
     V, E, F = ptr.numel() - 1, idx.numel(), 100
