@@ -8,14 +8,13 @@
 //   range key per edge -> STABLE radix sort of the edge ids by range (the CSR order inside a range IS row-major, in-row order kept:
 //   exactly the reference's order) -> sub-row starts by comparing neighbours -> max-scan (start of the enclosing sub-row) -> group
 //   starts every NG positions -> prefix sum = group ids -> scatter ptr_s / target -> row -> groups lists by a stable sort of the
-//   group ids by row -> flagged ids.
+//   group ids by row -> flagged ids.  The sort and the scans are prims.cuh (hand-written, wave64).
 // Only per-GROUP arrays (a few MB) come to the host: the span cut is a greedy walk and the schedule queries read them.
 // Results are identical to the host builders' (tests/test_gpu_blocked.py compares both with the oracle's restatement).
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 
 #include "devbuf.h"
+#include "prims.cuh"
 
 namespace gnnagg {
 
@@ -178,13 +177,9 @@ struct Sorted {   // the edges in (range, CSR) order
     DevBuf<unsigned> key_s;
 };
 
-#define CUB_TRY(call)                                                                                              \
-    do {                                                                                                           \
-        hipError_t _e = (call);                                                                                    \
-        if (_e != hipSuccess) return fail(GNNAGG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e));      \
-    } while (0)
+struct Tmp { DevBuf<int> counts, scan; };   // scratch of the primitives (grow-only across the calls of one build)
 
-int sort_edges_by_range(const int *d_ptr, const int *d_idx, int V, int E, int P, int width, hipStream_t st, Sorted &o, DevBuf<char> &tmp)
+int sort_edges_by_range(const int *d_ptr, const int *d_idx, int V, int E, int P, int width, hipStream_t st, Sorted &o, Tmp &tmp)
 {
     int rc;
     DevBuf<unsigned> key;
@@ -195,38 +190,26 @@ int sort_edges_by_range(const int *d_ptr, const int *d_idx, int V, int E, int P,
     hipLaunchKernelGGL(k_range_keys, dim3(blocks_for(E)), dim3(kThreads), 0, st, d_idx, E, width, P, key.p, val.p);
     int bits = 1;
     while ((1 << bits) < P) ++bits;
-    size_t tb = 0;
-    CUB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.p, o.key_s.p, val.p, o.eperm.p, E, 0, bits, st));
-    size_t tb2 = 0;
-    CUB_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tb2, o.row_of.p, o.row_of.p, hipcub::Max(), E, st));
-    if ((rc = tmp.reserve(std::max(tb, tb2) + 256))) return rc;
-    size_t t = tmp.n;
-    CUB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, key.p, o.key_s.p, val.p, o.eperm.p, E, 0, bits, st));   // stable: CSR order inside a range
+    if ((rc = prims::sort_pairs(key.p, o.key_s.p, val.p, o.eperm.p, E, bits, tmp.counts, tmp.scan, st))) return rc;   // stable: CSR order inside a range
     HIP_TRY(hipMemsetAsync(o.row_of.p, 0, (size_t)E * sizeof(int), st));
     hipLaunchKernelGGL(k_mark_row_starts, dim3(blocks_for(V)), dim3(kThreads), 0, st, d_ptr, V, o.row_of.p);
-    t = tmp.n;
-    CUB_TRY(hipcub::DeviceScan::InclusiveScan(tmp.p, t, o.row_of.p, o.row_of.p, hipcub::Max(), E, st));
+    if ((rc = prims::scan<prims::OpMax, false>(o.row_of.p, o.row_of.p, E, tmp.scan, st))) return rc;
     hipLaunchKernelGGL(k_gather_sorted, dim3(blocks_for(E)), dim3(kThreads), 0, st, o.eperm.p, o.row_of.p, d_idx, E, o.row_s.p, o.idx_s.p);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));   // key / val go out of scope
     return GNNAGG_OK;
 }
 
 // gflag / gid (exclusive prefix sum of gflag) of the groups of the sorted edge list; *G_out groups
-int cut_groups(const Sorted &s, int E, int ng, hipStream_t st, DevBuf<int> &gflag, DevBuf<int> &gid, DevBuf<char> &tmp, int *G_out)
+int cut_groups(const Sorted &s, int E, int ng, hipStream_t st, DevBuf<int> &gflag, DevBuf<int> &gid, Tmp &tmp, int *G_out)
 {
     int rc;
     DevBuf<int> ss;
     if ((rc = ss.alloc((size_t)E)) || (rc = gflag.alloc((size_t)E)) || (rc = gid.alloc((size_t)E))) return rc;
     hipLaunchKernelGGL(k_subrow_starts, dim3(blocks_for(E)), dim3(kThreads), 0, st, s.key_s.p, s.row_s.p, E, ss.p);
-    size_t tb = 0, tb2 = 0;
-    CUB_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tb, ss.p, ss.p, hipcub::Max(), E, st));
-    CUB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, gflag.p, gid.p, E, st));
-    if ((rc = tmp.reserve(std::max(tb, tb2) + 256))) return rc;
-    size_t t = tmp.n;
-    CUB_TRY(hipcub::DeviceScan::InclusiveScan(tmp.p, t, ss.p, ss.p, hipcub::Max(), E, st));
+    if ((rc = prims::scan<prims::OpMax, false>(ss.p, ss.p, E, tmp.scan, st))) return rc;
     hipLaunchKernelGGL(k_group_flags, dim3(blocks_for(E)), dim3(kThreads), 0, st, ss.p, E, ng, gflag.p);
-    t = tmp.n;
-    CUB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, gflag.p, gid.p, E, st));
+    if ((rc = prims::scan<prims::OpSum, true>(gflag.p, gid.p, E, tmp.scan, st))) return rc;
     int last[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&last[0], gid.p + (E - 1), sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&last[1], gflag.p + (E - 1), sizeof(int), hipMemcpyDeviceToHost, st));
@@ -242,16 +225,11 @@ int gpu_max_col(const int *d_idx, int E, hipStream_t st, int *max_col)
     *max_col = 0;
     if (E <= 0) return GNNAGG_OK;
     DevBuf<int> out;
-    DevBuf<char> tmp;
     int rc;
-    if ((rc = out.alloc(1))) return rc;
-    size_t tb = 0;
-    CUB_TRY(hipcub::DeviceReduce::Max(nullptr, tb, d_idx, out.p, E, st));
-    if ((rc = tmp.reserve(tb + 256))) return rc;
-    size_t t = tmp.n;
-    CUB_TRY(hipcub::DeviceReduce::Max(tmp.p, t, d_idx, out.p, E, st));
+    if ((rc = out.alloc(1)) || (rc = prims::reduce<prims::OpMax>(d_idx, E, out.p, st))) return rc;
     HIP_TRY(hipMemcpyAsync(max_col, out.p, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (*max_col < 0) *max_col = 0;
     return GNNAGG_OK;
 }
 
@@ -262,7 +240,7 @@ int gpu_build_blocked_plan(const int *d_ptr, const int *d_idx, int V, int E, int
     const int width = total_cols / par_num;
     if (width < 1) return fail(GNNAGG_ERR_STATE, "internal: more ranges than columns");
     int rc;
-    DevBuf<char> tmp;
+    Tmp tmp;
     Sorted s;
     if ((rc = sort_edges_by_range(d_ptr, d_idx, V, E, par_num, width, st, s, tmp))) return rc;
     DevBuf<int> gflag, gid;
@@ -279,20 +257,14 @@ int gpu_build_blocked_plan(const int *d_ptr, const int *d_idx, int V, int E, int
     hipLaunchKernelGGL(k_count_groups, dim3(blocks_for(G)), dim3(kThreads), 0, st, o.target.p, G, groups_of.p);
     hipLaunchKernelGGL(k_iota, dim3(blocks_for(G)), dim3(kThreads), 0, st, iota.p, G);
     {
-        DevBuf<unsigned> tkey;
-        if ((rc = tkey.alloc((size_t)G))) return rc;
-        const unsigned *tin = reinterpret_cast<const unsigned *>(o.target.p);   // (row ids are non-negative: one SortPairs<unsigned, int> serves every sort here)
+        DevBuf<unsigned> tin, tkey;   // (the sort clobbers its input: a copy of the targets; row ids are non-negative)
+        if ((rc = tin.alloc((size_t)G)) || (rc = tkey.alloc((size_t)G))) return rc;
+        HIP_TRY(hipMemcpyAsync(tin.p, o.target.p, (size_t)G * sizeof(int), hipMemcpyDeviceToDevice, st));
         int bits = 1;
         while ((1L << bits) < (long)V) ++bits;
-        size_t tb = 0, tb2 = 0;
-        CUB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, tin, tkey.p, iota.p, o.rg_idx.p, G, 0, bits, st));
-        CUB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, groups_of.p, o.rg_ptr.p, V + 1, st));
-        if ((rc = tmp.reserve(std::max(tb, tb2) + 256))) return rc;
-        size_t t = tmp.n;
-        CUB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, tin, tkey.p, iota.p, o.rg_idx.p, G, 0, bits, st));
-        t = tmp.n;
-        CUB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, groups_of.p, o.rg_ptr.p, V + 1, st));
-        HIP_TRY(hipStreamSynchronize(st));   // tkey goes out of scope
+        if ((rc = prims::sort_pairs(tin.p, tkey.p, iota.p, o.rg_idx.p, G, bits, tmp.counts, tmp.scan, st))) return rc;
+        if ((rc = prims::scan<prims::OpSum, true>(groups_of.p, o.rg_ptr.p, (long)V + 1, tmp.scan, st))) return rc;
+        HIP_TRY(hipStreamSynchronize(st));   // tin / tkey go out of scope
     }
     if ((rc = o.idx_f.alloc((size_t)E))) return rc;
     hipLaunchKernelGGL(k_flag_ids, dim3(blocks_for(E)), dim3(kThreads), 0, st, s.idx_s.p, gflag.p, s.row_s.p, groups_of.p, E, o.idx_f.p);
@@ -338,7 +310,7 @@ int gpu_build_chain_plan(const int *d_ptr, const int *d_idx, const int *h_ptr, i
     const int width = total_cols / par_num;
     if (width < 1) return GNNAGG_OK;
     int rc;
-    DevBuf<char> tmp;
+    Tmp tmp;
     Sorted s;
     if ((rc = sort_edges_by_range(d_ptr, d_idx, V, E, par_num, width, st, s, tmp))) return rc;
     {   // neighbors ascending in every row?  (a row's sub-rows per range, range after range, are then the row in CSR order)
@@ -375,18 +347,12 @@ int gpu_build_chain_plan(const int *d_ptr, const int *d_idx, const int *h_ptr, i
     int rbits = 1;
     while ((1 << rbits) < par_num + 1) ++rbits;
     {
-        size_t tb = 0, tb2 = 0, tb3 = 0;
-        CUB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key_len.p, key_o.p, iota.p, ord1.p, G0, 0, 32, st));
-        CUB_TRY(hipcub::DeviceReduce::Sum(nullptr, tb2, keep.p, kept.p, G0, st));
-        CUB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, lens.p, nptr.p, G0 + 1, st));
-        if ((rc = tmp.reserve(std::max(tb, std::max(tb2, tb3)) + 256))) return rc;
-        size_t t = tmp.n;
-        CUB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, key_len.p, key_o.p, iota.p, ord1.p, G0, 0, 32, st));      // longest first (stable)
+        int lbits = 1;   // key_len = ~len: its low lbits bits ascend as len descends, for every len < 2^lbits
+        while ((1L << lbits) <= (long)E && lbits < 32) ++lbits;
+        if ((rc = prims::sort_pairs(key_len.p, key_o.p, iota.p, ord1.p, G0, lbits, tmp.counts, tmp.scan, st))) return rc;   // longest first (stable)
         hipLaunchKernelGGL(k_gather_u32, dim3(blocks_for(G0)), dim3(kThreads), 0, st, key_range.p, ord1.p, G0, key_r2.p);
-        t = tmp.n;
-        CUB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, t, key_r2.p, key_o.p, ord1.p, ord.p, G0, 0, rbits, st));       // then by range (stable)
-        t = tmp.n;
-        CUB_TRY(hipcub::DeviceReduce::Sum(tmp.p, t, keep.p, kept.p, G0, st));
+        if ((rc = prims::sort_pairs(key_r2.p, key_o.p, ord1.p, ord.p, G0, rbits, tmp.counts, tmp.scan, st))) return rc;      // then by range (stable)
+        if ((rc = prims::reduce<prims::OpSum>(keep.p, G0, kept.p, st))) return rc;
     }
     int G = 0;
     HIP_TRY(hipMemcpyAsync(&G, kept.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -395,10 +361,7 @@ int gpu_build_chain_plan(const int *d_ptr, const int *d_idx, const int *h_ptr, i
     if (G == 0) return GNNAGG_OK;
     hipLaunchKernelGGL(k_chain_lens, dim3(blocks_for(G0)), dim3(kThreads), 0, st, ord.p, ptr0.p, G0, G, lens.p, inv.p);
     HIP_TRY(hipMemsetAsync(lens.p + G0, 0, sizeof(int), st));
-    {
-        size_t t = tmp.n;
-        CUB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, t, lens.p, nptr.p, G0 + 1, st));
-    }
+    if ((rc = prims::scan<prims::OpSum, true>(lens.p, nptr.p, (long)G0 + 1, tmp.scan, st))) return rc;
     DevBuf<unsigned> grange;
     if ((rc = o.target.alloc((size_t)G)) || (rc = grange.alloc((size_t)G))) return rc;
     hipLaunchKernelGGL(k_chain_groups, dim3(blocks_for(G)), dim3(kThreads), 0, st, ord.p, target0.p, gkey0.p, G, o.target.p, grange.p);
