@@ -451,6 +451,7 @@ def partitioned_run(args, dev, rank, world, strong, steps, warmup, transport, do
     Vg, Eg = (V1, E1) if strong else (V1 * world, E1 * world)
     # rank 0 generates the global graph on its GPU (seeded, community order = "locality reorder applied on load"); every
     # rank receives the row offsets (to cut the same nnz-balanced partition) and ONLY ITS OWN rows' neighbor ids
+    dog.arm(300, "graph generation + distribution of the row slices")
     if rank == 0:
         ptr_t, idx_t = gnc.graph.powerlaw_csr(Vg, Eg, seed=123, device=dev, community_order=True, p_local=1.0 - args.global_share)
     else:
@@ -554,11 +555,10 @@ TRANSPORT_NAMES = {"rccl": "C-ABI step (gnnagg_dist_step_gcn: pack kernel + grou
                    "torch": "torch.distributed all_to_all_single per stage + the aggregation launches from Python"}
 
 
-def run_multi(args, dev, rank, world):
+def run_multi(args, dev, rank, world, dog):
     import torch.distributed as dist
     backend = dist.get_backend()
     transport = os.environ.get("BENCH_TRANSPORT") or ("rccl" if backend == "nccl" else "torch")
-    dog = Watchdog()
     strong = args.config == "P"  # BASELINE configs[4]: ONE products-shaped graph row-partitioned over the N GPUs
     m = partitioned_run(args, dev, rank, world, strong, args.steps, args.warmup, transport, dog)
     # one driver pass yields both: the N > 1 headline line (weak scaling, feat 128) carries BASELINE configs[4] -- the products-shaped
@@ -655,16 +655,25 @@ def supervise_rank(args, json_fd):
     rank = int(os.environ.get("RANK", "0"))
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     first = os.environ.get("BENCH_TRANSPORT") or ("rccl" if backend == "nccl" else "torch")
-    attempts = [first] + (["torch"] if first == "rccl" and os.environ.get("BENCH_NO_FALLBACK") != "1" else [])
-    rc = 1
-    for i, tr in enumerate(attempts):
-        env = dict(os.environ, BENCH_CHILD="1", BENCH_TRANSPORT=tr)
+    # (transport, backend) in the order tried: the C-ABI RCCL step; torch.distributed's all_to_all_single over the same RCCL; and, when
+    # the nccl backend itself is what fails (no peer access, a broken fabric), the same all_to_all_single over gloo -- halo rows
+    # staged through the host: slow, still a measured and oracle-checked line, and it says which transport it is
+    attempts = [(first, backend)]
+    if os.environ.get("BENCH_NO_FALLBACK") != "1":
+        if first == "rccl":
+            attempts.append(("torch", backend))
+        if backend == "nccl":
+            attempts.append(("torch", "gloo"))
+    rc, reasons = 1, []
+    for i, (tr, be) in enumerate(attempts):
+        env = dict(os.environ, BENCH_CHILD="1", BENCH_TRANSPORT=tr, BENCH_BACKEND=be)
         if i > 0:
             # a fresh rendezvous for the fresh processes: rank 0's child hosts the store itself on the next port
-            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + 1)
+            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + i)
             env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
-            env["BENCH_FALLBACK_REASON"] = "the %s transport's ranks exited with code %d (17: first step failed the oracle check, 18: watchdog on a hung exchange); " \
-                                           "this line was measured on the fallback transport in fresh processes" % (attempts[0], rc)
+            reasons.append("the %s transport's ranks (backend %s) exited with code %d" % (attempts[i - 1][0], attempts[i - 1][1], rc))
+            env["BENCH_FALLBACK_REASON"] = "; ".join(reasons) + " (17: first step failed the oracle check, 18: watchdog on a hung exchange or " \
+                                           "rendezvous); this line was measured on the fallback transport in fresh processes"
             log("bench.py rank %d: %s" % (rank, env["BENCH_FALLBACK_REASON"]))
         r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)
         rc = r.returncode
@@ -736,11 +745,13 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("BENCH_BACKEND", "nccl")
+        dog = Watchdog()
+        dog.arm(300, "rendezvous + communicator (%s backend)" % backend)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        out = run_multi(args, dev, rank, world)
+        out = run_multi(args, dev, rank, world, dog)
         dist.barrier()
         dist.destroy_process_group()
     else:

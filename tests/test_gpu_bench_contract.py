@@ -108,6 +108,18 @@ def test_failed_rccl_ranks_fall_back_to_torch_transport_in_fresh_processes():
     assert d["transport"] == "torch" and d["transport_fallback"] and "rccl" in d["transport_fallback"]
 
 
+def test_failed_nccl_backend_falls_back_to_gloo_in_fresh_processes():
+    """Third level of the same ladder: when the nccl backend itself fails -- here: the driver's exact N = 2 launch with both ranks on ONE
+    GPU, which RCCL refuses for the C-ABI step AND for torch.distributed -- the ranks start once more on all_to_all_single over gloo
+    (halo rows through the host).  A slow line that says what it is instead of rc != 0."""
+    d = run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"], env={"BENCH_ONE_GPU": "1", "BENCH_PRODUCTS": "0"},
+            launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", "29581"])
+    check_common(d, 2, 2, 1)
+    assert d["transport"] == "torch" and d["backend"] == "gloo" and d["rccl_ranks"] is None
+    assert "rccl" in d["transport_fallback"] and "backend nccl" in d["transport_fallback"]
+
+
 def test_products_strong_scaling_two_ranks_on_one_gpu_over_gloo():
     """BASELINE configs[4] through the N > 1 code: ONE products-shaped graph (2 449 029 x 123 718 280, feat 100) row-partitioned over
     the ranks, halo pull inside every timed step, every rank checked against the oracle before the timed region."""
