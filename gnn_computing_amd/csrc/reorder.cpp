@@ -258,16 +258,15 @@ struct IntMap {
     }
 };
 
-// The same greedy with SEVERAL WALKERS (one per thread) for graphs where the serial pass takes minutes (products-shaped: 5.4
-// minutes of one core).  Every walker runs the serial algorithm with its OWN state -- its own LRU model of an L2, its own
-// scores and bucket queue (hash-mapped: only the clusters its cached sources vote for have an entry) -- and the walkers
-// share nothing but the read-only lists and one `placed` flag per cluster, taken with an atomic exchange when a walker pops
-// the cluster (a candidate somebody else placed meanwhile is dropped).  A walker without candidates takes the next unplaced
-// cluster in first-member order as a new seed.  The walkers' sequences are concatenated; source-less clusters follow.  (A
-// first version let a cluster be the candidate of ONE walker at a time so that the dense score arrays could be shared: a
-// popular source entering one walker's cache then claimed thousands of clusters all over the graph and hid them from the
-// walker they belonged to -- window footprint 0.44 serial, 0.49 / 0.54 / 0.63 with 2 / 4 / 8 walkers.)  The result depends
-// on thread timing (it is always a valid permutation); the single-walker path stays deterministic.
+// The same greedy with SEVERAL WALKERS for graphs where the serial pass takes minutes (products-shaped: 5.4 minutes of one core).
+// Every walker runs the serial algorithm with its OWN state -- its own LRU model of an L2, its own scores and bucket queue
+// (hash-mapped: only the clusters its cached sources vote for have an entry) -- and the walkers share nothing but the read-only
+// lists and one `placed` flag per cluster.  A walker without candidates takes the next unplaced cluster of its stripe of the
+// cluster list as a new seed.  The walkers' sequences are concatenated; source-less clusters follow.  (A first version let a
+// cluster be the candidate of ONE walker at a time so that the dense score arrays could be shared: a popular source entering one
+// walker's cache then claimed thousands of clusters all over the graph and hid them from the walker they belonged to -- window
+// footprint 0.44 serial, 0.49 / 0.54 / 0.63 with 2 / 4 / 8 walkers.  Round 3 ran one free-running walker per thread with an
+// atomic exchange on `placed`: the order depended on thread timing and on the thread count; the rounds below remove both.)
 static void emit_cache_greedy_parallel(const int *ptr, const int *idx, int V, const std::vector<std::vector<int>> &members,
                                        int cache_rows, int walkers, int *rows_out)
 {
@@ -320,30 +319,53 @@ static void emit_cache_greedy_parallel(const int *ptr, const int *idx, int V, co
             }
     }
     constexpr int kBuckets = 128;
-    std::vector<char> placed((size_t)NC, 0);   // accessed through __atomic builtins
-    std::vector<std::vector<int>> seqs((size_t)walkers);
-    int seed_cursor = 0;   // shared, atomic
-#pragma omp parallel num_threads(walkers)
-    {
-        const int w = omp_get_thread_num();
-        std::vector<int> &out = seqs[w];
-        struct Cand { long score; int bprev, bnext, inb; };
-        IntMap<Cand> cand((size_t)1 << 20);    // clusters this walker's cached sources vote for
-        std::vector<int> bhead(kBuckets + 1, -1);
+    // Bulk-synchronous rounds make the result a function of the input and the walker count alone: inside a round every walker
+    // sees the `placed` flags as they stood when the round began plus its own claims (a bit per cluster), and places up to
+    // kRoundSteps clusters; between rounds ONE thread merges the claims in walker order -- a cluster two walkers claimed in the same
+    // round stays with the lower walker and leaves the other's sequence (its sources stay in that walker's cache model: harmless
+    // and, like everything else here, independent of timing).  New seeds come from the walker's own stripe of the cluster list
+    // first, then from the stripes after it.  The walkers are logical: a round is an `omp for` over them, so the thread count
+    // changes the speed and not the order.
+    constexpr int kRoundSteps = 64;
+    std::vector<char> placed((size_t)NC, 0);   // written between rounds only
+    struct Cand { long score; int bprev, bnext, inb; };
+    struct Walker {
+        IntMap<Cand> cand{(size_t)1 << 14};    // clusters this walker's cached sources vote for
+        std::vector<int> bhead = std::vector<int>(kBuckets + 1, -1);
         int top = -1;
         // LRU over source rows of THIS walker: slots in a ring of cache_rows + 1 entries, key -> slot in a hash map
         std::unordered_map<int, int> slot_of;
-        slot_of.reserve((size_t)cache_rows * 2);
-        std::vector<int> skey((size_t)cache_rows + 1), sprev((size_t)cache_rows + 1, -1), snext((size_t)cache_rows + 1, -1), free_slots;
-        for (int i = cache_rows; i >= 0; --i) free_slots.push_back(i);
+        std::vector<int> skey, sprev, snext, free_slots;
         int head = -1, tail = -1;
-        auto b_unlink = [&](int c, Cand &e) {
+        std::vector<uint64_t> mine;            // claims of the current round
+        std::vector<int> claims, seq, stripe_cur;
+    };
+    std::vector<Walker> ws((size_t)walkers);
+    std::vector<int> stripe_lo((size_t)walkers + 1);
+    for (int w = 0; w <= walkers; ++w) stripe_lo[w] = (int)((long)NC * w / walkers);
+#pragma omp parallel for schedule(static, 1)
+    for (int w = 0; w < walkers; ++w) {
+        Walker &W = ws[w];
+        W.slot_of.reserve((size_t)cache_rows * 2);
+        W.skey.resize((size_t)cache_rows + 1);
+        W.sprev.assign((size_t)cache_rows + 1, -1);
+        W.snext.assign((size_t)cache_rows + 1, -1);
+        for (int i = cache_rows; i >= 0; --i) W.free_slots.push_back(i);
+        W.mine.assign(((size_t)NC + 63) / 64, 0);
+        W.stripe_cur.resize((size_t)walkers);
+        for (int j = 0; j < walkers; ++j) W.stripe_cur[j] = stripe_lo[j];
+    }
+    auto run_round = [&](int w) {
+        Walker &W = ws[w];
+        IntMap<Cand> &cand = W.cand;
+        std::vector<int> &bhead = W.bhead;
+        auto taken = [&](int c) { return placed[c] || ((W.mine[(size_t)c >> 6] >> (c & 63)) & 1); };
+        auto b_unlink = [&](Cand &e) {
             const int b = e.inb;
             if (b < 0) return;
             if (e.bprev >= 0) cand.find(e.bprev)->bnext = e.bnext; else bhead[b] = e.bnext;
             if (e.bnext >= 0) cand.find(e.bnext)->bprev = e.bprev;
             e.inb = -1;
-            (void)c;
         };
         auto b_link = [&](int c, Cand &e) {   // to the front of the bucket its score belongs to
             const int b = e.score <= 0 ? -1 : (int)std::min<long>(e.score * kBuckets / edges[c], kBuckets);
@@ -352,79 +374,95 @@ static void emit_cache_greedy_parallel(const int *ptr, const int *idx, int V, co
             if (bhead[b] >= 0) cand.find(bhead[b])->bprev = c;
             bhead[b] = c;
             e.inb = b;
-            if (b > top) top = b;
+            if (b > W.top) W.top = b;
         };
         auto vote = [&](int s, int sign) {   // source s entered (+1) / left (-1) this walker's cache
             if (tp[s + 1] - tp[s] > kHubCut) return;
             for (long k = tp[s]; k < tp[s + 1]; ++k) {
                 const int c = tc[k];
-                if (__atomic_load_n(&placed[c], __ATOMIC_RELAXED)) continue;
+                if (taken(c)) continue;
                 Cand *e = cand.find(c);
                 if (!e) {
                     if (sign < 0) continue;
                     e = cand.insert(c, Cand{0, -1, -1, -1});
                 }
-                b_unlink(c, *e);
+                b_unlink(*e);
                 e->score += sign * (long)tm[k];
                 if (e->score <= 0) cand.erase(c);
                 else b_link(c, *e);
             }
         };
         auto lru_unlink = [&](int sl) {
-            if (sprev[sl] >= 0) snext[sprev[sl]] = snext[sl]; else head = snext[sl];
-            if (snext[sl] >= 0) sprev[snext[sl]] = sprev[sl]; else tail = sprev[sl];
+            if (W.sprev[sl] >= 0) W.snext[W.sprev[sl]] = W.snext[sl]; else W.head = W.snext[sl];
+            if (W.snext[sl] >= 0) W.sprev[W.snext[sl]] = W.sprev[sl]; else W.tail = W.sprev[sl];
         };
         auto lru_front = [&](int sl) {
-            sprev[sl] = -1; snext[sl] = head;
-            if (head >= 0) sprev[head] = sl;
-            head = sl;
-            if (tail < 0) tail = sl;
+            W.sprev[sl] = -1; W.snext[sl] = W.head;
+            if (W.head >= 0) W.sprev[W.head] = sl;
+            W.head = sl;
+            if (W.tail < 0) W.tail = sl;
         };
         auto touch = [&](int s) {
-            auto it = slot_of.find(s);
-            if (it != slot_of.end()) { lru_unlink(it->second); lru_front(it->second); return; }
-            const int sl = free_slots.back();
-            free_slots.pop_back();
-            skey[sl] = s;
-            slot_of.emplace(s, sl);
+            auto it = W.slot_of.find(s);
+            if (it != W.slot_of.end()) { lru_unlink(it->second); lru_front(it->second); return; }
+            const int sl = W.free_slots.back();
+            W.free_slots.pop_back();
+            W.skey[sl] = s;
+            W.slot_of.emplace(s, sl);
             lru_front(sl);
             vote(s, +1);
-            if ((int)slot_of.size() > cache_rows) {
-                const int old = tail;
+            if ((int)W.slot_of.size() > cache_rows) {
+                const int old = W.tail;
                 lru_unlink(old);
-                const int so = skey[old];
-                slot_of.erase(so);
-                free_slots.push_back(old);
+                const int so = W.skey[old];
+                W.slot_of.erase(so);
+                W.free_slots.push_back(old);
                 vote(so, -1);
             }
         };
-        for (;;) {
+        for (int step = 0; step < kRoundSteps; ++step) {
             int c = -1;
-            for (;;) {   // best candidate nobody else has placed meanwhile
-                while (top >= 0 && bhead[top] < 0) --top;
-                if (top < 0) break;
-                const int t = bhead[top];
-                b_unlink(t, *cand.find(t));
+            for (;;) {   // best candidate nobody had placed when the round began
+                while (W.top >= 0 && bhead[W.top] < 0) --W.top;
+                if (W.top < 0) break;
+                const int t = bhead[W.top];
+                b_unlink(*cand.find(t));
                 cand.erase(t);
-                if (!__atomic_exchange_n(&placed[t], (char)1, __ATOMIC_ACQ_REL)) { c = t; break; }
+                if (!taken(t)) { c = t; break; }
             }
-            if (c < 0) {   // no candidate related to this walker's cache: a new seed from the unplaced pool
-                for (;;) {
-                    const int sd = __atomic_fetch_add(&seed_cursor, 1, __ATOMIC_RELAXED);
-                    if (sd >= NC) break;
-                    if (cp[sd] == cp[sd + 1]) continue;   // source-less clusters are written last
-                    if (!__atomic_exchange_n(&placed[sd], (char)1, __ATOMIC_ACQ_REL)) { c = sd; break; }
+            if (c < 0) {   // no candidate related to this walker's cache: a new seed, own stripe first
+                for (int j = 0; j < walkers && c < 0; ++j) {
+                    const int st = (w + j) % walkers;
+                    int &cur = W.stripe_cur[st];
+                    while (cur < stripe_lo[st + 1] && (cp[cur] == cp[cur + 1] || taken(cur))) ++cur;   // source-less clusters are written last
+                    if (cur < stripe_lo[st + 1]) c = cur++;
                 }
                 if (c < 0) break;
-                if (Cand *e = cand.find(c)) { b_unlink(c, *e); cand.erase(c); }
+                if (Cand *e = cand.find(c)) { b_unlink(*e); cand.erase(c); }
             }
-            out.push_back(c);
+            W.mine[(size_t)c >> 6] |= 1ULL << (c & 63);
+            W.claims.push_back(c);
             for (long k = cp[c]; k < cp[c + 1]; ++k) touch(cs[k]);
         }
+    };
+    for (;;) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int w = 0; w < walkers; ++w) run_round(w);
+        long claimed = 0;
+        for (int w = 0; w < walkers; ++w) {   // merge in walker order
+            Walker &W = ws[w];
+            claimed += (long)W.claims.size();
+            for (int c : W.claims) {
+                W.mine[(size_t)c >> 6] = 0;
+                if (!placed[c]) { placed[c] = 1; W.seq.push_back(c); }
+            }
+            W.claims.clear();
+        }
+        if (claimed == 0) break;
     }
     int pos = 0;
     for (int w = 0; w < walkers; ++w)
-        for (int c : seqs[w])
+        for (int c : ws[w].seq)
             for (int v : members[c]) rows_out[pos++] = v;
     long left = 0;
     for (int c = 0; c < NC; ++c)
@@ -545,9 +583,10 @@ int cluster_reorder(const int *ptr, const int *idx, int V, double threshold, int
     }
     if (order_mode == 1) {
         // several walkers from the size on where the serial pass takes tens of seconds (GNNAGG_REORDER_WALKERS: 1 = always the
-        // deterministic serial pass, N = N walkers)
+        // serial pass, N = N logical walkers; either way the order is deterministic)
         const int walkers_env = getenv("GNNAGG_REORDER_WALKERS") ? atoi(getenv("GNNAGG_REORDER_WALKERS")) : 0;  // (read per call: tests switch it)
-        int walkers = walkers_env > 0 ? walkers_env : (ptr[V] >= 20000000 ? std::min(omp_get_max_threads(), 64) : 1);
+        // (a fixed count, not the thread count: the order must not depend on the machine it was computed on)
+        int walkers = walkers_env > 0 ? walkers_env : (ptr[V] >= 20000000 ? 64 : 1);
         walkers = std::max(1, std::min(walkers, (int)members.size() / 4096 + 1));
         if (walkers > 1) emit_cache_greedy_parallel(ptr, idx, V, members, cache_rows, walkers, rows_out);
         else emit_cache_greedy(ptr, idx, V, members, cache_rows, rows_out);

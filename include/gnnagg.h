@@ -316,7 +316,8 @@ int gnnagg_cluster_reorder(const int *h_ptr, const int *h_idx, int num_v, float 
  * reference script, cluster2.py:156-171; = gnnagg_cluster_reorder).  order_mode 1: cache-aware greedy -- each next cluster
  * is the one whose rows find the largest share of their source rows among the cache_rows most recently gathered rows (an
  * LRU model of one XCD's L2; 0 = 4096 rows, 2 MB of 512-byte feature rows), so clusters with overlapping neighbor sets
- * become neighbors in the new numbering. */
+ * become neighbors in the new numbering.  Deterministic: the rows are a function of the arguments (graphs of 20 M edges and more
+ * are walked by 64 logical walkers in bulk-synchronous rounds -- GNNAGG_REORDER_WALKERS overrides the count, never the thread count). */
 int gnnagg_cluster_reorder_ex(const int *h_ptr, const int *h_idx, int num_v, float threshold, int num_perm, int cluster_cap,
                               unsigned long long seed, int order_mode, int cache_rows, int *h_rows_out, int *num_clusters);
 

@@ -48,7 +48,7 @@ run(ptr, idx, "plain (as generated)")
 t0 = time.perf_counter()
 rows, _ = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=8192)
 print(json.dumps({"reorder_generator_s": time.perf_counter() - t0, "host_threads": os.cpu_count(),
-                  "walkers": os.environ.get("GNNAGG_REORDER_WALKERS", "auto (min(threads, 64))")}), flush=True)
+                  "walkers": os.environ.get("GNNAGG_REORDER_WALKERS", "auto (64 logical walkers above 20 M edges)")}), flush=True)
 assert len(rows) == V and np.array_equal(np.sort(rows), np.arange(V))
 nptr, nidx, _ = gnc.reorder_csr(ptr, idx, rows)
 run(nptr, nidx, "cache-aware greedy reorder applied on load")

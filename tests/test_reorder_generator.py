@@ -152,7 +152,9 @@ def _window_footprint(ptr, idx, order, W=4096, long_row=64):
 def test_parallel_walkers_keep_the_quality_of_the_serial_greedy_order(monkeypatch):
     """order_mode 1 with several walkers (reorder.cpp, emit_cache_greedy_parallel: the products-shaped graph went from 5.4 minutes
     of one core to about a minute on 8): a valid permutation whose window footprint stays with the serial pass's -- far below the
-    scattered input order's -- whatever the thread timing was."""
+    scattered input order's.  The walkers are logical and advance in bulk-synchronous rounds, so the order is a function of the
+    input and the walker count alone: the same with one thread, three or all of them."""
+    import ctypes
     V, E = 60000, 1800000
     ptr_t, idx_t = graph.powerlaw_csr(V, E, seed=11)
     ptr, idx = ptr_t.numpy(), idx_t.numpy()
@@ -166,3 +168,13 @@ def test_parallel_walkers_keep_the_quality_of_the_serial_greedy_order(monkeypatc
     p64, i64 = ptr.astype(np.int64), idx.astype(np.int64)
     f_id, f_ser, f_par = (_window_footprint(p64, i64, o.astype(np.int64)) for o in (np.arange(V), serial, par))
     assert f_ser < 0.8 * f_id and f_par < f_ser * 1.06, (f_id, f_ser, f_par)
+    gomp = ctypes.CDLL("libgomp.so.1")                                       # the OpenMP runtime the library is linked against
+    gomp.omp_get_max_threads.restype = ctypes.c_int
+    n0 = gomp.omp_get_max_threads()
+    try:
+        for threads in (1, 3):
+            gomp.omp_set_num_threads(threads)
+            again, _ = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=4096)
+            assert np.array_equal(again, par), "4 walkers on %d thread(s) gave another order" % threads
+    finally:
+        gomp.omp_set_num_threads(n0)
