@@ -570,7 +570,10 @@ __global__ __launch_bounds__(kBlock) void k_dense_rows(const int *__restrict__ r
 //    chain from LDS.  The loads of round r+1 are issued before round r is consumed.  Heaviest rows first.
 //    (A 15 k-edge row takes ~0.3 ms this way instead of 1.49 ms; the consumer's ~20 cycles per edge bound it.
 //    A column-major stage read with b128 was tried and lost to its scattered LDS writes.)
-static constexpr int kLongBlock = 512;
+static constexpr int kLongBlock = 512;   // hub rows: seven gather wavefronts, 114 KB of LDS -- one workgroup per CU
+// Rows between the two (`medium`: too long for one lane group's latency-bound walk, far too many to give each a CU) take the same
+// kernel at 128 threads: ONE gather wavefront (64 neighbor segments per round), 16.5 KB of LDS, nine workgroups per CU.
+static constexpr int kMediumBlock = 128;
 
 struct RowsLongArgs {
     const int4 *r1;  // {beg, end, row, -}
@@ -587,17 +590,16 @@ struct RowsLongArgs {
     float slope;
 };
 
-static constexpr int kLongGatherThreads = kLongBlock - 64;  // wavefront 0 only consumes
 static constexpr int kLongU = 8;                            // neighbors per gather group per round
 
-template <int VEC>
-constexpr int long_round_edges() { return (kLongGatherThreads / (32 / VEC)) * kLongU; }
+template <int VEC, int BLOCK>
+constexpr int long_round_edges() { return ((BLOCK - 64) / (32 / VEC)) * kLongU; }   // (wavefront 0 only consumes)
 
-template <int VEC, bool IS_MAX, bool IS_GAT>
-__global__ __launch_bounds__(kLongBlock) void k_gcn_rows_long(const RowsLongArgs a)
+template <int VEC, bool IS_MAX, bool IS_GAT, int BLOCK = kLongBlock>
+__global__ __launch_bounds__(BLOCK) void k_gcn_rows_long(const RowsLongArgs a)
 {
     constexpr int GL = 32 / VEC;                 // lanes of one gather group: GL * VEC = 32 columns = 128 bytes
-    constexpr int NG = kLongGatherThreads / GL;  // gather groups per workgroup
+    constexpr int NG = (BLOCK - 64) / GL;        // gather groups per workgroup
     constexpr int U = kLongU;
     constexpr int RE = NG * U;                   // edges per round
     // two stage buffers + two weight buffers [RE]: round r+1 is written while round r is consumed, so one barrier per
@@ -926,23 +928,27 @@ int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)
     const bool is_gat = L.att != nullptr;
     if (is_gat && (a.dhead % 32) != 0) return fail(GNNAGG_ERR_ARG, "long-row GAT kernel needs head width % 32 == 0");
     const int grid = a.n1 * a.ntiles32;
-#define LAUNCH_LONG(V)                                                                                               \
+#define LAUNCH_LONG(V, B)                                                                                            \
     {                                                                                                                \
-        const size_t lds = (size_t)long_round_edges<V>() * (2 * 32 + 2) * sizeof(float);                             \
-        if (is_gat)      LAUNCH_LONG_K((k_gcn_rows_long<V, false, true>))                                            \
-        else if (is_max) LAUNCH_LONG_K((k_gcn_rows_long<V, true, false>))                                            \
-        else             LAUNCH_LONG_K((k_gcn_rows_long<V, false, false>))                                           \
+        const size_t lds = (size_t)long_round_edges<V, B>() * (2 * 32 + 2) * sizeof(float);                          \
+        if (is_gat)      LAUNCH_LONG_K((k_gcn_rows_long<V, false, true, B>), B)                                      \
+        else if (is_max) LAUNCH_LONG_K((k_gcn_rows_long<V, true, false, B>), B)                                      \
+        else             LAUNCH_LONG_K((k_gcn_rows_long<V, false, false, B>), B)                                     \
     }
-#define LAUNCH_LONG_K(K)                                                                                             \
+#define LAUNCH_LONG_K(K, B)                                                                                          \
     {                                                                                                                \
         static OncePerDevice big_lds_ok; /* > 64 KB of dynamic LDS needs the attribute: once per instantiation AND device */ \
-        if (big_lds_ok.first()) {                                                                                    \
+        if (lds > 64 * 1024 && big_lds_ok.first()) {                                                                 \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             big_lds_ok.done();                                                                                       \
         }                                                                                                            \
-        hipLaunchKernelGGL(K, dim3(grid), dim3(kLongBlock), lds, stream, a);                                         \
+        hipLaunchKernelGGL(K, dim3(grid), dim3(B), lds, stream, a);                                                  \
     }
-    if (vec == 4) LAUNCH_LONG(4) else if (vec == 2) LAUNCH_LONG(2) else LAUNCH_LONG(1)
+    if (L.medium) {
+        if (vec == 4) LAUNCH_LONG(4, kMediumBlock) else if (vec == 2) LAUNCH_LONG(2, kMediumBlock) else LAUNCH_LONG(1, kMediumBlock)
+    } else {
+        if (vec == 4) LAUNCH_LONG(4, kLongBlock) else if (vec == 2) LAUNCH_LONG(2, kLongBlock) else LAUNCH_LONG(1, kLongBlock)
+    }
 #undef LAUNCH_LONG_K
 #undef LAUNCH_LONG
     HIP_TRY(hipGetLastError());

@@ -99,11 +99,12 @@ struct BalancedPlan {
 };
 static constexpr int kSegChunksHost = 16;  // kSegChunks in kernel_util.cuh
 
-// GNNAGG_MODE_ROWS plan of a GCN aggregator (k_gcn_rows_plan): short rows per lane group, long rows per workgroup.
+// GNNAGG_MODE_ROWS plan of a GCN aggregator: short rows per lane group (r0), hub rows per 512-thread workgroup (r1), the rows
+// between the two per 128-thread workgroup (r2: "medium").  r1_rows lists the rows of r1 then r2 (products of the fused GEMM).
 struct RowsPlan {
     bool valid = false;
-    int n0 = 0, n1 = 0, long_deg = 256;
-    DevBuf<int> r0, r1, r1_rows;
+    int n0 = 0, n1 = 0, n2 = 0, long_deg = 256, med_deg = 256;
+    DevBuf<int> r0, r1, r2, r1_rows;
     std::vector<long> r0_cost_prefix;
 };
 
@@ -139,6 +140,7 @@ struct Ctx {
     DevBuf<float> yt;        // tiled image of Y the chains of that mode pass through
     DevBuf<float> den_t;     // ... and, GAT, the per-tile image of the softmax denominators
     int opt_rows_blocked = 1;
+    int opt_rows_medium = 0;    // "rows_medium_edges": rows above this many edges (up to the hub threshold) take the 128-thread workgroups (0: library rule, -1: none)
     int opt_rb_hub_edges = 0;   // "rows_hub_edges": rows with a (row, range) sub-row above this many edges leave the chained launches (0: library rule)
     RowsPlan rows_plan;      // GCN rows mode
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
@@ -468,31 +470,44 @@ static int build_rows_plan(Ctx *c)
     // row on lane groups, 45.8 at 4 * avg, 41.0 at 16 * avg, 40.0 at 32 * avg; reddit-shaped GAT 47.2 / 19.8 / 16.8 / 16.5;
     // products-shaped 9.8 at 1024 but 89 at 256 (the short rows starve).
     p.long_deg = std::max(1024, 16 * c->avg_deg());
+    // Between the two: a lane group walks its row 8 gathers at a time, each batch waiting for the one before it -- a 1000-edge row
+    // is ~125 dependent round trips (~150 us), and on a small graph that tail IS the launch (arxiv-shaped: 170 us of short rows
+    // against 74 us for the whole balanced launch).  Rows above med_deg edges take the 128-thread form of the long-row kernel
+    // instead: one gather wavefront + the consumer, 16.5 KB of LDS, nine workgroups per CU -- no CU is taken away from the short
+    // rows the way the 512-thread form does it.  Per edge that form is dearer than a lane group (half of its lanes consume), so it
+    // only pays where the tail shows: med_deg grows with the graph (a lane group's longest row should stay ~1/5 of what the launch
+    // takes anyway) and the class is empty from 4.6 M edges on.  Measured, rows mode: arxiv-shaped 186 -> 121-127 us (thresholds
+    // 256 / 128; 512: 135); products-shaped 9.8 ms without the class, 10.0-11.9 ms with thresholds 512 ... 64.
+    p.med_deg = c->opt_rows_medium > 0 ? c->opt_rows_medium : c->opt_rows_medium < 0 ? p.long_deg : std::max(128, (int)(c->E / 4500));
+    p.med_deg = std::min(p.med_deg, p.long_deg);
     std::vector<int> r0;
     struct Long { int beg, end, row; };
-    std::vector<Long> longs;
+    std::vector<Long> longs, meds;
     p.r0_cost_prefix.assign(1, 0);
     for (int r = 0; r < c->V; ++r) {
         const int beg = c->h_ptr[r], end = c->h_ptr[r + 1];
-        if (end - beg <= p.long_deg) {
+        if (end - beg <= p.med_deg) {
             r0.insert(r0.end(), {beg, end, r, r});
             p.r0_cost_prefix.push_back(p.r0_cost_prefix.back() + (end - beg) + kItemCost);
+        } else if (end - beg <= p.long_deg) {
+            meds.push_back({beg, end, r});
         } else {
             longs.push_back({beg, end, r});
         }
     }
-    std::stable_sort(longs.begin(), longs.end(), [](const Long &a, const Long &b) { return a.end - a.beg > b.end - b.beg; });
-    std::vector<int> r1;
-    for (const Long &l : longs) r1.insert(r1.end(), {l.beg, l.end, l.row, 0});
+    const auto heavier = [](const Long &a, const Long &b) { return a.end - a.beg > b.end - b.beg; };
+    std::stable_sort(longs.begin(), longs.end(), heavier);
+    std::stable_sort(meds.begin(), meds.end(), heavier);
+    std::vector<int> r1, r2, rows;
+    for (const Long &l : longs) { r1.insert(r1.end(), {l.beg, l.end, l.row, 0}); rows.push_back(l.row); }
+    for (const Long &l : meds) { r2.insert(r2.end(), {l.beg, l.end, l.row, 0}); rows.push_back(l.row); }
     p.n0 = (int)(r0.size() / 4);
     p.n1 = (int)(r1.size() / 4);
+    p.n2 = (int)(r2.size() / 4);
     if ((rc = p.r0.upload(r0))) return rc;
     if ((rc = p.r1.upload(r1))) return rc;
-    {
-        std::vector<int> rows;
-        for (const Long &l : longs) rows.push_back(l.row);
-        if ((rc = p.r1_rows.upload(rows))) return rc;
-    }
+    if ((rc = p.r2.upload(r2))) return rc;
+    if ((rc = p.r1_rows.upload(rows))) return rc;
     p.valid = true;
     return GNNAGG_OK;
 }
@@ -1273,11 +1288,17 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
             if ((rc = launch_gcn_rows_long(R, fork ? c->aux_stream : c->stream))) return rc;
             if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
         }
+        if (p.n2 > 0) {  // medium rows: ahead of the short rows on this stream (heaviest first; many workgroups per CU)
+            GcnRowsLongLaunch R;
+            R.r1 = p.r2.p; R.n1 = p.n2; R.idx = c->d_idx; R.val = c->d_val; R.x = x; R.y = y; R.feat = feat; R.reduce = reduce;
+            R.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0; R.medium = 1;
+            if ((rc = launch_gcn_rows_long(R, c->stream))) return rc;
+        }
         GcnPlanLaunch P;  // short rows: the descriptor path of the plan kernel (no segments, no hubs)
         P.t0 = p.r0.p; P.n0 = p.n0; P.t0_cost_prefix = p.r0_cost_prefix.data();
         P.row_ptr = c->d_ptr; P.idx = c->d_idx; P.val = c->d_val; P.x = x; P.y = y; P.feat = feat; P.reduce = reduce;
         P.xcd_remap = c->xcd_remap; P.num_rows = c->V; P.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
-        const bool nn_rows_ok = nn && (p.n1 == 0 || feat <= 15000);
+        const bool nn_rows_ok = nn && (p.n1 + p.n2 == 0 || feat <= 15000);
         if (nn_rows_ok) {  // short rows: epilogue of the plan kernel (or the GEMM right behind it)
             P.nn_weight = nn->weight; P.nn_out = nn->out; P.nn_cols = nn->cols;
         }
@@ -1285,8 +1306,8 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         if (fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));  // join
         if (rc || !nn) return rc;
         if (!nn_rows_ok) return launch_dense_nn(y, nn->weight, nn->out, c->V, nn->cols, feat, c->stream);
-        if (p.n1 > 0)  // the long rows' products, once their chains have joined
-            rc = launch_dense_rows(p.r1_rows.p, p.n1, y, nn->weight, nn->out, feat, nn->cols, c->stream);
+        if (p.n1 + p.n2 > 0)  // the long and medium rows' products, once their chains have joined
+            rc = launch_dense_rows(p.r1_rows.p, p.n1 + p.n2, y, nn->weight, nn->out, feat, nn->cols, c->stream);
         return rc;
     }
     GcnLaunch L;
@@ -1436,8 +1457,9 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
         // (auxiliary stream) when a 32-column tile lies inside one head
         if (!c->rows_plan.valid && (rc = build_rows_plan(c))) return rc;
         RowsPlan &p = c->rows_plan;
-        const bool long_ok = p.n1 > 0 && ((feat / heads) % 32) == 0;
-        if (p.n1 == 0 || long_ok) {
+        const bool tile_in_head = ((feat / heads) % 32) == 0;
+        const bool long_ok = p.n1 > 0 && tile_in_head;
+        if (p.n1 + p.n2 == 0 || tile_in_head) {
             const bool fork = long_ok && c->use_aux_stream;
             if (long_ok) {
                 if (fork) {
@@ -1454,6 +1476,12 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
                 R.att = att; R.heads = heads; R.slope = slope;
                 if ((rc = launch_gcn_rows_long(R, fork ? c->aux_stream : c->stream))) return rc;
                 if (fork) HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
+            }
+            if (p.n2 > 0) {  // medium rows, ahead of the short rows on this stream
+                GcnRowsLongLaunch R;
+                R.r1 = p.r2.p; R.n1 = p.n2; R.idx = c->d_idx; R.x = x; R.y = y; R.feat = feat;
+                R.att = att; R.heads = heads; R.slope = slope; R.medium = 1;
+                if ((rc = launch_gcn_rows_long(R, c->stream))) return rc;
             }
             GatPlanLaunch P;
             P.t0 = p.r0.p; P.n0 = p.n0; P.t0_cost_prefix = p.r0_cost_prefix.data();
@@ -1662,6 +1690,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "rows_blocked") c->opt_rows_blocked = value;
     else if (n == "host_plan") replan = true;
     else if (n == "rows_hub_edges") { c->opt_rb_hub_edges = std::max(0, value); replan = true; }
+    else if (n == "rows_medium_edges") { c->opt_rows_medium = value; c->rows_plan.valid = false; }
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
     if (replan) {
         c->force_host_plan = (n == "host_plan") ? (value != 0) : 0;

@@ -200,6 +200,7 @@ struct GcnRowsLongLaunch {
     const float *att = nullptr;  // non-null: GAT flavour (fused edge softmax), needs (feat / heads) % 32 == 0
     int heads = 1;
     float slope = 0.2f;
+    int medium = 0;  // 1: the 128-thread form (rows of the medium class: many workgroups per CU)
 };
 
 struct GatLaunch {

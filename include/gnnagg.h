@@ -131,6 +131,12 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *                                         compare them), 5-10 x the construction time.  0 (default)
  *   "rows_blocked"                        1 (default): GNNAGG_MODE_ROWS runs its canonical chains on the 2-D blocked order where the
  *                                         graph allows it (gnnagg_rows_blocked_ranges); 0: always the row kernels.  Same bits either way
+ *   "rows_medium_edges"                   GNNAGG_MODE_ROWS on the row kernels: rows above this many edges, up to the hub threshold
+ *                                         max(1024, 16 x mean degree), run on 128-thread workgroups (one gather wavefront + the chain)
+ *                                         instead of one lane group each.  0 (default): max(128, E / 4500), an empty class from 4.6 M
+ *                                         edges on; -1: no such class.  Same bits whatever the value
+ *   "rows_hub_edges"                      chained rows mode: rows with a (row, range) sub-row above this many edges leave the chained
+ *                                         launches for the long-row kernel (0: the library's rule)
  * [GNNAGG_XCD_REMAP] 0 / 1 / 2 (workgroup -> XCD mapping: identity / equal-count / work-balanced ranges, default 2) and [GNNAGG_PLAN] 0
  * (the round-1 item kernels + k_combine instead of the plan kernels) are environment-only measurement switches (scripts/tune_gcn.py).
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */

@@ -53,9 +53,17 @@ for cfg in (sys.argv[1:] or ["A", "P1", "R", "G"]):
         bal = lambda: agg.run(x, y, 512, "balanced", reduce=red)     # noqa: E731
         rows_fn = lambda: agg.run(x, y, 512, 0, reduce=red)          # noqa: E731
     n = 100 if cfg == "A" else 10
+    if os.environ.get("ROWS_AUX"):   # 0: hub rows on the same stream, one launch after the other (per-kernel times stand alone)
+        agg.set_option("aux_stream", int(os.environ["ROWS_AUX"]))
+    if os.environ.get("ROWS_MEDIUM_SET"):
+        agg.set_option("rows_medium_edges", int(os.environ["ROWS_MEDIUM_SET"]))
     out["balanced_before_us"] = t(bal, iters=n)
     out["rows_us"] = t(rows_fn, iters=n)
     out["balanced_after_us"] = t(bal, iters=n)
+    # ROWS_MEDIUM="-1,64,128,256": the rows mode again per threshold of the medium class ("rows_medium_edges"; -1 = no medium class)
+    for m in [int(v) for v in os.environ.get("ROWS_MEDIUM", "").split(",") if v]:
+        agg.set_option("rows_medium_edges", m)
+        out["rows_medium_%d_us" % m] = t(rows_fn, iters=n)
     print(json.dumps(out), flush=True)
     del agg, x, y
     torch.cuda.empty_cache()

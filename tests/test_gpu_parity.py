@@ -1200,6 +1200,47 @@ def test_rows_mode_long_rows_odd_widths_and_reductions(F, weights):
         assert np.array_equal(y.cpu().numpy(), fn(ptr, idx, oval, x)), red
 
 
+@pytest.mark.parametrize("F,H", [(128, 4), (30, 1), (33, 1), (602, 1), (256, 8)])
+@pytest.mark.parametrize("medium", [0, 16, 700, -1])
+def test_rows_mode_medium_rows_take_the_128_thread_form(F, H, medium):
+    """Rows between the lane-group class and the hub class (option "rows_medium_edges": 0 = the library's rule -- 128 edges on a
+    graph this small --, -1 = no such class) run the long-row kernel with ONE gather wavefront: 64 edges per round, so rows of
+    130 ... 1000 edges take 3 ... 16 rounds with ragged last ones, beside hub rows on the 512-thread form and short rows on lane
+    groups.  The chain is the reference's sequential one whichever class a row falls in: sum / mean / max bit-exact for every
+    threshold, GAT (head width a multiple of 32) within the fused bound, and the fused dense combine sees the medium rows' products."""
+    V = 3000
+    rng = np.random.default_rng(29)
+    deg = rng.integers(0, 10, V)
+    deg[[3, 40, 41, 900, 1700, 2500, 2998]] = [130, 191, 257, 640, 1000, 1023, 5000]
+    deg[rng.choice(np.arange(100, 800), 40, replace=False)] = rng.integers(129, 400, 40)
+    ptr = np.zeros(V + 1, np.int32)
+    ptr[1:] = np.cumsum(deg)
+    E = int(ptr[-1])
+    idx = rng.integers(0, V, E).astype(np.int32)
+    x, val = rand((V, F), 1), rand(E, 2)
+    agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), dev(val), F, F)
+    agg.set_option("rows_medium_edges", medium)
+    y = torch.full((V, F), 7.0, device=DEV)
+    for red, fn in (("sum", orc.gcn_seq), ("mean", orc.gcn_mean), ("max", orc.gcn_max)):
+        y.fill_(7.0)
+        agg.run(dev(x), y, 512, 0, reduce=red)
+        assert np.array_equal(y.cpu().numpy(), fn(ptr, idx, val, x)), red
+    if F == 128:   # aggregation -> dense combine in one call: the medium rows' products come from the rows-list GEMM
+        w = rand((F, 48), 5)
+        out = torch.full((V, 48), 7.0, device=DEV)
+        agg.run_with_nn(dev(x), y, dev(w), out, 512, 0)
+        ysum = orc.gcn_seq(ptr, idx, val, x)
+        assert np.array_equal(y.cpu().numpy(), ysum)
+        assert np.array_equal(out.cpu().numpy(), orc.matmul_nn(ysum, w))
+    if (F // H) % 32 == 0 and H > 1:
+        att = rand((V, H, 2), 3) * 0.4
+        gat = gnc.Aggregator_GAT(dev(ptr), dev(idx), F, F)
+        gat.set_option("rows_medium_edges", medium)
+        y.fill_(7.0)
+        gat.run(dev(x), dev(att), y, 128, 0, heads=H)
+        np.testing.assert_allclose(y.cpu().numpy(), orc.gat_fused(ptr, idx, att, x, H), rtol=3e-6, atol=1e-6)
+
+
 def test_check_csr_flags_bad_input():
     ptr = np.array([0, 2, 1, 4], np.int32)           # row 1 has ptr[1] > ptr[2]
     idx = np.array([0, 5, 2, -1], np.int32)          # 5 and -1 are outside [0, 3)
