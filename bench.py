@@ -160,7 +160,8 @@ print(json.dumps({"median_s": float(np.median(times)), "passes": len(times), "th
 
 
 def cpu_baseline(ptr, idx, val, x, budget_s=10.0):
-    """The oracle (port of aggr_gcn.h:13-35; OpenMP over rows, `schedule(dynamic, 64)`, AVX2 FMA over columns) timed on the host cores:
+    """The oracle (port of aggr_gcn.h:13-35; OpenMP over rows, `schedule(dynamic, 64)`; a row's 128 columns in eight AVX-512 accumulators --
+    64 in AVX2 ones on a host without AVX-512 --, the next edges' rows prefetched) timed on the host cores:
     whole passes over the same arxiv-shaped workload, in a CHILD process with the threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores:
     SURVEY 8d) -- the pinning must not touch this process, whose main thread issues the timed GPU launches.  A quick sweep picks the
     thread count first (all hardware threads is rarely the fastest for a 90 MB gather working set), then the rest of the budget is
@@ -189,7 +190,7 @@ def cpu_baseline(ptr, idx, val, x, budget_s=10.0):
     return {"value": len(idx) / m["median_s"], "unit": "edges/s", "cores": m["threads"], "kind": "port", "cpu_model": model,
             "hardware_threads": m["hardware_threads"],
             "sample": "%d full passes of the same arxiv-shaped workload (median %.2f ms) on %d of %d hardware threads (best of a thread-count "
-                      "sweep), OpenMP over rows, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores) in a child process" % (
+                      "sweep), OpenMP over rows, register accumulators + software prefetch, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores) in a child process" % (
                           m["passes"], m["median_s"] * 1e3, m["threads"], m["hardware_threads"])}
 
 
