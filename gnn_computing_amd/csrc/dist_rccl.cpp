@@ -8,6 +8,7 @@
 // librccl is loaded lazily with dlopen: libgnnagg.so has no link-time dependency on it (the single-GPU path never needs
 // it), and a process that already holds a copy -- torch ships one -- keeps using that copy (RTLD_NOLOAD first).
 #include <dlfcn.h>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <unistd.h>
@@ -43,6 +44,12 @@ static RcclApi *rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // test hook: another library with the same eight entry points (tests/fake_rccl: ranks as processes sharing one GPU, so that
+        // the step's multi-peer code runs on a one-GPU box).  RTLD_LOCAL: its symbols must not shadow the real librccl torch maps
+        if (const char *over = getenv("GNNAGG_RCCL_LIB")) {
+            if (*over) api.h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!api.h)
         for (const char *n : names)
             if ((api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;  // a copy this process already mapped
         if (!api.h)

@@ -23,11 +23,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, overlap, q, stages=1):
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
+
+
+def _worker(rank, world, port, overlap, q, stages=1, transport="torch"):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if transport == "rccl":   # the C-ABI step with the test double behind ncclSend / ncclRecv (read when the library first needs RCCL)
+        os.environ["GNNAGG_RCCL_LIB"] = FAKE_RCCL
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import gnn_computing_amd as gnc
@@ -39,7 +44,10 @@ def _worker(rank, world, port, overlap, q, stages=1):
         ptr, idx = ptr_t.numpy(), idx_t.numpy()
         rng = np.random.default_rng(3)
         x, val = rng.standard_normal((V, F), dtype=np.float32), rng.standard_normal(E, dtype=np.float32)
-        pg = PartitionedGCN(ptr, idx, val, F, device="cuda:0", overlap=overlap, stages=stages)
+        pg = PartitionedGCN(ptr, idx, val, F, device="cuda:0", overlap=overlap, stages=stages, transport=transport)
+        if transport == "rccl":
+            assert "libfakerccl" in open("/proc/self/maps").read()   # the double really is what the library bound
+            assert pg.hx.rccl is not None and pg.hx.n_stages == (stages[1] if isinstance(stages, tuple) else world - 1 if stages == "owner" else stages)
         r0, r1 = int(pg.hx.bounds[rank]), int(pg.hx.bounds[rank + 1])
         pg.set_local_x(torch.from_numpy(x[r0:r1]).cuda())
         ok = True
@@ -60,7 +68,7 @@ def _worker(rank, world, port, overlap, q, stages=1):
         H, FG = 8, 256
         xg = rng.standard_normal((V, FG), dtype=np.float32)
         att = (rng.standard_normal((V, H, 2), dtype=np.float32) * 0.4).astype(np.float32)
-        gat = PartitionedGAT(ptr, idx, FG, H, device="cuda:0", overlap=overlap, stages=stages)
+        gat = PartitionedGAT(ptr, idx, FG, H, device="cuda:0", overlap=overlap, stages=stages, transport=transport)
         gat.set_local(torch.from_numpy(xg[r0:r1]).cuda(), torch.from_numpy(att[r0:r1]).cuda())
         y_ref = orc.gat_fused(ptr, idx, att, xg, H)[r0:r1]
         wn = orc.gat_att(ptr, idx, att, H, 0.2)                       # normalised weights [E, H]
@@ -93,6 +101,33 @@ def test_two_ranks_one_gpu(overlap, stages):
         assert p.exitcode == 0
     for rank, ok, ok_halo, n_halo, n_send in res:
         assert ok, "rank %d: partitioned aggregation differs from the single-GPU oracle result" % rank
+        assert ok_halo, "rank %d: halo rows differ" % rank
+        assert n_halo > 0 and n_send > 0
+
+
+@pytest.mark.parametrize("world,stages", [(2, 1), (2, ("stripe", 3)), (3, "owner"), (4, ("stripe", 2)), (4, "owner")])
+def test_cabi_step_with_several_peers_on_one_gpu(world, stages):
+    """The ONE-CALL step of the C-ABI (gnnagg_dist_step_gcn / _gat: pack kernel, per stage a grouped ncclSend / ncclRecv to every
+    peer of the stage, events, local-source pass beside the exchange, halo-source pass per stage) with 2, 3 and 4 ranks.  RCCL
+    needs a GPU per rank and the box has one, so the eight nccl entry points the library binds are served by a test double
+    (tests/fake_rccl: ranks are processes sharing cuda:0, a message is a mailbox file in /dev/shm; matched per pair in posting
+    order, sizes checked on both ends).  Everything on the library's side of ncclSend / ncclRecv is the production code: the
+    offsets of several peers inside a stage, the stage-major buffers, owner and stripe plans, GCN sum / mean / max and the GAT
+    numerator / denominator passes -- all against the oracle on the global graph."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfakerccl.so is not built (__graft_entry__.build() builds it)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, True, q, stages, "rccl")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, ok_halo, n_halo, n_send in res:
+        assert ok, "rank %d: the C-ABI step's result differs from the single-GPU oracle result" % rank
         assert ok_halo, "rank %d: halo rows differ" % rank
         assert n_halo > 0 and n_send > 0
 
