@@ -108,6 +108,23 @@ def test_failed_rccl_ranks_fall_back_to_torch_transport_in_fresh_processes():
     assert d["transport"] == "torch" and d["transport_fallback"] and "rccl" in d["transport_fallback"]
 
 
+def test_two_ranks_on_the_cabi_rccl_step_through_the_test_double():
+    """The default transport of the N > 1 line -- the one-call C-ABI step, gnnagg_dist_step_gcn -- through bench.py's own code path
+    (communicator from gnnagg_dist_comm_create, `rccl_ranks` from gnnagg_dist_comm_info, oracle check of the first step, timed
+    steps) with two ranks on the one GPU: the nccl entry points are served by tests/fake_rccl (GNNAGG_RCCL_LIB), the plan
+    exchange by gloo.  No fallback may be taken."""
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
+    assert os.path.exists(fake), "tests/fake_rccl/libfakerccl.so is not built (__graft_entry__.build() builds it)"
+    d = run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu"],
+            env={"BENCH_ONE_GPU": "1", "BENCH_BACKEND": "gloo", "BENCH_TRANSPORT": "rccl", "BENCH_PRODUCTS": "0", "BENCH_NO_FALLBACK": "1",
+                 "GNNAGG_RCCL_LIB": fake},
+            launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", "29577"])
+    check_common(d, 2, 3, 1)
+    assert d["transport"] == "rccl" and d["rccl_ranks"] == 2 and d["transport_fallback"] is None and d["halo_stages"] >= 1
+    assert d["config"]["verified_against_oracle"] is True
+
+
 def test_failed_nccl_backend_falls_back_to_gloo_in_fresh_processes():
     """Third level of the same ladder: when the nccl backend itself fails -- here: the driver's exact N = 2 launch with both ranks on ONE
     GPU, which RCCL refuses for the C-ABI step AND for torch.distributed -- the ranks start once more on all_to_all_single over gloo
