@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,11 +50,14 @@ static T *to_device(const std::vector<T> &h)
     return p;
 }
 
+// --check: feature c of global row g (exactly representable, so the halo comparison is bit-exact)
+static float closed_form(int g, int c) { return (float)(((long)g * 131 + (long)c * 71) % 1013) / 1013.0f - 0.5f; }
+
 int main(int argc, char **argv)
 {
     std::string dataset, datadir = "../data/", idfile = "/tmp/gnnagg_dist.id", plan = "overlap";
     std::string stages = "1";   // staged exchange (overlap plan): K stripes of every peer's rows, or "owner" (one ring distance per stage)
-    int feat = 128, iters = 20;
+    int feat = 128, iters = 20, check = 0;   // --check 1: features are a closed form of the GLOBAL row id; halo rows and results verified on the host
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
         if (k == "--dataset") dataset = argv[i + 1];
@@ -63,9 +67,10 @@ int main(int argc, char **argv)
         else if (k == "--idfile") idfile = argv[i + 1];
         else if (k == "--plan") plan = argv[i + 1];
         else if (k == "--stages") stages = argv[i + 1];
+        else if (k == "--check") check = atoi(argv[i + 1]);
         else { fprintf(stderr, "unknown flag %s\n", k.c_str()); return 2; }
     }
-    if (dataset.empty()) { fprintf(stderr, "usage: dist_step.out --dataset D [--datadir DIR] [--feature-len F] [--iters K] [--idfile PATH] [--plan overlap|onepass] [--stages K|owner]\n"); return 2; }
+    if (dataset.empty()) { fprintf(stderr, "usage: dist_step.out --dataset D [--datadir DIR] [--feature-len F] [--iters K] [--idfile PATH] [--plan overlap|onepass] [--stages K|owner] [--check 1]\n"); return 2; }
     const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), local_rank = env_int("LOCAL_RANK", 0);
     HCK(hipSetDevice(local_rank));
     gnnagg_set_abort_on_error(0);
@@ -135,6 +140,9 @@ int main(int argc, char **argv)
         std::mt19937_64 gen(123 + rank);
         std::normal_distribution<float> nd(0.f, 1.f);
         for (auto &v : hx) v = nd(gen);
+        if (check)
+            for (int r = 0; r < n_local; ++r)
+                for (int c = 0; c < feat; ++c) hx[(size_t)r * feat + c] = closed_form(r0 + r, c);
     }
     float *d_x_ext = nullptr, *d_send = nullptr, *d_y = nullptr;
     HCK(hipMalloc((void **)&d_x_ext, sizeof(float) * std::max<size_t>((size_t)(n_local + n_halo) * feat, 1)));
@@ -193,6 +201,30 @@ int main(int argc, char **argv)
     };
     for (int i = 0; i < 3; ++i) step();
     HCK(hipStreamSynchronize(stream));
+    if (check) {
+        // every rank checks, without any further exchange: the halo rows it pulled against the closed form of their global ids,
+        // and its result rows against the sum over its CSR slice computed on the host (unit weights, double accumulation)
+        std::vector<int> slot_gid((size_t)std::max(n_halo, 1));
+        for (int i = 0; i < n_halo; ++i) slot_gid[(size_t)(n_stages > 1 ? new_of_old[(size_t)i] : i)] = halo_ids[i];
+        std::vector<float> got_halo((size_t)n_halo * feat), got_y((size_t)n_local * feat);
+        HCK(hipMemcpy(got_halo.data(), d_x_halo, sizeof(float) * got_halo.size(), hipMemcpyDeviceToHost));
+        HCK(hipMemcpy(got_y.data(), d_y, sizeof(float) * got_y.size(), hipMemcpyDeviceToHost));
+        long bad_halo = 0, bad_y = 0;
+        for (int sl = 0; sl < n_halo; ++sl)
+            for (int c = 0; c < feat; ++c) bad_halo += got_halo[(size_t)sl * feat + c] != closed_form(slot_gid[(size_t)sl], c);
+        for (int r = 0; r < n_local; ++r)
+            for (int c = 0; c < feat; c += 7) {
+                double ref = 0.0, mag = 0.0;
+                for (int e = lptr[r]; e < lptr[r + 1]; ++e) {
+                    const int gid = lidx[e] < n_local ? r0 + lidx[e] : slot_gid[(size_t)(lidx[e] - n_local)];
+                    ref += closed_form(gid, c);
+                    mag += std::fabs(closed_form(gid, c));
+                }
+                bad_y += std::fabs((double)got_y[(size_t)r * feat + c] - ref) > 1e-5 * mag + 1e-30;
+            }
+        fprintf(stderr, "{\"check\": \"rank %d\", \"halo_rows\": %d, \"bad_halo_values\": %ld, \"bad_results\": %ld}\n", rank, n_halo, bad_halo, bad_y);
+        if (bad_halo || bad_y) return 3;
+    }
     hipEvent_t a, b;
     HCK(hipEventCreate(&a)); HCK(hipEventCreate(&b));
     HCK(hipEventRecord(a, stream));

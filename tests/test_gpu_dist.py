@@ -199,6 +199,43 @@ def test_dist_step_driver_single_rank(tmp_path):
         assert lines[0]["plan"] == plan and lines[1]["summary"] == "slowest rank" and lines[1]["edges_per_s"] > 0
 
 
+@pytest.mark.parametrize("world,plan,stages", [(2, "overlap", "2"), (3, "overlap", "owner"), (3, "onepass", "1"), (4, "overlap", "3")])
+def test_dist_step_driver_with_several_ranks_on_one_gpu(tmp_path, world, plan, stages):
+    """drivers/dist_step.cpp as it is launched on a node -- one process per rank, the communicator id passed through the file
+    rendezvous (gnnagg_dist_comm_create_from_file), the request lists through gnnagg_dist_alltoallv, then the one-call step --
+    with 2-4 ranks sharing the GPU over the nccl test double.  `--check 1`: every rank verifies the halo rows it pulled (bit-exact
+    against a closed form of their global ids) and its result rows (host sum over its CSR slice) and exits 3 on a mismatch."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import gnn_computing_amd as gnc
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfakerccl.so is not built (__graft_entry__.build() builds it)")
+    d = str(tmp_path) + "/"
+    ptr, idx = gnc.graph.powerlaw_csr(5000, 60000, seed=3)
+    gnc.graph.write_graph_files(d, "tiny", ptr.numpy(), idx.numpy(), text=True)
+    exe = os.path.join(ROOT, "drivers", "dist_step.out")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")])
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", GNNAGG_RCCL_LIB=FAKE_RCCL)
+        procs.append(subprocess.Popen([exe, "--dataset", "tiny", "--datadir", d, "--feature-len", "64", "--iters", "3", "--idfile", d + "id",
+                                       "--plan", plan, "--stages", stages, "--check", "1"], stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=300)[1] for p in procs]
+    n_halo = 0
+    for r, (p, err) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d: %s" % (r, err[-2000:])
+        lines = [json.loads(l) for l in err.splitlines() if l.startswith("{")]
+        chk = [l for l in lines if "check" in l][0]
+        assert chk["bad_halo_values"] == 0 and chk["bad_results"] == 0
+        n_halo += chk["halo_rows"]
+        step = [l for l in lines if "n_local" in l][0]
+        assert step["world"] == world and step["plan"] == plan and step["n_halo"] == chk["halo_rows"]
+    assert n_halo > 0
+
+
 def test_single_call_step_at_world_one_costs_what_a_launch_costs():
     """gnnagg_dist_step_gcn / _gat: the whole row-partitioned step behind ONE C-ABI call.  At world 1 the
     exchange is degenerate -- no communication stream is ever created -- and the call must cost what the single-GPU launch costs:
