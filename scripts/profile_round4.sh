@@ -14,10 +14,13 @@ cp $OUT/cal/fetch_calibration.txt $OUT/cal/fetch_calibration.json $OUT/ 2>/dev/n
 rm -rf $OUT/cal/cal_pmc_* $OUT/cal/cal_trace
 # 3. plan construction (device builder against the host builders), rows modes, GAT chains
 python3 scripts/exp_plan_time.py reddit > $OUT/plan_time.txt 2>&1
-python3 scripts/exp_rows_mode.py A P1 R G > $OUT/rows_mode.txt 2>&1
+ROWS_MEDIUM=-1 python3 scripts/exp_rows_mode.py A P1 R G > $OUT/rows_mode.txt 2>&1   # rows_medium_-1_us: without the medium class
+[ -x scripts/micro/bin/fma_chain ] && scripts/micro/bin/fma_chain > $OUT/fma_chain.txt 2>&1
 python3 scripts/exp_rows_blocked_gat.py > $OUT/rows_gat.txt 2>&1
 # 4. the N > 1 bench line on this one GPU (two ranks over gloo: test hooks), launched the way the driver launches N = 1
 BENCH_ONE_GPU=1 BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu > $OUT/bench_2ranks_one_gpu.json 2> $OUT/bench_2ranks_one_gpu.err
+# 4b. the same line on its default transport, the one-call C-ABI step, with the nccl entry points served by the test double
+BENCH_ONE_GPU=1 BENCH_BACKEND=gloo BENCH_TRANSPORT=rccl BENCH_NO_FALLBACK=1 BENCH_PRODUCTS=0 GNNAGG_RCCL_LIB=$PWD/tests/fake_rccl/libfakerccl.so python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu > $OUT/bench_2ranks_cabi_step_double.json 2> $OUT/bench_2ranks_cabi_step_double.err
 # 5. drivers, the reference's kernels beside this library, GEMM, 3-layer forward
 python3 scripts/run_drivers.py 128 > $OUT/drivers.txt 2>&1
 python3 tests/perf_reference_on_mi355x.py > $OUT/reference_on_mi355x.jsonl 2> $OUT/reference_on_mi355x.err
