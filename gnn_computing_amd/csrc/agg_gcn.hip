@@ -581,7 +581,7 @@ struct RowsLongArgs {
     const float *val;
     const float *x;
     float *y;
-    int n1, feat, ntiles32, mean, relu;
+    int n1, feat, ntiles, mean, relu;   // ntiles: column tiles of TW floats
     // GAT flavour (reference aggr_gat, aggr_gat.h:116-164): the edge weight is exp(leaky(att[row,h,0] + att[src,h,1]))
     // computed by the gathering lanes; the consumer also runs the denominator chain.  Needs dhead % 32 == 0 so
     // that a 32-column tile lies inside one head.
@@ -592,13 +592,17 @@ struct RowsLongArgs {
 
 static constexpr int kLongU = 8;                            // neighbors per gather group per round
 
-template <int VEC, int BLOCK>
-constexpr int long_round_edges() { return ((BLOCK - 64) / (32 / VEC)) * kLongU; }   // (wavefront 0 only consumes)
+template <int VEC, int BLOCK, int TW = 32>
+constexpr int long_round_edges() { return ((BLOCK - 64) / (TW / VEC)) * kLongU; }   // (wavefront 0 only consumes)
 
-template <int VEC, bool IS_MAX, bool IS_GAT, int BLOCK = kLongBlock>
+// TW = 64 (hub form, GCN flavours): the consumer's upper 32 lanes run chains too -- the same instruction stream serves 64 columns, so a
+// launch with many hub rows (bound by the consumers' 12 cycles per step, one consumer per CU) needs half the workgroups.  A single
+// row gets no faster (its chain is as long) and has half the gather wavefronts working for it: the launcher takes TW = 64 only where
+// the (row, tile) items outnumber the CUs.
+template <int VEC, bool IS_MAX, bool IS_GAT, int BLOCK = kLongBlock, int TW = 32>
 __global__ __launch_bounds__(BLOCK) void k_gcn_rows_long(const RowsLongArgs a)
 {
-    constexpr int GL = 32 / VEC;                 // lanes of one gather group: GL * VEC = 32 columns = 128 bytes
+    constexpr int GL = TW / VEC;                 // lanes of one gather group: GL * VEC = TW columns = 128 (256) bytes
     constexpr int NG = (BLOCK - 64) / GL;        // gather groups per workgroup
     constexpr int U = kLongU;
     constexpr int RE = NG * U;                   // edges per round
@@ -611,16 +615,16 @@ __global__ __launch_bounds__(BLOCK) void k_gcn_rows_long(const RowsLongArgs a)
     // wavefront write 64-byte-strided quads that all fall on the same 8 of the 32 banks (4x slower stores, which also
     // delay the consumer's reads); with it one store instruction covers every bank evenly.
     extern __shared__ float lds[];
-    float *stage0 = lds, *stage1 = lds + RE * 32, *wst0 = lds + 2 * RE * 32, *wst1 = wst0 + RE;
+    float *stage0 = lds, *stage1 = lds + RE * TW, *wst0 = lds + 2 * RE * TW, *wst1 = wst0 + RE;
     const int F = a.feat;
-    const int tile = (int)blockIdx.x % a.ntiles32;
-    const int4 d = a.r1[(int)blockIdx.x / a.ntiles32];
+    const int tile = (int)blockIdx.x % a.ntiles;
+    const int4 d = a.r1[(int)blockIdx.x / a.ntiles];
     const int nrounds = (d.y - d.x + RE - 1) / RE;
-    const int head = IS_GAT ? (tile * 32) / a.dhead : 0;
+    const int head = IS_GAT ? (tile * TW) / a.dhead : 0;
     if (threadIdx.x < 64) {
         // ---- consumer wavefront: lane c < 32 owns column tile*32 + c and runs its chain from LDS in edge order
         const int c = (int)threadIdx.x;
-        const bool consumer = c < 32 && tile * 32 + c < F;
+        const bool consumer = c < TW && tile * TW + c < F;
         float acc = IS_MAX ? -INFINITY : 0.0f, den = 0.0f;
         auto step = [&](float xs, float ws) {
             if (IS_MAX) {
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(BLOCK) void k_gcn_rows_long(const RowsLongArgs a)
             auto load32 = [&](float4 (&xs)[8], float4 (&ws)[8], int k) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {  // k % 32 == 0: swz(k/4 + q) == (q >> 1) & 3
-                    xs[q] = *reinterpret_cast<const float4 *>(&stage[(((k >> 2) + q) * 32 + (c ^ ((q >> 1) & 3))) * 4]);
+                    xs[q] = *reinterpret_cast<const float4 *>(&stage[(((k >> 2) + q) * TW + (c ^ ((q >> 1) & 3))) * 4]);
                     ws[q] = *reinterpret_cast<const float4 *>(&wst[k + 4 * q]);
                 }
             };
@@ -671,20 +675,37 @@ __global__ __launch_bounds__(BLOCK) void k_gcn_rows_long(const RowsLongArgs a)
                     if (k0 >= nfull) break;
                 }
             }
-            for (; k0 < n; ++k0) step(stage[((k0 >> 2) * 32 + (c ^ ((k0 >> 3) & 3))) * 4 + (k0 & 3)], wst[k0]);
+            if (n - k0 >= 16) {   // rounds that are not a multiple of 32 edges (RE = 112 at TW = 64 with 2-float lanes): one 16-step batch
+                float4 xs[4], ws[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kq = (k0 >> 2) + q;
+                    xs[q] = *reinterpret_cast<const float4 *>(&stage[(kq * TW + (c ^ ((kq >> 1) & 3))) * 4]);
+                    ws[q] = *reinterpret_cast<const float4 *>(&wst[k0 + 4 * q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    step(xs[q].x, ws[q].x);
+                    step(xs[q].y, ws[q].y);
+                    step(xs[q].z, ws[q].z);
+                    step(xs[q].w, ws[q].w);
+                }
+                k0 += 16;
+            }
+            for (; k0 < n; ++k0) step(stage[((k0 >> 2) * TW + (c ^ ((k0 >> 3) & 3))) * 4 + (k0 & 3)], wst[k0]);
         }
         if (consumer) {
             if (IS_GAT) acc = acc / den;  // aggr_gat.h:163 (rows here are never empty)
             else if (a.mean) acc = acc / (float)(d.y - d.x);
             if (!IS_GAT && a.relu) acc = acc > 0.0f ? acc : 0.0f;
-            a.y[(size_t)d.z * F + tile * 32 + c] = acc;
+            a.y[(size_t)d.z * F + tile * TW + c] = acc;
         }
         return;
     }
     // ---- gather wavefronts: group g fetches the 128-byte tile segments of edges base + g*U .. +U of every round
     const int t = (int)threadIdx.x - 64;
     const int g = t / GL, lane = t & (GL - 1);
-    const int col = tile * 32 + lane * VEC;
+    const int col = tile * TW + lane * VEC;
     const bool col_ok = col < F;
     const float *__restrict__ xcol = a.x + col;
     const float a_dst = IS_GAT ? a.att[((size_t)d.z * a.heads + head) * 2] : 0.0f;
@@ -728,7 +749,7 @@ __global__ __launch_bounds__(BLOCK) void k_gcn_rows_long(const RowsLongArgs a)
                 const int swz = (kq >> 1) & 3;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
-                    *reinterpret_cast<float4 *>(&stage[(kq * 32 + ((lane * VEC + j) ^ swz)) * 4]) =
+                    *reinterpret_cast<float4 *>(&stage[(kq * TW + ((lane * VEC + j) ^ swz)) * 4]) =
                         make_float4(xv[4 * hq].v[j], xv[4 * hq + 1].v[j], xv[4 * hq + 2].v[j], xv[4 * hq + 3].v[j]);
             }
         }
@@ -922,18 +943,27 @@ int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)
     else if (L.feat % 2 == 0 && aligned(L.x, 8)) vec = 2;
     RowsLongArgs a;
     a.r1 = reinterpret_cast<const int4 *>(L.r1); a.idx = L.idx; a.val = L.val; a.x = L.x; a.y = L.y;
-    a.n1 = L.n1; a.feat = L.feat; a.ntiles32 = ceil_div(L.feat, 32); a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.relu = L.relu;
+    a.n1 = L.n1; a.feat = L.feat; a.ntiles = ceil_div(L.feat, 32); a.mean = L.reduce == GNNAGG_REDUCE_MEAN; a.relu = L.relu;
     a.att = L.att; a.heads = L.heads; a.dhead = L.heads > 0 ? L.feat / L.heads : L.feat; a.slope = L.slope;
     const bool is_max = L.reduce == GNNAGG_REDUCE_MAX;
     const bool is_gat = L.att != nullptr;
     if (is_gat && (a.dhead % 32) != 0) return fail(GNNAGG_ERR_ARG, "long-row GAT kernel needs head width % 32 == 0");
-    const int grid = a.n1 * a.ntiles32;
+    // 64-column tiles for the hub form where the launch is bound by consumer throughput, not by one row's chain (see the kernel)
+    const bool wide = !L.medium && !is_gat && L.feat > 32 && (L.tile_w == 64 || (L.tile_w == 0 && (long)a.n1 * a.ntiles > 2L * device_cu_count()));
+    if (wide) a.ntiles = ceil_div(L.feat, 64);
+    const int grid = a.n1 * a.ntiles;
 #define LAUNCH_LONG(V, B)                                                                                            \
     {                                                                                                                \
         const size_t lds = (size_t)long_round_edges<V, B>() * (2 * 32 + 2) * sizeof(float);                          \
         if (is_gat)      LAUNCH_LONG_K((k_gcn_rows_long<V, false, true, B>), B)                                      \
         else if (is_max) LAUNCH_LONG_K((k_gcn_rows_long<V, true, false, B>), B)                                      \
         else             LAUNCH_LONG_K((k_gcn_rows_long<V, false, false, B>), B)                                     \
+    }
+#define LAUNCH_WIDE(V)                                                                                               \
+    {                                                                                                                \
+        const size_t lds = (size_t)long_round_edges<V, kLongBlock, 64>() * (2 * 64 + 2) * sizeof(float);             \
+        if (is_max) LAUNCH_LONG_K((k_gcn_rows_long<V, true, false, kLongBlock, 64>), kLongBlock)                     \
+        else        LAUNCH_LONG_K((k_gcn_rows_long<V, false, false, kLongBlock, 64>), kLongBlock)                    \
     }
 #define LAUNCH_LONG_K(K, B)                                                                                          \
     {                                                                                                                \
@@ -944,13 +974,16 @@ int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)
         }                                                                                                            \
         hipLaunchKernelGGL(K, dim3(grid), dim3(B), lds, stream, a);                                                  \
     }
-    if (L.medium) {
+    if (wide) {
+        if (vec == 4) LAUNCH_WIDE(4) else if (vec == 2) LAUNCH_WIDE(2) else LAUNCH_WIDE(1)
+    } else if (L.medium) {
         if (vec == 4) LAUNCH_LONG(4, kMediumBlock) else if (vec == 2) LAUNCH_LONG(2, kMediumBlock) else LAUNCH_LONG(1, kMediumBlock)
     } else {
         if (vec == 4) LAUNCH_LONG(4, kLongBlock) else if (vec == 2) LAUNCH_LONG(2, kLongBlock) else LAUNCH_LONG(1, kLongBlock)
     }
 #undef LAUNCH_LONG_K
 #undef LAUNCH_LONG
+#undef LAUNCH_WIDE
     HIP_TRY(hipGetLastError());
     return GNNAGG_OK;
 }

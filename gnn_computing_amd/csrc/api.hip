@@ -140,6 +140,7 @@ struct Ctx {
     DevBuf<float> yt;        // tiled image of Y the chains of that mode pass through
     DevBuf<float> den_t;     // ... and, GAT, the per-tile image of the softmax denominators
     int opt_rows_blocked = 1;
+    int opt_hub_tile = 0;       // "rows_hub_tile": column-tile width of the 512-thread long-row form, GCN flavours (0: the launcher's rule; 32; 64)
     int opt_rows_medium = 0;    // "rows_medium_edges": rows above this many edges (up to the hub threshold) take the 128-thread workgroups (0: library rule, -1: none)
     int opt_rb_hub_edges = 0;   // "rows_hub_edges": rows with a (row, range) sub-row above this many edges leave the chained launches (0: library rule)
     RowsPlan rows_plan;      // GCN rows mode
@@ -1027,6 +1028,7 @@ static int run_rows_blocked(Ctx *c, const float *x, float *y, int feat, int redu
     const bool fork = rb.n1 > 0 && c->use_aux_stream;
     auto hub_rows = [&](hipStream_t st) -> int {
         GcnRowsLongLaunch R;
+            R.tile_w = c->opt_hub_tile;
         R.r1 = rb.r1.p; R.n1 = rb.n1; R.idx = c->d_idx; R.val = c->d_val; R.x = x; R.y = y; R.feat = feat; R.reduce = reduce;
         R.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
         return launch_gcn_rows_long(R, st);
@@ -1115,6 +1117,7 @@ static int run_rows_blocked_gat(Ctx *c, const float *x, const float *att, float 
     const bool fork = rb.n1 > 0 && c->use_aux_stream;
     auto hub_rows = [&](hipStream_t st) -> int {
         GcnRowsLongLaunch R;
+            R.tile_w = c->opt_hub_tile;
         R.r1 = rb.r1.p; R.n1 = rb.n1; R.idx = c->d_idx; R.x = x; R.y = y; R.feat = feat; R.att = att; R.heads = heads; R.slope = slope;
         return launch_gcn_rows_long(R, st);
     };
@@ -1283,6 +1286,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
                 HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
             }
             GcnRowsLongLaunch R;
+            R.tile_w = c->opt_hub_tile;
             R.r1 = p.r1.p; R.n1 = p.n1; R.idx = c->d_idx; R.val = c->d_val; R.x = x; R.y = y; R.feat = feat; R.reduce = reduce;
             R.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0;
             if ((rc = launch_gcn_rows_long(R, fork ? c->aux_stream : c->stream))) return rc;
@@ -1290,6 +1294,7 @@ static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int red
         }
         if (p.n2 > 0) {  // medium rows: ahead of the short rows on this stream (heaviest first; many workgroups per CU)
             GcnRowsLongLaunch R;
+            R.tile_w = c->opt_hub_tile;
             R.r1 = p.r2.p; R.n1 = p.n2; R.idx = c->d_idx; R.val = c->d_val; R.x = x; R.y = y; R.feat = feat; R.reduce = reduce;
             R.relu = (flags & GNNAGG_FLAG_RELU) ? 1 : 0; R.medium = 1;
             if ((rc = launch_gcn_rows_long(R, c->stream))) return rc;
@@ -1472,6 +1477,7 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
                     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
                 }
                 GcnRowsLongLaunch R;
+            R.tile_w = c->opt_hub_tile;
                 R.r1 = p.r1.p; R.n1 = p.n1; R.idx = c->d_idx; R.x = x; R.y = y; R.feat = feat;
                 R.att = att; R.heads = heads; R.slope = slope;
                 if ((rc = launch_gcn_rows_long(R, fork ? c->aux_stream : c->stream))) return rc;
@@ -1479,6 +1485,7 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
             }
             if (p.n2 > 0) {  // medium rows, ahead of the short rows on this stream
                 GcnRowsLongLaunch R;
+            R.tile_w = c->opt_hub_tile;
                 R.r1 = p.r2.p; R.n1 = p.n2; R.idx = c->d_idx; R.x = x; R.y = y; R.feat = feat;
                 R.att = att; R.heads = heads; R.slope = slope; R.medium = 1;
                 if ((rc = launch_gcn_rows_long(R, c->stream))) return rc;
@@ -1690,6 +1697,10 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     else if (n == "rows_blocked") c->opt_rows_blocked = value;
     else if (n == "host_plan") replan = true;
     else if (n == "rows_hub_edges") { c->opt_rb_hub_edges = std::max(0, value); replan = true; }
+    else if (n == "rows_hub_tile") {
+        if (value != 0 && value != 32 && value != 64) return fail(GNNAGG_ERR_ARG, "rows_hub_tile: 0, 32 or 64");
+        c->opt_hub_tile = value;
+    }
     else if (n == "rows_medium_edges") { c->opt_rows_medium = value; c->rows_plan.valid = false; }
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
     if (replan) {

@@ -201,6 +201,7 @@ struct GcnRowsLongLaunch {
     int heads = 1;
     float slope = 0.2f;
     int medium = 0;  // 1: the 128-thread form (rows of the medium class: many workgroups per CU)
+    int tile_w = 0;  // hub form, GCN flavours: 0 = the launcher's rule, 32 / 64 = that column-tile width ("rows_hub_tile")
 };
 
 struct GatLaunch {

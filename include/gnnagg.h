@@ -135,6 +135,8 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *                                         max(1024, 16 x mean degree), run on 128-thread workgroups (one gather wavefront + the chain)
  *                                         instead of one lane group each.  0 (default): max(128, E / 4500), an empty class from 4.6 M
  *                                         edges on; -1: no such class.  Same bits whatever the value
+ *   "rows_hub_tile"                       GNNAGG_MODE_ROWS, hub rows (GCN flavours): 32- or 64-column tiles per workgroup of the long-row
+ *                                         kernel; 0 (default): 64 where the launch has more (row, tile) items than twice the CUs.  Same bits
  *   "rows_hub_edges"                      chained rows mode: rows with a (row, range) sub-row above this many edges leave the chained
  *                                         launches for the long-row kernel (0: the library's rule)
  * [GNNAGG_XCD_REMAP] 0 / 1 / 2 (workgroup -> XCD mapping: identity / equal-count / work-balanced ranges, default 2) and [GNNAGG_PLAN] 0

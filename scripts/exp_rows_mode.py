@@ -55,6 +55,8 @@ for cfg in (sys.argv[1:] or ["A", "P1", "R", "G"]):
     n = 100 if cfg == "A" else 10
     if os.environ.get("ROWS_AUX"):   # 0: hub rows on the same stream, one launch after the other (per-kernel times stand alone)
         agg.set_option("aux_stream", int(os.environ["ROWS_AUX"]))
+    if os.environ.get("ROWS_HUB_TILE") and cfg != "G":
+        agg.set_option("rows_hub_tile", int(os.environ["ROWS_HUB_TILE"]))
     if os.environ.get("ROWS_MEDIUM_SET"):
         agg.set_option("rows_medium_edges", int(os.environ["ROWS_MEDIUM_SET"]))
     out["balanced_before_us"] = t(bal, iters=n)

@@ -1194,10 +1194,14 @@ def test_rows_mode_long_rows_odd_widths_and_reductions(F, weights):
     agg = gnc.Aggregator_GCN(dev(ptr), dev(idx), None if val is None else dev(val), F, F)
     oval = val if val is not None else np.ones(E, np.float32)
     y = torch.full((V, F), 7.0, device=DEV)
-    for red, fn in (("sum", orc.gcn_seq), ("mean", orc.gcn_mean), ("max", orc.gcn_max)):
-        y.fill_(7.0)
-        agg.run(dev(x), y, 512, 0, reduce=red)
-        assert np.array_equal(y.cpu().numpy(), fn(ptr, idx, oval, x)), red
+    # "rows_hub_tile": 32-column tiles (one consumer lane per column in half a wavefront) or 64-column ones (the whole wavefront consumes:
+    # the form a launch with many hub rows takes by itself); 64 with 1- and 2-float lanes has rounds of 56 / 112 edges (16-step batches)
+    for tile_w in (32, 64):
+        agg.set_option("rows_hub_tile", tile_w)
+        for red, fn in (("sum", orc.gcn_seq), ("mean", orc.gcn_mean), ("max", orc.gcn_max)):
+            y.fill_(7.0)
+            agg.run(dev(x), y, 512, 0, reduce=red)
+            assert np.array_equal(y.cpu().numpy(), fn(ptr, idx, oval, x)), (red, tile_w)
 
 
 @pytest.mark.parametrize("F,H", [(128, 4), (30, 1), (33, 1), (602, 1), (256, 8), (96, 4)])
