@@ -132,6 +132,27 @@ def test_two_ranks_on_the_cabi_rccl_step_through_the_test_double():
     assert d["config"]["verified_against_oracle"] is True
 
 
+def test_eight_ranks_on_the_cabi_rccl_step_through_the_test_double():
+    """The rank count the line is specified for (BASELINE: 1 / 2 / 4 / 8 GPUs): `python3 bench.py --gpus 8` without a launcher, eight
+    ranks on the one GPU, the one-call C-ABI step with seven peers per rank and the owner plan's seven stages (one ring distance each) --
+    the nccl entry points served by tests/fake_rccl.  Every rank's first step is checked against the oracle inside bench.py."""
+    fake = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
+    assert os.path.exists(fake), "tests/fake_rccl/libfakerccl.so is not built (__graft_entry__.build() builds it)"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_ONE_GPU="1", BENCH_BACKEND="gloo", BENCH_TRANSPORT="rccl", BENCH_PRODUCTS="0", BENCH_NO_FALLBACK="1", BENCH_STAGES="owner",
+               GNNAGG_RCCL_LIB=fake)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    check_common(d, 8, 2, 1)
+    assert d["transport"] == "rccl" and d["rccl_ranks"] == 8 and d["halo_stages"] == 7 and d["transport_fallback"] is None
+    assert d["config"]["verified_against_oracle"] is True and d["config"]["num_e"] == 8 * 1166243
+    assert 0.3 < d["remote_edge_share"] < 0.5      # 7/8 of the generator's 50 % global picks
+
+
 def test_failed_nccl_backend_falls_back_to_gloo_in_fresh_processes():
     """Third level of the same ladder: when the nccl backend itself fails -- here: the driver's exact N = 2 launch with both ranks on ONE
     GPU, which RCCL refuses for the C-ABI step AND for torch.distributed -- the ranks start once more on all_to_all_single over gloo
