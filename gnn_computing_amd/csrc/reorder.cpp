@@ -326,7 +326,10 @@ static void emit_cache_greedy_parallel(const int *ptr, const int *idx, int V, co
     // and, like everything else here, independent of timing).  New seeds come from the walker's own stripe of the cluster list
     // first, then from the stripes after it.  The walkers are logical: a round is an `omp for` over them, so the thread count
     // changes the speed and not the order.
-    constexpr int kRoundSteps = 64;
+#ifndef GNNAGG_REORDER_ROUND
+#define GNNAGG_REORDER_ROUND 256
+#endif
+    constexpr int kRoundSteps = GNNAGG_REORDER_ROUND;
     std::vector<char> placed((size_t)NC, 0);   // written between rounds only
     struct Cand { long score; int bprev, bnext, inb; };
     struct Walker {
