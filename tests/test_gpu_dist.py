@@ -105,7 +105,7 @@ def test_two_ranks_one_gpu(overlap, stages):
         assert n_halo > 0 and n_send > 0
 
 
-@pytest.mark.parametrize("world,stages", [(2, 1), (2, ("stripe", 3)), (3, "owner"), (4, ("stripe", 2)), (4, "owner")])
+@pytest.mark.parametrize("world,stages", [(2, 1), (2, ("stripe", 3)), (3, "owner"), (4, ("stripe", 2)), (4, "owner"), (8, ("stripe", 2))])
 def test_cabi_step_with_several_peers_on_one_gpu(world, stages):
     """The ONE-CALL step of the C-ABI (gnnagg_dist_step_gcn / _gat: pack kernel, per stage a grouped ncclSend / ncclRecv to every
     peer of the stage, events, local-source pass beside the exchange, halo-source pass per stage) with 2, 3 and 4 ranks.  RCCL
