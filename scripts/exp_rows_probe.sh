@@ -2,7 +2,7 @@
 # per-kernel durations of the rows mode on the headline input, per library build and with / without the second stream
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for lib in ${LIBS:-main nodpp dpp_nocons dpp_nogather r3_nocons r3_nogather}; do
+for lib in ${LIBS:-main}; do
   for aux in 1 0; do
     if [ "$lib" = main ]; then unset GNNAGG_LIB; else export GNNAGG_LIB=$R/gnn_computing_amd/csrc/build/ab/libgnnagg_$lib.so; fi
     export ROWS_AUX=$aux ROWS_MEDIUM_SET=256
