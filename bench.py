@@ -323,7 +323,8 @@ def run_single(args, dev):
         "reorder_minhash_clusters": {"value": E / (results["reorder_minhash_clusters"][0] / args.steps),
                                      "avg_launch_us": results["reorder_minhash_clusters"][1] * 1e6,
                                      "note": "the reference's clustering (MinHash-64, LSH 0.2, cap 64) in first-member order"},
-        "reorder_prep_s": t_reorder, "schedule_prep_s": prep.get("schedule_prep_s"),
+        "reorder_prep_s": t_reorder, "reorder_walkers": int(os.environ.get("GNNAGG_REORDER_WALKERS", "0")) or (64 if E >= 20000000 else 1),
+        "schedule_prep_s": prep.get("schedule_prep_s"),
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(nptr, nidx, val, x[rows], args.cpu_budget)
@@ -414,6 +415,7 @@ def run_other_config(args, dev):
         if not ok:
             raise SystemExit("bench.py --config P1: the reordered arm differs from the oracle")
         reordered = {"value": E / (wall_r / steps), "ms_per_step": wall_r / steps * 1e3, "avg_launch_us": dev_r * 1e6, "reorder_prep_s": t_reorder,
+                     "reorder_walkers": int(os.environ.get("GNNAGG_REORDER_WALKERS", "0")) or (64 if E >= 20000000 else 1),
                      "verified_against_oracle": True,
                      "what": "the same graph renumbered by gnnagg_cluster_reorder_ex (cache-aware greedy order, cluster_cap 1, cache model 8192 rows) "
                              "and loaded like a .reorder_thres_0.2 file; first 2000 rows checked against the oracle"}
