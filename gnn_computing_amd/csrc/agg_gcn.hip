@@ -592,18 +592,25 @@ struct RowsLongArgs {
 
 static constexpr int kLongU = 8;                            // neighbors per gather group per round
 
-template <int VEC, int BLOCK, int TW = 32>
-constexpr int long_round_edges() { return ((BLOCK - 64) / (TW / VEC)) * kLongU; }   // (wavefront 0 only consumes)
+template <int VEC, int BLOCK, int TW = 32, int NC = 1>
+constexpr int long_round_edges() { return ((BLOCK - 64 * NC) / (TW / VEC)) * kLongU; }   // (the first NC wavefronts only consume)
 
 // TW = 64 (hub form, GCN flavours): the consumer's upper 32 lanes run chains too -- the same instruction stream serves 64 columns, so a
 // launch with many hub rows (bound by the consumers' 12 cycles per step, one consumer per CU) needs half the workgroups.  A single
 // row gets no faster (its chain is as long) and has half the gather wavefronts working for it: the launcher takes TW = 64 only where
 // the (row, tile) items outnumber the CUs.
-template <int VEC, bool IS_MAX, bool IS_GAT, int BLOCK = kLongBlock, int TW = 32>
+// NC = 2 (GCN flavours): TWO consumer wavefronts take the round's 64-step batches in turn.  A consumer reads its batch from LDS into
+// registers while the other one runs the chain, then waits for the accumulators -- {value, batches done} pairs in LDS, one 8-byte slot per
+// lane -- and runs its 64 steps register-fed: the ds_read_b128 instructions (14 issue cycles each, 7 of the 12 cycles of a step) leave the
+// chain's critical path; what remains is the FMA (5.1) and the hand-over once per 64 steps (~300 cycles: LDS write, poll, LDS read).
+// arxiv-shaped, the 15 k-edge row: 95 -> 80 us alone, 99 -> 85 us beside the short rows; rows mode 122.5 -> 114 us.  With 64-column
+// tiles (the throughput-bound launches) the same form loses -- products-shaped 9.1 -> 10.4 ms -- and is not instantiated.
+static constexpr int kLongBlock2 = 576;   // 2 consumers + 7 gather wavefronts: rounds of 448 edges = 7 batches
+template <int VEC, bool IS_MAX, bool IS_GAT, int BLOCK = kLongBlock, int TW = 32, int NC = 1>
 __global__ __launch_bounds__(BLOCK) void k_gcn_rows_long(const RowsLongArgs a)
 {
     constexpr int GL = TW / VEC;                 // lanes of one gather group: GL * VEC = TW columns = 128 (256) bytes
-    constexpr int NG = (BLOCK - 64) / GL;        // gather groups per workgroup
+    constexpr int NG = (BLOCK - 64 * NC) / GL;   // gather groups per workgroup
     constexpr int U = kLongU;
     constexpr int RE = NG * U;                   // edges per round
     // two stage buffers + two weight buffers [RE]: round r+1 is written while round r is consumed, so one barrier per
@@ -621,7 +628,77 @@ __global__ __launch_bounds__(BLOCK) void k_gcn_rows_long(const RowsLongArgs a)
     const int4 d = a.r1[(int)blockIdx.x / a.ntiles];
     const int nrounds = (d.y - d.x + RE - 1) / RE;
     const int head = IS_GAT ? (tile * TW) / a.dhead : 0;
-    if (threadIdx.x < 64) {
+    if constexpr (NC == 2) {
+      if (threadIdx.x < 128) {
+        static_assert(NC == 1 || (!IS_GAT && RE % 64 == 0), "two consumers: GCN flavours, rounds of whole 64-step batches");
+        const int cw = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // which consumer
+        const int c = (int)threadIdx.x & 63, cc = c & (TW - 1);   // (lanes past the tile shadow a real column; only `consumer` lanes store)
+        const bool consumer = c < TW && tile * TW + c < F;
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(wst1 + RE) + c;
+        if (cw == 0) __hip_atomic_store(slot, (unsigned long long)__float_as_uint(IS_MAX ? -INFINITY : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int gb = 0;   // batches of 64 steps so far, over all rounds: batch gb belongs to consumer gb & 1
+        for (int r = 0; r < nrounds; ++r) {
+            __syncthreads();  // round r is staged (round 0: and the slots are initialised)
+            const float *stage = (r & 1) ? stage1 : stage0, *wst = (r & 1) ? wst1 : wst0;
+            const int base = d.x + r * RE;
+            const int n = d.y - base < RE ? d.y - base : RE;
+            const int nb = (n + 63) >> 6;
+            for (int i = 0; i < nb; ++i, ++gb) {
+                if ((gb & 1) != cw) continue;
+                const int k = i << 6;
+                const int nk = n - k < 64 ? n - k : 64;
+                float4 xs[16], ws[16];   // (reads past the round's last edge stay inside the stage buffers: RE is a multiple of 64)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int kq = (k >> 2) + q;
+                    xs[q] = *reinterpret_cast<const float4 *>(&stage[(kq * TW + (cc ^ ((kq >> 1) & 3))) * 4]);
+                    ws[q] = *reinterpret_cast<const float4 *>(&wst[k + 4 * q]);
+                }
+                unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while ((int)(v >> 32) != gb) {
+#ifdef GNNAGG_EXP_POLL_SLEEP
+                    __builtin_amdgcn_s_sleep(GNNAGG_EXP_POLL_SLEEP);
+#endif
+                    v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                float acc = __uint_as_float((unsigned)v);
+                auto step = [&](float x1, float w1) {
+                    if (IS_MAX) {
+                        const float p = x1 * w1;
+                        acc = p > acc ? p : acc;
+                    } else {
+                        acc = __builtin_fmaf(x1, w1, acc);
+                    }
+                };
+                if (nk == 64) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        step(xs[q].x, ws[q].x); step(xs[q].y, ws[q].y); step(xs[q].z, ws[q].z); step(xs[q].w, ws[q].w);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        if (4 * q < nk) step(xs[q].x, ws[q].x);
+                        if (4 * q + 1 < nk) step(xs[q].y, ws[q].y);
+                        if (4 * q + 2 < nk) step(xs[q].z, ws[q].z);
+                        if (4 * q + 3 < nk) step(xs[q].w, ws[q].w);
+                    }
+                }
+                if (r == nrounds - 1 && i == nb - 1) {
+                    if (consumer) {
+                        if (a.mean) acc = acc / (float)(d.y - d.x);
+                        if (a.relu) acc = acc > 0.0f ? acc : 0.0f;
+                        a.y[(size_t)d.z * F + tile * TW + c] = acc;
+                    }
+                } else {
+                    __hip_atomic_store(slot, ((unsigned long long)(unsigned)(gb + 1) << 32) | __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        return;
+      }
+    }
+    if (NC == 1 && threadIdx.x < 64) {
         // ---- consumer wavefront: lane c < 32 owns column tile*32 + c and runs its chain from LDS in edge order
         const int c = (int)threadIdx.x;
         const bool consumer = c < TW && tile * TW + c < F;
@@ -703,7 +780,7 @@ __global__ __launch_bounds__(BLOCK) void k_gcn_rows_long(const RowsLongArgs a)
         return;
     }
     // ---- gather wavefronts: group g fetches the 128-byte tile segments of edges base + g*U .. +U of every round
-    const int t = (int)threadIdx.x - 64;
+    const int t = (int)threadIdx.x - 64 * NC;
     const int g = t / GL, lane = t & (GL - 1);
     const int col = tile * TW + lane * VEC;
     const bool col_ok = col < F;
@@ -974,7 +1051,11 @@ int launch_gcn_rows_long(const GcnRowsLongLaunch &L, void *stream_v)
         }                                                                                                            \
         hipLaunchKernelGGL(K, dim3(grid), dim3(B), lds, stream, a);                                                  \
     }
-    if (wide) {
+    if (!L.medium && !is_gat && !wide && vec == 4) {   // hub rows, 16-byte lanes: two consumer wavefronts (see the kernel)
+        const size_t lds = (size_t)long_round_edges<4, kLongBlock2, 32, 2>() * (2 * 32 + 2) * sizeof(float) + 64 * sizeof(unsigned long long);
+        if (is_max) LAUNCH_LONG_K((k_gcn_rows_long<4, true, false, kLongBlock2, 32, 2>), kLongBlock2)
+        else        LAUNCH_LONG_K((k_gcn_rows_long<4, false, false, kLongBlock2, 32, 2>), kLongBlock2)
+    } else if (wide) {
         if (vec == 4) LAUNCH_WIDE(4) else if (vec == 2) LAUNCH_WIDE(2) else LAUNCH_WIDE(1)
     } else if (L.medium) {
         if (vec == 4) LAUNCH_LONG(4, kMediumBlock) else if (vec == 2) LAUNCH_LONG(2, kMediumBlock) else LAUNCH_LONG(1, kMediumBlock)

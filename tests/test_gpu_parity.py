@@ -1176,11 +1176,13 @@ def test_rows_mode_isolated_hub_gcn_and_gat(F, H):
     assert np.all(y.cpu().numpy()[deg == 0] == 0)
 
 
-@pytest.mark.parametrize("F", [30, 33, 130, 602])
+@pytest.mark.parametrize("F", [30, 33, 130, 602, 64, 100, 128])
 @pytest.mark.parametrize("weights", [True, False])
 def test_rows_mode_long_rows_odd_widths_and_reductions(F, weights):
     """Rows mode with several long rows (1.5 k - 9 k edges: 4 - 21 rounds of the long-row kernel, ragged last round) at
-    widths that take the 1- and 2-float lane packs and a ragged last 32-column tile; sum / mean / max, bit-exact."""
+    widths that take the 1- and 2-float lane packs and a ragged last 32-column tile, and at multiples of 4 (16-byte lanes: the form with
+    two consumer wavefronts handing the accumulators to each other every 64 steps; F = 100: a last tile of 4 columns); sum / mean / max,
+    bit-exact."""
     V = 3000
     rng = np.random.default_rng(23)
     deg = rng.integers(0, 10, V)
