@@ -34,7 +34,7 @@ FEAT = 128
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 L2_PEAK_GBPS = 34500.0  # same guide, "L2": 4 MiB per XCD, ~34.5 TB/s aggregate (the 2-D blocked order gathers from L2)
 L2_GATHER_MEASURED_GBPS = 24500.0  # measured here: 256-byte row gathers from an XCD's own L2 (profiles/r02/gather_ceiling.txt)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def algorithmic_bytes(V, E, F, explicit_val=True):
@@ -64,7 +64,7 @@ def pmc_traffic(tag):
     -> scripts/prof_config.sh -> profiles/<round>/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, the
     gfx950 correction of MI355X_MICROARCH.md).  Returns (dominant kernel's bytes, all kernels' bytes per step, label, stale):
     `stale` is True when the build the counters were collected on is not the library running now."""
-    for rnd in (PROFILE_ROUND, "r03", "r02"):
+    for rnd in (PROFILE_ROUND, "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if os.path.exists(f):
             d = json.load(open(f)).get(tag)
@@ -277,6 +277,9 @@ def run_single(args, dev):
     _, probe_u_s, _ = time_steps(lambda: agg_u.probe_gather(dx, mode), args.steps, args.warmup, lambda: None)
     _, kern_u_s, _ = time_steps(lambda: agg_u.run(dx, y, 512, mode), args.steps, args.warmup, lambda: None)
     traffic, _, traffic_label, traffic_stale = pmc_traffic("A")
+    # ceilings that bound the bytes `achieved` divides: 512-byte row gathers, ids uniform over a window the size
+    # of X (Infinity-Cache resident, like this input's X) and over 5 GB (HBM), measured in this process
+    ceil_mall, ceil_hbm = gather_ceiling(dev, "g512_mall"), gather_ceiling(dev, "g512_hbm")
     other = "no_reorder" if which == "reorder" else "reorder"
     # roofline: bound = HBM / fabric bandwidth, 8 TB/s.  `achieved` = ALGORITHMIC (gather-model)
     # bytes over the kernel's average launch time -- on this input most of those bytes are served by L2 / Infinity Cache, so it
@@ -295,10 +298,19 @@ def run_single(args, dev):
         "achieved_gbps": achieved,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (traffic_gbps / HBM_PEAK_GBPS) if traffic_gbps else achieved / HBM_PEAK_GBPS,
-                     "frac_is": ("counter traffic (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel, per launch; the x 2 calibrated on this "
-                                 "kernel's own 512-byte row gathers: known bytes / counter = 1.986, profiles/r04/fetch_calibration.txt) / average "
-                                 "launch time / 8 TB/s" if traffic_gbps else
-                                 "algorithmic bytes / average launch time / 8 TB/s (no counter file found)"),
+                     "frac_is": ("counter traffic (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel, per launch, from the committed profile; the "
+                                 "x 2 calibrated on this kernel's own 512-byte row gathers: known bytes / counter = 1.986, "
+                                 "profiles/r04/fetch_calibration.txt) / average launch time / 8 TB/s.  The counters sit on the L2's fabric side: "
+                                 "these bytes INCLUDE Infinity-Cache hits (X = 86.7 MB is resident there), so this is fabric traffic over the HBM "
+                                 "peak, not an HBM utilisation; `frac_vs_gather_ceiling` is the ratio whose denominator bounds its numerator"
+                                 if traffic_gbps else "algorithmic bytes / average launch time / 8 TB/s (no counter file found)"),
+                     "frac_vs_gather_ceiling": achieved / ceil_mall["gbps"],
+                     "frac_vs_gather_ceiling_is": "gather-model bytes / average launch time / the rate measured in this process for 512-byte row "
+                                                  "gathers with ids uniform over an X-sized (86.7 MB, Infinity-Cache-resident) window; ids with "
+                                                  "locality also hit in L2, which a uniform window cannot, so the ratio may exceed 1",
+                     "gather_ceiling": {"gbps": ceil_mall["gbps"], "us": ceil_mall["us"], "what": ceil_mall["what"]},
+                     "gather_ceiling_hbm": {"gbps": ceil_hbm["gbps"], "us": ceil_hbm["us"], "what": ceil_hbm["what"]},
+                     "traffic_frac_of_mall_gather_ceiling": (traffic_gbps / ceil_mall["gbps"]) if traffic_gbps else None,
                      "traffic": traffic, "traffic_source": traffic_label, "traffic_stale": traffic_stale,
                      "traffic_gbps": traffic_gbps,
                      "algorithmic_frac": achieved / HBM_PEAK_GBPS,
@@ -326,27 +338,157 @@ def run_single(args, dev):
         "reorder_prep_s": t_reorder, "reorder_walkers": int(os.environ.get("GNNAGG_REORDER_WALKERS", "0")) or (64 if E >= 20000000 else 1),
         "schedule_prep_s": prep.get("schedule_prep_s"),
     }
+    if mode == "balanced" and which == "reorder":
+        del agg0, agg2, agg_u, dx, dx2, rid
+        torch.cuda.empty_cache()
+        out["configs"] = other_configs(args, dev, nptr, nidx, val, x[rows])
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(nptr, nidx, val, x[rows], args.cpu_budget)
     return out
 
 
-def run_other_config(args, dev):
-    """The other single-GPU configurations of BASELINE.json (parity-test cases; not the default bench line):
-    R = reddit-shaped SAGE mean F=602, G = reddit-shaped GAT 8x32, P1 = products-shaped GCN F=100."""
+def pick_rows(ptr_h, k, seed, hubs=3):
+    """k random rows + the `hubs` heaviest rows + an empty row (what tests/test_gpu_fullsize.py samples)."""
+    deg = np.diff(ptr_h)
+    rng = np.random.default_rng(seed)
+    rows = set(rng.integers(0, len(deg), k).tolist())
+    rows.update(np.argsort(deg)[-hubs:].tolist())
+    empties = np.nonzero(deg == 0)[0]
+    if len(empties):
+        rows.add(int(empties[0]))
+    return np.array(sorted(rows), np.int64)
+
+
+def sample_rows(ptr_h, idx, rows):
+    """Sub-CSR of the chosen rows (numpy), column ids unchanged; also the edge positions of those rows."""
+    sub_ptr = np.zeros(len(rows) + 1, np.int32)
+    sub_ptr[1:] = np.cumsum(ptr_h[rows + 1] - ptr_h[rows])
+    parts = [idx[int(ptr_h[r]):int(ptr_h[r + 1])] for r in rows]
+    sub_idx = torch.cat(parts).cpu().numpy() if parts else np.empty(0, np.int32)
+    eids = np.concatenate([np.arange(ptr_h[r], ptr_h[r + 1]) for r in rows]).astype(np.int64)
+    return sub_ptr, sub_idx, eids
+
+
+def sum_rows_f64(sp, si, xh, vh=None, w=None, heads=1):
+    """Float64 value of the sampled rows' aggregation (the truth the fp32 orders are judged against): sum_e v_e x[idx_e], or with
+    per-edge per-head weights w[E', H].  Chunked so that a 800 k-edge hub row never materialises more than 64 k gathered rows."""
+    n, F = len(sp) - 1, xh.shape[1]
+    out = np.zeros((n, F))
+    for k in range(n):
+        for e0 in range(int(sp[k]), int(sp[k + 1]), 65536):
+            e1 = min(e0 + 65536, int(sp[k + 1]))
+            g = xh[si[e0:e1]].astype(np.float64)
+            if w is not None:
+                g = g.reshape(e1 - e0, heads, F // heads) * w[e0:e1, :, None]
+                out[k] += g.sum(axis=0).reshape(F)
+            elif vh is not None:
+                out[k] += (g * vh[e0:e1, None].astype(np.float64)).sum(axis=0)
+            else:
+                out[k] += g.sum(axis=0)
+    return out
+
+
+def verify_config(cfg, agg, ptr, idx, x, y, att=None, val=None, heads=1):
+    """The timed step's output against the oracle on a sample of rows (random rows + the heaviest hubs + an empty row): per-row
+    results depend only on that row's edges, so a row sample is exact where the whole 115 M-edge pass would take the oracle minutes.
+    R / P1: BIT-EQUAL to the library's order restated by the oracle (orc.locality_schedule / neighbor_grouping + gcn_grouped), and inside
+    north_star's 1e-5 * sum_e |v_e x_e| of the float64 value.  G: inside 1e-5 (condition-aware) of the restated order (orc.gat_grouped)
+    and of the float64 edge-softmax.  The reference's own CSR-order fp32 chain (orc.gcn_seq / gat_fused) is measured against the same
+    float64 value and reported as `reference_order_worst_ratio`: on an 800 k-edge hub row the sequential chain itself sits at 0.7 - 1.1
+    of that bound, so it cannot serve as the yardstick there.  Raises on a mismatch."""
+    from oracle import oracle as orc
+    ptr_h = ptr.cpu().numpy()
+    rows = pick_rows(ptr_h, 40 if cfg != "P1" else 200, 1)
+    sp, si, eids = sample_rows(ptr_h, idx, rows)
+    xh = x.cpu().numpy()
+    got = y[torch.from_numpy(rows).to(y.device)].cpu().numpy()
+    chunk, seg = agg.balanced_params()
+    parts = agg.balanced_partitions()
+    n = len(rows)
+    if cfg in ("R", "P1"):
+        if cfg == "R":
+            vh = None
+            ps, ix, tg, _ = orc.locality_schedule(sp, si, parts, agg.balanced_partition_columns(), ng=chunk)
+            div = np.maximum(np.diff(sp), 1)[:, None].astype(np.float32)
+            restated, chain = orc.gcn_grouped(ps, tg, ix, None, xh, n, seg=0) / div, orc.gcn_mean(sp, si, None, xh)
+            how = "bit-equal to the restated 2-D blocked order (orc.locality_schedule + gcn_grouped, then the IEEE division by the degree)"
+        else:
+            vh = val[torch.from_numpy(eids).to(val.device)].cpu().numpy() if val is not None else None
+            ps, tg = orc.neighbor_grouping(sp, chunk)
+            div = np.ones((n, 1), np.float32)
+            restated, chain = orc.gcn_grouped(ps, tg, si, vh, xh, n, seg=seg), orc.gcn_seq(sp, si, vh, xh)
+            how = "bit-equal to the restated chunked order (orc.neighbor_grouping + gcn_grouped)"
+        exact = np.array_equal(got, restated)
+        truth = sum_rows_f64(sp, si, xh, vh) / div
+        bound = 1e-5 * orc.gcn_abs_scale(sp, si, vh, xh).astype(np.float64) / div + 1e-30
+        ratio, ref_ratio = float((np.abs(got - truth) / bound).max()), float((np.abs(chain - truth) / bound).max())
+        ok = exact and ratio <= 1.0
+        how += "; within 1e-5 * sum|v x| of the float64 value"
+    else:
+        H, F = heads, x.shape[1]
+        atth = att.cpu().numpy()
+        att_mix = atth.copy()                      # centre term of compact row k at [k,:,0], source terms at [id,:,1]
+        att_mix[:n, :, 0] = atth[rows, :, 0]
+        ps, ix, tg, _ = orc.locality_schedule(sp, si, parts, agg.balanced_partition_columns(), ng=chunk)
+        restated, _, _ = orc.gat_grouped(ps, tg, ix, att_mix, xh, n, H, seg=0)
+        # float64 edge softmax of the sampled rows (aggr_gat.h:125-163 in exact arithmetic, slope 0.2)
+        sc = np.repeat(atth[rows, :, 0].astype(np.float64), np.diff(sp), axis=0) + atth[si, :, 1].astype(np.float64)
+        w = np.exp(np.maximum(sc, 0.2 * sc))
+        den = np.add.reduceat(w, sp[:-1][np.diff(sp) > 0], axis=0)
+        nz = np.diff(sp) > 0
+        wn = w / np.repeat(den, np.diff(sp)[nz], axis=0)
+        truth = sum_rows_f64(sp, si, xh, w=wn, heads=H)
+        scale = sum_rows_f64(sp, si, np.abs(xh), w=wn, heads=H)
+        bound = 1e-5 * (scale + np.abs(truth)) + 1e-30
+        ratio = float(max((np.abs(got - truth) / bound).max(), (np.abs(got.astype(np.float64) - restated) / bound).max()))
+        ref_ratio = float((np.abs(orc.gat_fused(sp, si, att_mix, xh, H) - truth) / bound).max())
+        ok = ratio <= 1.0 and not np.isnan(got).any()
+        how = ("within 1e-5 * (sum_e w_e |x_e| + |y|) of the restated 2-D blocked order (orc.gat_grouped) and of the float64 edge softmax "
+               "(aggr_gat.h:125-163 in exact arithmetic)")
+    if not ok:
+        raise RuntimeError("config %s: the timed step's output differs from the oracle on the sampled rows (worst ratio to the bound %.3g)" % (cfg, ratio))
+    return {"verified_against_oracle": True, "verified_rows": int(n), "verified_how": how, "worst_ratio_to_1e-5_bound": ratio,
+            "reference_order_worst_ratio": ref_ratio,
+            "reference_order_is": "the reference's own CSR-order fp32 chain (oracle restatement of aggr_gcn.h:13-35 / aggr_gat.h:125-163) against the "
+                                  "same float64 value, in units of the same bound"}
+
+
+_CEILINGS = {}
+
+
+def gather_ceiling(dev, key):
+    """Measured in THIS process (gnnagg_probe_row_gather, a few ms each): what the memory system offers to row gathers in the kernels'
+    own access shape when the gathered rows live in one level -- the denominators of `frac_vs_gather_ceiling`."""
+    if key not in _CEILINGS:
+        import gnn_computing_amd as gnc
+        seg, pitch, window, private = {
+            "g512_mall": (512, 512, 169343 * 512, False),    # config A: X = 86.7 MB, Infinity-Cache resident
+            "g512_hbm": (512, 512, 5 << 30, False),          # 512-B rows from a 5 GB window: HBM
+            "g256_l2": (256, 256, 2 << 20, True),            # R / G: 256-B tile rows out of each XCD's own L2 (2 MB slice each)
+            "g400_hbm": (400, 400, 5 << 30, False),          # P1: 400-B rows at a 400-B pitch, X = 980 MB: HBM
+        }[key]
+        _CEILINGS[key] = gnc.probe.row_gather_ceiling(dev, seg, pitch, window, private)
+        torch.cuda.empty_cache()
+    return _CEILINGS[key]
+
+
+def measure_config(cfg, args, dev, graph=None):
+    """One of the other single-GPU configurations of BASELINE.json, timed like the headline (time_steps) and checked against the oracle
+    on sampled rows: R = reddit-shaped SAGE mean F=602, G = reddit-shaped GAT 8x32, P1 = products-shaped GCN F=100 on one GPU.
+    Reference call sequences being timed: Figure9/main.cu:59-74 (GCN run), Figure10/main_a.cu:82-110 (GAT run)."""
     import gnn_computing_amd as gnc
-    name = {"R": "reddit", "G": "reddit", "P1": "products"}[args.config]
-    ptr, idx = gnc.graph.dataset(name, device=dev)
+    name = {"R": "reddit", "G": "reddit", "P1": "products"}[cfg]
+    ptr, idx = graph if graph is not None else gnc.graph.dataset(name, device=dev)
     V, E = ptr.numel() - 1, idx.numel()
-    H = 1
-    if args.config == "R":
+    H, att, val = 1, None, None
+    if cfg == "R":
         F, what = 602, "reddit-shaped CSR %dx%d, GraphSAGE mean, feat=602, implicit weights, mode=balanced" % (V, E)
         agg = gnc.Aggregator_GCN(ptr, idx, None, F, F)
         x, y = torch.randn((V, F), device=dev), torch.empty((V, F), device=dev)
         step = lambda: agg.run(x, y, 512, "balanced", reduce="mean")  # noqa: E731
         B = E * (4 * F + 4) + V * 4 * F + 4 * (V + 1)
-        kernel = "k_gcn_span (+ k_tile_x, k_combine_groups)"
-    elif args.config == "G":
+        kernel, ceil_key = "k_gcn_span (+ k_tile_x, k_combine_groups)", "g256_l2"
+    elif cfg == "G":
         H, F = 8, 256
         what = "reddit-shaped CSR %dx%d, GAT 8 heads x 32 fused edge-softmax + SpMM, mode=balanced" % (V, E)
         agg = gnc.Aggregator_GAT(ptr, idx, F, F)
@@ -354,14 +496,15 @@ def run_other_config(args, dev):
         att = torch.randn((V, H, 2), device=dev)
         step = lambda: agg.run(x, att, y, 128, "balanced", heads=H)  # noqa: E731
         B = E * (4 * F + 4 + 4 * H) + V * (4 * F + 4 * H) + 4 * (V + 1)
-        kernel = "k_gat_span (+ k_tile_x, k_combine_groups_gat)"
+        kernel, ceil_key = "k_gat_span (+ k_tile_x, k_combine_groups_gat)", "g256_l2"
     else:
         F, what = 100, "products-shaped CSR %dx%d, GCN sum, feat=100, explicit unit weights, mode=balanced, 1 GPU" % (V, E)
-        agg = gnc.Aggregator_GCN(ptr, idx, torch.ones(E, device=dev), F, F)
+        val = torch.ones(E, device=dev)
+        agg = gnc.Aggregator_GCN(ptr, idx, val, F, F)
         x, y = torch.randn((V, F), device=dev), torch.empty((V, F), device=dev)
         step = lambda: agg.run(x, y, 512, "balanced")  # noqa: E731
         B = algorithmic_bytes(V, E, F)
-        kernel = "k_gcn_plan"
+        kernel, ceil_key = "k_gcn_plan", "g400_hbm"
     steps, warm = min(args.steps, 20), min(args.warmup, 3)
     # the first call builds the library-chosen order (on the device: plan_gpu.hip) and reserves the scratch; reported separately, like
     # the reference's neighbor_grouping_schedule_time (graph_schedule.h:125-127)
@@ -372,30 +515,33 @@ def run_other_config(args, dev):
     t_first = time.perf_counter() - t_first
     plan = agg.plan_info()
     wall, dev_s, med_s = time_steps(step, steps, warm, lambda: None)
+    verified = verify_config(cfg, agg, ptr, idx, x, y, att=att, val=val, heads=H)
     achieved = B / dev_s / 1e9
     # the gather probe of the same launch sequence (same id / value / attention-term loads and row gathers, no chains, no stores)
-    if args.config == "G":
+    if cfg == "G":
         _, probe_s, _ = time_steps(lambda: agg.probe_gather(x, att, "balanced", heads=H), steps, warm, lambda: None)
     else:
         _, probe_s, _ = time_steps(lambda: agg.probe_gather(x, "balanced"), steps, warm, lambda: None)
-    traffic, traffic_step, traffic_label, traffic_stale = pmc_traffic(args.config)
-    explicit = args.config == "P1"
-    C = (2 * V * 4 * F + E * (4 + (4 if explicit else 0)) + (V + 1) * 4) + (V * 8 * H * 2 if args.config == "G" else 0)
+    traffic, traffic_step, traffic_label, traffic_stale = pmc_traffic(cfg)
+    explicit = cfg == "P1"
+    C = (2 * V * 4 * F + E * (4 + (4 if explicit else 0)) + (V + 1) * 4) + (V * 8 * H * 2 if cfg == "G" else 0)
     blocked = agg.balanced_partitions() > 1
-    # roofline.  P1 (chunked plan, X far larger than the caches): HBM / fabric bound, frac = counter traffic
-    # of the step / step time / 8 TB/s.  R and G (2-D blocked order: the gathered tile rows are served by the XCDs' L2s): the
-    # bound is the L2, frac = gather-model bytes / step time / 34.5 TB/s (the guide's L2 figure); the rate measured here for
-    # 256-byte row gathers out of an L2 is 24.5 TB/s (`frac_of_measured_l2_gather`).  The probe ratio is `probe_frac`.
+    ceil = gather_ceiling(dev, ceil_key if blocked or cfg == "P1" else "g512_hbm")
+    # roofline.  P1 (chunked plan, X far larger than the caches): HBM / fabric bound, frac = counter
+    # traffic of the step / step time / 8 TB/s.  R and G (2-D blocked order: the gathered tile rows are served by the XCDs' L2s): the
+    # bound is the L2, frac = gather-model bytes / step time / 34.5 TB/s (the guide's L2 figure).  `frac_vs_gather_ceiling` divides the
+    # same gather-model rate by the rate MEASURED in this process for the same segment size out of the level the rows live in.
     if blocked:
         bound, peak, frac = "l2", L2_PEAK_GBPS, achieved / L2_PEAK_GBPS
         frac_is = "gather-model (algorithmic) bytes / step time / 34.5 TB/s (MI355X_MICROARCH.md: aggregate L2 bandwidth)"
     else:
         bound, peak = "hbm", HBM_PEAK_GBPS
         frac = (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else achieved / HBM_PEAK_GBPS
-        frac_is = ("counter traffic of the step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE) / step time / 8 TB/s" if traffic_step
+        frac_is = ("counter traffic of the step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, committed profile; fabric-side bytes: "
+                   "Infinity-Cache hits included) / step time / 8 TB/s" if traffic_step
                    else "algorithmic bytes / step time / 8 TB/s (no counter file found)")
     reordered, n_parts = None, agg.balanced_partitions()
-    if args.config == "P1" and os.environ.get("BENCH_P1_REORDER") == "1":
+    if cfg == "P1" and os.environ.get("BENCH_P1_REORDER") == "1":
         # the same workload with the locality reorder applied on load (what the headline line does; the generator -- the library's
         # cache-aware greedy order, 64 logical walkers on a graph this size -- takes tens of seconds of host time, so this arm is opt-in).
         # Reported beside the line, never as `value`
@@ -419,27 +565,108 @@ def run_other_config(args, dev):
                      "verified_against_oracle": True,
                      "what": "the same graph renumbered by gnnagg_cluster_reorder_ex (cache-aware greedy order, cluster_cap 1, cache model 8192 rows) "
                              "and loaded like a .reorder_thres_0.2 file; first 2000 rows checked against the oracle"}
-    return {"metric": "aggregated edges/sec, config %s" % args.config, "value": E / (wall / steps), "unit": "edges/s",
-            "with_locality_reorder": reordered,
-            "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": wall / steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": what, "num_v": V, "num_e": E, "feat": F, "source_partitions": n_parts},
-            "achieved_gbps": achieved,
-            "schedule_prep_s": plan["plan_s"], "first_call_s": t_first, "plan_bytes": plan["plan_bytes"], "scratch_bytes": plan["scratch_bytes"],
-            "schedule_prep_is": "wall seconds the library-chosen order took to build inside the first call (0: the chunked plan, built on the host in "
-                                "O(V)); first_call_s = plan + scratch allocation + one step; plan_bytes / scratch_bytes = device memory the plan's "
-                                "arrays / the partial rows and tiled images hold",
-            "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": frac, "frac_is": frac_is,
-                         "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_label,
-                         "traffic_stale": traffic_stale, "kernel": kernel, "algorithmic_bytes": B,
-                         "compulsory_bytes": C, "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
-                         "probe_frac": probe_s / dev_s, "ceiling_probe_us": probe_s * 1e6,
-                         "frac_of_measured_l2_gather": achieved / L2_GATHER_MEASURED_GBPS if blocked else None,
-                         "hbm_peak_gbps": HBM_PEAK_GBPS, "gather_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
-                         "traffic_frac_of_hbm_peak": (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else None,
-                         "compulsory_frac_of_hbm_peak": C / dev_s / 1e9 / HBM_PEAK_GBPS,
-                         "note": "times are of the whole step (R / G: column-tiling of X, aggregation, ordered combine); `traffic` is "
-                                 "the dominant kernel's fabric-side bytes per launch, `traffic_step` all kernels of a step"}}
+    rec = {"metric": "aggregated edges/sec, config %s" % cfg, "value": E / (wall / steps), "unit": "edges/s",
+           "with_locality_reorder": reordered,
+           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": wall / steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": what, "num_v": V, "num_e": E, "feat": F, "source_partitions": n_parts},
+           "achieved_gbps": achieved,
+           "schedule_prep_s": plan["plan_s"], "first_call_s": t_first, "plan_bytes": plan["plan_bytes"], "scratch_bytes": plan["scratch_bytes"],
+           "schedule_prep_is": "wall seconds the library-chosen order took to build inside the first call (0: the chunked plan, built on the host in "
+                               "O(V)); first_call_s = plan + scratch allocation + one step; plan_bytes / scratch_bytes = device memory the plan's "
+                               "arrays / the partial rows and tiled images hold",
+           "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": frac, "frac_is": frac_is,
+                        "frac_vs_gather_ceiling": achieved / ceil["gbps"],
+                        "gather_ceiling": {"gbps": ceil["gbps"], "us": ceil["us"], "what": ceil["what"]},
+                        "frac_vs_gather_ceiling_is": "gather-model bytes / step time / the rate measured in this process for the same segment "
+                                                     "size out of the level the gathered rows live in (gnnagg_probe_row_gather)",
+                        "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_label,
+                        "traffic_stale": traffic_stale, "kernel": kernel, "algorithmic_bytes": B,
+                        "compulsory_bytes": C, "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
+                        "avg_launch_is": "HIP events around the K steps / K: the whole step (every kernel it launches); per-kernel averages "
+                                         "are in profiles/%s/summary_%s.txt" % (PROFILE_ROUND, cfg),
+                        "probe_frac": probe_s / dev_s, "ceiling_probe_us": probe_s * 1e6,
+                        "hbm_peak_gbps": HBM_PEAK_GBPS, "gather_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
+                        "traffic_frac_of_hbm_peak": (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else None,
+                        "compulsory_frac_of_hbm_peak": C / dev_s / 1e9 / HBM_PEAK_GBPS,
+                        "note": "times are of the whole step (R / G: column-tiling of X, aggregation, ordered combine); `traffic` is "
+                                "the dominant kernel's fabric-side bytes per launch, `traffic_step` all kernels of a step"}}
+    rec.update(verified)
+    return rec
+
+
+def run_other_config(args, dev):
+    return measure_config(args.config, args, dev)
+
+
+def measure_rows_mode(args, dev, nptr, nidx, val, x_rows, ceil):
+    """The headline input in GNNAGG_MODE_ROWS: the literal aggr_gcn order (aggr_gcn.h:5-36), every row one sequential FMA chain in CSR
+    order, bit-equal to the oracle's gcn_seq over the WHOLE output."""
+    import gnn_computing_amd as gnc
+    from oracle import oracle as orc
+    V, E = len(nptr) - 1, len(nidx)
+    agg = gnc.Aggregator_GCN(torch.from_numpy(nptr).to(dev), torch.from_numpy(nidx).to(dev), torch.from_numpy(val).to(dev), FEAT, FEAT)
+    dx = torch.from_numpy(np.ascontiguousarray(x_rows)).to(dev)
+    y = torch.empty((V, FEAT), dtype=torch.float32, device=dev)
+    step = lambda: agg.run(dx, y, 512, "rows")  # noqa: E731
+    step()
+    torch.cuda.synchronize()
+    plan = agg.plan_info()
+    wall, dev_s, med_s = time_steps(step, args.steps, args.warmup, lambda: None)
+    if not np.array_equal(y.cpu().numpy(), orc.gcn_seq(nptr, nidx, val, x_rows)):
+        raise RuntimeError("rows mode differs from the oracle's CSR-order chains")
+    B = algorithmic_bytes(V, E, FEAT)
+    achieved = B / dev_s / 1e9
+    traffic, traffic_step, traffic_label, traffic_stale = pmc_traffic("A_rows")
+    return {"metric": "aggregated edges/sec, GCN SpMM feat=128, canonical rows mode", "value": E / (wall / args.steps), "unit": "edges/s",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "config": {"workload": "the headline input (arxiv-shaped, locality reorder applied on load) in GNNAGG_MODE_ROWS: `scheduled = 0` "
+                                   "= aggr_gcn's own order, one sequential FMA chain per row", "num_v": V, "num_e": E, "feat": FEAT},
+            "achieved_gbps": achieved, "schedule_prep_s": plan["plan_s"], "plan_bytes": plan["plan_bytes"], "scratch_bytes": plan["scratch_bytes"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else achieved / HBM_PEAK_GBPS,
+                         "frac_is": ("counter traffic of the step (committed profile; fabric-side bytes, Infinity-Cache hits included) / step time / 8 TB/s"
+                                     if traffic_step else "algorithmic bytes / step time / 8 TB/s (no counter file for this mode): cache-served, "
+                                     "not an HBM utilisation -- see frac_vs_gather_ceiling"),
+                         "frac_vs_gather_ceiling": achieved / ceil["gbps"],
+                         "gather_ceiling": {"gbps": ceil["gbps"], "us": ceil["us"], "what": ceil["what"]},
+                         "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_label, "traffic_stale": traffic_stale,
+                         "kernel": "k_gcn_plan (short rows) beside k_gcn_rows_long (medium rows, hub rows) on forked streams",
+                         "algorithmic_bytes": B, "compulsory_bytes": compulsory_bytes(V, E, FEAT),
+                         "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
+                         "avg_launch_is": "HIP events around the K steps / K: the whole step (fork, the row kernels, join)",
+                         "probe_frac": None},
+            "verified_against_oracle": True, "verified_rows": V,
+            "verified_how": "whole output np.array_equal to orc.gcn_seq (the reference's aggr_gcn chain order)"}
+
+
+def other_configs(args, dev, nptr, nidx, val, x_rows):
+    """The sub-records of the N = 1 line: every other single-GPU configuration BASELINE.json names, so that one driver command times
+    them all.  A failure in one of them is recorded in its place and never takes the headline line down."""
+    import gnn_computing_amd as gnc
+    which = [c for c in os.environ.get("BENCH_CONFIGS", "A_rows,R,G,P1").split(",") if c]
+    out, reddit = {}, None
+    for cfg in which:
+        t0 = time.perf_counter()
+        try:
+            if cfg == "A_rows":
+                out[cfg] = measure_rows_mode(args, dev, nptr, nidx, val, x_rows, gather_ceiling(dev, "g512_mall"))
+            elif cfg in ("R", "G"):
+                if reddit is None:
+                    reddit = gnc.graph.dataset("reddit", device=dev)
+                out[cfg] = measure_config(cfg, args, dev, graph=reddit)
+            elif cfg == "P1":
+                reddit = None
+                torch.cuda.empty_cache()
+                out[cfg] = measure_config(cfg, args, dev)
+            else:
+                raise ValueError("unknown config %r" % cfg)
+            out[cfg]["bench_wall_s"] = time.perf_counter() - t0
+        except Exception as e:  # noqa: BLE001
+            log("bench.py: sub-record %s failed: %r" % (cfg, e))
+            out[cfg] = {"error": repr(e), "bench_wall_s": time.perf_counter() - t0}
+        torch.cuda.empty_cache()
+    return out
 
 
 class Watchdog:
@@ -517,6 +744,15 @@ def partitioned_run(args, dev, rank, world, strong, steps, warmup, transport, do
         gnc._lib.check(gnc.lib().gnnagg_dist_comm_info(hx.rccl._h, ctypes.byref(rr), ctypes.byref(ww)))
         assert rr.value == rank
         rccl_ranks = ww.value
+    # what carried the halo rows, stated by the library itself (gnnagg_dist_transport_info) and by the devices the ranks sit on: an
+    # N > 1 line from N processes on ONE GPU over a test double of the nccl* calls must not be able to pass for a scaling point
+    if hx.rccl is not None:
+        rccl_library, rccl_override, bus = hx.rccl.transport_info()
+    else:
+        rccl_library, rccl_override, bus = None, False, device_bus_id(dev)
+    buses = [None] * world
+    dist.all_gather_object(buses, "%s" % (bus,))
+    distinct_devices = len(set(buses))
     # correctness outside the timed region: features that are a closed form of the GLOBAL row id, so every rank can check
     # the halo rows it pulled and (on its first rows) the aggregation against the oracle without any further exchange
 
@@ -576,7 +812,22 @@ def partitioned_run(args, dev, rank, world, strong, steps, warmup, transport, do
     return {"Vg": Vg, "Eg": Eg, "feat": feat, "step_s": wall / steps, "step_nx_s": wall_nx / steps, "steps": steps, "warmup": warmup,
             "halo_bytes_all": float(halo[0].item()), "halo_bytes_max_rank": float(halo_max[0].item()),
             "remote_edge_share": float(halo[2].item()) / max(float(halo[1].item()), 1.0),
-            "rccl_ranks": rccl_ranks, "plan_s": float(tp.item()), "n_stages": n_stages, "stage_mode": stage_mode}
+            "rccl_ranks": rccl_ranks, "plan_s": float(tp.item()), "n_stages": n_stages, "stage_mode": stage_mode,
+            "rccl_library": rccl_library, "rccl_library_is_override": rccl_override, "distinct_devices": distinct_devices,
+            "device_pci_bus_ids": buses}
+
+
+def device_bus_id(dev):
+    """PCI bus id of a torch device (the torch transports have no C-ABI communicator to ask)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev.index or 0)) == 0:
+            return buf.value.decode()
+    except OSError:
+        pass
+    return "device-%d" % int(dev.index or 0)
 
 
 TRANSPORT_NAMES = {"rccl": "C-ABI step (gnnagg_dist_step_gcn: pack kernel + grouped ncclSend/ncclRecv per stage on the step's own stream)",
@@ -598,19 +849,32 @@ def run_multi(args, dev, rank, world, dog):
         return None
     feat, Vg, Eg, step_s = m["feat"], m["Vg"], m["Eg"], m["step_s"]
     B = algorithmic_bytes(Vg, Eg, feat)
+    double = bool(m["rccl_library_is_override"]) or m["distinct_devices"] < world
+    if double:
+        how = []
+        if m["distinct_devices"] < world:
+            how.append("%d ranks on %d GPU%s" % (world, m["distinct_devices"], "" if m["distinct_devices"] == 1 else "s"))
+        if m["rccl_library_is_override"]:
+            how.append("a test double of the nccl* entry points (GNNAGG_RCCL_LIB = %s)" % m["rccl_library"])
+        link = "halo pull per step -- FUNCTIONAL CHECK, NOT A SCALING POINT: " + ", ".join(how) + "; no interconnect was exercised"
+    else:
+        link = "halo pull per step over xGMI"
+    transport_is = TRANSPORT_NAMES[transport] + ("" if not double else " -- " + link)
     out = {
         "metric": "aggregated edges/sec, GCN SpMM feat=%d" % feat, "value": Eg / step_s, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s power-law CSR (%dx%d, seed 123, community order, %d %% of a row's sources are global-popularity picks: "
-                               "--global-share), GCN sum, feat=%d, 1-D row partition + halo pull per step over xGMI (%s; %s; local-source "
+                               "--global-share), GCN sum, feat=%d, 1-D row partition + %s (%s; %s; local-source "
                                "edges overlap the exchange, stage s's halo-source edges overlap stage s + 1)" % (
                                    "products-shaped" if strong else "%d x arxiv-shaped" % world, Vg, Eg, round(args.global_share * 100), feat,
-                                   TRANSPORT_NAMES[transport], "stages: " + m["stage_mode"]),
+                                   link, TRANSPORT_NAMES[transport], "stages: " + m["stage_mode"]),
                    "num_v": Vg, "num_e": Eg, "feat": feat, "halo_bytes_per_step_all_ranks": m["halo_bytes_all"],
                    "global_share": args.global_share, "verified_against_oracle": True},
-        "transport": transport, "transport_is": TRANSPORT_NAMES[transport], "backend": backend, "rccl_ranks": m["rccl_ranks"],
+        "transport": transport, "transport_is": transport_is, "backend": backend, "rccl_ranks": m["rccl_ranks"],
+        "rccl_library": m["rccl_library"], "rccl_library_is_override": m["rccl_library_is_override"],
+        "distinct_devices": m["distinct_devices"], "device_pci_bus_ids": m["device_pci_bus_ids"], "test_double": double,
         "transport_fallback": os.environ.get("BENCH_FALLBACK_REASON"),
         "halo_stages": m["n_stages"], "plan_s": m["plan_s"],
         "achieved_gbps": B / step_s / 1e9,
@@ -628,7 +892,7 @@ def run_multi(args, dev, rank, world, dog):
                      "unit": "GB/s", "frac": B / step_s / 1e9 / world / HBM_PEAK_GBPS, "traffic": None,
                      "frac_is": "per-GPU share of the gather-model bytes / step time (exchange included) / 8 TB/s; cache-served gathers "
                                 "count, so this is not an HBM utilisation",
-                     "kernel": "per-GPU share of the step (halo exchange over xGMI included; gather-model bytes, cache-served "
+                     "kernel": "per-GPU share of the step (halo exchange included; gather-model bytes, cache-served "
                                "gathers count: see the N = 1 line for the measured ceiling)", "algorithmic_bytes": B,
                      "halo_bytes_per_rank": m["halo_bytes_all"] / world, "halo_bytes_max_rank": m["halo_bytes_max_rank"]},
     }
@@ -640,7 +904,9 @@ def run_multi(args, dev, rank, world, dog):
             "scaling": "strong", "halo_bytes_per_step_all_ranks": ps["halo_bytes_all"], "halo_bytes_max_rank": ps["halo_bytes_max_rank"],
             "exposed_comm_ms_per_step": max(0.0, (ps["step_s"] - ps["step_nx_s"]) * 1e3),
             "no_exchange_ms_per_step": ps["step_nx_s"] * 1e3, "remote_edge_share": ps["remote_edge_share"], "halo_stages": ps["n_stages"],
-            "plan_s": ps["plan_s"], "rccl_ranks": ps["rccl_ranks"], "verified_against_oracle": True}
+            "plan_s": ps["plan_s"], "rccl_ranks": ps["rccl_ranks"], "verified_against_oracle": True,
+            "distinct_devices": ps["distinct_devices"], "rccl_library": ps["rccl_library"],
+            "test_double": bool(ps["rccl_library_is_override"]) or ps["distinct_devices"] < world}
     return out
 
 

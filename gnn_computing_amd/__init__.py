@@ -11,5 +11,6 @@ from .aggregator import (  # noqa: F401
     reorder_csr, neighbor_grouping_schedule, locality_schedule, partition_rows, halo_plan, cluster_reorder, matmul_NN,
 )
 from . import graph  # noqa: F401
+from . import probe  # noqa: F401
 from . import autograd  # noqa: F401
 from .autograd import gat_aggregate, gcn_aggregate  # noqa: F401

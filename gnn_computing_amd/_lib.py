@@ -59,6 +59,7 @@ SIGNATURES = {
     "gnnagg_gcn_run_ex": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "gnnagg_gcn_probe_gather": (c_int, [c_int64, c_void_p, c_int, c_int]),
     "gnnagg_gat_probe_gather": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "gnnagg_probe_row_gather": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, ctypes.c_longlong, c_int, c_void_p]),
     "gnnagg_gcn_run_clock": (c_int, [c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, P_INT, P_INT]),
     "gnnagg_wall_clock_hz": (ctypes.c_longlong, []),
     "gnnagg_gcn_run_edgewise": (c_int, [c_int64, c_void_p, c_void_p, c_int]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     "gnnagg_dist_comm_create_from_file": (c_int, [c_char_p, c_int, c_int, c_int, ctypes.POINTER(c_int64)]),
     "gnnagg_dist_comm_destroy": (c_int, [c_int64]),
     "gnnagg_dist_comm_info": (c_int, [c_int64, P_INT, P_INT]),
+    "gnnagg_dist_transport_info": (c_int, [c_int64, c_char_p, c_int, c_char_p, c_int, P_INT]),
     "gnnagg_dist_alltoallv": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gnnagg_dist_halo_exchange": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gnnagg_pack_rows2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -1989,6 +1989,12 @@ int gnnagg_gat_probe_gather(gnnagg_handle h, const float *d_x, const float *d_at
     return gat_run(c, d_x, d_att, const_cast<float *>(d_x), feat, heads, 0.2f, mode, nullptr, 1);
 }
 
+int gnnagg_probe_row_gather(const void *d_rows, long long pitch_bytes, int seg_bytes, const int *d_ids, long long n_ids, int ids_per_group,
+                            void *hip_stream)
+{
+    return launch_probe_row_gather(d_rows, (long)pitch_bytes, seg_bytes, d_ids, (long)n_ids, ids_per_group, hip_stream);
+}
+
 int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, int heads, float slope)
 {
     GET_CTX(h);

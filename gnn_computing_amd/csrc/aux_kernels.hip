@@ -1148,4 +1148,66 @@ int launch_tile_att(const float *att, float *as_t, float *ac_t, int rows, int he
     return GNNAGG_OK;
 }
 
+// ------------------------------------------------------------------------- row-gather ceiling probe (measurement aid)
+// What the memory system delivers to ROW GATHERS in the aggregation kernels' own access shape, by where the gathered rows live
+// (one XCD's L2, the Infinity Cache, HBM): the caller chooses the window through the ids it passes.  A lane group of LANES lanes
+// reads `per_group` ids (one coalesced load per LANES ids, broadcast lane to lane), gathers `active` x 16 B of row id at
+// rows + id * pitch with 8 gathers in flight, XOR-consumes them and never stores (gnnagg_probe_row_gather; bench.py divides the
+// bytes of its gather model by this launch's time to get the ceiling each roofline fraction is quoted against).
+template <int LANES>
+__global__ __launch_bounds__(256) void k_probe_row_gather(const int *__restrict__ ids, const char *__restrict__ rows, long pitch, int active,
+                                                          int per_group, unsigned *sink)
+{
+    constexpr int U = 8, GPB = 256 / LANES;
+    const int lane = threadIdx.x & (LANES - 1), grp = threadIdx.x / LANES;
+    const int *my = ids + ((long)blockIdx.x * GPB + grp) * per_group;
+    const char *col = rows + lane * 16;
+    const bool on = lane < active;
+    uint4 acc = {0, 0, 0, 0};
+    int cur = my[lane];
+    for (int cb = 0; cb < per_group; cb += LANES) {
+        int nxt = 0;
+        if (cb + LANES < per_group) nxt = my[cb + LANES + lane];
+#pragma unroll 1
+        for (int j = 0; j < LANES; j += U) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = __shfl(cur, j + u, LANES);
+                v[u] = on ? *reinterpret_cast<const uint4 *>(col + (long)s * pitch) : uint4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { acc.x ^= v[u].x; acc.y ^= v[u].y; acc.z ^= v[u].z; acc.w ^= v[u].w; }
+        }
+        cur = nxt;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9U) sink[0] = acc.x;  // practically never: keeps the loads alive
+}
+
+int launch_probe_row_gather(const void *rows, long pitch, int seg_bytes, const int *ids, long n_ids, int per_group, void *stream_v)
+{
+    if (!rows || !ids || pitch < 16 || (pitch & 15) || seg_bytes < 16 || seg_bytes > 1024 || (seg_bytes & 15) || n_ids <= 0)
+        return fail(GNNAGG_ERR_ARG, "probe_row_gather: rows / ids null, or pitch / seg_bytes not multiples of 16 (seg_bytes in 16 .. 1024)");
+    const int active = seg_bytes / 16;
+    int lanes = 8;
+    while (lanes < active) lanes <<= 1;
+    const int gpb = 256 / lanes;
+    if (per_group <= 0 || per_group % lanes || n_ids % ((long)per_group * gpb))
+        return fail(GNNAGG_ERR_ARG, "probe_row_gather: ids_per_group must be a multiple of the lane-group width and n_ids a multiple of ids_per_group x groups per 256-thread block");
+    unsigned *sink = device_probe_sink();
+    if (!sink) return fail(GNNAGG_ERR_HIP, "probe: no sink");
+    const long nb = n_ids / ((long)per_group * gpb);
+    if (nb > 0x7fffffffL) return fail(GNNAGG_ERR_ARG, "probe_row_gather: too many ids for one launch");
+    hipStream_t stream = (hipStream_t)stream_v;
+    const char *r = (const char *)rows;
+    switch (lanes) {
+        case 8:  hipLaunchKernelGGL((k_probe_row_gather<8>), dim3((unsigned)nb), dim3(256), 0, stream, ids, r, pitch, active, per_group, sink); break;
+        case 16: hipLaunchKernelGGL((k_probe_row_gather<16>), dim3((unsigned)nb), dim3(256), 0, stream, ids, r, pitch, active, per_group, sink); break;
+        case 32: hipLaunchKernelGGL((k_probe_row_gather<32>), dim3((unsigned)nb), dim3(256), 0, stream, ids, r, pitch, active, per_group, sink); break;
+        default: hipLaunchKernelGGL((k_probe_row_gather<64>), dim3((unsigned)nb), dim3(256), 0, stream, ids, r, pitch, active, per_group, sink); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
 }  // namespace gnnagg

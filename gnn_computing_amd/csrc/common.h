@@ -294,6 +294,7 @@ int launch_pack_rows2(const float *x, const float *att, const int *ids, int n, i
 int launch_unpack_rows2(const float *in, int n, int feat, int att_w, float *x_out, float *att_out, void *stream);
 // xt[t][r][0..tile_w) = x[r][t*tile_w ..] (zero beyond feat): the column-tiled image of X the 2-D blocked mode gathers from
 int launch_tile_x(const float *x, float *xt, int rows, int feat, int tile_w, void *stream);
+int launch_probe_row_gather(const void *rows, long pitch, int seg_bytes, const int *ids, long n_ids, int per_group, void *stream);
 int launch_tile_att(const float *att, float *as_t, float *ac_t, int rows, int heads, int ht, void *stream);
 
 }  // namespace gnnagg

@@ -36,6 +36,8 @@ struct RcclApi {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string path;        // file the eight entry points really come from (dladdr), for gnnagg_dist_transport_info
+    bool overridden = false; // loaded through GNNAGG_RCCL_LIB (a test double), not the system's librccl
 };
 
 static RcclApi *rccl()
@@ -48,6 +50,7 @@ static RcclApi *rccl()
         // the step's multi-peer code runs on a one-GPU box).  RTLD_LOCAL: its symbols must not shadow the real librccl torch maps
         if (const char *over = getenv("GNNAGG_RCCL_LIB")) {
             if (*over) api.h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            api.overridden = api.h != nullptr;
         }
         if (!api.h)
         for (const char *n : names)
@@ -62,6 +65,8 @@ static RcclApi *rccl()
 #undef LOAD
         if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv)
             api.h = nullptr;
+        Dl_info info;
+        if (api.h && dladdr(reinterpret_cast<void *>(api.Send), &info) && info.dli_fname) api.path = info.dli_fname;
     });
     return api.h ? &api : nullptr;
 }
@@ -76,6 +81,7 @@ static RcclApi *rccl()
 struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    int device = -1;   // HIP device that was current when the communicator was made (ncclCommInitRank binds to it)
 };
 
 static std::mutex g_comm_mu;
@@ -118,6 +124,7 @@ int gnnagg_dist_comm_create(const char *id128, int rank, int world, gnnagg_comm 
     memcpy(&id, id128, sizeof(id));
     Comm *c = new Comm;
     c->rank = rank; c->world = world;
+    (void)hipGetDevice(&c->device);
     const ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);  // binds to the calling thread's current HIP device
     if (r != ncclSuccess) {
         delete c;
@@ -246,6 +253,20 @@ int gnnagg_dist_comm_info(gnnagg_comm h, int *rank, int *world)
     if (!c) return fail(GNNAGG_ERR_ARG, "invalid or destroyed communicator");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
+    return GNNAGG_OK;
+}
+
+int gnnagg_dist_transport_info(gnnagg_comm h, char *library_path, int library_path_cap, char *pci_bus_id, int pci_bus_id_cap, int *is_override)
+{
+    Comm *c = lookup_comm(h);
+    if (!c) return fail(GNNAGG_ERR_ARG, "invalid or destroyed communicator");
+    RcclApi *R = rccl();
+    if (library_path && library_path_cap > 0) snprintf(library_path, (size_t)library_path_cap, "%s", R ? R->path.c_str() : "");
+    if (is_override) *is_override = R && R->overridden ? 1 : 0;
+    if (pci_bus_id && pci_bus_id_cap > 0) {
+        pci_bus_id[0] = 0;
+        if (c->device >= 0 && hipDeviceGetPCIBusId(pci_bus_id, pci_bus_id_cap, c->device) != hipSuccess) pci_bus_id[0] = 0;
+    }
     return GNNAGG_OK;
 }
 

@@ -114,6 +114,13 @@ class RcclTransport:
         except Exception:
             pass
 
+    def transport_info(self):
+        """(library the nccl* entry points were loaded from, True if that was the GNNAGG_RCCL_LIB override, PCI bus id of the device this
+        communicator is bound to) -- gnnagg_dist_transport_info; what a measurement over this communicator must state."""
+        path, bus, over = ctypes.create_string_buffer(1024), ctypes.create_string_buffer(64), ctypes.c_int(0)
+        check(lib().gnnagg_dist_transport_info(self._h, path, 1024, bus, 64, ctypes.byref(over)))
+        return path.value.decode(), bool(over.value), bus.value.decode()
+
     def alltoallv(self, send, send_counts, recv, recv_counts):
         """Contiguous device tensors, counts in elements of send.element_size() per rank; on the current stream."""
         n = self.world

@@ -220,6 +220,15 @@ int gnnagg_gcn_probe_gather(gnnagg_handle h, const float *d_x, int feat, int mod
 /* The same for gnnagg_gat_run on the 2-D blocked balanced order (k_gat_span): neighbor ids, compact attention terms and
  * tile-row gathers as in the real run, no exp, no chain, no store.  GNNAGG_ERR_ARG on the other GAT paths. */
 int gnnagg_gat_probe_gather(gnnagg_handle h, const float *d_x, const float *d_att, int feat, int heads, int mode);
+/* Measurement aid (no reference counterpart): the rate the memory system offers to ROW GATHERS in these kernels' own access shape,
+ * independent of any graph.  One launch; lane groups of L lanes (L = the power of two >= seg_bytes / 16, 8 .. 64; 256 / L groups per
+ * workgroup) each take `ids_per_group` consecutive entries of d_ids (coalesced id loads, 8 gathers in flight) and read seg_bytes at
+ * d_rows + id * pitch_bytes; the data is XOR-consumed and never stored.  Where the gathered rows live -- one XCD's L2, the Infinity
+ * Cache, HBM -- is the caller's choice of ids (workgroup b runs on XCD b % 8).  seg_bytes and pitch_bytes multiples of 16,
+ * ids_per_group a multiple of L, n_ids a multiple of ids_per_group x 256 / L.  Asynchronous on hip_stream.  bench.py times this
+ * launch to quote each roofline fraction against a ceiling that bounds the bytes it divides (gather-model bytes are cache-served). */
+int gnnagg_probe_row_gather(const void *d_rows, long long pitch_bytes, int seg_bytes, const int *d_ids, long long n_ids, int ids_per_group,
+                            void *hip_stream);
 /* Aggregator_GCN::run_clock, aggr_gcn.h:462-489 (Figure 8 load-balance study).  Runs the one-item-per-lane-group
  * kernel of mode rows (the reference's aggr_gcn_clock) or scheduled (aggr_gcn_target_clock) with per-workgroup
  * stamps: d_timer[3b] = start, [3b+1] = end (ticks of the constant wall clock, gnnagg_wall_clock_hz), [3b+2] = CU id.
@@ -388,6 +397,11 @@ int gnnagg_dist_comm_create(const char *id128, int rank, int world, gnnagg_comm 
 int gnnagg_dist_comm_create_from_file(const char *path, int rank, int world, int timeout_s, gnnagg_comm *out);
 int gnnagg_dist_comm_destroy(gnnagg_comm c);
 int gnnagg_dist_comm_info(gnnagg_comm c, int *rank, int *world);
+/* What really carries this communicator's messages, so that a measurement can say it: the file the nccl* entry points were
+ * loaded from (dladdr), whether that was the GNNAGG_RCCL_LIB override (a test double: ranks as processes on one GPU) and the PCI bus id
+ * of the HIP device the communicator is bound to (ranks all-gather it: fewer distinct ids than ranks = ranks sharing a GPU).  Any
+ * output may be NULL; strings are NUL-terminated and truncated to their capacity. */
+int gnnagg_dist_transport_info(gnnagg_comm c, char *library_path, int library_path_cap, char *pci_bus_id, int pci_bus_id_cap, int *is_override);
 int gnnagg_dist_alltoallv(gnnagg_comm c, const void *d_send, const long long *h_send_counts, void *d_recv,
                           const long long *h_recv_counts, int elem_bytes, void *hip_stream);
 int gnnagg_dist_halo_exchange(gnnagg_comm c, const float *d_x_local, const int *d_send_ids, const long long *h_send_rows,

@@ -61,6 +61,27 @@ def test_headline_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "edges/s" and c["sample"]
     assert d["value"] > 8.07e9          # north_star: >= 60 % of the HBM-read roofline in gather-model bytes = 8.07 G edges/s
+    # a denominator that bounds the bytes it divides: the ceilings are measured in the bench process
+    assert abs(r["frac_vs_gather_ceiling"] - r["achieved"] / r["gather_ceiling"]["gbps"]) < 1e-9 and "Infinity-Cache" in r["frac_is"]
+    assert 4000 < r["gather_ceiling_hbm"]["gbps"] < 9000 and 5000 < r["gather_ceiling"]["gbps"] < 12000
+    # every other single-GPU configuration of BASELINE.json rides in the same driver command, oracle-verified
+    sizes = {"A_rows": (169343, 1166243, 128), "R": (232965, 114615891, 602), "G": (232965, 114615891, 256), "P1": (2449029, 123718280, 100)}
+    assert set(d["configs"]) == set(sizes)
+    for name, (V, E, F) in sizes.items():
+        c = d["configs"][name]
+        assert "error" not in c, (name, c)
+        assert (c["config"]["num_v"], c["config"]["num_e"], c["config"]["feat"]) == (V, E, F)
+        assert c["verified_against_oracle"] is True and c["verified_rows"] > 0 and c["steps"] >= 1
+        assert abs(c["value"] - E / (c["ms_per_step"] * 1e-3)) < 1e-6 * c["value"]
+        q = c["roofline"]
+        assert q["avg_launch_us"] > 0 and q["algorithmic_bytes"] > 0 and "frac_is" in q and "traffic" in q and "probe_frac" in q
+        assert abs(q["achieved"] - q["algorithmic_bytes"] / (q["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * q["achieved"]
+        assert abs(q["frac_vs_gather_ceiling"] - q["achieved"] / q["gather_ceiling"]["gbps"]) < 1e-9
+        assert "schedule_prep_s" in c and c["scratch_bytes"] >= 0
+        if name != "A_rows":
+            assert c["worst_ratio_to_1e-5_bound"] <= 1.0
+    assert d["configs"]["R"]["roofline"]["bound"] == "l2" and d["configs"]["P1"]["roofline"]["bound"] == "hbm"
+    assert d["configs"]["A_rows"]["value"] < d["value"]     # the canonical chains cost more than the balanced order
 
 
 def test_other_config_line():
@@ -86,6 +107,9 @@ def test_two_ranks_on_one_gpu_over_gloo():
     check_common(d, 2, 3, 1)
     check_multi(d)
     assert d["transport"] == "torch" and d["rccl_ranks"] is None and d["transport_fallback"] is None
+    # two ranks on ONE GPU: the line must say so and never claim an interconnect
+    assert d["distinct_devices"] == 1 and d["test_double"] is True and "NOT A SCALING POINT" in d["config"]["workload"]
+    assert "xGMI" not in d["config"]["workload"] and "xGMI" not in d["transport_is"] and d["products_strong"]["test_double"] is True
 
 
 def test_two_ranks_without_a_launcher():
@@ -115,6 +139,15 @@ def test_failed_rccl_ranks_fall_back_to_torch_transport_in_fresh_processes():
     assert d["transport"] == "torch" and d["transport_fallback"] and "rccl" in d["transport_fallback"]
 
 
+def check_labelled_as_double(d, fake):
+    """a record that says n_gpus = N, rccl_ranks = N from ONE GPU must not be able to pass for a scaling point -- the
+    library names the file its nccl* entry points came from (gnnagg_dist_transport_info), the ranks all-gather their PCI bus ids."""
+    assert os.path.samefile(d["rccl_library"], fake) and d["rccl_library_is_override"] is True
+    assert d["distinct_devices"] == 1 and len(set(d["device_pci_bus_ids"])) == 1 and len(d["device_pci_bus_ids"]) == d["n_gpus"]
+    assert d["test_double"] is True and "NOT A SCALING POINT" in d["config"]["workload"] and "test double" in d["transport_is"]
+    assert "over xGMI" not in d["config"]["workload"] and "over xGMI" not in d["transport_is"]
+
+
 def test_two_ranks_on_the_cabi_rccl_step_through_the_test_double():
     """The default transport of the N > 1 line -- the one-call C-ABI step, gnnagg_dist_step_gcn -- through bench.py's own code path
     (communicator from gnnagg_dist_comm_create, `rccl_ranks` from gnnagg_dist_comm_info, oracle check of the first step, timed
@@ -130,6 +163,7 @@ def test_two_ranks_on_the_cabi_rccl_step_through_the_test_double():
     check_common(d, 2, 3, 1)
     assert d["transport"] == "rccl" and d["rccl_ranks"] == 2 and d["transport_fallback"] is None and d["halo_stages"] >= 1
     assert d["config"]["verified_against_oracle"] is True
+    check_labelled_as_double(d, fake)
 
 
 def test_eight_ranks_on_the_cabi_rccl_step_through_the_test_double():
@@ -151,6 +185,7 @@ def test_eight_ranks_on_the_cabi_rccl_step_through_the_test_double():
     assert d["transport"] == "rccl" and d["rccl_ranks"] == 8 and d["halo_stages"] == 7 and d["transport_fallback"] is None
     assert d["config"]["verified_against_oracle"] is True and d["config"]["num_e"] == 8 * 1166243
     assert 0.3 < d["remote_edge_share"] < 0.5      # 7/8 of the generator's 50 % global picks
+    check_labelled_as_double(d, fake)
 
 
 def test_failed_nccl_backend_falls_back_to_gloo_in_fresh_processes():
