@@ -729,7 +729,10 @@ def partitioned_run(args, dev, rank, world, strong, steps, warmup, transport, do
         del buf
     del ptr_t
     val_slice = np.ones(e1 - e0, np.float32)
-    stages = os.environ.get("BENCH_STAGES", "auto")
+    # One stage (a single grouped send / recv per step) by default: the staged, pipelined exchange has only ever run over the test double
+    # of the nccl* calls (no box on this pool has two GPUs), so it stays opt-in -- BENCH_STAGES=auto | owner | N -- until it has run
+    # over real RCCL with a peer
+    stages = os.environ.get("BENCH_STAGES", "1")
     stages = int(stages) if stages.lstrip("-").isdigit() else stages
     t_plan = time.perf_counter()
     dog.arm(240, "communicator + plan exchange (%s transport)" % transport)
@@ -941,12 +944,42 @@ def launch_ranks(args, json_fd):
     return r.returncode if r.returncode != 0 else (0 if n == 1 else 1)
 
 
+def agree_on_outcome(rank, world, attempt, rc, timeout_s=420.0):
+    """The supervisors of one node agree on what an attempt did before any of them starts the next one (a rank whose child
+    failed must not open a rendezvous that the ranks whose children returned 0 never join).  Every supervisor is a child of the same
+    launcher process, so a directory named after that parent is shared and private to this job; rank r drops its child's exit code
+    there, rank 0 also the port of the next rendezvous (a free one, checked).  Returns (worst exit code over all ranks, next port), or
+    (None, None) when some rank never reported -- then nobody retries."""
+    import tempfile
+    d = os.path.join(tempfile.gettempdir(), "gnnagg_bench_sup_%d" % os.getppid(), "attempt%d" % attempt)
+    os.makedirs(d, exist_ok=True)
+
+    def drop(name, text):
+        tmp = os.path.join(d, ".%s.%d" % (name, os.getpid()))
+        with open(tmp, "w") as f:
+            f.write(text)
+        os.replace(tmp, os.path.join(d, name))
+    if rank == 0:
+        drop("port", str(free_port()))
+    drop("rank%d" % rank, str(rc))
+    t_end = time.monotonic() + timeout_s
+    names = ["rank%d" % r for r in range(world)] + ["port"]
+    while time.monotonic() < t_end:
+        if all(os.path.exists(os.path.join(d, n)) for n in names):
+            codes = [int(open(os.path.join(d, "rank%d" % r)).read().strip() or "1") for r in range(world)]
+            worst = next((c for c in codes if c != 0), 0)
+            return worst, int(open(os.path.join(d, "port")).read().strip())
+        time.sleep(0.2)
+    return None, None
+
+
 def supervise_rank(args, json_fd):
     """A rank process under a launcher (WORLD_SIZE > 1): runs the real rank in a FRESH child -- first on the C-ABI RCCL step, and
-    if that child exits non-zero (oracle mismatch: 17, watchdog: 18, a crash) once more in another fresh child on
-    torch.distributed's all_to_all_single.  Never touches the GPU itself; nothing is restarted in place."""
+    if any rank's child exits non-zero (oracle mismatch: 17, watchdog: 18, a crash) once more in another fresh child on
+    torch.distributed's all_to_all_single.  The decision is taken by all supervisors together (agree_on_outcome).  Never touches the
+    GPU itself; nothing is restarted in place."""
     import subprocess
-    rank = int(os.environ.get("RANK", "0"))
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     first = os.environ.get("BENCH_TRANSPORT") or ("rccl" if backend == "nccl" else "torch")
     # (transport, backend) in the order tried: the C-ABI RCCL step; torch.distributed's all_to_all_single over the same RCCL; and, when
@@ -958,19 +991,23 @@ def supervise_rank(args, json_fd):
             attempts.append(("torch", backend))
         if backend == "nccl":
             attempts.append(("torch", "gloo"))
-    rc, reasons = 1, []
+    rc, reasons, port = 1, [], None
     for i, (tr, be) in enumerate(attempts):
         env = dict(os.environ, BENCH_CHILD="1", BENCH_TRANSPORT=tr, BENCH_BACKEND=be)
         if i > 0:
-            # a fresh rendezvous for the fresh processes: rank 0's child hosts the store itself on the next port
-            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + i)
+            # a fresh rendezvous for the fresh processes: rank 0's child hosts the store itself, on the port rank 0's supervisor picked
+            env["MASTER_PORT"] = str(port)
             env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
             reasons.append("the %s transport's ranks (backend %s) exited with code %d" % (attempts[i - 1][0], attempts[i - 1][1], rc))
             env["BENCH_FALLBACK_REASON"] = "; ".join(reasons) + " (17: first step failed the oracle check, 18: watchdog on a hung exchange or " \
                                            "rendezvous); this line was measured on the fallback transport in fresh processes"
             log("bench.py rank %d: %s" % (rank, env["BENCH_FALLBACK_REASON"]))
         r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)
-        rc = r.returncode
+        own = r.returncode
+        rc, port = agree_on_outcome(rank, world, i, own)
+        if rc is None:
+            log("bench.py rank %d: the other ranks' supervisors never reported attempt %d; giving up" % (rank, i))
+            return own or 1
         if rc == 0:
             if rank == 0:
                 return 0 if relay_json(r.stdout, json_fd) == 1 else 1

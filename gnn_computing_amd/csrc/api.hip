@@ -103,6 +103,7 @@ static constexpr int kSegChunksHost = 16;  // kSegChunks in kernel_util.cuh
 // between the two per 128-thread workgroup (r2: "medium").  r1_rows lists the rows of r1 then r2 (products of the fused GEMM).
 struct RowsPlan {
     bool valid = false;
+    bool medium_ok = true;   // false: built without the medium class (a GAT head width the long-row kernel cannot serve)
     int n0 = 0, n1 = 0, n2 = 0, long_deg = 256, med_deg = 256;
     DevBuf<int> r0, r1, r2, r1_rows;
     std::vector<long> r0_cost_prefix;
@@ -460,11 +461,13 @@ static int ensure_sorted_rows(Ctx *c, BalancedPlan &p)
     return p.t0_sorted.upload(sorted);
 }
 
-static int build_rows_plan(Ctx *c)
+static int build_rows_plan(Ctx *c, bool medium_ok = true)
 {
     int rc = fetch_host_ptr(c);
     if (rc) return rc;
     RowsPlan &p = c->rows_plan;
+    p.valid = false;
+    p.medium_ok = medium_ok;
     // The workgroup-per-row kernel finishes a long chain sooner (parallel gathers, one lane per column consuming), but a CU
     // holds one such workgroup while it could hold dozens of lane groups walking their own rows, so it only takes rows far
     // above the average degree: max(1024, 16 * avg).  Measured (rows mode, ms): reddit-shaped SAGE F=602 56.3 with every
@@ -481,6 +484,9 @@ static int build_rows_plan(Ctx *c)
     // 256 / 128; 512: 135); products-shaped 9.8 ms without the class, 10.0-11.9 ms with thresholds 512 ... 64.
     p.med_deg = c->opt_rows_medium > 0 ? c->opt_rows_medium : c->opt_rows_medium < 0 ? p.long_deg : std::max(128, (int)(c->E / 4500));
     p.med_deg = std::min(p.med_deg, p.long_deg);
+    // (GAT, head width not a multiple of 32: the long-row kernel's 32-column tiles would straddle heads, so the medium class -- whose
+    // only kernel that is -- stays with the lane groups; a graph without hub rows then runs entirely on k_gat_plan's descriptor path)
+    if (!medium_ok) p.med_deg = p.long_deg;
     std::vector<int> r0;
     struct Long { int beg, end, row; };
     std::vector<Long> longs, meds;
@@ -573,6 +579,7 @@ static int build_partitioned_gpu(Ctx *c, int parts, int ng, bool *done)
     if ((unsigned)mx > 0x3fffffffu) return GNNAGG_OK;   // the two flag bits are not free
     int par_num = parts == -1 ? parts_for_cols(c, (long)mx + 1) : parts;
     par_num = std::max(1, std::min(par_num, mx + 1));
+    if (par_num > 65535) return GNNAGG_OK;   // the device builder keeps the range in 16 bits; the host builder takes any count ("partitions" = N)
     GpuBlockedPlan g;
     if ((rc = gpu_build_blocked_plan(c->d_ptr, c->d_idx, c->V, c->E, par_num, mx + 1, ng, kSpanEdges, c->stream, g))) return rc;
     Schedule &s = c->sched[1];
@@ -1460,9 +1467,9 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
     if (mode == GNNAGG_MODE_ROWS && c->use_plan && !newval && heads > 0 && feat % heads == 0) {
         // canonical order: short rows on the descriptor path of k_gat_plan, isolated hub rows on the long-row kernel
         // (auxiliary stream) when a 32-column tile lies inside one head
-        if (!c->rows_plan.valid && (rc = build_rows_plan(c))) return rc;
-        RowsPlan &p = c->rows_plan;
         const bool tile_in_head = ((feat / heads) % 32) == 0;
+        if ((!c->rows_plan.valid || c->rows_plan.medium_ok != tile_in_head) && (rc = build_rows_plan(c, tile_in_head))) return rc;
+        RowsPlan &p = c->rows_plan;
         const bool long_ok = p.n1 > 0 && tile_in_head;
         if (p.n1 + p.n2 == 0 || tile_in_head) {
             const bool fork = long_ok && c->use_aux_stream;

@@ -408,6 +408,18 @@ static int step_abandon(DistStep *st, hipStream_t stream, int rc)
     if (ev && hipEventRecord(ev, st->comm_stream) == hipSuccess) (void)hipStreamWaitEvent(stream, ev, 0);
     return fail(rc, msg);
 }
+// A HIP call between fork and join that fails takes the abandon path too (the fork is ALWAYS joined, also during a capture) ...
+#define HIPD_STEP(expr)                                                                                                                   \
+    do {                                                                                                                                  \
+        hipError_t _e = (expr);                                                                                                           \
+        if (_e != hipSuccess) return step_abandon(st, stream, fail(GNNAGG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)));   \
+    } while (0)
+// ... and a failed join of one stage is recorded while the remaining stages are still joined
+#define HIPD_JOIN(expr)                                                                                                   \
+    do {                                                                                                                  \
+        hipError_t _e = (expr);                                                                                           \
+        if (_e != hipSuccess && !rc) rc = fail(GNNAGG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    } while (0)
 // stage s of the exchange on the communication stream, rows of `row_floats` floats, then its event
 static int step_exchange_stage(DistStep *st, int s, const float *d_send_buf, float *d_recv, int row_floats)
 {
@@ -513,14 +525,14 @@ int gnnagg_dist_step_gcn(gnnagg_dist_step_t h, const float *d_x_local, float *d_
             return step_abandon(st, stream, rc);
         for (int s = 0; s < S; ++s) {
             if ((rc = step_exchange_stage(st, s, d_send_buf, d_x_halo, feat))) return step_abandon(st, stream, rc);
-            HIPD_TRY(hipEventRecord(st->ev_stage[(size_t)s], st->comm_stream));
+            HIPD_STEP(hipEventRecord(st->ev_stage[(size_t)s], st->comm_stream));
         }
     }
     rc = gnnagg_set_stream(st->agg_local, stream);
     if (!rc) rc = gnnagg_gcn_run_ex(st->agg_local, d_x_local, d_y, feat, GNNAGG_MODE_BALANCED, reduce, 0);   // overlaps the exchange
     for (int s = 0; s < S; ++s) {
         // the caller's stream joins every stage (the last one is the join of the fork), on the error path too
-        if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_stage[(size_t)s], 0));
+        if (ex) HIPD_JOIN(hipStreamWaitEvent(stream, st->ev_stage[(size_t)s], 0));
         if (rc || !st->agg_remote[(size_t)s] || st->stage_recv0[(size_t)s + 1] == st->stage_recv0[(size_t)s]) continue;
         if (!(rc = gnnagg_set_stream(st->agg_remote[(size_t)s], stream)))
             rc = gnnagg_gcn_run_ex(st->agg_remote[(size_t)s], d_x_halo, d_y, feat, GNNAGG_MODE_BALANCED, reduce, GNNAGG_FLAG_ACCUMULATE);
@@ -552,7 +564,7 @@ int gnnagg_dist_step_gat(gnnagg_dist_step_t h, float *d_x_ext, float *d_att_ext,
             if (nr > 0 && (rc = launch_unpack_rows2(d_recv_buf + (size_t)r0 * w, (int)nr, feat, aw, d_x_ext + ((size_t)n_local + r0) * feat,
                                                     d_att_ext + ((size_t)n_local + r0) * aw, st->comm_stream)))
                 return step_abandon(st, stream, rc);
-            HIPD_TRY(hipEventRecord(st->ev_stage[(size_t)s], st->comm_stream));
+            HIPD_STEP(hipEventRecord(st->ev_stage[(size_t)s], st->comm_stream));
         }
     }
     // numerators and denominators of the local-source edges while the exchange is in flight; every halo-source pass adds its own,
@@ -560,14 +572,15 @@ int gnnagg_dist_step_gat(gnnagg_dist_step_t h, float *d_x_ext, float *d_att_ext,
     if ((rc = gnnagg_set_stream(st->agg_local, stream))) return ex ? step_abandon(st, stream, rc) : rc;
     if (!st->any_remote()) {
         // (a step made without halo-source aggregators: one pass over X_ext.  It reads the halo tail, so it runs BEHIND the exchange)
-        for (int s = 0; ex && s < S; ++s) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_stage[(size_t)s], 0));
+        for (int s = 0; ex && s < S; ++s) HIPD_JOIN(hipStreamWaitEvent(stream, st->ev_stage[(size_t)s], 0));
+        if (rc) return rc;
         return gnnagg_gat_run(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, GNNAGG_MODE_BALANCED, nullptr);
     }
     int last = -1;
     for (int s = 0; s < S; ++s) if (st->agg_remote[(size_t)s]) last = s;
     rc = gnnagg_gat_run_part(st->agg_local, d_x_ext, d_att_ext, d_y, feat, heads, slope, 1, d_den);
     for (int s = 0; s < S; ++s) {
-        if (ex) HIPD_TRY(hipStreamWaitEvent(stream, st->ev_stage[(size_t)s], 0));   // joined on the error path too
+        if (ex) HIPD_JOIN(hipStreamWaitEvent(stream, st->ev_stage[(size_t)s], 0));   // joined on the error path too
         if (rc || !st->agg_remote[(size_t)s]) continue;
         if (!(rc = gnnagg_set_stream(st->agg_remote[(size_t)s], stream)))
             rc = gnnagg_gat_run_part(st->agg_remote[(size_t)s], d_x_ext, d_att_ext, d_y, feat, heads, slope, s == last ? 2 : 3, d_den);

@@ -28,7 +28,8 @@ except Exception:
     commit = os.environ.get("GNNAGG_BUILD_LABEL", "unknown")
 kernels = []
 PLAN_KERNELS = ("k_range_keys", "k_mark_row_starts", "k_rows_unsorted", "k_gather_sorted", "k_subrow_starts", "k_group_flags", "k_scatter_groups",
-                "k_count_groups", "k_iota", "k_flag_ids", "k_mark_hub_rows", "k_chain_", "k_gather_u32")
+                "k_count_groups", "k_iota", "k_flag_ids", "k_mark_hub_rows", "k_chain_", "k_gather_u32",
+                "prims::")   # prims:: = the plan builder's scan / sort / reduce primitives (prims.cuh): once per handle too
 print("# config %s %s -- per-launch averages; traffic = FETCH_SIZE*2*1024 + WRITE_SIZE*1024 (fabric side, Infinity-Cache hits included)" % (cfg, sys.argv[3] if len(sys.argv) > 3 else ""))
 tot = 0.0
 for k, (s, n) in sorted(dur.items(), key=lambda t: -t[1][0]):
@@ -53,7 +54,7 @@ for k, (s, n) in sorted(dur.items(), key=lambda t: -t[1][0]):
     if extra:
         print("      " + "  ".join("%s=%.4g" % (n, v) for n, v in sorted(extra.items())))
     tot += avg
-print("sum of per-launch averages: %.1f us" % tot)
+print("sum of per-launch averages (the kernels of ONE step; plan-time kernels excluded): %.1f us" % tot)
 json.dump({"config": cfg, "options": sys.argv[3] if len(sys.argv) > 3 else "", "build": os.environ.get("GNNAGG_BUILD_LABEL", commit),
            "_correction": "FETCH_SIZE (KB) x 2 x 1024 (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE "
                           "(KB) x 1024; fabric-side counters, Infinity-Cache hits included; separate --pmc passes",

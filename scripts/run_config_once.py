@@ -10,8 +10,9 @@ import gnn_computing_amd as gnc  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "R"
 dev = torch.device("cuda", 0)
-name, F = {"A": ("arxiv", 128), "R": ("reddit", 602), "G": ("reddit", 256), "P1": ("products", 100)}[cfg]
-if cfg == "A":   # the headline workload of bench.py: arxiv-shaped, locality reorder applied on load, explicit unit weights
+name, F = {"A": ("arxiv", 128), "A_rows": ("arxiv", 128), "R": ("reddit", 602), "G": ("reddit", 256), "P1": ("products", 100)}[cfg]
+mode = "rows" if cfg == "A_rows" else "balanced"   # A_rows: the headline input in GNNAGG_MODE_ROWS (the literal aggr_gcn order)
+if cfg in ("A", "A_rows"):   # the headline workload of bench.py: arxiv-shaped, locality reorder applied on load, explicit unit weights
     import numpy as np
     p, i = gnc.graph.dataset(name)
     p, i = p.numpy(), i.numpy()
@@ -29,9 +30,10 @@ if cfg == "G":
     agg.schedule_balanced(0)
     run = lambda: agg.run(x, att, y, 128, "balanced", heads=8)  # noqa: E731
 else:
-    agg = gnc.Aggregator_GCN(ptr, idx, torch.ones(idx.numel(), device=dev) if cfg in ("A", "P1") else None, F, F)
-    agg.schedule_balanced(0)
-    run = lambda: agg.run(x, y, 128, "balanced", reduce="mean" if cfg == "R" else "sum")  # noqa: E731
-for _ in range(20 if cfg == "A" else 5):
+    agg = gnc.Aggregator_GCN(ptr, idx, torch.ones(idx.numel(), device=dev) if cfg in ("A", "A_rows", "P1") else None, F, F)
+    if mode == "balanced":
+        agg.schedule_balanced(0)
+    run = lambda: agg.run(x, y, 128, mode, reduce="mean" if cfg == "R" else "sum")  # noqa: E731
+for _ in range(20 if cfg in ("A", "A_rows") else 5):
     run()
 torch.cuda.synchronize()

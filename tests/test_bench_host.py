@@ -1,0 +1,65 @@
+"""CPU: the host logic of bench.py that needs no GPU -- the supervisors' agreement before a transport fallback, the gather-model byte
+counts of SURVEY 8d, and the float64 yardstick the sub-records are verified against."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import bench
+rank, world, rc = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+out = []
+for attempt in range(2):
+    out.append(bench.agree_on_outcome(rank, world, attempt, rc if attempt == 0 else 0, timeout_s=30.0))
+print(json.dumps(out))
+"""
+
+
+def test_supervisors_agree_before_falling_back():
+    """a subset of ranks failing must not leave the failed ranks alone in a new rendezvous.  Three supervisors (children of
+    this process, like ranks under one launcher); one child 'failed' with 17: all three see 17 and the SAME next port, then 0."""
+    procs = [subprocess.Popen([sys.executable, "-c", CHILD, ROOT, str(r), "3", "17" if r == 1 else "0"], stdout=subprocess.PIPE, text=True)
+             for r in range(3)]
+    outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert all(o[0][0] == 17 for o in outs) and len({o[0][1] for o in outs}) == 1 and outs[0][0][1] > 0
+    assert all(o[1][0] == 0 for o in outs) and len({o[1][1] for o in outs}) == 1
+
+
+def test_a_missing_supervisor_ends_the_ladder():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.agree_on_outcome(0, 2, 7, 0, timeout_s=1.0) == (None, None)
+
+
+def test_byte_models_of_survey_8d():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.algorithmic_bytes(169343, 1166243, 128) == 693827352      # config A
+    assert bench.compulsory_bytes(169343, 1166243, 128) == 183414552
+
+
+def test_float64_yardstick_matches_a_dense_product():
+    sys.path.insert(0, ROOT)
+    import bench
+    bench.np = np
+    rng = np.random.default_rng(3)
+    V, F, H = 50, 8, 2
+    deg = rng.integers(0, 9, 6)
+    sp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    si = rng.integers(0, V, sp[-1]).astype(np.int32)
+    x = rng.standard_normal((V, F)).astype(np.float32)
+    v = rng.standard_normal(sp[-1]).astype(np.float32)
+    w = rng.random((sp[-1], H))
+    for k in range(6):
+        e = slice(int(sp[k]), int(sp[k + 1]))
+        assert np.allclose(bench.sum_rows_f64(sp, si, x, v)[k], (x[si[e]].astype(np.float64) * v[e, None]).sum(0))
+        assert np.allclose(bench.sum_rows_f64(sp, si, x)[k], x[si[e]].astype(np.float64).sum(0))
+        ref = (x[si[e]].astype(np.float64).reshape(-1, H, F // H) * w[e][:, :, None]).sum(0).reshape(F)
+        assert np.allclose(bench.sum_rows_f64(sp, si, x, w=w, heads=H)[k], ref)
