@@ -2,6 +2,8 @@
 // the edge-wise and naive SpMM baselines, validators, the dense combine GEMM, the CSR check and the halo pack.
 #include "kernel_util.cuh"
 
+#include <type_traits>
+
 namespace gnnagg {
 
 // ------------------------------------------------------------------------- CSR -> edge list
@@ -407,6 +409,12 @@ __global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, c
 #ifndef GNNAGG_GEMM_KC
 #define GNNAGG_GEMM_KC 32
 #endif
+#ifndef GNNAGG_GEMM_PIPE
+#define GNNAGG_GEMM_PIPE 0   // lean form: explicit two-stage operand pipeline with scheduling-group barriers (A/B switch)
+#endif
+#ifndef GNNAGG_GEMM_SWAP
+#define GNNAGG_GEMM_SWAP 1   // lean form: operands swapped, transposed accumulator, 16-byte C stores (A/B switch: 0 = round 4's dword stores)
+#endif
 static constexpr int kBigT = 128, kBigKC = GNNAGG_GEMM_KC, kBigPA = kBigKC + 1;
 #ifndef GNNAGG_GEMM_WGS
 #define GNNAGG_GEMM_WGS (GNNAGG_GEMM_KC <= 16 ? 3 : 2)
@@ -661,32 +669,74 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_lean(const float *__r
 #pragma unroll
         for (int j = 0; j < NB; ++j) *reinterpret_cast<float4 *>(Bs + lb[j]) = rb[j];
     };
-    auto mma = [&](int rbk, const float *As, const float *Bs) {
+    // RBK (32-row blocks of this tile: 4 except at the end of a strip) is a compile-time constant of the burst: with a run-time count every
+    // MFMA sat in a basic block of its own behind a scalar branch (ISA of round 4's kernel: 64 one-MFMA blocks, ~190 branch instructions and
+    // a wait per chunk), so nothing could be scheduled across them
+    auto mma = [&](auto rbk_c, const float *As, const float *Bs) {
+        constexpr int RBK = decltype(rbk_c)::value;
         const float *ap = As + (lane & 31) * kBigPA + (lane >> 5);
         const float *bp = Bs + (lane >> 5) * kBigT + 32 * wave + (lane & 31);
-        float a_cur[4], a_nxt[4], b_cur, b_nxt;
+#if GNNAGG_GEMM_PIPE
+        // two k-steps (a "pair": 2 RBK MFMAs, 512 cycles of the matrix pipe at RBK = 4) per stage; the operand reads of pair p + 1 are
+        // issued BEFORE the MFMAs of pair p and land under them (left to itself the compiler issues them behind the pair's last MFMA
+        // and waits for them in front of the next one: the LDS latency shows once per pair)
+        float a[2][RBK][2], b[2][2];
+        auto rd = [&](int buf, int pr) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_cur[i] = ap[i * 32 * kBigPA];
+            for (int i = 0; i < RBK; ++i) { a[buf][i][0] = ap[i * 32 * kBigPA + 4 * pr]; a[buf][i][1] = ap[i * 32 * kBigPA + 4 * pr + 2]; }
+            b[buf][0] = bp[4 * pr * kBigT]; b[buf][1] = bp[(4 * pr + 2) * kBigT];
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int pr = 0; pr < kBigKC / 4; ++pr) {
+            if (pr + 1 < kBigKC / 4) rd((pr + 1) & 1, pr + 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < RBK; ++i) {
+#if GNNAGG_GEMM_SWAP
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[pr & 1][kk], a[pr & 1][i][kk], acc[i], 0, 0, 0);
+#else
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pr & 1][i][kk], b[pr & 1][kk], acc[i], 0, 0, 0);
+#endif
+                }
+            if (pr + 1 < kBigKC / 4) __builtin_amdgcn_sched_group_barrier(0x100, RBK + 1, 0);   // DS reads of the next pair first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * RBK, 0);                              // ... then this pair's MFMAs
+        }
+#else
+        float a_cur[RBK], a_nxt[RBK], b_cur, b_nxt;
+#pragma unroll
+        for (int i = 0; i < RBK; ++i) a_cur[i] = ap[i * 32 * kBigPA];
         b_cur = bp[0];
 #pragma unroll
         for (int t = 0; t < kBigKC / 2; ++t) {
             if (t + 1 < kBigKC / 2) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a_nxt[i] = ap[i * 32 * kBigPA + 2 * (t + 1)];
+                for (int i = 0; i < RBK; ++i) a_nxt[i] = ap[i * 32 * kBigPA + 2 * (t + 1)];
                 b_nxt = bp[2 * (t + 1) * kBigT];
             }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b_cur, acc[0], 0, 0, 0);
-            if (rbk > 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b_cur, acc[1], 0, 0, 0);
-            if (rbk > 2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[2], b_cur, acc[2], 0, 0, 0);
-            if (rbk > 3) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[3], b_cur, acc[3], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
+            for (int i = 0; i < RBK; ++i) {
+#if GNNAGG_GEMM_SWAP
+                // the weight strip rides as the A operand and the 32 rows of X as the B operand: the accumulator is the TRANSPOSED 32 x 32
+                // block, so a lane ends up with four CONSECUTIVE COLUMNS of one output row per register quad -- 16-byte stores.  Same
+                // products, same k order (a * b = b * a): the same bits.
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur, a_cur[i], acc[i], 0, 0, 0);
+#else
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur, acc[i], 0, 0, 0);
+#endif
+            }
+#pragma unroll
+            for (int i = 0; i < RBK; ++i) a_cur[i] = a_nxt[i];
             b_cur = b_nxt;
         }
+#endif
     };
     const int nchunks = (K + kBigKC - 1) / kBigKC;
     const int ntiles = (nblk + 3) >> 2, total = ntiles * nchunks;
+#if !GNNAGG_GEMM_SWAP
     const int colc = (32 * wave + (lane & 31)) * (int)sizeof(float);
+#endif
     fetch(blk0 * 32, 0);
     stash(As0, Bs0, 0);
     __syncthreads();
@@ -705,7 +755,10 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_lean(const float *__r
         // phases shrink, the fetch phase grows, 191.8-205 against 194 us; a second register set with chunk g + 2 in flight -- 195.5; K chunks
         // of 16 with 3 / 4 workgroups per CU -- 193.6 / 207.5; the next chunk's stash folded into the second half of the burst -- the stash
         // phase goes from 19 % to 4 % of the period and the burst grows by as much: 200 against 194 us at the same ratio to rocBLAS)
-        mma(rbk, As, Bs);
+        if (rbk == 4) mma(std::integral_constant<int, 4>{}, As, Bs);
+        else if (rbk == 3) mma(std::integral_constant<int, 3>{}, As, Bs);
+        else if (rbk == 2) mma(std::integral_constant<int, 2>{}, As, Bs);
+        else mma(std::integral_constant<int, 1>{}, As, Bs);
         TL_STAMP(2);
         if (last_c) {
             // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); a descriptor rebased to
@@ -714,6 +767,32 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_lean(const float *__r
             const size_t cr = co < c_bytes ? c_bytes - co : 0;
             const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C + ((size_t)row0 * N + col0), 0,
                                                                                     (int)(unsigned)(cr < 0xfffffffcULL ? cr : 0xfffffffcULL), 0x00020000);
+#if GNNAGG_GEMM_SWAP
+            // transposed accumulator: row = 32 i + (lane & 31), columns 32 wave + 8 q + 4 (lane >> 5) + 0 .. 3 in registers 4 q .. 4 q + 3
+            const int voff = ((lane & 31) * N + 32 * wave + 4 * (lane >> 5)) * (int)sizeof(float);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < rbk) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        u4 v;
+                        v[0] = __float_as_uint(acc[i][4 * qd]); v[1] = __float_as_uint(acc[i][4 * qd + 1]);
+                        v[2] = __float_as_uint(acc[i][4 * qd + 2]); v[3] = __float_as_uint(acc[i][4 * qd + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, crsrc, voff, (32 * i * N + 8 * qd) * (int)sizeof(float), 0);
+                    }
+                }
+            }
+            // A store of more than 8 bytes reads its upper data registers a cycle after it issues; the VALU write that follows needs wait
+            // states in between.  The compiler inserts them inside a basic block, but here the last 16-byte store falls through a block
+            // boundary straight into the zeroing (ISA: buffer_store_dwordx4 v[12:15] / .LBB: v_mov_b32 v15, 0) and a few hundred elements
+            // of a 131 072-row product came out as 0.  The wait states are written out.
+            asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) acc[i][reg] = 0.0f;
+            }
+#else
             const int voff = 4 * (lane >> 5) * N * (int)sizeof(float) + colc;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -726,6 +805,7 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_lean(const float *__r
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) acc[i][reg] = 0.0f;
             }
+#endif
         }
         TL_STAMP(3);
         if (g + 1 < total) stash((g & 1) ? As0 : As1, (g & 1) ? Bs0 : Bs1, nk0);

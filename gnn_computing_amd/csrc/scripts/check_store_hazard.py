@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""ISA lint for a hazard the gfx950 code generator left open once (aux_kernels.hip, k_dense_nn_lean, round 5): a VMEM / LDS store of more
+than 8 bytes reads its upper data registers a cycle after it issues, so a VALU write of one of those registers needs wait states in
+between.  The compiler inserts them inside a basic block; when the store is the LAST instruction of a block and the next block starts
+with such a write, nothing separated them.  usage: check_store_hazard.py file.s [...]   (hipcc --save-temps=obj ... gives the .s files)
+Prints every place where a >8-byte store is followed, within two instructions and across labels only, by a VALU write of its data."""
+import re
+import sys
+
+STORE = re.compile(r"^\s*(buffer_store_dwordx[34]|global_store_dwordx[34]|flat_store_dwordx[34]|scratch_store_dwordx[34]|ds_write_b96|ds_write_b128)\s+(.*)$")
+RANGE = re.compile(r"v\[(\d+):(\d+)\]")
+WRITE = re.compile(r"^\s*(v_\w+)\s+(v\[(\d+):(\d+)\]|v(\d+))")
+
+
+def data_regs(op, args):
+    regs = RANGE.findall(args)
+    if not regs:
+        return set()
+    # data operand: first vector range for buffer stores, the LAST for global / flat / ds stores with an address first
+    lo, hi = (regs[0] if op.startswith("buffer") else regs[-1])
+    lo, hi = int(lo), int(hi)
+    return set(range(lo, hi + 1)) if hi - lo >= 2 else set()
+
+
+bad = 0
+for path in sys.argv[1:]:
+    lines = open(path).read().split("\n")
+    func = "?"
+    code = []   # (line number, text, is_label)
+    for n, l in enumerate(lines, 1):
+        t = l.split(";")[0].rstrip()
+        if not t.strip():
+            continue
+        if re.match(r"^[A-Za-z_.$][\w.$]*:", t):
+            if not t.startswith(".L"):
+                func = t.split(":")[0]
+            code.append((n, t, True, func))
+        elif t.startswith("\t") and not t.strip().startswith("."):
+            code.append((n, t, False, func))
+    for i, (n, t, lab, fn) in enumerate(code):
+        m = STORE.match(t)
+        if not m:
+            continue
+        regs = data_regs(m.group(1), m.group(2))
+        if not regs:
+            continue
+        seen, crossed = 0, False
+        for (n2, t2, lab2, _) in code[i + 1:i + 8]:
+            if lab2:
+                crossed = True
+                continue
+            if t2.strip().startswith("s_nop") or t2.strip().startswith("s_waitcnt"):
+                break
+            w = WRITE.match(t2)
+            if w and not w.group(1).startswith("v_cmp"):
+                dst = set(range(int(w.group(3)), int(w.group(4)) + 1)) if w.group(3) else {int(w.group(5))}
+                if dst & regs and crossed:
+                    print("%s:%d %s: `%s` then (across a label) `%s`" % (path, n, fn, t.strip(), t2.strip()))
+                    bad += 1
+                    break
+            seen += 1
+            if seen >= 2:
+                break
+print("%d suspicious place(s)" % bad)
+sys.exit(1 if bad else 0)
