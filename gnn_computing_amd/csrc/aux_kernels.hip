@@ -409,11 +409,8 @@ __global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, c
 #ifndef GNNAGG_GEMM_KC
 #define GNNAGG_GEMM_KC 32
 #endif
-#ifndef GNNAGG_GEMM_PIPE
-#define GNNAGG_GEMM_PIPE 0   // lean form: explicit two-stage operand pipeline with scheduling-group barriers (A/B switch)
-#endif
 #ifndef GNNAGG_GEMM_SWAP
-#define GNNAGG_GEMM_SWAP 1   // lean form: operands swapped, transposed accumulator, 16-byte C stores (A/B switch: 0 = round 4's dword stores)
+#define GNNAGG_GEMM_SWAP 0   // lean form, A/B switch: 1 = operands swapped, transposed accumulator, 16-byte C stores (measured equal: profiles/r05/gemm_forms.txt)
 #endif
 static constexpr int kBigT = 128, kBigKC = GNNAGG_GEMM_KC, kBigPA = kBigKC + 1;
 #ifndef GNNAGG_GEMM_WGS
@@ -676,34 +673,6 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_lean(const float *__r
         constexpr int RBK = decltype(rbk_c)::value;
         const float *ap = As + (lane & 31) * kBigPA + (lane >> 5);
         const float *bp = Bs + (lane >> 5) * kBigT + 32 * wave + (lane & 31);
-#if GNNAGG_GEMM_PIPE
-        // two k-steps (a "pair": 2 RBK MFMAs, 512 cycles of the matrix pipe at RBK = 4) per stage; the operand reads of pair p + 1 are
-        // issued BEFORE the MFMAs of pair p and land under them (left to itself the compiler issues them behind the pair's last MFMA
-        // and waits for them in front of the next one: the LDS latency shows once per pair)
-        float a[2][RBK][2], b[2][2];
-        auto rd = [&](int buf, int pr) {
-#pragma unroll
-            for (int i = 0; i < RBK; ++i) { a[buf][i][0] = ap[i * 32 * kBigPA + 4 * pr]; a[buf][i][1] = ap[i * 32 * kBigPA + 4 * pr + 2]; }
-            b[buf][0] = bp[4 * pr * kBigT]; b[buf][1] = bp[(4 * pr + 2) * kBigT];
-        };
-        rd(0, 0);
-#pragma unroll
-        for (int pr = 0; pr < kBigKC / 4; ++pr) {
-            if (pr + 1 < kBigKC / 4) rd((pr + 1) & 1, pr + 1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < RBK; ++i) {
-#if GNNAGG_GEMM_SWAP
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[pr & 1][kk], a[pr & 1][i][kk], acc[i], 0, 0, 0);
-#else
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pr & 1][i][kk], b[pr & 1][kk], acc[i], 0, 0, 0);
-#endif
-                }
-            if (pr + 1 < kBigKC / 4) __builtin_amdgcn_sched_group_barrier(0x100, RBK + 1, 0);   // DS reads of the next pair first ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * RBK, 0);                              // ... then this pair's MFMAs
-        }
-#else
         float a_cur[RBK], a_nxt[RBK], b_cur, b_nxt;
 #pragma unroll
         for (int i = 0; i < RBK; ++i) a_cur[i] = ap[i * 32 * kBigPA];
@@ -730,7 +699,6 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_lean(const float *__r
             for (int i = 0; i < RBK; ++i) a_cur[i] = a_nxt[i];
             b_cur = b_nxt;
         }
-#endif
     };
     const int nchunks = (K + kBigKC - 1) / kBigKC;
     const int ntiles = (nblk + 3) >> 2, total = ntiles * nchunks;
