@@ -88,10 +88,10 @@ def time_steps(step_fn, steps, warmup, barrier):
     median comes from a separate pass with one event pair per launch, after the timed region."""
     # Host hygiene first (nothing of it is inside the timed region): the GPU boxes run this process in a CPU-quota'd container,
     # where a host thread that has been busy-waiting can be descheduled for 45-55 ms (seen once per few hundred launches,
-    # scripts/exp_stall_hunt.py: GPU times unaffected); an idle period lets the quota window roll over, and the collector stays
+    # scripts/history/exp_stall_hunt.py: GPU times unaffected); an idle period lets the quota window roll over, and the collector stays
     # off while the K launches are issued.  The W warm-up steps come AFTER it and run straight into the timed region: a device
     # left idle between the warm-up and the first timed launch -- even for the few milliseconds of a gc.collect() -- starts
-    # the K steps cold (scripts/exp_timed_region.py, K = 20: 80.3 us per step with the idle period after the warm-up, 75.2 us
+    # the K steps cold (scripts/history/exp_timed_region.py, K = 20: 80.3 us per step with the idle period after the warm-up, 75.2 us
     # with the warm-up after it).
     import gc
     gc.collect()
