@@ -944,14 +944,19 @@ def launch_ranks(args, json_fd):
     return r.returncode if r.returncode != 0 else (0 if n == 1 else 1)
 
 
+def sup_dir():
+    """Directory the supervisors of ONE job share: named after their common parent (the launcher) and the job's rendezvous port."""
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), "gnnagg_bench_sup_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+
+
 def agree_on_outcome(rank, world, attempt, rc, timeout_s=420.0):
     """The supervisors of one node agree on what an attempt did before any of them starts the next one (a rank whose child
     failed must not open a rendezvous that the ranks whose children returned 0 never join).  Every supervisor is a child of the same
     launcher process, so a directory named after that parent is shared and private to this job; rank r drops its child's exit code
     there, rank 0 also the port of the next rendezvous (a free one, checked).  Returns (worst exit code over all ranks, next port), or
     (None, None) when some rank never reported -- then nobody retries."""
-    import tempfile
-    d = os.path.join(tempfile.gettempdir(), "gnnagg_bench_sup_%d" % os.getppid(), "attempt%d" % attempt)
+    d = os.path.join(sup_dir(), "attempt%d" % attempt)
     os.makedirs(d, exist_ok=True)
 
     def drop(name, text):
@@ -992,6 +997,9 @@ def supervise_rank(args, json_fd):
         if backend == "nccl":
             attempts.append(("torch", "gloo"))
     rc, reasons, port = 1, [], None
+    if rank == 0:   # a directory of the same name can only be a leftover of an earlier job whose launcher had this pid
+        import shutil
+        shutil.rmtree(sup_dir(), ignore_errors=True)
     for i, (tr, be) in enumerate(attempts):
         env = dict(os.environ, BENCH_CHILD="1", BENCH_TRANSPORT=tr, BENCH_BACKEND=be)
         if i > 0:

@@ -63,3 +63,13 @@ def test_float64_yardstick_matches_a_dense_product():
         assert np.allclose(bench.sum_rows_f64(sp, si, x)[k], x[si[e]].astype(np.float64).sum(0))
         ref = (x[si[e]].astype(np.float64).reshape(-1, H, F // H) * w[e][:, :, None]).sum(0).reshape(F)
         assert np.allclose(bench.sum_rows_f64(sp, si, x, w=w, heads=H)[k], ref)
+
+
+def test_isa_lint_for_the_cross_block_store_hazard():
+    """Second tier (GNNAGG_TEST_TIER=2; ~3 minutes of hipcc): `make -C gnn_computing_amd/csrc lint` -- no kernel file's assembly has a
+    store of more than 8 bytes followed across a basic-block boundary by a VALU write of its data registers."""
+    import pytest
+    if os.environ.get("GNNAGG_TEST_TIER") != "2":
+        pytest.skip("second tier: set GNNAGG_TEST_TIER=2 (make -C gnn_computing_amd/csrc lint)")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "gnn_computing_amd", "csrc"), "lint"], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0 and "0 suspicious place(s)" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
