@@ -409,6 +409,9 @@ __global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, c
 #ifndef GNNAGG_GEMM_KC
 #define GNNAGG_GEMM_KC 32
 #endif
+#ifndef GNNAGG_GEMM_AHEAD
+#define GNNAGG_GEMM_AHEAD 1   // 1: 16-byte-aligned lean shapes with K % 32 == 0 run on k_dense_nn_ahead (chunks requested two periods ahead, hand-counted vmcnt); 0: k_dense_nn_lean<4>
+#endif
 #ifndef GNNAGG_GEMM_SWAP
 #define GNNAGG_GEMM_SWAP 0   // lean form, A/B switch: 1 = operands swapped, transposed accumulator, 16-byte C stores (measured equal: profiles/r05/gemm_forms.txt)
 #endif
@@ -784,6 +787,209 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_lean(const float *__r
     }
 }
 
+// k_dense_nn_lean with every chunk requested TWO periods before it is written to LDS, the wait for it counted by hand (round 5).
+// Timing variants (profiles/r05/gemm_forms.txt) put the loss of the lean kernel against its compute-only rate on the HBM stream of A
+// arriving late: with A served from L2 the same kernel runs at the compute-only rate.  A second register set alone does not buy a
+// second period: hipcc's s_waitcnt bookkeeping does not survive the loop back-edge and the barrier -- it waits vmcnt(0) in front of the
+// LDS writes, for the chunk requested a moment ago as well -- and a load whose destination is a compiler-visible value may be copied
+// (v_mov) before it has landed.  So the producer side is inline assembly on FIXED registers the compiler never sees:
+// `amdgpu_num_vgpr(192)` keeps its allocator below v192 (it needs 155), the two register sets are v192-v223 and v224-v255 (named as
+// clobbers, so the kernel descriptor still says 256), and the loads, the one wait -- `s_waitcnt vmcnt(8)`: everything but the eight
+// newest -- and the LDS writes are written out.  vmcnt also counts the C stores of a tile's last chunk; loads return in order among
+// loads, so "at most 8 outstanding" always covers the 8 oldest loads.  Every iteration requests exactly 8 loads (past the end of the
+// strip: the last chunk again), so the count is the same everywhere.  Chunk h travels in register set h & 1 and lands in LDS image
+// h & 1.  Same arithmetic as k_dense_nn_lean: bit-exact.  16-byte aligned A rows and K % 32 == 0; other shapes stay on k_dense_nn_lean.
+// Measured (profiles/r05/gemm_forms.txt): 169 343 x 512 @ 512 x 128 204 -> 192 us (115.6 TF); THREE periods (three sets from v160, the
+// compiler squeezed into 160 registers, the image of a chunk a run-time value) 198.6 us -- two is where it pays.
+#define GNNAGG_AHEAD_LOAD(REGS, C0, C1, C2, C3, OFF, RSRC) \
+    asm volatile("buffer_load_dwordx4 " REGS ", %0, %1, 0 offen" :: "v"(OFF), "s"(RSRC) : "memory", C0, C1, C2, C3)
+#define GNNAGG_AHEAD_STASH_A(R0, R1, R2, R3, ADDR) \
+    asm volatile("ds_write2_b32 %0, " R0 ", " R1 " offset1:1\n\tds_write2_b32 %0, " R2 ", " R3 " offset0:2 offset1:3" :: "v"(ADDR) : "memory")
+#define GNNAGG_AHEAD_STASH_B(REGS, ADDR) asm volatile("ds_write_b128 %0, " REGS :: "v"(ADDR) : "memory")
+__global__ __launch_bounds__(256, kBigWgs) __attribute__((amdgpu_num_vgpr(192))) void k_dense_nn_ahead(
+    const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K, int nb32, int nstrips)
+{
+    extern __shared__ float lds[];
+    constexpr int KQ = kBigKC / 4, NA = kBigT * KQ / 256, NB = kBigKC * (kBigT / 4) / 256;
+    static_assert(NA == 4 && NB == 4, "the register sets and the hand-counted wait below assume 4 + 4 loads of 16 bytes per chunk");
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) float *lds_f;
+    const int col0 = blockIdx.y * kBigT;
+    const int q = nb32 / nstrips, extra = nb32 - q * nstrips, sidx = blockIdx.x;
+    const int blk0 = sidx * q + (sidx < extra ? sidx : extra), nblk = q + (sidx < extra ? 1 : 0);
+    if (nblk == 0) return;
+    float *As0 = lds, *As1 = lds + kBigT * kBigPA, *Bs0 = lds + 2 * kBigT * kBigPA, *Bs1 = Bs0 + kBigKC * kBigT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    // per-thread constants: byte offsets of this thread's pieces inside a chunk (global) and LDS byte addresses inside image 0
+    int voa[NA], vob[NB];
+    unsigned la0[NA], lb0[NB];
+    const unsigned img_a = kBigT * kBigPA * (unsigned)sizeof(float), img_b = kBigKC * kBigT * (unsigned)sizeof(float);   // image 1 = image 0 + this
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int p = (int)threadIdx.x + 256 * j;
+        voa[j] = ((p / KQ) * K + (p % KQ) * 4) * (int)sizeof(float);
+        la0[j] = (unsigned)(unsigned long long)(lds_f)(As0 + (p / KQ) * kBigPA + (p % KQ) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        vob[j] = (((int)(threadIdx.x >> 5) + 8 * j) * N + (int)(threadIdx.x & 31) * 4) * (int)sizeof(float);
+        lb0[j] = (unsigned)(unsigned long long)(lds_f)(Bs0 + ((int)(threadIdx.x >> 5) + 8 * j) * kBigT + (int)(threadIdx.x & 31) * 4);
+    }
+    const size_t a_bytes = (size_t)M * K * sizeof(float), b_bytes = (size_t)K * N * sizeof(float);
+    // a raw buffer descriptor by hand (base, stride 0, bytes, the flags __builtin_amdgcn_make_buffer_rsrc is given elsewhere in this file)
+    auto rsrc_of = [](const float *base, size_t bytes) -> u4 {
+        const unsigned long long a = (unsigned long long)base;
+        u4 r;
+        r[0] = (unsigned)a; r[1] = (unsigned)(a >> 32) & 0xffffu; r[2] = (unsigned)(bytes < 0xfffffffcULL ? bytes : 0xfffffffcULL); r[3] = 0x00020000u;
+        return r;
+    };
+    const int nchunks = K / kBigKC;
+    const int ntiles = (nblk + 3) >> 2, total = ntiles * nchunks;
+    // the next chunk to REQUEST: (fc, frow0), index fi; past the last chunk of the strip the last one is requested again
+    int fc = 0, frow0 = blk0 * 32, fi = 0;
+#define GNNAGG_AHEAD_FETCH(SET)                                                                                                                       \
+    {                                                                                                                                                 \
+        const int k0_ = fc * kBigKC;                                                                                                                  \
+        const size_t ao_ = ((size_t)frow0 * K + k0_) * sizeof(float), bo_ = ((size_t)k0_ * N + col0) * sizeof(float);                                 \
+        const u4 ar_ = rsrc_of(A + ((size_t)frow0 * K + k0_), ao_ < a_bytes ? a_bytes - ao_ : 0);                                                     \
+        const u4 br_ = rsrc_of(B + ((size_t)k0_ * N + col0), bo_ < b_bytes ? b_bytes - bo_ : 0);                                                      \
+        if (SET == 0) {                                                                                                                               \
+            GNNAGG_AHEAD_LOAD("v[192:195]", "v192", "v193", "v194", "v195", voa[0], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[196:199]", "v196", "v197", "v198", "v199", voa[1], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[200:203]", "v200", "v201", "v202", "v203", voa[2], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[204:207]", "v204", "v205", "v206", "v207", voa[3], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[208:211]", "v208", "v209", "v210", "v211", vob[0], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[212:215]", "v212", "v213", "v214", "v215", vob[1], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[216:219]", "v216", "v217", "v218", "v219", vob[2], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[220:223]", "v220", "v221", "v222", "v223", vob[3], br_);                                                             \
+        } else {                                                                                                                                      \
+            GNNAGG_AHEAD_LOAD("v[224:227]", "v224", "v225", "v226", "v227", voa[0], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[228:231]", "v228", "v229", "v230", "v231", voa[1], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[232:235]", "v232", "v233", "v234", "v235", voa[2], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[236:239]", "v236", "v237", "v238", "v239", voa[3], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[240:243]", "v240", "v241", "v242", "v243", vob[0], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[244:247]", "v244", "v245", "v246", "v247", vob[1], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[248:251]", "v248", "v249", "v250", "v251", vob[2], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[252:255]", "v252", "v253", "v254", "v255", vob[3], br_);                                                             \
+        }                                                                                                                                             \
+        if (fi + 1 < total) { ++fi; if (fc + 1 == nchunks) { fc = 0; frow0 += kBigT; } else ++fc; }                                                   \
+    }
+    // set SET (landed: the caller waited) -> LDS image SET; then the LDS writes are drained so that the set can be requested into again
+#define GNNAGG_AHEAD_STASH(SET)                                                                                                                       \
+    {                                                                                                                                                 \
+        if (SET == 0) {                                                                                                                               \
+            GNNAGG_AHEAD_STASH_A("v192", "v193", "v194", "v195", la0[0]);                                                                             \
+            GNNAGG_AHEAD_STASH_A("v196", "v197", "v198", "v199", la0[1]);                                                                             \
+            GNNAGG_AHEAD_STASH_A("v200", "v201", "v202", "v203", la0[2]);                                                                             \
+            GNNAGG_AHEAD_STASH_A("v204", "v205", "v206", "v207", la0[3]);                                                                             \
+            GNNAGG_AHEAD_STASH_B("v[208:211]", lb0[0]);                                                                                               \
+            GNNAGG_AHEAD_STASH_B("v[212:215]", lb0[1]);                                                                                               \
+            GNNAGG_AHEAD_STASH_B("v[216:219]", lb0[2]);                                                                                               \
+            GNNAGG_AHEAD_STASH_B("v[220:223]", lb0[3]);                                                                                               \
+        } else {                                                                                                                                      \
+            GNNAGG_AHEAD_STASH_A("v224", "v225", "v226", "v227", la0[0] + img_a);                                                                     \
+            GNNAGG_AHEAD_STASH_A("v228", "v229", "v230", "v231", la0[1] + img_a);                                                                     \
+            GNNAGG_AHEAD_STASH_A("v232", "v233", "v234", "v235", la0[2] + img_a);                                                                     \
+            GNNAGG_AHEAD_STASH_A("v236", "v237", "v238", "v239", la0[3] + img_a);                                                                     \
+            GNNAGG_AHEAD_STASH_B("v[240:243]", lb0[0] + img_b);                                                                                       \
+            GNNAGG_AHEAD_STASH_B("v[244:247]", lb0[1] + img_b);                                                                                       \
+            GNNAGG_AHEAD_STASH_B("v[248:251]", lb0[2] + img_b);                                                                                       \
+            GNNAGG_AHEAD_STASH_B("v[252:255]", lb0[3] + img_b);                                                                                       \
+        }                                                                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                                            \
+    }
+    auto mma = [&](auto rbk_c, const float *As, const float *Bs) __attribute__((always_inline)) {
+        constexpr int RBK = decltype(rbk_c)::value;
+        const float *ap = As + (lane & 31) * kBigPA + (lane >> 5);
+        const float *bp = Bs + (lane >> 5) * kBigT + 32 * wave + (lane & 31);
+        float a_cur[RBK], a_nxt[RBK], b_cur, b_nxt;
+#pragma unroll
+        for (int i = 0; i < RBK; ++i) a_cur[i] = ap[i * 32 * kBigPA];
+        b_cur = bp[0];
+#pragma unroll
+        for (int t = 0; t < kBigKC / 2; ++t) {
+            if (t + 1 < kBigKC / 2) {
+#pragma unroll
+                for (int i = 0; i < RBK; ++i) a_nxt[i] = ap[i * 32 * kBigPA + 2 * (t + 1)];
+                b_nxt = bp[2 * (t + 1) * kBigT];
+            }
+#pragma unroll
+            for (int i = 0; i < RBK; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RBK; ++i) a_cur[i] = a_nxt[i];
+            b_cur = b_nxt;
+        }
+    };
+    const int colc = (32 * wave + (lane & 31)) * (int)sizeof(float);
+    int c = 0, row0 = blk0 * 32, left = nblk;   // the chunk being multiplied
+    // prologue: chunks 0 and 1 requested, chunk 0 landed and written, chunk 2 requested
+    GNNAGG_AHEAD_FETCH(0)
+    GNNAGG_AHEAD_FETCH(1)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    GNNAGG_AHEAD_STASH(0)
+    GNNAGG_AHEAD_FETCH(0)
+    __syncthreads();
+    for (int g0 = 0; g0 < total; g0 += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {   // unrolled: the register set and the LDS image of a chunk (h & 1) are compile-time constants
+            const int g = g0 + half;
+            if (g >= total) break;
+            // ---- multiply chunk g (image g & 1)
+            const float *As = half ? As1 : As0, *Bs = half ? Bs1 : Bs0;
+            const int rbk = left < 4 ? left : 4;
+            const bool last_c = c + 1 == nchunks;
+            if (rbk == 4) mma(std::integral_constant<int, 4>{}, As, Bs);
+            else if (rbk == 3) mma(std::integral_constant<int, 3>{}, As, Bs);
+            else if (rbk == 2) mma(std::integral_constant<int, 2>{}, As, Bs);
+            else mma(std::integral_constant<int, 1>{}, As, Bs);
+            if (last_c) {
+                // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); descriptor rebased to C[row0][col0]
+                const size_t co = ((size_t)row0 * N + col0) * sizeof(float), c_bytes = (size_t)M * N * sizeof(float);
+                const size_t cr = co < c_bytes ? c_bytes - co : 0;
+                const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C + ((size_t)row0 * N + col0), 0,
+                                                                                        (int)(unsigned)(cr < 0xfffffffcULL ? cr : 0xfffffffcULL), 0x00020000);
+                const int voff = 4 * (lane >> 5) * N * (int)sizeof(float) + colc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < rbk) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][reg]), crsrc, voff,
+                                                                  (32 * i + (reg & 3) + 8 * (reg >> 2)) * N * (int)sizeof(float), 0);
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) acc[i][reg] = 0.0f;
+                }
+                c = 0; row0 += kBigT; left -= 4;
+            } else {
+                ++c;
+            }
+            // ---- chunk g + 1 (requested two periods ago; everything but the 8 newest loads has landed) goes to the other image, and the
+            //      set it frees takes the request of chunk g + 3 (past the end: the last chunk once more -- the count stays the same)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (half == 0) {
+                if (g + 1 < total) GNNAGG_AHEAD_STASH(1)
+                GNNAGG_AHEAD_FETCH(1)
+            } else {
+                if (g + 1 < total) GNNAGG_AHEAD_STASH(0)
+                GNNAGG_AHEAD_FETCH(0)
+            }
+            __syncthreads();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#undef GNNAGG_AHEAD_FETCH
+#undef GNNAGG_AHEAD_STASH
+#undef GNNAGG_AHEAD_LOAD
+#undef GNNAGG_AHEAD_STASH_A
+#undef GNNAGG_AHEAD_STASH_B
+
 // Tall-skinny variant for the aggregation widths (K <= 128, K % 4 == 0): every wavefront keeps its B operands -- the
 // whole W[K, 32] column block, 64 VGPRs -- in registers for the life of the kernel and walks 32-row tiles of A on its own:
 // 16 coalesced 16-byte loads per lane fetch the NEXT tile while the current one is multiplied; the tile passes through a
@@ -910,6 +1116,10 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
             // lean form: whole 128-column tiles, 16-byte aligned B rows, A rows 16- or 8-byte aligned, row pitches inside 32-bit offsets
             const bool lean = (N % kBigT) == 0 && bvec && av >= 2 && (size_t)kBigT * K * sizeof(float) < 0x7fffffffULL &&
                               (size_t)kBigKC * N * sizeof(float) < 0x7fffffffULL;
+#if GNNAGG_GEMM_AHEAD
+            if (lean && av == 4 && (K % kBigKC) == 0) WIDE_CALL(k_dense_nn_ahead)
+            else
+#endif
             if (lean && av == 4) WIDE_CALL(k_dense_nn_lean<4>)
             else if (lean) WIDE_CALL(k_dense_nn_lean<2>)
             else if (av == 4) WIDE_CALL(k_dense_nn_strip<4>)
