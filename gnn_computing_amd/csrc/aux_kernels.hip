@@ -409,6 +409,9 @@ __global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, c
 #ifndef GNNAGG_GEMM_KC
 #define GNNAGG_GEMM_KC 32
 #endif
+#ifndef GNNAGG_GEMM_AHEAD_PIPE
+#define GNNAGG_GEMM_AHEAD_PIPE 1   // k_dense_nn_ahead: operand reads one k-pair ahead of the MFMAs (0: the compiler's order; 2: the reads spread between the MFMAs)
+#endif
 #ifndef GNNAGG_GEMM_AHEAD
 #define GNNAGG_GEMM_AHEAD 1   // 1: 16-byte-aligned lean shapes with K % 32 == 0 run on k_dense_nn_ahead (chunks requested two periods ahead, hand-counted vmcnt); 0: k_dense_nn_lean<4>
 #endif
@@ -907,6 +910,43 @@ __global__ __launch_bounds__(256, kBigWgs) __attribute__((amdgpu_num_vgpr(192)))
         constexpr int RBK = decltype(rbk_c)::value;
         const float *ap = As + (lane & 31) * kBigPA + (lane >> 5);
         const float *bp = Bs + (lane >> 5) * kBigT + 32 * wave + (lane & 31);
+#if GNNAGG_GEMM_AHEAD_PIPE
+        // two k-steps (a "pair": 2 RBK MFMAs) per stage; the operand reads of pair p + 1 are issued BEFORE the MFMAs of pair p (left to
+        // itself the compiler issues them behind the pair's last MFMA and waits for them in front of the next one)
+        float a[2][RBK][2], b[2][2];
+#define GNNAGG_RD(BUF, PR)                                                                                                    \
+        {                                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < RBK; ++i) {                                                                 \
+                a[BUF][i][0] = ap[i * 32 * kBigPA + 4 * (PR)]; a[BUF][i][1] = ap[i * 32 * kBigPA + 4 * (PR) + 2];             \
+            }                                                                                                                 \
+            b[BUF][0] = bp[4 * (PR) * kBigT]; b[BUF][1] = bp[(4 * (PR) + 2) * kBigT];                                         \
+        }
+        GNNAGG_RD(0, 0)
+#pragma unroll
+        for (int pr = 0; pr < kBigKC / 4; ++pr) {
+            if (pr + 1 < kBigKC / 4) GNNAGG_RD((pr + 1) & 1, pr + 1)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < RBK; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pr & 1][i][kk], b[pr & 1][kk], acc[i], 0, 0, 0);
+#if GNNAGG_GEMM_AHEAD_PIPE == 2   // the next pair's reads spread between this pair's MFMAs, one behind each of the first RBK + 1
+            if (pr + 1 < kBigKC / 4) {
+#pragma unroll
+                for (int r = 0; r < RBK + 1; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * RBK - (RBK + 1), 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * RBK, 0);
+            }
+#else
+            if (pr + 1 < kBigKC / 4) __builtin_amdgcn_sched_group_barrier(0x100, RBK + 1, 0);   // DS reads of the next pair first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * RBK, 0);                              // ... then this pair's MFMAs
+#endif
+        }
+#undef GNNAGG_RD
+#else
         float a_cur[RBK], a_nxt[RBK], b_cur, b_nxt;
 #pragma unroll
         for (int i = 0; i < RBK; ++i) a_cur[i] = ap[i * 32 * kBigPA];
@@ -924,6 +964,7 @@ __global__ __launch_bounds__(256, kBigWgs) __attribute__((amdgpu_num_vgpr(192)))
             for (int i = 0; i < RBK; ++i) a_cur[i] = a_nxt[i];
             b_cur = b_nxt;
         }
+#endif
     };
     const int colc = (32 * wave + (lane & 31)) * (int)sizeof(float);
     int c = 0, row0 = blk0 * 32, left = nblk;   // the chunk being multiplied
