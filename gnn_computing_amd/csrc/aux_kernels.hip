@@ -988,28 +988,8 @@ __global__ __launch_bounds__(256, kBigWgs) __attribute__((amdgpu_num_vgpr(192)))
             else if (rbk == 3) mma(std::integral_constant<int, 3>{}, As, Bs);
             else if (rbk == 2) mma(std::integral_constant<int, 2>{}, As, Bs);
             else mma(std::integral_constant<int, 1>{}, As, Bs);
-            if (last_c) {
-                // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); descriptor rebased to C[row0][col0]
-                const size_t co = ((size_t)row0 * N + col0) * sizeof(float), c_bytes = (size_t)M * N * sizeof(float);
-                const size_t cr = co < c_bytes ? c_bytes - co : 0;
-                const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C + ((size_t)row0 * N + col0), 0,
-                                                                                        (int)(unsigned)(cr < 0xfffffffcULL ? cr : 0xfffffffcULL), 0x00020000);
-                const int voff = 4 * (lane >> 5) * N * (int)sizeof(float) + colc;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < rbk) {
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][reg]), crsrc, voff,
-                                                                  (32 * i + (reg & 3) + 8 * (reg >> 2)) * N * (int)sizeof(float), 0);
-                    }
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) acc[i][reg] = 0.0f;
-                }
-                c = 0; row0 += kBigT; left -= 4;
-            } else {
-                ++c;
-            }
+            const int srow0 = row0, srbk = rbk;   // (the tile whose last chunk this is: its C stores go out BEHIND the request below)
+            if (last_c) { c = 0; row0 += kBigT; left -= 4; } else ++c;
             // ---- chunk g + 1 (requested two periods ago; everything but the 8 newest loads has landed) goes to the other image, and the
             //      set it frees takes the request of chunk g + 3 (past the end: the last chunk once more -- the count stays the same)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -1019,6 +999,29 @@ __global__ __launch_bounds__(256, kBigWgs) __attribute__((amdgpu_num_vgpr(192)))
             } else {
                 if (g + 1 < total) GNNAGG_AHEAD_STASH(0)
                 GNNAGG_AHEAD_FETCH(0)
+            }
+            if (last_c) {
+                // The tile's C stores, behind the wait and the request: in front of the wait they were its 64 newest operations, and
+                // "all but the 8 newest" then meant the stores just issued AND the chunk requested a period ago.  Here the next wait finds
+                // them a whole period old.  (Still safe: at most 8 outstanding operations cannot be the 8 needed loads unless the 8
+                // younger loads are outstanding too -- loads return in order.)
+                // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); descriptor rebased to C[srow0][col0]
+                const size_t co = ((size_t)srow0 * N + col0) * sizeof(float), c_bytes = (size_t)M * N * sizeof(float);
+                const size_t cr = co < c_bytes ? c_bytes - co : 0;
+                const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C + ((size_t)srow0 * N + col0), 0,
+                                                                                        (int)(unsigned)(cr < 0xfffffffcULL ? cr : 0xfffffffcULL), 0x00020000);
+                const int voff = 4 * (lane >> 5) * N * (int)sizeof(float) + colc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < srbk) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][reg]), crsrc, voff,
+                                                                  (32 * i + (reg & 3) + 8 * (reg >> 2)) * N * (int)sizeof(float), 0);
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) acc[i][reg] = 0.0f;
+                }
             }
             __syncthreads();
         }
@@ -1030,6 +1033,267 @@ __global__ __launch_bounds__(256, kBigWgs) __attribute__((amdgpu_num_vgpr(192)))
 #undef GNNAGG_AHEAD_LOAD
 #undef GNNAGG_AHEAD_STASH_A
 #undef GNNAGG_AHEAD_STASH_B
+
+// The same kernel for A rows that are only 8-byte aligned and any even K (the 602-wide layer): a piece is two 8-byte loads, 12 loads per
+// chunk (`s_waitcnt vmcnt(12)`), and the last chunk of a ragged K is masked in the registers before it goes to LDS (A's k beyond K belongs
+// to the next row, not to nothing; B's rows beyond K are outside its descriptor).
+#define GNNAGG_AHEAD_LOAD(REGS, C0, C1, C2, C3, OFF, RSRC) \
+    asm volatile("buffer_load_dwordx4 " REGS ", %0, %1, 0 offen" :: "v"(OFF), "s"(RSRC) : "memory", C0, C1, C2, C3)
+#define GNNAGG_AHEAD_LOAD2(C0, C1, C2, C3, OFF, RSRC)                                                                              \
+    asm volatile("buffer_load_dwordx2 v[" C0 ":" C1 "], %0, %1, 0 offen\n\tbuffer_load_dwordx2 v[" C2 ":" C3 "], %0, %1, 0 offen offset:8" \
+                 :: "v"(OFF), "s"(RSRC) : "memory", "v" C0, "v" C1, "v" C2, "v" C3)
+#define GNNAGG_AHEAD_MASK(C0, C1, C2, C3, CBASE)                                                                                    \
+    {                                                                                                                              \
+        const int c_ = (CBASE);                                                                                                    \
+        const unsigned m0_ = c_ < K ? 0xffffffffu : 0u, m1_ = c_ + 1 < K ? 0xffffffffu : 0u, m2_ = c_ + 2 < K ? 0xffffffffu : 0u,   \
+                       m3_ = c_ + 3 < K ? 0xffffffffu : 0u;                                                                         \
+        asm volatile("v_and_b32 v" C0 ", %0, v" C0 "\n\tv_and_b32 v" C1 ", %1, v" C1 "\n\tv_and_b32 v" C2 ", %2, v" C2 "\n\tv_and_b32 v" C3 ", %3, v" C3 \
+                     :: "v"(m0_), "v"(m1_), "v"(m2_), "v"(m3_) : "memory", "v" C0, "v" C1, "v" C2, "v" C3);                          \
+    }
+#define GNNAGG_AHEAD_STASH_A(R0, R1, R2, R3, ADDR) \
+    asm volatile("ds_write2_b32 %0, " R0 ", " R1 " offset1:1\n\tds_write2_b32 %0, " R2 ", " R3 " offset0:2 offset1:3" :: "v"(ADDR) : "memory")
+#define GNNAGG_AHEAD_STASH_B(REGS, ADDR) asm volatile("ds_write_b128 %0, " REGS :: "v"(ADDR) : "memory")
+__global__ __launch_bounds__(256, kBigWgs) __attribute__((amdgpu_num_vgpr(192))) void k_dense_nn_ahead2(
+    const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K, int nb32, int nstrips)
+{
+    extern __shared__ float lds[];
+    constexpr int KQ = kBigKC / 4, NA = kBigT * KQ / 256, NB = kBigKC * (kBigT / 4) / 256;
+    static_assert(NA == 4 && NB == 4, "the register sets and the hand-counted wait below assume 4 pieces of A (two 8-byte loads each) + 4 of B per chunk");
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) float *lds_f;
+    const int col0 = blockIdx.y * kBigT;
+    const int q = nb32 / nstrips, extra = nb32 - q * nstrips, sidx = blockIdx.x;
+    const int blk0 = sidx * q + (sidx < extra ? sidx : extra), nblk = q + (sidx < extra ? 1 : 0);
+    if (nblk == 0) return;
+    float *As0 = lds, *As1 = lds + kBigT * kBigPA, *Bs0 = lds + 2 * kBigT * kBigPA, *Bs1 = Bs0 + kBigKC * kBigT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    // per-thread constants: byte offsets of this thread's pieces inside a chunk (global) and LDS byte addresses inside image 0
+    int voa[NA], vob[NB];
+    unsigned la0[NA], lb0[NB];
+    const unsigned img_a = kBigT * kBigPA * (unsigned)sizeof(float), img_b = kBigKC * kBigT * (unsigned)sizeof(float);   // image 1 = image 0 + this
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int p = (int)threadIdx.x + 256 * j;
+        voa[j] = ((p / KQ) * K + (p % KQ) * 4) * (int)sizeof(float);
+        la0[j] = (unsigned)(unsigned long long)(lds_f)(As0 + (p / KQ) * kBigPA + (p % KQ) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        vob[j] = (((int)(threadIdx.x >> 5) + 8 * j) * N + (int)(threadIdx.x & 31) * 4) * (int)sizeof(float);
+        lb0[j] = (unsigned)(unsigned long long)(lds_f)(Bs0 + ((int)(threadIdx.x >> 5) + 8 * j) * kBigT + (int)(threadIdx.x & 31) * 4);
+    }
+    const size_t a_bytes = (size_t)M * K * sizeof(float), b_bytes = (size_t)K * N * sizeof(float);
+    // a raw buffer descriptor by hand (base, stride 0, bytes, the flags __builtin_amdgcn_make_buffer_rsrc is given elsewhere in this file)
+    auto rsrc_of = [](const float *base, size_t bytes) -> u4 {
+        const unsigned long long a = (unsigned long long)base;
+        u4 r;
+        r[0] = (unsigned)a; r[1] = (unsigned)(a >> 32) & 0xffffu; r[2] = (unsigned)(bytes < 0xfffffffcULL ? bytes : 0xfffffffcULL); r[3] = 0x00020000u;
+        return r;
+    };
+    const int nchunks = (K + kBigKC - 1) / kBigKC;
+    const int ntiles = (nblk + 3) >> 2, total = ntiles * nchunks;
+    // the next chunk to REQUEST: (fc, frow0), index fi; past the last chunk of the strip the last one is requested again
+    int fc = 0, frow0 = blk0 * 32, fi = 0;
+    int sc = 0;   // chunk-in-tile of the next chunk to WRITE to LDS (its k0 decides the ragged mask)
+#define GNNAGG_AHEAD_FETCH(SET)                                                                                                                       \
+    {                                                                                                                                                 \
+        const int k0_ = fc * kBigKC;                                                                                                                  \
+        const size_t ao_ = ((size_t)frow0 * K + k0_) * sizeof(float), bo_ = ((size_t)k0_ * N + col0) * sizeof(float);                                 \
+        const u4 ar_ = rsrc_of(A + ((size_t)frow0 * K + k0_), ao_ < a_bytes ? a_bytes - ao_ : 0);                                                     \
+        const u4 br_ = rsrc_of(B + ((size_t)k0_ * N + col0), bo_ < b_bytes ? b_bytes - bo_ : 0);                                                      \
+        if (SET == 0) {                                                                                                                               \
+            GNNAGG_AHEAD_LOAD2("192", "193", "194", "195", voa[0], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD2("196", "197", "198", "199", voa[1], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD2("200", "201", "202", "203", voa[2], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD2("204", "205", "206", "207", voa[3], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[208:211]", "v208", "v209", "v210", "v211", vob[0], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[212:215]", "v212", "v213", "v214", "v215", vob[1], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[216:219]", "v216", "v217", "v218", "v219", vob[2], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[220:223]", "v220", "v221", "v222", "v223", vob[3], br_);                                                             \
+        } else {                                                                                                                                      \
+            GNNAGG_AHEAD_LOAD2("224", "225", "226", "227", voa[0], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD2("228", "229", "230", "231", voa[1], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD2("232", "233", "234", "235", voa[2], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD2("236", "237", "238", "239", voa[3], ar_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[240:243]", "v240", "v241", "v242", "v243", vob[0], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[244:247]", "v244", "v245", "v246", "v247", vob[1], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[248:251]", "v248", "v249", "v250", "v251", vob[2], br_);                                                             \
+            GNNAGG_AHEAD_LOAD("v[252:255]", "v252", "v253", "v254", "v255", vob[3], br_);                                                             \
+        }                                                                                                                                             \
+        if (fi + 1 < total) { ++fi; if (fc + 1 == nchunks) { fc = 0; frow0 += kBigT; } else ++fc; }                                                   \
+    }
+    // set SET (landed: the caller waited) -> LDS image SET; then the LDS writes are drained so that the set can be requested into again
+#define GNNAGG_AHEAD_STASH(SET, K0)                                                                                                                   \
+    {                                                                                                                                                 \
+        if ((K0) + kBigKC > K) {   /* the ragged last chunk (workgroup-uniform) */                                                                    \
+            if (SET == 0) {                                                                                                                           \
+            GNNAGG_AHEAD_MASK("192", "193", "194", "195", (K0) + (((int)threadIdx.x + 256 * 0) % KQ) * 4)                                             \
+            GNNAGG_AHEAD_MASK("196", "197", "198", "199", (K0) + (((int)threadIdx.x + 256 * 1) % KQ) * 4)                                             \
+            GNNAGG_AHEAD_MASK("200", "201", "202", "203", (K0) + (((int)threadIdx.x + 256 * 2) % KQ) * 4)                                             \
+            GNNAGG_AHEAD_MASK("204", "205", "206", "207", (K0) + (((int)threadIdx.x + 256 * 3) % KQ) * 4)                                             \
+            } else {                                                                                                                                  \
+            GNNAGG_AHEAD_MASK("224", "225", "226", "227", (K0) + (((int)threadIdx.x + 256 * 0) % KQ) * 4)                                             \
+            GNNAGG_AHEAD_MASK("228", "229", "230", "231", (K0) + (((int)threadIdx.x + 256 * 1) % KQ) * 4)                                             \
+            GNNAGG_AHEAD_MASK("232", "233", "234", "235", (K0) + (((int)threadIdx.x + 256 * 2) % KQ) * 4)                                             \
+            GNNAGG_AHEAD_MASK("236", "237", "238", "239", (K0) + (((int)threadIdx.x + 256 * 3) % KQ) * 4)                                             \
+            }                                                                                                                                         \
+        }                                                                                                                                             \
+        if (SET == 0) {                                                                                                                               \
+            GNNAGG_AHEAD_STASH_A("v192", "v193", "v194", "v195", la0[0]);                                                                             \
+            GNNAGG_AHEAD_STASH_A("v196", "v197", "v198", "v199", la0[1]);                                                                             \
+            GNNAGG_AHEAD_STASH_A("v200", "v201", "v202", "v203", la0[2]);                                                                             \
+            GNNAGG_AHEAD_STASH_A("v204", "v205", "v206", "v207", la0[3]);                                                                             \
+            GNNAGG_AHEAD_STASH_B("v[208:211]", lb0[0]);                                                                                               \
+            GNNAGG_AHEAD_STASH_B("v[212:215]", lb0[1]);                                                                                               \
+            GNNAGG_AHEAD_STASH_B("v[216:219]", lb0[2]);                                                                                               \
+            GNNAGG_AHEAD_STASH_B("v[220:223]", lb0[3]);                                                                                               \
+        } else {                                                                                                                                      \
+            GNNAGG_AHEAD_STASH_A("v224", "v225", "v226", "v227", la0[0] + img_a);                                                                     \
+            GNNAGG_AHEAD_STASH_A("v228", "v229", "v230", "v231", la0[1] + img_a);                                                                     \
+            GNNAGG_AHEAD_STASH_A("v232", "v233", "v234", "v235", la0[2] + img_a);                                                                     \
+            GNNAGG_AHEAD_STASH_A("v236", "v237", "v238", "v239", la0[3] + img_a);                                                                     \
+            GNNAGG_AHEAD_STASH_B("v[240:243]", lb0[0] + img_b);                                                                                       \
+            GNNAGG_AHEAD_STASH_B("v[244:247]", lb0[1] + img_b);                                                                                       \
+            GNNAGG_AHEAD_STASH_B("v[248:251]", lb0[2] + img_b);                                                                                       \
+            GNNAGG_AHEAD_STASH_B("v[252:255]", lb0[3] + img_b);                                                                                       \
+        }                                                                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                                            \
+    }
+    auto mma = [&](auto rbk_c, const float *As, const float *Bs) __attribute__((always_inline)) {
+        constexpr int RBK = decltype(rbk_c)::value;
+        const float *ap = As + (lane & 31) * kBigPA + (lane >> 5);
+        const float *bp = Bs + (lane >> 5) * kBigT + 32 * wave + (lane & 31);
+#if GNNAGG_GEMM_AHEAD_PIPE
+        // two k-steps (a "pair": 2 RBK MFMAs) per stage; the operand reads of pair p + 1 are issued BEFORE the MFMAs of pair p (left to
+        // itself the compiler issues them behind the pair's last MFMA and waits for them in front of the next one)
+        float a[2][RBK][2], b[2][2];
+#define GNNAGG_RD(BUF, PR)                                                                                                    \
+        {                                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < RBK; ++i) {                                                                 \
+                a[BUF][i][0] = ap[i * 32 * kBigPA + 4 * (PR)]; a[BUF][i][1] = ap[i * 32 * kBigPA + 4 * (PR) + 2];             \
+            }                                                                                                                 \
+            b[BUF][0] = bp[4 * (PR) * kBigT]; b[BUF][1] = bp[(4 * (PR) + 2) * kBigT];                                         \
+        }
+        GNNAGG_RD(0, 0)
+#pragma unroll
+        for (int pr = 0; pr < kBigKC / 4; ++pr) {
+            if (pr + 1 < kBigKC / 4) GNNAGG_RD((pr + 1) & 1, pr + 1)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < RBK; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pr & 1][i][kk], b[pr & 1][kk], acc[i], 0, 0, 0);
+#if GNNAGG_GEMM_AHEAD_PIPE == 2   // the next pair's reads spread between this pair's MFMAs, one behind each of the first RBK + 1
+            if (pr + 1 < kBigKC / 4) {
+#pragma unroll
+                for (int r = 0; r < RBK + 1; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * RBK - (RBK + 1), 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * RBK, 0);
+            }
+#else
+            if (pr + 1 < kBigKC / 4) __builtin_amdgcn_sched_group_barrier(0x100, RBK + 1, 0);   // DS reads of the next pair first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * RBK, 0);                              // ... then this pair's MFMAs
+#endif
+        }
+#undef GNNAGG_RD
+#else
+        float a_cur[RBK], a_nxt[RBK], b_cur, b_nxt;
+#pragma unroll
+        for (int i = 0; i < RBK; ++i) a_cur[i] = ap[i * 32 * kBigPA];
+        b_cur = bp[0];
+#pragma unroll
+        for (int t = 0; t < kBigKC / 2; ++t) {
+            if (t + 1 < kBigKC / 2) {
+#pragma unroll
+                for (int i = 0; i < RBK; ++i) a_nxt[i] = ap[i * 32 * kBigPA + 2 * (t + 1)];
+                b_nxt = bp[2 * (t + 1) * kBigT];
+            }
+#pragma unroll
+            for (int i = 0; i < RBK; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RBK; ++i) a_cur[i] = a_nxt[i];
+            b_cur = b_nxt;
+        }
+#endif
+    };
+    const int colc = (32 * wave + (lane & 31)) * (int)sizeof(float);
+    int c = 0, row0 = blk0 * 32, left = nblk;   // the chunk being multiplied
+    // prologue: chunks 0 and 1 requested, chunk 0 landed and written, chunk 2 requested
+    GNNAGG_AHEAD_FETCH(0)
+    GNNAGG_AHEAD_FETCH(1)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    GNNAGG_AHEAD_STASH(0, 0)
+    sc = nchunks > 1 ? 1 : 0;
+    GNNAGG_AHEAD_FETCH(0)
+    __syncthreads();
+    for (int g0 = 0; g0 < total; g0 += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {   // unrolled: the register set and the LDS image of a chunk (h & 1) are compile-time constants
+            const int g = g0 + half;
+            if (g >= total) break;
+            // ---- multiply chunk g (image g & 1)
+            const float *As = half ? As1 : As0, *Bs = half ? Bs1 : Bs0;
+            const int rbk = left < 4 ? left : 4;
+            const bool last_c = c + 1 == nchunks;
+            if (rbk == 4) mma(std::integral_constant<int, 4>{}, As, Bs);
+            else if (rbk == 3) mma(std::integral_constant<int, 3>{}, As, Bs);
+            else if (rbk == 2) mma(std::integral_constant<int, 2>{}, As, Bs);
+            else mma(std::integral_constant<int, 1>{}, As, Bs);
+            const int srow0 = row0, srbk = rbk;   // (the tile whose last chunk this is: its C stores go out BEHIND the request below)
+            if (last_c) { c = 0; row0 += kBigT; left -= 4; } else ++c;
+            // ---- chunk g + 1 (requested two periods ago; everything but the 8 newest loads has landed) goes to the other image, and the
+            //      set it frees takes the request of chunk g + 3 (past the end: the last chunk once more -- the count stays the same)
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (half == 0) {
+                if (g + 1 < total) { GNNAGG_AHEAD_STASH(1, sc * kBigKC) sc = sc + 1 == nchunks ? 0 : sc + 1; }
+                GNNAGG_AHEAD_FETCH(1)
+            } else {
+                if (g + 1 < total) { GNNAGG_AHEAD_STASH(0, sc * kBigKC) sc = sc + 1 == nchunks ? 0 : sc + 1; }
+                GNNAGG_AHEAD_FETCH(0)
+            }
+            if (last_c) {
+                // The tile's C stores, behind the wait and the request: in front of the wait they were its 64 newest operations, and
+                // "all but the 8 newest" then meant the stores just issued AND the chunk requested a period ago.  Here the next wait finds
+                // them a whole period old.  (Still safe: at most 8 outstanding operations cannot be the 8 needed loads unless the 8
+                // younger loads are outstanding too -- loads return in order.)
+                // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); descriptor rebased to C[srow0][col0]
+                const size_t co = ((size_t)srow0 * N + col0) * sizeof(float), c_bytes = (size_t)M * N * sizeof(float);
+                const size_t cr = co < c_bytes ? c_bytes - co : 0;
+                const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C + ((size_t)srow0 * N + col0), 0,
+                                                                                        (int)(unsigned)(cr < 0xfffffffcULL ? cr : 0xfffffffcULL), 0x00020000);
+                const int voff = 4 * (lane >> 5) * N * (int)sizeof(float) + colc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < srbk) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][reg]), crsrc, voff,
+                                                                  (32 * i + (reg & 3) + 8 * (reg >> 2)) * N * (int)sizeof(float), 0);
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) acc[i][reg] = 0.0f;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#undef GNNAGG_AHEAD_FETCH
+#undef GNNAGG_AHEAD_STASH
+#undef GNNAGG_AHEAD_LOAD
+#undef GNNAGG_AHEAD_STASH_A
+#undef GNNAGG_AHEAD_STASH_B
+#undef GNNAGG_AHEAD_LOAD2
+#undef GNNAGG_AHEAD_MASK
 
 // Tall-skinny variant for the aggregation widths (K <= 128, K % 4 == 0): every wavefront keeps its B operands -- the
 // whole W[K, 32] column block, 64 VGPRs -- in registers for the life of the kernel and walks 32-row tiles of A on its own:
@@ -1159,6 +1423,7 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
                               (size_t)kBigKC * N * sizeof(float) < 0x7fffffffULL;
 #if GNNAGG_GEMM_AHEAD
             if (lean && av == 4 && (K % kBigKC) == 0) WIDE_CALL(k_dense_nn_ahead)
+            else if (lean && av == 2) WIDE_CALL(k_dense_nn_ahead2)
             else
 #endif
             if (lean && av == 4) WIDE_CALL(k_dense_nn_lean<4>)

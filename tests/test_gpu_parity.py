@@ -561,13 +561,18 @@ def test_matmul_nn_bit_exact(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(1500, 128, 512), (1100, 100, 70), (2049, 200, 33), (1024, 65, 1), (3000, 129, 602), (3000, 128, 602),
                                    (20001, 128, 36), (40003, 132, 34), (60001, 128, 33), (70536, 128, 40), (131072, 128, 8), (9000, 300, 64),
-                                   (5000, 256, 602), (4099, 384, 128), (33000, 128, 30), (1025, 128, 2)])
+                                   (5000, 256, 602), (4099, 384, 128), (33000, 128, 30), (1025, 128, 2),
+                                   # k_dense_nn_ahead / _ahead2 (chunks requested two periods ahead on fixed registers, hand-counted vmcnt): strips of
+                                   # several tiles, one to sixty-four chunks per tile, ragged K, two column tiles
+                                   (70536, 128, 64), (131072, 128, 96), (131072, 128, 32), (50001, 128, 70), (131072, 256, 34), (8191, 128, 2048),
+                                   (300000, 128, 32), (60001, 128, 602)])
 def test_matmul_nn_wide_kernel_bit_exact(M, N, K):
     """The wide-output kernels (taken for N > 64, M >= 1024 -- the 512 -> 128 layer): persistent strips of 32-row blocks walked in tiles
     of up to 128 rows, the chunk pipeline running across tiles.  k_dense_nn_lean (N % 128 == 0, A rows 16- or 8-byte aligned: buffer
     descriptors rebased per chunk, out-of-range rows / k zeroed by the hardware, masks on a ragged last K chunk only) and k_dense_nn_strip
     (everything else: ragged N, odd K, scalar loads).  Ragged M / N / K, every last-tile height (32 / 64 / 96 / 128 rows), strips of one
-    and of several tiles, several column tiles, K smaller than a chunk -- still the oracle's ascending-k chain bit for bit."""
+    and of several tiles, several column tiles, K smaller than a chunk -- still the oracle's ascending-k chain bit for bit.  Shapes with
+    N % 128 == 0 and aligned rows run on k_dense_nn_ahead (K % 32 == 0, 16-byte rows) / k_dense_nn_ahead2 (even K, 8-byte rows)."""
     A, B = rand((M, K), 1), rand((K, N), 2)
     C = gnc.matmul_NN(dev(A), dev(B))
     torch.cuda.synchronize()
