@@ -394,6 +394,86 @@ __global__ __launch_bounds__(256) void k_dense_nn(const float *__restrict__ A, c
     }
 }
 
+// The narrow layers (K = 32 / 64 / 96 / 128 -> 32 or 64 columns) are one round of workgroups: 1323 tiles of 128 rows all resident at once,
+// and in k_dense_nn each of them walks its K chunks one after the other -- request, wait, LDS, barrier, 16 MFMAs, barrier -- so a tile is
+// NCH HBM latencies in a row and the launch is as long as that chain (27 us for 169 343 x 128 @ 128 x 32, half the HBM roofline, the same as
+// rocBLAS).  Here ALL of a tile's chunks are requested before anything else happens, in straight-line code (NCH is a template parameter: no
+// loop back-edge for the compiler's vmcnt bookkeeping to get lost at), and they are written to LDS and multiplied in order while the later
+// ones are still in flight; the tile's whole B strip (K x 32 floats) goes to LDS once.  Same operand layout, same ascending-k chain per
+// output as k_dense_nn: bit-exact.  16-byte aligned A rows, K = 32 NCH <= 128.
+template <int NCH, int NCB>
+__global__ __launch_bounds__(256) void k_dense_nn_up(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N)
+{
+    // NCB = 32-column blocks per workgroup (1: N <= 32; 2: N <= 64 -- the tile of A is read once for both, not once per column block)
+    constexpr int K = NCH * kGemmKC, BC = NCB * kGemmCols, NIMG = NCB == 1 ? 2 : 1;   // (two A images only where the LDS has room for them)
+    __shared__ float As[NIMG][kGemmRows * kGemmPitch];
+    __shared__ float Bs[K * BC];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const int row0 = blockIdx.x * kGemmRows, col0 = blockIdx.y * BC;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // A through a descriptor rebased to the tile: rows beyond M are outside it (zeros)
+    const size_t a_off = (size_t)row0 * K * sizeof(float), a_all = (size_t)M * K * sizeof(float);
+    const size_t a_left = a_off < a_all ? a_all - a_off : 0;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A) + (size_t)row0 * K, 0,
+                                                                            (int)(unsigned)(a_left < 0xfffffffcULL ? a_left : 0xfffffffcULL), 0x00020000);
+    u4 ra[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            ra[c][j] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, ((((int)threadIdx.x >> 3) + 32 * j) * K + c * kGemmKC + ((int)threadIdx.x & 7) * 4) * (int)sizeof(float), 0, 0);
+    // the B strip: K x BC floats, NCH x NCB x 4 per thread (column guard by clamp + select: no branch)
+    constexpr int NBV = NCH * NCB * 4;
+    float rb[NBV];
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+        const int e = (int)threadIdx.x + 256 * j, kk = e / BC, cc = col0 + (e % BC);
+        const float v = B[(size_t)kk * N + (cc < N ? cc : N - 1)];
+        rb[j] = cc < N ? v : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) Bs[(int)threadIdx.x + 256 * j] = rb[j];
+    f32x16 acc[NCB];
+#pragma unroll
+    for (int n = 0; n < NCB; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float *as = As[NIMG == 2 ? (c & 1) : 0];
+        if (NIMG == 1 && c > 0) __syncthreads();   // one image: every wavefront is done with chunk c - 1 before chunk c overwrites it
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float *d = as + (((int)threadIdx.x >> 3) + 32 * j) * kGemmPitch + ((int)threadIdx.x & 7) * 4;
+            d[0] = __uint_as_float(ra[c][j][0]); d[1] = __uint_as_float(ra[c][j][1]); d[2] = __uint_as_float(ra[c][j][2]); d[3] = __uint_as_float(ra[c][j][3]);
+        }
+        __syncthreads();   // (two images: chunk c + 1 is written while chunk c is still being read by slower wavefronts)
+        float av[kGemmKC / 2];
+#pragma unroll
+        for (int t = 0; t < kGemmKC / 2; ++t) av[t] = as[(wave * 32 + (lane & 31)) * kGemmPitch + 2 * t + (lane >> 5)];
+#pragma unroll
+        for (int n = 0; n < NCB; ++n) {
+            float bv[kGemmKC / 2];
+#pragma unroll
+            for (int t = 0; t < kGemmKC / 2; ++t) bv[t] = Bs[(c * kGemmKC + 2 * t + (lane >> 5)) * BC + n * kGemmCols + (lane & 31)];
+#pragma unroll
+            for (int t = 0; t < kGemmKC / 2; ++t) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[n], 0, 0, 0);
+        }
+    }
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int n = 0; n < NCB; ++n) {
+        const int col = col0 + n * kGemmCols + (lane & 31);
+        if (col < N) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (row < M) C[(size_t)row * N + col] = acc[n][reg];
+            }
+        }
+    }
+}
+
 // Wide-N variant (N > 64: the 512 -> 128 layer of the 3-layer models): a workgroup owns a TM x 128 output tile (TM = 128 for the
 // bulk), so A is read from HBM once whatever N is (k_dense_nn re-reads it per 32-column block); wavefront w owns the tile's columns
 // [32 w, 32 w + 32) over all TM rows -- TM / 32 accumulators of 32 x 32: a k-step of 2 feeds TM / 32 MFMAs from TM / 32 + 1 operand
@@ -1437,6 +1517,23 @@ int launch_dense_nn(const float *A, const float *B, float *C, int M, int N, int 
         }
     }
     const dim3 grid(ceil_div(M, kGemmRows), ceil_div(N, kGemmCols));
+    if (K % kGemmKC == 0 && K <= 4 * kGemmKC && ((uintptr_t)A & 15) == 0 && (size_t)kGemmRows * K * sizeof(float) < 0x7fffffffULL) {
+        // every chunk of a tile requested up front (k_dense_nn_up); 33 .. 64 columns: both 32-column blocks in one workgroup
+        const bool two = N > kGemmCols && N <= 2 * kGemmCols;
+        const dim3 g(ceil_div(M, kGemmRows), two ? 1 : ceil_div(N, kGemmCols));
+#define UP_CALL(NCH_) \
+        { if (two) hipLaunchKernelGGL((k_dense_nn_up<NCH_, 2>), g, dim3(256), 0, stream, A, B, C, M, N); \
+          else hipLaunchKernelGGL((k_dense_nn_up<NCH_, 1>), g, dim3(256), 0, stream, A, B, C, M, N); }
+        switch (K / kGemmKC) {
+            case 1: UP_CALL(1) break;
+            case 2: UP_CALL(2) break;
+            case 3: UP_CALL(3) break;
+            default: UP_CALL(4) break;
+        }
+#undef UP_CALL
+        HIP_TRY(hipGetLastError());
+        return GNNAGG_OK;
+    }
     hipLaunchKernelGGL(k_dense_nn, grid, dim3(256), 0, stream, A, B, C, M, N, K);
     HIP_TRY(hipGetLastError());
     return GNNAGG_OK;

@@ -548,7 +548,11 @@ def test_edge_softmax_kernels_with_hub_rows(H):
         assert np.array_equal(w.cpu().numpy(), orc.gat_div_each(ptr, center.cpu().numpy(), wh))
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 5, 3), (300, 32, 128), (1000, 64, 64), (513, 100, 602), (129, 33, 7)])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 5, 3), (300, 32, 128), (1000, 64, 64), (513, 100, 602), (129, 33, 7),
+                                   # k_dense_nn_up<1..4> (K = 32 / 64 / 96 / 128: every chunk of a tile requested up front): ragged M, ragged N,
+                                   # two column blocks, the arxiv-sized layer, 450 k rows (just under the row count where k_dense_nn_tall takes over)
+                                   (169343, 32, 128), (169343, 64, 128), (100001, 33, 96), (70001, 7, 64), (50003, 64, 32), (127, 64, 128),
+                                   (450000, 32, 128)])
 def test_matmul_nn_bit_exact(M, N, K):
     """Dense combine GEMM (reference include/dense.h:4-23) on f32 MFMA: ascending-k fmaf chain == oracle."""
     A, B = rand((M, K), 1), rand((K, N), 2)
