@@ -62,4 +62,40 @@ for path in sys.argv[1:]:
             if seen >= 2:
                 break
 print("%d suspicious place(s)" % bad)
-sys.exit(1 if bad else 0)
+
+# Second check: k_dense_nn_ahead / _ahead2 keep their prefetch registers (v192 .. v255) out of the compiler's hands with amdgpu_num_vgpr(192) and
+# count their own vmcnt.  A toolchain that stopped honouring the attribute, or spilled (scratch loads carry vmcnt waits of their own), would corrupt
+# products silently: outside the ;;#ASMSTART ... ;;#ASMEND blocks no instruction of those kernels may name a VGPR >= 192 or touch scratch.
+VREG = re.compile(r"\bv\[?(\d+)(?::(\d+))?\]?")
+fixed_bad = 0
+for path in sys.argv[1:]:
+    func, inasm = None, False
+    for n, l in enumerate(open(path).read().split("\n"), 1):
+        m = re.match(r"^(_Z\w*k_dense_nn_ahead\w*):", l)
+        if m:
+            func, inasm = m.group(1), False
+            continue
+        if func and ".Lfunc_end" in l:
+            func = None
+        if not func:
+            continue
+        if "ASMSTART" in l:
+            inasm = True
+            continue
+        if "ASMEND" in l:
+            inasm = False
+            continue
+        t = l.split(";")[0]
+        if not t.startswith("\t") or t.strip().startswith("."):
+            continue
+        if "scratch_" in t:
+            print("%s:%d %s: scratch access `%s`" % (path, n, func, t.strip()))
+            fixed_bad += 1
+        if not inasm:
+            for r in VREG.finditer(t):
+                if int(r.group(2) or r.group(1)) >= 192:
+                    print("%s:%d %s: the compiler uses a reserved register: `%s`" % (path, n, func, t.strip()))
+                    fixed_bad += 1
+                    break
+print("%d violation(s) of the fixed-register discipline of k_dense_nn_ahead*" % fixed_bad)
+sys.exit(1 if bad or fixed_bad else 0)
