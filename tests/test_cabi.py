@@ -62,6 +62,13 @@ def test_bad_handle_and_arguments():
     n = ctypes.c_int(0)
     assert L.gnnagg_neighbor_grouping_schedule(None, 4, 3, None, None, ctypes.byref(n)) == _lib.ERR_ARG
     assert L.gnnagg_partition_rows(None, 3, 2, None) == _lib.ERR_ARG
+    # round 5: the gather-ceiling probe checks its geometry before it touches the device; the transport query rejects a dead communicator
+    buf = np.zeros(1024, np.int32)
+    for pitch, seg, n_ids, per_group in [(16, 16, 0, 8), (24, 16, 256, 8), (512, 520, 512, 64), (512, 2048, 512, 64), (512, 512, 100, 32), (512, 512, 512, 24)]:
+        assert L.gnnagg_probe_row_gather(buf.ctypes.data, pitch, seg, buf.ctypes.data, n_ids, per_group, None) == _lib.ERR_ARG, (pitch, seg, n_ids, per_group)
+    assert L.gnnagg_probe_row_gather(None, 512, 512, buf.ctypes.data, 512, 32, None) == _lib.ERR_ARG
+    path, bus, over = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64), ctypes.c_int(7)
+    assert L.gnnagg_dist_transport_info(ctypes.c_int64(4242), path, 64, bus, 64, ctypes.byref(over)) == _lib.ERR_ARG
 
 
 def test_file_rendezvous_rejects_what_a_crashed_launch_left_behind(tmp_path):
