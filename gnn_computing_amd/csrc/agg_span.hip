@@ -172,16 +172,18 @@ __global__ __launch_bounds__(256) SPAN_WAVES_ATTR void k_gcn_span(const SpanArgs
                     if (HAS_VAL) sig ^= __float_as_uint(w[u]);
                     continue;
                 }
-                if (col_ok) {
+                // Every lane accumulates, also the lanes beyond the last feature column: they did not gather, their xv is whatever the
+                // register held, and their acc is never stored (every store below is behind col_ok).  With an `if (col_ok)` here the compiler
+                // adds unconditionally anyway and then SELECTS -- four v_cndmask per gathered value, a third of this kernel's vector
+                // instructions (12.9 per gather instruction, profiles/r05/summary_R_sq.txt); without them R runs 15.40 -> 15.27 ms.
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        if (IS_MAX) {
-                            const float p = HAS_VAL ? xv[u].v[k] * w[u] : xv[u].v[k];
-                            acc[k] = p > acc[k] ? p : acc[k];
-                        } else {
-                            // implicit unit weights: fma(x, 1, acc) == acc + x exactly
-                            acc[k] = HAS_VAL ? __builtin_fmaf(xv[u].v[k], w[u], acc[k]) : acc[k] + xv[u].v[k];
-                        }
+                for (int k = 0; k < VEC; ++k) {
+                    if (IS_MAX) {
+                        const float p = HAS_VAL ? xv[u].v[k] * w[u] : xv[u].v[k];
+                        acc[k] = p > acc[k] ? p : acc[k];
+                    } else {
+                        // implicit unit weights: fma(x, 1, acc) == acc + x exactly
+                        acc[k] = HAS_VAL ? __builtin_fmaf(xv[u].v[k], w[u], acc[k]) : acc[k] + xv[u].v[k];
                     }
                 }
                 if (CHAIN && (sr[u] & kLastFlag)) {  // the sub-row ends: its chain goes back to Yt, the next row's carry takes over
