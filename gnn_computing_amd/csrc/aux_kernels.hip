@@ -508,7 +508,7 @@ static constexpr int kBigWgs = GNNAGG_GEMM_WGS;   // workgroups per CU (LDS: 33.
 // AV > 1 also says N % 4 == 0 and B 16-byte aligned: every 4-float piece of B is one aligned load.
 // (Round 3's k_dense_nn_big -- one 128-row tile per workgroup, a last round of smaller tiles -- is gone: the strips below do the same
 // arithmetic without a partial last round; its text is in git history, its numbers in profiles/r03/gemm.txt.)
-#ifdef GNNAGG_GEMM_TIMELINE   // A/B builds only (scripts/exp_gemm_timeline.py): s_memtime stamps of wave 0 of every workgroup, six per chunk
+#ifdef GNNAGG_GEMM_TIMELINE   // A/B builds only (scripts/history/exp_gemm_timeline.py): s_memtime stamps of wave 0 of every workgroup, six per chunk
 __device__ unsigned long long *g_gemm_tl = nullptr;
 #define TL_STAMP(slot) do { if (g_gemm_tl && threadIdx.x == 0 && g < 64) g_gemm_tl[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + g) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256, kBigWgs) void k_dense_nn_strip(const float *__
     }
 }
 
-// Round 4, second step: the LEAN form of the strip kernel.  A per-phase timeline (scripts/exp_gemm_timeline.py, s_memtime stamps) showed
+// Round 4, second step: the LEAN form of the strip kernel.  A per-phase timeline (scripts/history/exp_gemm_timeline.py, s_memtime stamps) showed
 // where a chunk goes: issuing the 8 loads of the next chunk 20 % of the period, the 64 MFMAs 35 %, the stash 20 %, the barrier 12 % -- and the
 // MFMA phase runs at 80 ticks per MFMA, i.e. the two wavefronts of a SIMD ALTERNATE: while one bursts, every other instruction of its
 // neighbour (address arithmetic, clamps, masks, LDS writes: ~210 per chunk) trickles out between MFMAs at ~30 ticks apiece.  The matrix

@@ -140,7 +140,7 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *   "rows_hub_edges"                      chained rows mode: rows with a (row, range) sub-row above this many edges leave the chained
  *                                         launches for the long-row kernel (0: the library's rule)
  * [GNNAGG_XCD_REMAP] 0 / 1 / 2 (workgroup -> XCD mapping: identity / equal-count / work-balanced ranges, default 2) and [GNNAGG_PLAN] 0
- * (the round-1 item kernels + k_combine instead of the plan kernels) are environment-only measurement switches (scripts/tune_gcn.py).
+ * (the round-1 item kernels + k_combine instead of the plan kernels) are environment-only measurement switches (scripts/history/tune_gcn.py).
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
 int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
 /* What the library-chosen blocked order cost to build and holds (the reference prints its schedule time, graph_schedule.h:125-127):
