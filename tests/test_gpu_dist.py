@@ -138,6 +138,202 @@ def test_cabi_step_with_several_peers_on_one_gpu(world, stages):
         assert n_halo > 0 and n_send > 0
 
 
+def _worker_late_peer(rank, world, port, q, stages, delay_us, late_ranks, graph):
+    """The C-ABI step against an ASYNCHRONOUS peer (tests/fake_rccl since round 6: stream-ordered copies, no host synchronisation inside a
+    group).  Before every step the halo tail (and for GAT the receive buffer) is NaN-poisoned and y is NaN-filled; the groups of
+    `late_ranks` sit behind a spin kernel of `delay_us`, so when gnnagg_dist_step_* returns the halo rows are provably not there yet:
+    only the step's own fork / stage events / join order the halo-source passes behind them.  graph=True: the step is captured into a
+    HIP graph by every rank and replayed with new inputs."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GNNAGG_RCCL_LIB"] = FAKE_RCCL
+    if delay_us:
+        os.environ["FAKE_RCCL_DELAY_US"] = str(delay_us)
+        os.environ["FAKE_RCCL_DELAY_RANKS"] = ",".join(str(r) for r in late_ranks)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gnn_computing_amd as gnc
+        from gnn_computing_amd.dist import PartitionedGAT, PartitionedGCN
+        from oracle import oracle as orc
+        torch.cuda.set_device(0)
+        V, E, F, H, FG = 6000, 150000, 128, 8, 256
+        ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=11)
+        ptr, idx = ptr_t.numpy(), idx_t.numpy()
+        rng = np.random.default_rng(17)          # the same stream on every rank: the ranks agree on every step's global input
+        val = rng.standard_normal(E, dtype=np.float32)
+        pg = PartitionedGCN(ptr, idx, val, F, device="cuda:0", overlap=True, stages=stages, transport="rccl")
+        gat = PartitionedGAT(ptr, idx, FG, H, device="cuda:0", overlap=True, stages=stages, transport="rccl")
+        assert "libfakerccl" in open("/proc/self/maps").read() and pg._step.value and gat._step.value
+        r0, r1 = int(pg.hx.bounds[rank]), int(pg.hx.bounds[rank + 1])
+        nan = float("nan")
+
+        def inputs():
+            x = rng.standard_normal((V, F), dtype=np.float32)
+            xg = rng.standard_normal((V, FG), dtype=np.float32)
+            att = (rng.standard_normal((V, H, 2), dtype=np.float32) * 0.4).astype(np.float32)
+            return x, xg, att
+
+        def load(x, xg, att):
+            pg.set_local_x(torch.from_numpy(x[r0:r1]).cuda())
+            gat.set_local(torch.from_numpy(xg[r0:r1]).cuda(), torch.from_numpy(att[r0:r1]).cuda())
+            pg.x_halo.fill_(nan); pg.y.fill_(nan); pg.send_buf.fill_(nan)
+            n = gat.hx.n_local
+            gat.x_ext[n:].fill_(nan); gat.att_ext[n:].fill_(nan); gat.recv_buf.fill_(nan); gat.send_buf.fill_(nan); gat.y.fill_(nan)
+
+        def verify(x, xg, att, reduce="sum"):
+            y = pg.y.cpu().numpy()
+            ref = orc.gcn_seq(ptr, idx, val, x)[r0:r1]
+            scale = orc.gcn_abs_scale(ptr, idx, val, x)[r0:r1]
+            if reduce == "mean":
+                deg = np.maximum(np.diff(ptr), 1)[r0:r1, None].astype(np.float32)
+                ref, scale = ref / deg, scale / deg
+            good = bool(np.all(np.abs(y - ref) <= 1e-5 * scale + 1e-30)) if reduce != "max" else np.array_equal(y, orc.gcn_max(ptr, idx, val, x)[r0:r1])
+            good = good and np.array_equal(pg.x_halo.cpu().numpy(), x[pg.hx.halo_ids])
+            yg = gat.y.cpu().numpy()
+            y_ref = orc.gat_fused(ptr, idx, att, xg, H)[r0:r1]
+            wn = orc.gat_att(ptr, idx, att, H, 0.2)
+            sc = np.zeros((V, FG))
+            np.add.at(sc, np.repeat(np.arange(V), np.diff(ptr)), np.repeat(wn, FG // H, axis=1).astype(np.float64) * np.abs(xg[idx]))
+            good = good and bool(np.all(np.abs(yg - y_ref) <= 1e-5 * (sc[r0:r1] + np.abs(y_ref)) + 1e-30))
+            return good and np.array_equal(gat.x_ext[gat.hx.n_local:].cpu().numpy(), xg[gat.hx.halo_ids])
+
+        ok, host_ms, dev_ms = True, [], []
+        for it, red in enumerate(["sum", "mean", "max", "sum"]):
+            x, xg, att = inputs()
+            load(x, xg, att)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            pg.step(reduce=red)
+            gat.step()
+            host_ms.append((time.perf_counter() - t0) * 1e3)     # both calls have RETURNED ...
+            torch.cuda.synchronize()
+            dev_ms.append((time.perf_counter() - t0) * 1e3)      # ... long before the device is through (two groups' delays at least)
+            ok = ok and verify(x, xg, att, red)
+        replays = 0
+        if graph:
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            dist.barrier()
+            with torch.cuda.stream(st):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    pg.step()
+                    gat.step()
+            for _ in range(3):
+                x, xg, att = inputs()
+                load(x, xg, att)
+                torch.cuda.synchronize()
+                dist.barrier()
+                g.replay()
+                torch.cuda.synchronize()
+                ok = ok and verify(x, xg, att)
+                replays += 1
+            dist.barrier()
+        q.put((rank, ok, host_ms, dev_ms, replays, pg.hx.n_halo))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_late_peer(world, stages, delay_us, late_ranks, graph):
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfakerccl.so is not built (__graft_entry__.build() builds it)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_late_peer, args=(r, world, port, q, stages, delay_us, late_ranks, graph)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+@pytest.mark.parametrize("world,stages,late", [(2, 1, [1]), (3, ("stripe", 3), [1]), (3, "owner", [0, 2]), (4, ("stripe", 2), [2])])
+def test_cabi_step_is_ordered_by_its_events_not_by_luck(world, stages, late):
+    """VERDICT r5 item 1(a), the poison / delay test: halo tail NaN-filled before each step, the late ranks' groups 40 ms behind on the
+    DEVICE.  The calls return within a fraction of that (the double is asynchronous), the device needs at least the delay, and the result
+    is oracle-equal on every rank -- so the event waits, not the host's pace, put the halo-source passes behind the rows they read."""
+    delay_us = 40000
+    res = _run_late_peer(world, stages, delay_us, late, graph=False)
+    for rank, ok, host_ms, dev_ms, _, n_halo in res:
+        assert ok, "rank %d: a pass ran ahead of its halo rows (or the result differs from the oracle)" % rank
+        assert n_halo > 0
+        # steady state (the first step creates streams / arenas): the two calls return long before their 2+ delayed groups are through
+        assert min(host_ms[1:]) < 0.5 * delay_us * 1e-3, (rank, host_ms)
+        assert min(dev_ms[1:]) >= delay_us * 1e-3, (rank, dev_ms)
+
+
+def _worker_negative_control(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GNNAGG_RCCL_LIB=FAKE_RCCL, FAKE_RCCL_DELAY_US="40000", FAKE_RCCL_DELAY_RANKS="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gnn_computing_amd as gnc
+        from gnn_computing_amd.dist import PartitionedGCN
+        from oracle import oracle as orc
+        torch.cuda.set_device(0)
+        V, E, F = 6000, 150000, 128
+        ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=11)
+        ptr, idx = ptr_t.numpy(), idx_t.numpy()
+        x = np.random.default_rng(2).standard_normal((V, F), dtype=np.float32)
+        pg = PartitionedGCN(ptr, idx, None, F, device="cuda:0", overlap=True, stages=1, transport="rccl")
+        r0, r1 = int(pg.hx.bounds[rank]), int(pg.hx.bounds[rank + 1])
+        pg.set_local_x(torch.from_numpy(x[r0:r1]).cuda())
+        out = []
+        for ordered in (False, True, False, True):
+            pg.x_halo.fill_(float("nan"))
+            torch.cuda.synchronize()
+            dist.barrier()
+            work = pg.hx.exchange(pg.x_local, pg.x_halo, pg.send_buf, async_op=True)   # pack + grouped send / recv on the transport's stream
+            pg.compute("sum", work if ordered else None)                               # False: the halo-source pass is NOT put behind the exchange
+            torch.cuda.synchronize()
+            pg.hx.rccl.stream.synchronize()
+            y = pg.y.cpu().numpy()
+            ref = orc.gcn_seq(ptr, idx, None, x)[r0:r1]
+            scale = orc.gcn_abs_scale(ptr, idx, None, x)[r0:r1]
+            out.append((ordered, bool(np.isnan(y).any()), bool(np.all(np.abs(y - ref) <= 1e-5 * scale + 1e-30))))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_the_late_peer_test_can_fail():
+    """Negative control of the poison / delay test: the same exchange and passes issued by hand, once WITHOUT ordering the halo-source
+    pass behind the exchange.  Against the asynchronous double that pass reads the poison (NaN in y on every rank) -- against the
+    synchronous round-1..5 double it could not have -- and with the wait it is oracle-equal.  So a missing event wait in the step code
+    would be seen by test_cabi_step_is_ordered_by_its_events_not_by_luck."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfakerccl.so is not built (__graft_entry__.build() builds it)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_negative_control, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out in res:
+        for ordered, saw_nan, equal in out:
+            assert (not saw_nan and equal) if ordered else saw_nan, (rank, out)
+
+
+def test_cabi_step_replays_from_a_captured_graph_at_world_4():
+    """the staged GCN and GAT steps captured into ONE HIP graph by each of 4 ranks (stream operations only: pack,
+    grouped send / recv per stage, events, passes) and replayed three times with new inputs and a poisoned halo, one rank 5 ms late."""
+    res = _run_late_peer(4, ("stripe", 2), 5000, [3], graph=True)
+    for rank, ok, _, _, replays, n_halo in res:
+        assert ok and replays == 3 and n_halo > 0, "rank %d" % rank
+
+
 def test_rccl_transport_behind_the_cabi_single_rank(tmp_path):
     """gnnagg_dist_*: librccl is loaded on demand, a communicator is created on this GPU from a unique id (directly and
     through the id file a C++ launcher uses), the self part of an all-to-all-v is a stream-ordered copy, a halo exchange
