@@ -34,7 +34,7 @@ FEAT = 128
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 L2_PEAK_GBPS = 34500.0  # same guide, "L2": 4 MiB per XCD, ~34.5 TB/s aggregate (the 2-D blocked order gathers from L2)
 L2_GATHER_MEASURED_GBPS = 24500.0  # measured here: 256-byte row gathers from an XCD's own L2 (profiles/r02/gather_ceiling.txt)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def algorithmic_bytes(V, E, F, explicit_val=True):
@@ -64,7 +64,7 @@ def pmc_traffic(tag):
     -> scripts/prof_config.sh -> profiles/<round>/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, the
     gfx950 correction of MI355X_MICROARCH.md).  Returns (dominant kernel's bytes, all kernels' bytes per step, label, stale):
     `stale` is True when the build the counters were collected on is not the library running now."""
-    for rnd in (PROFILE_ROUND, "r04", "r03", "r02"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         if os.path.exists(f):
             d = json.load(open(f)).get(tag)
@@ -74,6 +74,17 @@ def pmc_traffic(tag):
                 return (d.get("hbm_bytes_per_launch"), d.get("all_kernels_bytes_per_step"),
                         "profiles/%s/pmc_traffic.json: %s" % (rnd, label), build != lib_md5())
     return None, None, None, None
+
+
+
+def load_with_locality_reorder(name, ptr, idx):
+    """The locality reorder APPLIED ON LOAD, the reference's way (load_graph(..., "_thres_0.2"), src/data.cu:96-133; our.py:79):
+    gnn_computing_amd.graph.reorder_on_load writes the graph in the reference's cache format and the permutation of the library's
+    generator as <dset>.reorder_thres_0.2, and the library's loader (gnnagg_load_graph) reads both and calls its reorderCSR.  The
+    permutation file is kept per box (keyed by the library build): generating it takes tens of seconds on the products-shaped graph.
+    Returns (ptr, idx, rows, seconds spent generating [0.0 on a cache hit], seconds spent loading)."""
+    import gnn_computing_amd as gnc
+    return gnc.graph.reorder_on_load(name, np.ascontiguousarray(ptr, np.int32), np.ascontiguousarray(idx, np.int32), key=lib_md5() or "x")
 
 
 def log(*a):
@@ -189,9 +200,8 @@ def cpu_baseline(ptr, idx, val, x, budget_s=10.0):
         pass
     return {"value": len(idx) / m["median_s"], "unit": "edges/s", "cores": m["threads"], "kind": "port", "cpu_model": model,
             "hardware_threads": m["hardware_threads"],
-            "sample": "%d full passes of the same arxiv-shaped workload (median %.2f ms) on %d of %d hardware threads (best of a thread-count "
-                      "sweep), OpenMP over rows, register accumulators + software prefetch, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores) in a child process" % (
-                          m["passes"], m["median_s"] * 1e3, m["threads"], m["hardware_threads"])}
+            "sample": "%d full passes of the same workload, median %.2f ms, %d of %d threads (best of a sweep), pinned; DESIGN.md 5" % (
+                m["passes"], m["median_s"] * 1e3, m["threads"], m["hardware_threads"])}
 
 
 def run_single(args, dev):
@@ -227,15 +237,10 @@ def run_single(args, dev):
     agg0 = build(ptr, idx)
     results["no_reorder"] = time_steps(lambda: agg0.run(dx, y, 512, mode), args.steps, args.warmup, lambda: None)
     # with the locality reorder applied on load (reference: load_graph(..., "_thres_0.2"), our.py:79)
-    t0 = time.perf_counter()
-    # the reorder GENERATOR (what writes a <dset>.reorder_thres_0.2 file; the reference's is the offline script
-    # script/cluster2.py) is the library's gnnagg_cluster_reorder_ex: cache-aware greedy ordering -- each next row is the one
-    # with the largest share of its source rows among the 8192 most recently gathered (an LRU model of an XCD's L2) -- over
-    # singleton clusters.  The reference's MinHash-64 + LSH(0.2) + capped-64 clustering written in first-member order
-    # (order="first_member") is timed beside it as "reorder_minhash_clusters".
-    rows, n_clusters = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=8192)
-    nptr, nidx, rev = gnc.reorder_csr(ptr, idx, rows)
-    t_reorder = time.perf_counter() - t0
+    # the reorder GENERATOR (what writes a <dset>.reorder_thres_0.2 file; the reference's is the offline script script/cluster2.py) is the
+    # library's gnnagg_cluster_reorder_ex; the file is applied by the library's loader (load_with_locality_reorder above).  The
+    # reference's MinHash-64 + LSH(0.2) + capped-64 clustering written in first-member order is timed beside it.
+    nptr, nidx, rows, t_reorder, t_load = load_with_locality_reorder("arxiv", ptr, idx)
     agg1 = build(nptr, nidx)
     dx1 = torch.from_numpy(np.ascontiguousarray(x[rows])).to(dev)
     results["reorder"] = time_steps(lambda: agg1.run(dx1, y, 512, mode), args.steps, args.warmup, lambda: None)
@@ -281,61 +286,48 @@ def run_single(args, dev):
     # of X (Infinity-Cache resident, like this input's X) and over 5 GB (HBM), measured in this process
     ceil_mall, ceil_hbm = gather_ceiling(dev, "g512_mall"), gather_ceiling(dev, "g512_hbm")
     other = "no_reorder" if which == "reorder" else "reorder"
-    # roofline: bound = HBM / fabric bandwidth, 8 TB/s.  `achieved` = ALGORITHMIC (gather-model)
-    # bytes over the kernel's average launch time -- on this input most of those bytes are served by L2 / Infinity Cache, so it
-    # can exceed the peak (`algorithmic_frac` > 1) and is NOT a utilisation.  `frac` = what the counters say crossed the fabric
-    # (`traffic`) over the same time over 8 TB/s; the probe ratio (this launch's own gather pattern without chains or stores)
-    # is `probe_frac`; compulsory bytes beside them.
+    # roofline.  bound = HBM / fabric bandwidth, 8 TB/s.  `achieved` = ALGORITHMIC (gather-model) bytes over the kernel's
+    # average launch time -- on this input most of those bytes are served by L2 / Infinity Cache, so it can exceed the peak
+    # (`algorithmic_frac` > 1) and is NOT a utilisation.  `frac` = what the counters say crossed the fabric (`traffic`, committed
+    # profile) over the same time over 8 TB/s; `frac_vs_gather_ceiling` divides the gather-model rate by the rate measured in this process
+    # for 512-byte row gathers uniform over an X-sized window; `probe_frac` = this launch's own gather pattern without chains or stores.
+    # What every field is, in full sentences: DESIGN.md section 5 ("fields of the bench line") -- the line itself stays short, the
+    # driver's record truncates strings.
     traffic_gbps = traffic / dev_s / 1e9 if traffic else None
     out = {
         "metric": "aggregated edges/sec, GCN SpMM feat=128", "value": E / (wall / args.steps), "unit": "edges/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "arxiv-shaped power-law CSR 169343x1166243 (seed 123), GCN sum, feat=128, "
-                               "explicit unit weights, %s, mode=%s" % (
-                                   "locality reorder (cache-aware greedy order, gnnagg_cluster_reorder_ex) applied on load like a .reorder_thres_0.2 file" if which == "reorder" else "no reorder", mode),
+        "config": {"workload": "arxiv-shaped CSR 169343x1166243 (seed 123), GCN sum, feat=128, unit weights, %s, mode=%s" % (
+                       "locality reorder applied on load (.reorder_thres_0.2)" if which == "reorder" else "no reorder", mode),
                    "num_v": V, "num_e": E, "feat": FEAT},
         "achieved_gbps": achieved,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (traffic_gbps / HBM_PEAK_GBPS) if traffic_gbps else achieved / HBM_PEAK_GBPS,
-                     "frac_is": ("counter traffic (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel, per launch, from the committed profile; the "
-                                 "x 2 calibrated on this kernel's own 512-byte row gathers: known bytes / counter = 1.986, "
-                                 "profiles/r04/fetch_calibration.txt) / average launch time / 8 TB/s.  The counters sit on the L2's fabric side: "
-                                 "these bytes INCLUDE Infinity-Cache hits (X = 86.7 MB is resident there), so this is fabric traffic over the HBM "
-                                 "peak, not an HBM utilisation; `frac_vs_gather_ceiling` is the ratio whose denominator bounds its numerator"
-                                 if traffic_gbps else "algorithmic bytes / average launch time / 8 TB/s (no counter file found)"),
+                     "frac_is": ("counter traffic (fabric side: Infinity-Cache hits included) / avg launch time / 8 TB/s; DESIGN.md 5"
+                                 if traffic_gbps else "algorithmic bytes / avg launch time / 8 TB/s (no counter file); DESIGN.md 5"),
                      "frac_vs_gather_ceiling": achieved / ceil_mall["gbps"],
-                     "frac_vs_gather_ceiling_is": "gather-model bytes / average launch time / the rate measured in this process for 512-byte row "
-                                                  "gathers with ids uniform over an X-sized (86.7 MB, Infinity-Cache-resident) window; ids with "
-                                                  "locality also hit in L2, which a uniform window cannot, so the ratio may exceed 1",
-                     "gather_ceiling": {"gbps": ceil_mall["gbps"], "us": ceil_mall["us"], "what": ceil_mall["what"]},
-                     "gather_ceiling_hbm": {"gbps": ceil_hbm["gbps"], "us": ceil_hbm["us"], "what": ceil_hbm["what"]},
+                     "frac_vs_gather_ceiling_is": "gather-model rate / measured uniform 512-B gather rate (X-sized window); locality may exceed 1",
+                     "gather_ceiling": {"gbps": ceil_mall["gbps"], "us": ceil_mall["us"]},
+                     "gather_ceiling_hbm": {"gbps": ceil_hbm["gbps"], "us": ceil_hbm["us"]},
                      "traffic_frac_of_mall_gather_ceiling": (traffic_gbps / ceil_mall["gbps"]) if traffic_gbps else None,
                      "traffic": traffic, "traffic_source": traffic_label, "traffic_stale": traffic_stale,
                      "traffic_gbps": traffic_gbps,
                      "algorithmic_frac": achieved / HBM_PEAK_GBPS,
                      "probe_frac": probe_s / dev_s, "probe_gbps": B / probe_s / 1e9,
-                     "probe_is": "time of the probe launch (this kernel's descriptor / id / value loads and row gathers, same "
-                                 "addresses and batching, no FMA chain, no store) over the kernel's time: how far the kernel is "
-                                 "from what its own access pattern costs -- says nothing about whether the pattern is good",
                      "kernel": "k_gcn_plan", "algorithmic_bytes": B, "compulsory_bytes": C,
                      "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
                      "ceiling_probe_us": probe_s * 1e6, "ceiling_probe_median_us": probe_med * 1e6,
-                     "uniform_random_ids": {"kernel_us": kern_u_s * 1e6, "probe_us": probe_u_s * 1e6,
-                                            "note": "same degrees, neighbor ids uniform in [0, V): the no-locality case"},
+                     "uniform_random_ids": {"kernel_us": kern_u_s * 1e6, "probe_us": probe_u_s * 1e6},
                      "gather_gbps": achieved, "hbm_peak_gbps": HBM_PEAK_GBPS,
                      "gather_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
-                     "compulsory_gbps": C / dev_s / 1e9, "compulsory_frac_of_hbm_peak": C / dev_s / 1e9 / HBM_PEAK_GBPS,
-                     "which_bytes": "algorithmic = one 512-B feature row + id + value per EDGE (mostly served by L2 / Infinity "
-                                    "Cache here: achieved / peak may exceed 1 and is not an HBM utilisation); compulsory "
-                                    "= X and Y once + CSR once (what HBM must move at least); traffic = rocprofv3 fabric-side "
-                                    "bytes (Infinity-Cache hits included)"},
+                     "compulsory_gbps": C / dev_s / 1e9, "compulsory_frac_of_hbm_peak": C / dev_s / 1e9 / HBM_PEAK_GBPS},
         other: {"value": E / (results[other][0] / args.steps), "avg_launch_us": results[other][1] * 1e6,
                 "achieved_gbps": B / results[other][1] / 1e9},
         "reorder_minhash_clusters": {"value": E / (results["reorder_minhash_clusters"][0] / args.steps),
-                                     "avg_launch_us": results["reorder_minhash_clusters"][1] * 1e6,
-                                     "note": "the reference's clustering (MinHash-64, LSH 0.2, cap 64) in first-member order"},
-        "reorder_prep_s": t_reorder, "reorder_walkers": int(os.environ.get("GNNAGG_REORDER_WALKERS", "0")) or (64 if E >= 20000000 else 1),
+                                     "avg_launch_us": results["reorder_minhash_clusters"][1] * 1e6},
+        "reorder_prep_s": t_reorder, "reorder_load_s": t_load, "reorder_cache_hit": t_reorder == 0.0,
+        "reorder_walkers": int(os.environ.get("GNNAGG_REORDER_WALKERS", "0")) or (64 if E >= 20000000 else 1),
         "schedule_prep_s": prep.get("schedule_prep_s"),
     }
     if mode == "balanced" and which == "reorder":
@@ -344,7 +336,37 @@ def run_single(args, dev):
         out["configs"] = other_configs(args, dev, nptr, nidx, val, x[rows])
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(nptr, nidx, val, x[rows], args.cpu_budget)
+    out["summary"] = summarize(out)   # LAST key of the line, <= 1 KB: what the driver's 2 000-character tail must show
     return out
+
+
+def summarize(out):
+    """Every record of the line in one compact object: name -> [ms_per_step, roofline.frac, frac_vs_gather_ceiling, verified_rows]
+    (A: the headline, whole output compared; *_no_reorder: the arm without the locality reorder)."""
+    def row(rec, verified_rows):
+        r = rec.get("roofline", {})
+        return [round(rec["ms_per_step"], 5), round(r.get("frac", 0.0), 4), round(r.get("frac_vs_gather_ceiling", 0.0), 4), verified_rows]
+    s = {"fields": ["ms_per_step", "roofline.frac", "frac_vs_gather_ceiling", "verified_rows"],
+         "A": row(out, out["config"]["num_v"])}
+    if "no_reorder" in out:
+        s["A_no_reorder_us"] = round(out["no_reorder"]["avg_launch_us"], 2)
+    ok = True
+    for name, c in (out.get("configs") or {}).items():
+        if "error" in c:
+            s[name], ok = "error", False
+            continue
+        s[name] = row(c, c.get("verified_rows", 0))
+        ok = ok and c.get("verified_against_oracle") is True
+        nr = c.get("no_reorder")
+        if nr:
+            s[name + "_no_reorder"] = [round(nr["ms_per_step"], 5), round(nr.get("frac", 0.0), 4), round(nr.get("frac_vs_gather_ceiling", 0.0), 4),
+                                       nr.get("verified_rows", 0)]
+            ok = ok and nr.get("verified_against_oracle") is True
+    s["edges_per_s"] = round(out["value"])
+    if "cpu_baseline" in out:
+        s["cpu_edges_per_s"] = round(out["cpu_baseline"]["value"])
+    s["verified"] = ok
+    return s
 
 
 def pick_rows(ptr_h, k, seed, hubs=3):
@@ -411,19 +433,19 @@ def verify_config(cfg, agg, ptr, idx, x, y, att=None, val=None, heads=1):
             ps, ix, tg, _ = orc.locality_schedule(sp, si, parts, agg.balanced_partition_columns(), ng=chunk)
             div = np.maximum(np.diff(sp), 1)[:, None].astype(np.float32)
             restated, chain = orc.gcn_grouped(ps, tg, ix, None, xh, n, seg=0) / div, orc.gcn_mean(sp, si, None, xh)
-            how = "bit-equal to the restated 2-D blocked order (orc.locality_schedule + gcn_grouped, then the IEEE division by the degree)"
+            how = "bit-equal to the restated 2-D blocked order"
         else:
             vh = val[torch.from_numpy(eids).to(val.device)].cpu().numpy() if val is not None else None
             ps, tg = orc.neighbor_grouping(sp, chunk)
             div = np.ones((n, 1), np.float32)
             restated, chain = orc.gcn_grouped(ps, tg, si, vh, xh, n, seg=seg), orc.gcn_seq(sp, si, vh, xh)
-            how = "bit-equal to the restated chunked order (orc.neighbor_grouping + gcn_grouped)"
+            how = "bit-equal to the restated chunked order"
         exact = np.array_equal(got, restated)
         truth = sum_rows_f64(sp, si, xh, vh) / div
         bound = 1e-5 * orc.gcn_abs_scale(sp, si, vh, xh).astype(np.float64) / div + 1e-30
         ratio, ref_ratio = float((np.abs(got - truth) / bound).max()), float((np.abs(chain - truth) / bound).max())
         ok = exact and ratio <= 1.0
-        how += "; within 1e-5 * sum|v x| of the float64 value"
+        how += "; within 1e-5 * sum|v x| of float64; DESIGN.md 5"
     else:
         H, F = heads, x.shape[1]
         atth = att.cpu().numpy()
@@ -443,14 +465,11 @@ def verify_config(cfg, agg, ptr, idx, x, y, att=None, val=None, heads=1):
         ratio = float(max((np.abs(got - truth) / bound).max(), (np.abs(got.astype(np.float64) - restated) / bound).max()))
         ref_ratio = float((np.abs(orc.gat_fused(sp, si, att_mix, xh, H) - truth) / bound).max())
         ok = ratio <= 1.0 and not np.isnan(got).any()
-        how = ("within 1e-5 * (sum_e w_e |x_e| + |y|) of the restated 2-D blocked order (orc.gat_grouped) and of the float64 edge softmax "
-               "(aggr_gat.h:125-163 in exact arithmetic)")
+        how = "within 1e-5 * (sum w|x| + |y|) of the restated blocked order and of the float64 edge softmax; DESIGN.md 5"
     if not ok:
         raise RuntimeError("config %s: the timed step's output differs from the oracle on the sampled rows (worst ratio to the bound %.3g)" % (cfg, ratio))
     return {"verified_against_oracle": True, "verified_rows": int(n), "verified_how": how, "worst_ratio_to_1e-5_bound": ratio,
-            "reference_order_worst_ratio": ref_ratio,
-            "reference_order_is": "the reference's own CSR-order fp32 chain (oracle restatement of aggr_gcn.h:13-35 / aggr_gat.h:125-163) against the "
-                                  "same float64 value, in units of the same bound"}
+            "reference_order_worst_ratio": ref_ratio}
 
 
 _CEILINGS = {}
@@ -482,116 +501,110 @@ def measure_config(cfg, args, dev, graph=None):
     V, E = ptr.numel() - 1, idx.numel()
     H, att, val = 1, None, None
     if cfg == "R":
-        F, what = 602, "reddit-shaped CSR %dx%d, GraphSAGE mean, feat=602, implicit weights, mode=balanced" % (V, E)
+        F, what = 602, "reddit-shaped CSR %dx%d, GraphSAGE mean, feat=602, mode=balanced" % (V, E)
         agg = gnc.Aggregator_GCN(ptr, idx, None, F, F)
         x, y = torch.randn((V, F), device=dev), torch.empty((V, F), device=dev)
-        step = lambda: agg.run(x, y, 512, "balanced", reduce="mean")  # noqa: E731
         B = E * (4 * F + 4) + V * 4 * F + 4 * (V + 1)
         kernel, ceil_key = "k_gcn_span (+ k_tile_x, k_combine_groups)", "g256_l2"
     elif cfg == "G":
         H, F = 8, 256
-        what = "reddit-shaped CSR %dx%d, GAT 8 heads x 32 fused edge-softmax + SpMM, mode=balanced" % (V, E)
+        what = "reddit-shaped CSR %dx%d, GAT 8 heads x 32 fused, mode=balanced" % (V, E)
         agg = gnc.Aggregator_GAT(ptr, idx, F, F)
         x, y = torch.randn((V, F), device=dev), torch.empty((V, F), device=dev)
         att = torch.randn((V, H, 2), device=dev)
-        step = lambda: agg.run(x, att, y, 128, "balanced", heads=H)  # noqa: E731
         B = E * (4 * F + 4 + 4 * H) + V * (4 * F + 4 * H) + 4 * (V + 1)
         kernel, ceil_key = "k_gat_span (+ k_tile_x, k_combine_groups_gat)", "g256_l2"
     else:
-        F, what = 100, "products-shaped CSR %dx%d, GCN sum, feat=100, explicit unit weights, mode=balanced, 1 GPU" % (V, E)
+        F, what = 100, "products-shaped CSR %dx%d, GCN sum, feat=100, unit weights, mode=balanced, 1 GPU" % (V, E)
         val = torch.ones(E, device=dev)
         agg = gnc.Aggregator_GCN(ptr, idx, val, F, F)
         x, y = torch.randn((V, F), device=dev), torch.empty((V, F), device=dev)
-        step = lambda: agg.run(x, y, 512, "balanced")  # noqa: E731
         B = algorithmic_bytes(V, E, F)
         kernel, ceil_key = "k_gcn_plan", "g400_hbm"
     steps, warm = min(args.steps, 20), min(args.warmup, 3)
-    # the first call builds the library-chosen order (on the device: plan_gpu.hip) and reserves the scratch; reported separately, like
-    # the reference's neighbor_grouping_schedule_time (graph_schedule.h:125-127)
-    torch.cuda.synchronize()
-    t_first = time.perf_counter()
-    step()
-    torch.cuda.synchronize()
-    t_first = time.perf_counter() - t_first
-    plan = agg.plan_info()
-    wall, dev_s, med_s = time_steps(step, steps, warm, lambda: None)
-    verified = verify_config(cfg, agg, ptr, idx, x, y, att=att, val=val, heads=H)
-    achieved = B / dev_s / 1e9
-    # the gather probe of the same launch sequence (same id / value / attention-term loads and row gathers, no chains, no stores)
-    if cfg == "G":
-        _, probe_s, _ = time_steps(lambda: agg.probe_gather(x, att, "balanced", heads=H), steps, warm, lambda: None)
-    else:
-        _, probe_s, _ = time_steps(lambda: agg.probe_gather(x, "balanced"), steps, warm, lambda: None)
-    traffic, traffic_step, traffic_label, traffic_stale = pmc_traffic(cfg)
     explicit = cfg == "P1"
     C = (2 * V * 4 * F + E * (4 + (4 if explicit else 0)) + (V + 1) * 4) + (V * 8 * H * 2 if cfg == "G" else 0)
-    blocked = agg.balanced_partitions() > 1
-    ceil = gather_ceiling(dev, ceil_key if blocked or cfg == "P1" else "g512_hbm")
-    # roofline.  P1 (chunked plan, X far larger than the caches): HBM / fabric bound, frac = counter
-    # traffic of the step / step time / 8 TB/s.  R and G (2-D blocked order: the gathered tile rows are served by the XCDs' L2s): the
-    # bound is the L2, frac = gather-model bytes / step time / 34.5 TB/s (the guide's L2 figure).  `frac_vs_gather_ceiling` divides the
-    # same gather-model rate by the rate MEASURED in this process for the same segment size out of the level the rows live in.
-    if blocked:
-        bound, peak, frac = "l2", L2_PEAK_GBPS, achieved / L2_PEAK_GBPS
-        frac_is = "gather-model (algorithmic) bytes / step time / 34.5 TB/s (MI355X_MICROARCH.md: aggregate L2 bandwidth)"
-    else:
-        bound, peak = "hbm", HBM_PEAK_GBPS
-        frac = (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else achieved / HBM_PEAK_GBPS
-        frac_is = ("counter traffic of the step (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, committed profile; fabric-side bytes: "
-                   "Infinity-Cache hits included) / step time / 8 TB/s" if traffic_step
-                   else "algorithmic bytes / step time / 8 TB/s (no counter file found)")
-    reordered, n_parts = None, agg.balanced_partitions()
-    if cfg == "P1" and os.environ.get("BENCH_P1_REORDER") == "1":
-        # the same workload with the locality reorder applied on load (what the headline line does; the generator -- the library's
-        # cache-aware greedy order, 64 logical walkers on a graph this size -- takes tens of seconds of host time, so this arm is opt-in).
-        # Reported beside the line, never as `value`
+
+    def measure_arm(agg, ptr_a, idx_a, tag):
+        """time_steps + oracle check + gather probe + roofline of one aggregator over one numbering of the graph"""
+        if cfg == "G":
+                probe = lambda: agg.probe_gather(x, att, "balanced", heads=H)  # noqa: E731
+        else:
+            step = lambda: agg.run(x, y, 512, "balanced", reduce="mean" if cfg == "R" else "sum")  # noqa: E731
+            probe = lambda: agg.probe_gather(x, "balanced")  # noqa: E731
+        # the first call builds the library-chosen order (on the device: plan_gpu.hip) and reserves the scratch; reported separately, like
+        # the reference's neighbor_grouping_schedule_time (graph_schedule.h:125-127)
+        torch.cuda.synchronize()
+        t_first = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t_first
+        plan = agg.plan_info()
+        wall, dev_s, med_s = time_steps(step, steps, warm, lambda: None)
+        verified = verify_config(cfg, agg, ptr_a, idx_a, x, y, att=att, val=val, heads=H)
+        achieved = B / dev_s / 1e9
+        _, probe_s, _ = time_steps(probe, steps, warm, lambda: None)
+        traffic, traffic_step, traffic_label, traffic_stale = pmc_traffic(tag)
+        blocked = agg.balanced_partitions() > 1
+        ceil = gather_ceiling(dev, ceil_key if blocked or cfg == "P1" else "g512_hbm")
+        # roofline.  P1 (chunked plan, X far larger than the caches): HBM / fabric bound, frac = counter traffic of the step / step time /
+        # 8 TB/s.  R and G (2-D blocked order: the gathered tile rows are served by the XCDs' L2s): the bound is the L2, frac = gather-model
+        # bytes / step time / 34.5 TB/s (the guide's L2 figure).  `frac_vs_gather_ceiling` divides the same gather-model rate by the rate
+        # MEASURED in this process for the same segment size with ids UNIFORM over a window in the level the rows live in -- an input with
+        # locality (hot sources, a reordered graph) can exceed it (ADVICE r5); `probe_frac` is the bounding ratio of the launch itself.
+        if blocked:
+            bound, peak, frac = "l2", L2_PEAK_GBPS, achieved / L2_PEAK_GBPS
+            frac_is = "gather-model bytes / step time / 34.5 TB/s (guide's aggregate L2 figure); DESIGN.md 5"
+        else:
+            bound, peak = "hbm", HBM_PEAK_GBPS
+            frac = (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else achieved / HBM_PEAK_GBPS
+            frac_is = ("counter traffic of the step (fabric side: Infinity-Cache hits included) / step time / 8 TB/s; DESIGN.md 5" if traffic_step
+                       else "algorithmic bytes / step time / 8 TB/s (no counter file); DESIGN.md 5")
+        rec = {"value": E / (wall / steps), "ms_per_step": wall / steps * 1e3, "achieved_gbps": achieved,
+               "schedule_prep_s": plan["plan_s"], "first_call_s": t_first, "plan_bytes": plan["plan_bytes"], "scratch_bytes": plan["scratch_bytes"],
+               "source_partitions": agg.balanced_partitions(),
+               "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": frac, "frac_is": frac_is,
+                            "frac_vs_gather_ceiling": achieved / ceil["gbps"],
+                            "gather_ceiling": {"gbps": ceil["gbps"], "us": ceil["us"]},
+                            "frac_vs_gather_ceiling_is": "gather-model rate / measured UNIFORM-id gather rate of the same segment size; locality may exceed 1",
+                            "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_label,
+                            "traffic_stale": traffic_stale, "kernel": kernel, "algorithmic_bytes": B,
+                            "compulsory_bytes": C, "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
+                            "probe_frac": probe_s / dev_s, "ceiling_probe_us": probe_s * 1e6,
+                            "hbm_peak_gbps": HBM_PEAK_GBPS, "gather_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
+                            "traffic_frac_of_hbm_peak": (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else None,
+                            "compulsory_frac_of_hbm_peak": C / dev_s / 1e9 / HBM_PEAK_GBPS}}
+        rec.update(verified)
+        return rec
+
+    arm = measure_arm(agg, ptr, idx, cfg)
+    no_reorder = None
+    if cfg == "P1" and os.environ.get("BENCH_P1_REORDER", "1") != "0":
+        # north_star applies the locality reorder ON LOAD and SURVEY 8(e) partitions after it, so the line's `value` is the reordered graph
+        # (like the headline); the generator's numbering rides beside it as `no_reorder` (VERDICT r5 item 3).  Both arms are checked
+        # against the oracle on sampled rows of their own numbering.
+        no_reorder = arm
         del agg
-        t0 = time.perf_counter()
-        hp, hi = ptr.cpu().numpy(), idx.cpu().numpy()
-        rows, _ = gnc.cluster_reorder(hp, hi, order="cache_greedy", cluster_cap=1, cache_rows=8192)
-        nptr, nidx, _ = gnc.reorder_csr(hp, hi, rows)
-        t_reorder = time.perf_counter() - t0
-        agg_r = gnc.Aggregator_GCN(torch.from_numpy(nptr).to(dev), torch.from_numpy(nidx).to(dev), torch.ones(E, device=dev), F, F)
-        wall_r, dev_r, _ = time_steps(lambda: agg_r.run(x, y, 512, "balanced"), steps, warm, lambda: None)
-        from oracle import oracle as orc
-        nchk = 2000
-        ref = orc.gcn_seq(nptr[:nchk + 1], nidx[:nptr[nchk]], np.ones(int(nptr[nchk]), np.float32), x.cpu().numpy())
-        scale = orc.gcn_abs_scale(nptr[:nchk + 1], nidx[:nptr[nchk]], np.ones(int(nptr[nchk]), np.float32), x.cpu().numpy())
-        ok = bool(np.all(np.abs(y[:nchk].cpu().numpy() - ref) <= 1e-5 * scale + 1e-30))
-        if not ok:
-            raise SystemExit("bench.py --config P1: the reordered arm differs from the oracle")
-        reordered = {"value": E / (wall_r / steps), "ms_per_step": wall_r / steps * 1e3, "avg_launch_us": dev_r * 1e6, "reorder_prep_s": t_reorder,
-                     "reorder_walkers": int(os.environ.get("GNNAGG_REORDER_WALKERS", "0")) or (64 if E >= 20000000 else 1),
-                     "verified_against_oracle": True,
-                     "what": "the same graph renumbered by gnnagg_cluster_reorder_ex (cache-aware greedy order, cluster_cap 1, cache model 8192 rows) "
-                             "and loaded like a .reorder_thres_0.2 file; first 2000 rows checked against the oracle"}
-    rec = {"metric": "aggregated edges/sec, config %s" % cfg, "value": E / (wall / steps), "unit": "edges/s",
-           "with_locality_reorder": reordered,
-           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": wall / steps * 1e3, "higher_is_better": True,
+        torch.cuda.empty_cache()
+        nptr, nidx, _, t_gen, t_load = load_with_locality_reorder("products", ptr.cpu().numpy(), idx.cpu().numpy())
+        ptr_r, idx_r = torch.from_numpy(nptr).to(dev), torch.from_numpy(nidx).to(dev)
+        agg = gnc.Aggregator_GCN(ptr_r, idx_r, val, F, F)
+        arm = measure_arm(agg, ptr_r, idx_r, "P1_reorder")
+        arm["with_locality_reorder"] = {"value": arm["value"], "ms_per_step": arm["ms_per_step"], "reorder_prep_s": t_gen, "reorder_load_s": t_load,
+                                        "reorder_cache_hit": t_gen == 0.0, "verified_against_oracle": arm["verified_against_oracle"],
+                                        "reorder_walkers": int(os.environ.get("GNNAGG_REORDER_WALKERS", "0")) or (64 if E >= 20000000 else 1)}
+        what += ", locality reorder applied on load (.reorder_thres_0.2)"
+        no_reorder = {k: no_reorder[k] for k in ("value", "ms_per_step", "verified_against_oracle", "verified_rows", "worst_ratio_to_1e-5_bound")} | {
+            "frac": no_reorder["roofline"]["frac"], "frac_vs_gather_ceiling": no_reorder["roofline"]["frac_vs_gather_ceiling"],
+            "avg_launch_us": no_reorder["roofline"]["avg_launch_us"], "probe_frac": no_reorder["roofline"]["probe_frac"],
+            "traffic_step": no_reorder["roofline"]["traffic_step"]}
+    rec = {"metric": "aggregated edges/sec, config %s" % cfg, "value": arm["value"], "unit": "edges/s",
+           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": arm["ms_per_step"], "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": what, "num_v": V, "num_e": E, "feat": F, "source_partitions": n_parts},
-           "achieved_gbps": achieved,
-           "schedule_prep_s": plan["plan_s"], "first_call_s": t_first, "plan_bytes": plan["plan_bytes"], "scratch_bytes": plan["scratch_bytes"],
-           "schedule_prep_is": "wall seconds the library-chosen order took to build inside the first call (0: the chunked plan, built on the host in "
-                               "O(V)); first_call_s = plan + scratch allocation + one step; plan_bytes / scratch_bytes = device memory the plan's "
-                               "arrays / the partial rows and tiled images hold",
-           "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": frac, "frac_is": frac_is,
-                        "frac_vs_gather_ceiling": achieved / ceil["gbps"],
-                        "gather_ceiling": {"gbps": ceil["gbps"], "us": ceil["us"], "what": ceil["what"]},
-                        "frac_vs_gather_ceiling_is": "gather-model bytes / step time / the rate measured in this process for the same segment "
-                                                     "size out of the level the gathered rows live in (gnnagg_probe_row_gather)",
-                        "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_label,
-                        "traffic_stale": traffic_stale, "kernel": kernel, "algorithmic_bytes": B,
-                        "compulsory_bytes": C, "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
-                        "avg_launch_is": "HIP events around the K steps / K: the whole step (every kernel it launches); per-kernel averages "
-                                         "are in profiles/%s/summary_%s.txt" % (PROFILE_ROUND, cfg),
-                        "probe_frac": probe_s / dev_s, "ceiling_probe_us": probe_s * 1e6,
-                        "hbm_peak_gbps": HBM_PEAK_GBPS, "gather_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
-                        "traffic_frac_of_hbm_peak": (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else None,
-                        "compulsory_frac_of_hbm_peak": C / dev_s / 1e9 / HBM_PEAK_GBPS,
-                        "note": "times are of the whole step (R / G: column-tiling of X, aggregation, ordered combine); `traffic` is "
-                                "the dominant kernel's fabric-side bytes per launch, `traffic_step` all kernels of a step"}}
-    rec.update(verified)
+           "config": {"workload": what, "num_v": V, "num_e": E, "feat": F, "source_partitions": arm["source_partitions"]}}
+    rec.update({k: v for k, v in arm.items() if k not in ("value", "ms_per_step", "source_partitions")})
+    rec.setdefault("with_locality_reorder", None)
+    rec["no_reorder"] = no_reorder
     return rec
 
 
@@ -620,24 +633,22 @@ def measure_rows_mode(args, dev, nptr, nidx, val, x_rows, ceil):
     traffic, traffic_step, traffic_label, traffic_stale = pmc_traffic("A_rows")
     return {"metric": "aggregated edges/sec, GCN SpMM feat=128, canonical rows mode", "value": E / (wall / args.steps), "unit": "edges/s",
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "config": {"workload": "the headline input (arxiv-shaped, locality reorder applied on load) in GNNAGG_MODE_ROWS: `scheduled = 0` "
-                                   "= aggr_gcn's own order, one sequential FMA chain per row", "num_v": V, "num_e": E, "feat": FEAT},
+            "config": {"workload": "the headline input in GNNAGG_MODE_ROWS (aggr_gcn's own order: one CSR-order FMA chain per row)",
+                       "num_v": V, "num_e": E, "feat": FEAT},
             "achieved_gbps": achieved, "schedule_prep_s": plan["plan_s"], "plan_bytes": plan["plan_bytes"], "scratch_bytes": plan["scratch_bytes"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (traffic_step / dev_s / 1e9 / HBM_PEAK_GBPS) if traffic_step else achieved / HBM_PEAK_GBPS,
-                         "frac_is": ("counter traffic of the step (committed profile; fabric-side bytes, Infinity-Cache hits included) / step time / 8 TB/s"
-                                     if traffic_step else "algorithmic bytes / step time / 8 TB/s (no counter file for this mode): cache-served, "
-                                     "not an HBM utilisation -- see frac_vs_gather_ceiling"),
+                         "frac_is": ("counter traffic of the step (fabric side: Infinity-Cache hits included) / step time / 8 TB/s; DESIGN.md 5"
+                                     if traffic_step else "algorithmic bytes / step time / 8 TB/s (no counter file); DESIGN.md 5"),
                          "frac_vs_gather_ceiling": achieved / ceil["gbps"],
-                         "gather_ceiling": {"gbps": ceil["gbps"], "us": ceil["us"], "what": ceil["what"]},
+                         "gather_ceiling": {"gbps": ceil["gbps"], "us": ceil["us"]},
                          "traffic": traffic, "traffic_step": traffic_step, "traffic_source": traffic_label, "traffic_stale": traffic_stale,
-                         "kernel": "k_gcn_plan (short rows) beside k_gcn_rows_long (medium rows, hub rows) on forked streams",
+                         "kernel": "k_gcn_plan (short rows) beside k_gcn_rows_long (medium, hub rows) on forked streams",
                          "algorithmic_bytes": B, "compulsory_bytes": compulsory_bytes(V, E, FEAT),
                          "avg_launch_us": dev_s * 1e6, "median_launch_us": med_s * 1e6,
-                         "avg_launch_is": "HIP events around the K steps / K: the whole step (fork, the row kernels, join)",
                          "probe_frac": None},
             "verified_against_oracle": True, "verified_rows": V,
-            "verified_how": "whole output np.array_equal to orc.gcn_seq (the reference's aggr_gcn chain order)"}
+            "verified_how": "whole output array_equal to orc.gcn_seq (aggr_gcn's chain order)"}
 
 
 def other_configs(args, dev, nptr, nidx, val, x_rows):
@@ -729,10 +740,13 @@ def partitioned_run(args, dev, rank, world, strong, steps, warmup, transport, do
         del buf
     del ptr_t
     val_slice = np.ones(e1 - e0, np.float32)
-    # One stage (a single grouped send / recv per step) by default: the staged, pipelined exchange has only ever run over the test double
-    # of the nccl* calls (no box on this pool has two GPUs), so it stays opt-in -- BENCH_STAGES=auto | owner | N -- until it has run
-    # over real RCCL with a peer
-    stages = os.environ.get("BENCH_STAGES", "1")
+    # Staged (pipelined) exchange by default: "auto" = stripes, one per 64 MB of halo rows, at most 4 (dist.py) -- the halo-source pass of stage s
+    # runs under stage s + 1.  Default since round 6: the staged step now runs against an ASYNCHRONOUS peer (tests/fake_rccl: stream-ordered
+    # copies, no host synchronisation inside a group) with the halo poisoned and a rank late on the device --
+    # tests/test_gpu_dist.py::test_cabi_step_is_ordered_by_its_events_not_by_luck (stripe 2 / 3, owner),
+    # ::test_the_late_peer_test_can_fail (its negative control) and ::test_cabi_step_replays_from_a_captured_graph_at_world_4.
+    # BENCH_STAGES=1 | owner | K overrides.
+    stages = os.environ.get("BENCH_STAGES", "auto")
     stages = int(stages) if stages.lstrip("-").isdigit() else stages
     t_plan = time.perf_counter()
     dog.arm(240, "communicator + plan exchange (%s transport)" % transport)
@@ -802,6 +816,28 @@ def partitioned_run(args, dev, rank, world, strong, steps, warmup, transport, do
     t_nx = torch.tensor([wall_nx], dtype=torch.float64, device=dev)
     dist.all_reduce(t_nx, op=dist.ReduceOp.MAX)
     wall_nx = float(t_nx.item())
+    # The parts of the step alone, so that an N > 1 line explains itself on first contact with hardware: the exchange
+    # (pack kernel + the step's own all-to-all-v(s): same transport, same per-peer byte counts, nothing beside it on the device), the
+    # local-source pass, the halo-source passes.  predicted = max(exchange, local) + halo: what the overlap plan should cost if the exchange
+    # and the local pass do not slow each other down.
+    dog.arm(120 + 0.5 * (steps + warmup) * 3, "exchange alone over the %s transport" % transport)
+    parts = {}
+    parts["exchange_alone"], _, _ = time_steps(lambda: hx.exchange(pg.x_local, pg.x_halo, pg.send_buf, async_op=False), steps, warmup, dist.barrier)
+    dog.disarm()
+    if pg.overlap:
+        parts["local_pass"], _, _ = time_steps(lambda: pg.agg_loc.run(pg.x_local, pg.y, 512, "balanced"), steps, warmup, dist.barrier)
+
+        def halo_passes():
+            for a in pg.agg_rem_stages:
+                if a is not None:
+                    a.run(pg.x_halo, pg.y, 512, "balanced", accumulate=True)
+        parts["halo_pass"], _, _ = time_steps(halo_passes, steps, warmup, dist.barrier)
+    else:
+        parts["local_pass"], parts["halo_pass"] = wall_nx, 0.0
+    tparts = torch.tensor([parts["exchange_alone"], parts["local_pass"], parts["halo_pass"]], dtype=torch.float64, device=dev)
+    dist.all_reduce(tparts, op=dist.ReduceOp.MAX)
+    peer_rows = torch.tensor([float(max([int(v) for p_, v in enumerate(hx.recv_counts) if p_ != rank] or [0]))], dtype=torch.float64, device=dev)
+    dist.all_reduce(peer_rows, op=dist.ReduceOp.MAX)
     tp = torch.tensor([t_plan], dtype=torch.float64, device=dev)
     dist.all_reduce(tp, op=dist.ReduceOp.MAX)
     n_stages, stage_mode = hx.n_stages, "%s x %d" % (hx.stage_mode, hx.n_stages)
@@ -817,7 +853,9 @@ def partitioned_run(args, dev, rank, world, strong, steps, warmup, transport, do
             "remote_edge_share": float(halo[2].item()) / max(float(halo[1].item()), 1.0),
             "rccl_ranks": rccl_ranks, "plan_s": float(tp.item()), "n_stages": n_stages, "stage_mode": stage_mode,
             "rccl_library": rccl_library, "rccl_library_is_override": rccl_override, "distinct_devices": distinct_devices,
-            "device_pci_bus_ids": buses}
+            "device_pci_bus_ids": buses,
+            "exchange_alone_s": float(tparts[0].item()) / steps, "local_pass_s": float(tparts[1].item()) / steps,
+            "halo_pass_s": float(tparts[2].item()) / steps, "largest_message_bytes": float(peer_rows.item()) * feat * 4}
 
 
 def device_bus_id(dev):
@@ -863,18 +901,28 @@ def run_multi(args, dev, rank, world, dog):
     else:
         link = "halo pull per step over xGMI"
     transport_is = TRANSPORT_NAMES[transport] + ("" if not double else " -- " + link)
+
+    def parts_of(mm):
+        """exchange / passes alone beside the step (all max over ranks): predicted_step_ms = max(exchange, local) + halo; link_gbps_per_peer =
+        the largest pairwise message of the step / the exchange's time (every pairwise message rides its own xGMI link, so the largest
+        one sets the time when the links are the limit)"""
+        ex, lo, ha = mm["exchange_alone_s"] * 1e3, mm["local_pass_s"] * 1e3, mm["halo_pass_s"] * 1e3
+        return {"exchange_alone_ms": ex, "local_pass_ms": lo, "halo_pass_ms": ha, "predicted_step_ms": max(ex, lo) + ha,
+                "link_gbps_per_peer": (mm["largest_message_bytes"] / mm["exchange_alone_s"] / 1e9) if mm["exchange_alone_s"] > 0 else None,
+                "largest_message_bytes": mm["largest_message_bytes"]}
     out = {
         "metric": "aggregated edges/sec, GCN SpMM feat=%d" % feat, "value": Eg / step_s, "unit": "edges/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+        # n_gpus = the GPUs the ranks really sit on: `ranks` processes on ONE device (a functional check on a one-GPU box) is not an N-GPU point
+        "n_gpus": m["distinct_devices"], "ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%s power-law CSR (%dx%d, seed 123, community order, %d %% of a row's sources are global-popularity picks: "
-                               "--global-share), GCN sum, feat=%d, 1-D row partition + %s (%s; %s; local-source "
-                               "edges overlap the exchange, stage s's halo-source edges overlap stage s + 1)" % (
+        "config": {"workload": "%s CSR %dx%d (seed 123, generated in its community order = a perfect locality reorder; %d %% global picks), GCN sum, "
+                               "feat=%d, 1-D row partition + %s; stages: %s" % (
                                    "products-shaped" if strong else "%d x arxiv-shaped" % world, Vg, Eg, round(args.global_share * 100), feat,
-                                   link, TRANSPORT_NAMES[transport], "stages: " + m["stage_mode"]),
+                                   link, m["stage_mode"]),
                    "num_v": Vg, "num_e": Eg, "feat": feat, "halo_bytes_per_step_all_ranks": m["halo_bytes_all"],
-                   "global_share": args.global_share, "verified_against_oracle": True},
+                   "global_share": args.global_share, "verified_against_oracle": True,
+                   "graph_numbering": "generator's hidden community order (perfect-reorder assumption: 73.2 vs 73.7 us on A, DESIGN.md 6)"},
         "transport": transport, "transport_is": transport_is, "backend": backend, "rccl_ranks": m["rccl_ranks"],
         "rccl_library": m["rccl_library"], "rccl_library_is_override": m["rccl_library_is_override"],
         "distinct_devices": m["distinct_devices"], "device_pci_bus_ids": m["device_pci_bus_ids"], "test_double": double,
@@ -885,24 +933,21 @@ def run_multi(args, dev, rank, world, dog):
         # beyond the same kernels with the halo rows already resident
         "exposed_comm_ms_per_step": max(0.0, (m["step_s"] - m["step_nx_s"]) * 1e3),
         "remote_edge_share": m["remote_edge_share"],
-        "no_exchange_upper_bound": {"value": Eg / m["step_nx_s"], "ms_per_step": m["step_nx_s"] * 1e3,
-                                    "note": "the same aggregation kernels with the halo rows already resident (static features: the "
-                                            "exchange hoisted out of the step); NOT the reported value -- it bounds what overlap can hide"},
+        "no_exchange_upper_bound": {"value": Eg / m["step_nx_s"], "ms_per_step": m["step_nx_s"] * 1e3},
+        "step_parts": parts_of(m),
         # per-GPU share of the step, halo exchange included: the bound is whichever of the xGMI links and the memory system
         # is slower for this partition -- reported against the HBM figure for continuity with the 1-GPU line, not as a
         # kernel roofline (that is the N = 1 line's job)
         "roofline": {"bound": "hbm", "achieved": B / step_s / 1e9 / world, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": B / step_s / 1e9 / world / HBM_PEAK_GBPS, "traffic": None,
-                     "frac_is": "per-GPU share of the gather-model bytes / step time (exchange included) / 8 TB/s; cache-served gathers "
-                                "count, so this is not an HBM utilisation",
-                     "kernel": "per-GPU share of the step (halo exchange included; gather-model bytes, cache-served "
-                               "gathers count: see the N = 1 line for the measured ceiling)", "algorithmic_bytes": B,
+                     "frac_is": "per-rank share of the gather-model bytes / step time (exchange included) / 8 TB/s; DESIGN.md 5",
+                     "kernel": "per-rank share of the whole step (halo exchange included)", "algorithmic_bytes": B,
                      "halo_bytes_per_rank": m["halo_bytes_all"] / world, "halo_bytes_max_rank": m["halo_bytes_max_rank"]},
     }
     if ps is not None:
         out["products_strong"] = {
-            "what": "BASELINE configs[4]: ONE products-shaped CSR (%dx%d, feat=100, GCN sum) row-partitioned over the same %d ranks, same "
-                    "transport; strong scaling: divide by the 1-GPU P1 line (bench.py --config P1)" % (ps["Vg"], ps["Eg"], world),
+            "what": "BASELINE configs[4]: ONE products-shaped CSR %dx%d, feat=100, GCN sum, over the same %d ranks (strong scaling)" % (ps["Vg"], ps["Eg"], world),
+            "step_parts": parts_of(ps),
             "value": ps["Eg"] / ps["step_s"], "unit": "edges/s", "ms_per_step": ps["step_s"] * 1e3, "steps": ps["steps"], "warmup": ps["warmup"],
             "scaling": "strong", "halo_bytes_per_step_all_ranks": ps["halo_bytes_all"], "halo_bytes_max_rank": ps["halo_bytes_max_rank"],
             "exposed_comm_ms_per_step": max(0.0, (ps["step_s"] - ps["step_nx_s"]) * 1e3),
@@ -910,6 +955,19 @@ def run_multi(args, dev, rank, world, dog):
             "plan_s": ps["plan_s"], "rccl_ranks": ps["rccl_ranks"], "verified_against_oracle": True,
             "distinct_devices": ps["distinct_devices"], "rccl_library": ps["rccl_library"],
             "test_double": bool(ps["rccl_library_is_override"]) or ps["distinct_devices"] < world}
+    sp = out["step_parts"]
+    out["summary"] = {"ranks": world, "distinct_devices": m["distinct_devices"], "test_double": double, "transport": transport, "stages": m["stage_mode"],
+                      "ms_per_step": round(step_s * 1e3, 4), "edges_per_s": round(Eg / step_s), "no_exchange_ms": round(m["step_nx_s"] * 1e3, 4),
+                      "exchange_alone_ms": round(sp["exchange_alone_ms"], 4), "local_pass_ms": round(sp["local_pass_ms"], 4),
+                      "halo_pass_ms": round(sp["halo_pass_ms"], 4), "predicted_step_ms": round(sp["predicted_step_ms"], 4),
+                      "link_gbps_per_peer": None if sp["link_gbps_per_peer"] is None else round(sp["link_gbps_per_peer"], 2),
+                      "halo_mb_per_rank": round(m["halo_bytes_all"] / world / 1e6, 2), "verified": True}
+    if ps is not None:
+        q = out["products_strong"]["step_parts"]
+        out["summary"]["P"] = {"ms_per_step": round(ps["step_s"] * 1e3, 4), "edges_per_s": round(ps["Eg"] / ps["step_s"]),
+                               "exchange_alone_ms": round(q["exchange_alone_ms"], 4), "local_pass_ms": round(q["local_pass_ms"], 4),
+                               "halo_pass_ms": round(q["halo_pass_ms"], 4), "predicted_step_ms": round(q["predicted_step_ms"], 4),
+                               "stages": ps["stage_mode"], "halo_mb_max_rank": round(ps["halo_bytes_max_rank"] / 1e6, 2)}
     return out
 
 
@@ -945,17 +1003,24 @@ def launch_ranks(args, json_fd):
 
 
 def sup_dir():
-    """Directory the supervisors of ONE job share: named after their common parent (the launcher) and the job's rendezvous port."""
+    """Directory the supervisors of ONE job on ONE node share.  Every supervisor of a node is a child of the same launcher process, so
+    the name carries that parent's pid AND its start time (field 22 of /proc/<pid>/stat: a later launcher that happens to get the same pid
+    cannot collide, so nothing ever has to be removed before use) and the job's rendezvous port."""
     import tempfile
-    return os.path.join(tempfile.gettempdir(), "gnnagg_bench_sup_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    ppid = os.getppid()
+    try:
+        start = open("/proc/%d/stat" % ppid).read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        start = "0"
+    return os.path.join(tempfile.gettempdir(), "gnnagg_bench_sup_%d_%s_%s" % (ppid, start, os.environ.get("MASTER_PORT", "0")))
 
 
-def agree_on_outcome(rank, world, attempt, rc, timeout_s=420.0):
-    """The supervisors of one node agree on what an attempt did before any of them starts the next one (a rank whose child
-    failed must not open a rendezvous that the ranks whose children returned 0 never join).  Every supervisor is a child of the same
-    launcher process, so a directory named after that parent is shared and private to this job; rank r drops its child's exit code
-    there, rank 0 also the port of the next rendezvous (a free one, checked).  Returns (worst exit code over all ranks, next port), or
-    (None, None) when some rank never reported -- then nobody retries."""
+def agree_on_outcome(local_rank, local_world, attempt, rc, timeout_s=420.0, need_port=True):
+    """The supervisors of ONE NODE agree on what an attempt did before any of them starts the next one (a rank whose child
+    failed must not open a rendezvous that the ranks whose children returned 0 never join).  The file set is the node's own ranks
+    (LOCAL_RANK / LOCAL_WORLD_SIZE: the directory is node-local -- ADVICE r5); the local leader also drops the port of the next
+    rendezvous (a free one, checked).  Returns (worst exit code over the node's ranks, next port), or (None, None) when some rank
+    never reported -- then nobody retries.  Multi-node jobs do not use it (supervise_rank: no fallback ladder there)."""
     d = os.path.join(sup_dir(), "attempt%d" % attempt)
     os.makedirs(d, exist_ok=True)
 
@@ -964,16 +1029,16 @@ def agree_on_outcome(rank, world, attempt, rc, timeout_s=420.0):
         with open(tmp, "w") as f:
             f.write(text)
         os.replace(tmp, os.path.join(d, name))
-    if rank == 0:
+    if local_rank == 0 and need_port:
         drop("port", str(free_port()))
-    drop("rank%d" % rank, str(rc))
+    drop("rank%d" % local_rank, str(rc))
     t_end = time.monotonic() + timeout_s
-    names = ["rank%d" % r for r in range(world)] + ["port"]
+    names = ["rank%d" % r for r in range(local_world)] + (["port"] if need_port else [])
     while time.monotonic() < t_end:
         if all(os.path.exists(os.path.join(d, n)) for n in names):
-            codes = [int(open(os.path.join(d, "rank%d" % r)).read().strip() or "1") for r in range(world)]
+            codes = [int(open(os.path.join(d, "rank%d" % r)).read().strip() or "1") for r in range(local_world)]
             worst = next((c for c in codes if c != 0), 0)
-            return worst, int(open(os.path.join(d, "port")).read().strip())
+            return worst, (int(open(os.path.join(d, "port")).read().strip()) if need_port else None)
         time.sleep(0.2)
     return None, None
 
@@ -996,10 +1061,14 @@ def supervise_rank(args, json_fd):
             attempts.append(("torch", backend))
         if backend == "nccl":
             attempts.append(("torch", "gloo"))
+    # the agreement is per node (its files are node-local).  A job that spans nodes has no channel here to agree across them, so it runs
+    # the first transport only and every supervisor reports its own child (the global WORLD_SIZE never fits a node's directory)
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    single_node = local_world == world
+    if not single_node:
+        attempts = attempts[:1]
     rc, reasons, port = 1, [], None
-    if rank == 0:   # a directory of the same name can only be a leftover of an earlier job whose launcher had this pid
-        import shutil
-        shutil.rmtree(sup_dir(), ignore_errors=True)
     for i, (tr, be) in enumerate(attempts):
         env = dict(os.environ, BENCH_CHILD="1", BENCH_TRANSPORT=tr, BENCH_BACKEND=be)
         if i > 0:
@@ -1012,10 +1081,19 @@ def supervise_rank(args, json_fd):
             log("bench.py rank %d: %s" % (rank, env["BENCH_FALLBACK_REASON"]))
         r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)
         own = r.returncode
-        rc, port = agree_on_outcome(rank, world, i, own)
+        if not single_node:
+            if rank == 0 and own == 0:
+                return 0 if relay_json(r.stdout, json_fd) == 1 else 1
+            return own
+        last = i + 1 == len(attempts)
+        rc, port = agree_on_outcome(local_rank, local_world, i, own, need_port=not last)
         if rc is None:
-            log("bench.py rank %d: the other ranks' supervisors never reported attempt %d; giving up" % (rank, i))
-            return own or 1
+            # some supervisor never reported: nobody starts another attempt.  A rank whose own child succeeded says so (its line, if it is
+            # rank 0, is still the measurement); only a failed child makes this supervisor fail
+            log("bench.py rank %d: the other ranks' supervisors never reported attempt %d; no further attempt" % (rank, i))
+            if own == 0 and rank == 0:
+                return 0 if relay_json(r.stdout, json_fd) == 1 else 1
+            return own
         if rc == 0:
             if rank == 0:
                 return 0 if relay_json(r.stdout, json_fd) == 1 else 1

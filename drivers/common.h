@@ -7,6 +7,21 @@
 
 #include "../include/compat/util.h"
 
+// `--dump DIR` (anywhere on the command line; stripped before the reference's argParse sees it): the class shim writes the operands
+// of the last call of each entry point into DIR (GNNAGG_COMPAT_DUMP, include/compat/util.h) -- the numbers behind the driver
+inline void strip_dump_flag(int &argc, char **argv)
+{
+    int w = 1;
+    for (int i = 1; i < argc; ++i) {
+        if (std::string(argv[i]) == "--dump" && i + 1 < argc) {
+            setenv("GNNAGG_COMPAT_DUMP", argv[++i], 1);
+            continue;
+        }
+        argv[w++] = argv[i];
+    }
+    argc = w;
+}
+
 inline float *device_normal(size_t count, unsigned long long seed)
 {
     std::vector<float> h(count);

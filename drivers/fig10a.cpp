@@ -18,6 +18,7 @@ __global__ void exp_leaky(float *v, int count, float slope)
 int main(int argc, char **argv)
 {
     const int times = 10;
+    strip_dump_flag(argc, argv);
     argParse(argc, argv);
     assert(GPUNUM == 1);
     int *tmp1 = nullptr, *tmp2 = nullptr;

@@ -9,6 +9,7 @@
 int main(int argc, char **argv)
 {
     const int times = 10;
+    strip_dump_flag(argc, argv);
     argParse(argc, argv);
     const int out_feature_len = outfea;
     assert(out_feature_len > 0);

@@ -32,6 +32,7 @@ static void analyse(const char *what, const std::vector<clocktype> &t, int nb, d
 
 int main(int argc, char **argv)
 {
+    strip_dump_flag(argc, argv);
     argParse(argc, argv);
     assert(GPUNUM == 1);
     int *tmp1 = nullptr, *tmp2 = nullptr;

@@ -10,6 +10,7 @@
 int main(int argc, char **argv)
 {
     const int times = 10;
+    strip_dump_flag(argc, argv);
     argParse(argc, argv);
     assert(GPUNUM == 1);
     int *tmp1 = nullptr, *tmp2 = nullptr;

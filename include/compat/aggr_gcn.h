@@ -69,12 +69,14 @@ public:
         feat_in = feat;
         checkGnnagg(gnnagg_gcn_run(handle, vin, vout, feat, scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS,
                                    GNNAGG_REDUCE_SUM));
+        dump_run(scheduled ? "gcn_run_s1" : "gcn_run_s0", vin, vout, feat);
         return 0.0;
     }
     // library-chosen chunking of long rows (no reference counterpart); reduce = GNNAGG_REDUCE_*
     double run_balanced(float *vin, float *vout, int feat, int reduce = GNNAGG_REDUCE_SUM)
     {
         checkGnnagg(gnnagg_gcn_run(handle, vin, vout, feat, GNNAGG_MODE_BALANCED, reduce));
+        dump_run("gcn_run_balanced", vin, vout, feat);
         return 0.0;
     }
     // reference aggr_gcn.h:446-460 (synchronous and timed, like the reference)
@@ -133,6 +135,11 @@ public:
     {
         (void)BLOCK_SIZE;
         checkGnnagg(gnnagg_gcn_run_with_nn(handle, vin, vout, weight, transformed, feat_in, feat_out, GNNAGG_MODE_SCHEDULED));
+        if (compat_dump_dir()) {
+            dump_run("gcn_run_with_nn", vin, vout, feat_in);
+            compat_dump("gcn_run_with_nn", "weight", weight, sizeof(float) * (size_t)feat_in * feat_out);
+            compat_dump("gcn_run_with_nn", "transformed", transformed, sizeof(float) * (size_t)num_v * feat_out);
+        }
     }
     // reference aggr_gcn.h:540-544
     void updateval(float *out_d_val)
@@ -148,6 +155,14 @@ public:
     }
 
 private:
+    void dump_run(const char *entry, const float *vin, const float *vout, int feat) const
+    {
+        if (!compat_dump_dir()) return;
+        dump_graph(entry);
+        compat_dump(entry, "val", d_val, sizeof(float) * (size_t)num_e);
+        compat_dump(entry, "x", vin, sizeof(float) * (size_t)num_v * feat);
+        compat_dump(entry, "y", vout, sizeof(float) * (size_t)num_v * feat);
+    }
     float *d_val = nullptr;
     int clock_capacity[2] = {0, 0};  // last answer of clock_blocks(scheduled = 0 / 1)
 };

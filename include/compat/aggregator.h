@@ -52,6 +52,13 @@ public:
         checkGnnagg(gnnagg_csr2edgelist(handle, d_edgelist));
     }
     int *edgelist() const { return d_edgelist; }
+    // GNNAGG_COMPAT_DUMP: the CSR this aggregator runs on (after load_graph's reorder, if any)
+    void dump_graph(const char *entry) const
+    {
+        if (!compat_dump_dir()) return;
+        compat_dump(entry, "ptr", d_ptr, sizeof(int) * ((size_t)num_v + 1));
+        compat_dump(entry, "idx", d_idx, sizeof(int) * (size_t)num_e);
+    }
 
     int feat_in = 0;
     int feat_out = 0;

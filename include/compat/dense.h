@@ -7,5 +7,10 @@ inline void matmul_NN(float *A, float *B, float *C, int inM, int inN, int inK, f
 {
     (void)tmp;
     checkGnnagg(gnnagg_matmul_nn(A, B, C, inM, inN, inK, nullptr));
+    if (compat_dump_dir()) {   // GNNAGG_COMPAT_DUMP (util.h)
+        compat_dump("matmul_NN", "A", A, sizeof(float) * (size_t)inM * inK);
+        compat_dump("matmul_NN", "B", B, sizeof(float) * (size_t)inK * inN);
+        compat_dump("matmul_NN", "C", C, sizeof(float) * (size_t)inM * inN);
+    }
 }
 #endif

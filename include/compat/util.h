@@ -145,6 +145,29 @@ public:
     int num_e = 0;
 };
 
+// GNNAGG_COMPAT_DUMP=<dir> (or `--dump <dir>` of the drivers under drivers/): the class shim writes the operands of the LAST call of each
+// of its entry points as raw little-endian arrays <dir>/<entry point>.<operand>.bin -- device memory copied out behind a device
+// synchronise -- so that a driver's NUMBERS, not only its exit code, can be checked from outside (tests/test_gpu_reference.py,
+// tests/test_gpu_parity.py compare them with the oracle).  The reference's drivers fill their inputs with cuRAND / hipRAND, so the inputs
+// are dumped with the outputs.  Off (one cached getenv) unless the variable is set; timings of a dumping run mean nothing.
+inline const char *compat_dump_dir()
+{
+    static const char *d = getenv("GNNAGG_COMPAT_DUMP");
+    return d && *d ? d : nullptr;
+}
+inline void compat_dump(const char *entry, const char *operand, const void *dev, size_t bytes)
+{
+    const char *d = compat_dump_dir();
+    if (!d || !dev) return;
+    std::vector<char> h(bytes);
+    checkHipErrors(hipDeviceSynchronize());
+    if (bytes) checkHipErrors(hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost));
+    const std::string path = std::string(d) + "/" + entry + "." + operand + ".bin";
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f || fwrite(h.data(), 1, bytes, f) != bytes) FatalError("GNNAGG_COMPAT_DUMP: cannot write " + path);
+    fclose(f);
+}
+
 // --dataset D --feature-len F [--datadir DIR] [--reorder SUFFIX] [--nei N] [--gpu-num N] [--outfea N]
 // [--partition-path P] [--limit N] [--limit2 N]; "--flag value" and "--flag=value" both accepted.
 inline void argParse(int argc, char **argv, int *p_limit = nullptr, int *p_limit2 = nullptr)

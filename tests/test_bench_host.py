@@ -38,6 +38,37 @@ def test_a_missing_supervisor_ends_the_ladder():
     assert bench.agree_on_outcome(0, 2, 7, 0, timeout_s=1.0) == (None, None)
 
 
+def test_agreement_is_per_node():
+    """the files are node-local, so the set a supervisor waits for is its node's ranks (LOCAL_RANK / LOCAL_WORLD_SIZE), never the
+    global WORLD_SIZE; the directory's name carries the launcher's pid AND start time, so nothing has to be removed before use."""
+    sys.path.insert(0, ROOT)
+    import bench
+    # a node with two local ranks of a (say) 16-rank job: the two agree without waiting for 16 files
+    procs = [subprocess.Popen([sys.executable, "-c", CHILD, ROOT, str(r), "2", "0"], stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [json.loads(p.communicate(timeout=60)[0].strip().splitlines()[-1]) for p in procs]
+    assert all(o[0][0] == 0 for o in outs)
+    d = bench.sup_dir()
+    assert str(os.getppid()) in os.path.basename(d) and len(os.path.basename(d).split("_")) >= 6
+    assert bench.agree_on_outcome(0, 1, 99, 0, timeout_s=5.0, need_port=False) == (0, None)
+
+
+def test_summary_is_compact_and_complete():
+    """the last key of the line, <= 1 KB, every record's numbers"""
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = lambda ms: {"ms_per_step": ms, "value": 1e10, "verified_against_oracle": True, "verified_rows": 44,   # noqa: E731
+                      "roofline": {"frac": 0.512345678, "frac_vs_gather_ceiling": 0.7512345}}
+    out = dict(rec(0.0757), config={"num_v": 169343}, no_reorder={"avg_launch_us": 85.123456},
+               configs={"A_rows": rec(0.113), "R": rec(15.28), "G": rec(7.65),
+                        "P1": dict(rec(7.29), no_reorder={"ms_per_step": 8.14, "frac": 0.9, "frac_vs_gather_ceiling": 1.2, "verified_rows": 204,
+                                                           "verified_against_oracle": True})},
+               cpu_baseline={"value": 1.5e8})
+    s = bench.summarize(out)
+    assert len(json.dumps(s)) <= 1024 and s["verified"] is True and s["R"] == [15.28, 0.5123, 0.7512, 44] and s["P1_no_reorder"][0] == 8.14
+    out["configs"]["G"] = {"error": "boom"}
+    assert bench.summarize(out)["verified"] is False
+
+
 def test_byte_models_of_survey_8d():
     sys.path.insert(0, ROOT)
     import bench

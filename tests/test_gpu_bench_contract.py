@@ -29,13 +29,37 @@ def run(args, env=None, launcher=None):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "stdout must carry exactly one JSON line, got %d" % len(lines)
+    check_summary_tail(lines[0])
     return json.loads(lines[0])
+
+
+def check_summary_tail(line):
+    """the driver keeps 2 000 characters of the line's tail and truncates strings -- so the line ENDS with a compact
+    `summary` object (<= 1 KB) that carries every record's numbers, and no string in the line is a paragraph."""
+    d = json.loads(line)
+    assert list(d)[-1] == "summary", list(d)[-3:]
+    tail = json.dumps(d["summary"])
+    assert len(tail) <= 1024 and line.rstrip().endswith(tail + "}"), len(tail)
+
+    def strings(o):
+        if isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, list):
+            for v in o:
+                yield from strings(v)
+        elif isinstance(o, str):
+            yield o
+    long = [t for t in strings(d) if len(t) > 200 and not t.startswith("/")]
+    # (the N > 1 workload / fallback strings say what carried the halo rows and why: they may run to a few hundred characters)
+    assert all(len(t) <= 700 for t in long) and len(long) <= 4, [t[:80] for t in long]
 
 
 def check_common(d, n_gpus, steps, warmup):
     for k in REQUIRED:
         assert k in d, k
-    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
+    # N > 1 lines from ranks that share ONE device say n_gpus = distinct devices and carry the rank count in `ranks` (VERDICT r5 item 6)
+    assert d.get("ranks", d["n_gpus"]) == n_gpus and d["n_gpus"] == d.get("distinct_devices", n_gpus) and d["steps"] == steps and d["warmup"] == warmup
     assert d["unit"] == "edges/s" and d["higher_is_better"] is True and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
@@ -82,6 +106,16 @@ def test_headline_line():
             assert c["worst_ratio_to_1e-5_bound"] <= 1.0
     assert d["configs"]["R"]["roofline"]["bound"] == "l2" and d["configs"]["P1"]["roofline"]["bound"] == "hbm"
     assert d["configs"]["A_rows"]["value"] < d["value"]     # the canonical chains cost more than the balanced order
+    # P1 is timed with the locality reorder applied on load, like the headline; the generator's numbering rides beside it
+    p1 = d["configs"]["P1"]
+    assert p1["with_locality_reorder"]["verified_against_oracle"] is True and "reorder" in p1["config"]["workload"]
+    assert p1["no_reorder"]["verified_against_oracle"] is True and p1["no_reorder"]["value"] > 0 and p1["no_reorder"]["worst_ratio_to_1e-5_bound"] <= 1.0
+    # the summary the driver's tail shows: every record's [ms_per_step, frac, frac_vs_gather_ceiling, verified_rows]
+    sm = d["summary"]
+    assert sm["verified"] is True and set(sm) >= {"A", "A_rows", "R", "G", "P1", "P1_no_reorder", "edges_per_s", "cpu_edges_per_s"}
+    for name in ("A_rows", "R", "G", "P1"):
+        assert abs(sm[name][0] - d["configs"][name]["ms_per_step"]) < 1e-4 and sm[name][3] == d["configs"][name]["verified_rows"]
+    assert abs(sm["A"][0] - d["ms_per_step"]) < 1e-4 and abs(sm["A"][1] - r["frac"]) < 1e-3
 
 
 def test_other_config_line():
@@ -97,6 +131,13 @@ def check_multi(d):
     p = d["products_strong"]      # ONE pass yields the feat-128 line and BASELINE configs[4] over the same ranks
     assert p["scaling"] == "strong" and p["value"] > 0 and p["verified_against_oracle"] is True and p["halo_bytes_per_step_all_ranks"] > 0
     assert "123718280" in p["what"] and p["exposed_comm_ms_per_step"] >= 0
+    # the parts of the step alone, so that the line explains itself (values mean nothing on one GPU, the schema does)
+    for rec in (d, p):
+        q = rec["step_parts"]
+        assert q["exchange_alone_ms"] > 0 and q["local_pass_ms"] > 0 and q["halo_pass_ms"] >= 0 and q["link_gbps_per_peer"] > 0
+        assert abs(q["predicted_step_ms"] - (max(q["exchange_alone_ms"], q["local_pass_ms"]) + q["halo_pass_ms"])) < 1e-9
+    sm = d["summary"]
+    assert sm["ranks"] == d["ranks"] and abs(sm["ms_per_step"] - d["ms_per_step"]) < 1e-3 and "P" in sm and sm["verified"] is True
 
 
 def test_two_ranks_on_one_gpu_over_gloo():
@@ -143,7 +184,7 @@ def check_labelled_as_double(d, fake):
     """a record that says n_gpus = N, rccl_ranks = N from ONE GPU must not be able to pass for a scaling point -- the
     library names the file its nccl* entry points came from (gnnagg_dist_transport_info), the ranks all-gather their PCI bus ids."""
     assert os.path.samefile(d["rccl_library"], fake) and d["rccl_library_is_override"] is True
-    assert d["distinct_devices"] == 1 and len(set(d["device_pci_bus_ids"])) == 1 and len(d["device_pci_bus_ids"]) == d["n_gpus"]
+    assert d["distinct_devices"] == 1 and d["n_gpus"] == 1 and len(set(d["device_pci_bus_ids"])) == 1 and len(d["device_pci_bus_ids"]) == d["ranks"]
     assert d["test_double"] is True and "NOT A SCALING POINT" in d["config"]["workload"] and "test double" in d["transport_is"]
     assert "over xGMI" not in d["config"]["workload"] and "over xGMI" not in d["transport_is"]
 

@@ -491,27 +491,58 @@ def test_hub_rows_block_cooperative_combine(F, ng):
 
 
 def test_cpp_drivers_run(tmp_path):
-    """The C++ class shim (include/compat/) + drivers with the reference's flags and call sequence
-    (Figure9/main.cu, Figure10/main_a.cu) run end to end on a small dataset directory."""
+    """The C++ class shim (include/compat/) + drivers with the reference's flags and call sequence (Figure9/main.cu:59-74,
+    Figure10/main_a.cu:82-110, main_b.cu:86-103) run end to end on a small dataset directory -- and what they COMPUTED is checked, not only
+    that they exit 0: `--dump DIR` makes the shim write the operands of the last call of every entry point
+    (GNNAGG_COMPAT_DUMP, include/compat/util.h) and tests/driver_dumps.py compares them with the oracle at the suite's bounds."""
     import json
     import os
     import subprocess
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import driver_dumps as dd
     d = str(tmp_path) + "/"
-    ptr, idx = gnc.graph.powerlaw_csr(5000, 60000, seed=3)
-    gnc.graph.write_graph_files(d, "tiny", ptr.numpy(), idx.numpy(), text=True)
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(5000, 60000, seed=3)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    gnc.graph.write_graph_files(d, "tiny", ptr, idx, text=True)
     rows = np.random.default_rng(1).permutation(5000).astype(np.int32)
     gnc.graph.write_reorder_file(d, "tiny", rows)
-    for exe, extra in (("fig9.out", ["--reorder", "_thres_0.2"]), ("fig9.out", []), ("fig10a.out", ["--nei", "32"]),
-                       ("fig10b.out", ["--outfea", "32"]), ("fig8.out", ["--nei", "16"])):
+    rptr, ridx, _, _ = orc.reorder_csr(ptr, idx, rows)
+    F = 64
+    cases = (("fig9.out", ["--reorder", "_thres_0.2"], {}), ("fig9.out", [], {"GNNAGG_FAST_ROWS": "0"}), ("fig10a.out", ["--nei", "32"], {}),
+             ("fig10b.out", ["--outfea", "32"], {}), ("fig8.out", ["--nei", "16"], {}))
+    for k, (exe, extra, env) in enumerate(cases):
         path = os.path.join(root, "drivers", exe)
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", os.path.join(root, "drivers")])
-        r = subprocess.run([path, "--dataset", "tiny", "--datadir", d, "--feature-len", "64"] + extra,
-                           capture_output=True, text=True, timeout=300)
+        dump = os.path.join(d, "dump%d" % k)
+        os.makedirs(dump)
+        r = subprocess.run([path, "--dataset", "tiny", "--datadir", d, "--feature-len", str(F), "--dump", dump] + extra,
+                           capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")]
         assert len(lines) >= 2 and all(l.get("seconds", l.get("actual_seconds", 0)) > 0 for l in lines)
+        p, i = (rptr, ridx) if "--reorder" in extra else (ptr, idx)
+        if exe == "fig9.out":
+            # run(x, y, B, 0): the balanced order by default (inside the bound), aggr_gcn's own chain -- bit-equal -- with GNNAGG_FAST_ROWS=0
+            dd.gcn(dump, "gcn_run_s0", p, i, F, exact=env.get("GNNAGG_FAST_ROWS") == "0")
+            dd.gcn(dump, "gcn_run_s1", p, i, F)
+            dd.gcn(dump, "gcn_run_balanced", p, i, F)
+        elif exe == "fig10a.out":
+            dd.edge_softmax_stages(dump, p, i, with_exp=True)
+            dd.gcn(dump, "gcn_run_s1", p, i, F)            # the adapter: weighted SpMM with run_att's values (aggr_gcn.h:540-544)
+            w = dd.read(dump, "gcn_run_s1", "val")
+            np.testing.assert_allclose(w, dd.read(dump, "gat_run_att", "val"), rtol=0, atol=0)
+            dd.gat(dump, "gat_run_s1", p, i, F)
+            dd.gat(dump, "gat_run_heads", p, i, F)
+            # adapter == fused (Figure 10a's claim), both inside the bound of the same edge softmax
+            ya, yf = dd.read(dump, "gcn_run_s1", "y"), dd.read(dump, "gat_run_s1", "y")
+            assert np.allclose(ya, yf, rtol=1e-4, atol=1e-5)
+        elif exe == "fig10b.out":
+            dd.gcn(dump, "gcn_run_s1", p, i, F)
+            dd.matmul(dump, M=5000, K=F, N=32)
+            dd.run_with_nn(dump, p, i, F, 32)
 
 
 @pytest.mark.parametrize("H", [1, 3, 4])

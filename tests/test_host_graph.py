@@ -160,3 +160,24 @@ def test_halo_stage_plan_both_ends_of_every_pair_agree(world, mode, k):
             assert np.array_equal(plans[r][1][:, q], plans[q][0][:, r])      # what r sends q in a stage is what q expects from r
     assert L.gnnagg_halo_stage_plan(None, None, 0, 0, 0, 1, ctypes.byref(ns), None, None, None, None) != 0
     assert L.gnnagg_halo_stage_plan(None, None, 2, 0, 0, 0, ctypes.byref(ns), None, None, None, None) != 0
+
+
+def test_reorder_on_load_goes_through_the_reference_file_formats(tmp_path):
+    """gnc.graph.reorder_on_load (what bench.py's arms with the locality reorder use): the permutation of the library's generator is written
+    as <dset>.reorder_thres_0.2 beside the .ptrdump / .edgedump caches and applied by gnnagg_load_graph exactly like src/data.cu:96-133 --
+    arrays equal to reorder_csr on the same permutation and to the oracle's restatement of reorderCSR; a second call finds the file."""
+    import gnn_computing_amd as gnc
+    from oracle import oracle as orc
+    ptr_t, idx_t = gnc.graph.powerlaw_csr(3000, 40000, seed=9)
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    p1, i1, rows, t_gen, _ = gnc.graph.reorder_on_load("tiny", ptr, idx, key="k", cache_dir=str(tmp_path))
+    assert t_gen > 0 and sorted(rows.tolist()) == list(range(3000))
+    files = set(os.listdir(tmp_path))
+    assert {"tiny_k.config", "tiny_k.graph.ptrdump", "tiny_k.graph.edgedump", "tiny_k.reorder_thres_0.2"} <= files
+    assert np.array_equal(np.array(open(tmp_path / "tiny_k.reorder_thres_0.2").read().split(), np.int32), rows)
+    q, j, _ = gnc.reorder_csr(ptr, idx, rows)
+    assert np.array_equal(p1, q) and np.array_equal(i1, j)
+    op, oi, _, _ = orc.reorder_csr(ptr, idx, rows)
+    assert np.array_equal(p1, op) and np.array_equal(i1, oi)
+    p2, i2, rows2, t_gen2, _ = gnc.graph.reorder_on_load("tiny", ptr, idx, key="k", cache_dir=str(tmp_path))
+    assert t_gen2 == 0.0 and np.array_equal(rows2, rows) and np.array_equal(i2, i1)
