@@ -528,7 +528,8 @@ def measure_config(cfg, args, dev, graph=None):
     def measure_arm(agg, ptr_a, idx_a, tag):
         """time_steps + oracle check + gather probe + roofline of one aggregator over one numbering of the graph"""
         if cfg == "G":
-                probe = lambda: agg.probe_gather(x, att, "balanced", heads=H)  # noqa: E731
+            step = lambda: agg.run(x, att, y, 128, "balanced", heads=H)  # noqa: E731
+            probe = lambda: agg.probe_gather(x, att, "balanced", heads=H)  # noqa: E731
         else:
             step = lambda: agg.run(x, y, 512, "balanced", reduce="mean" if cfg == "R" else "sum")  # noqa: E731
             probe = lambda: agg.probe_gather(x, "balanced")  # noqa: E731
@@ -1168,7 +1169,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        out = run_multi(args, dev, rank, world, dog)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):   # (a non-null stream: see below)
+            out = run_multi(args, dev, rank, world, dog)
         dist.barrier()
         dist.destroy_process_group()
     else:
@@ -1176,7 +1178,12 @@ def main():
             raise SystemExit("--gpus %d: WORLD_SIZE is 1 in the environment" % args.gpus)
         if args.config == "P":
             args.config = "P1"
-        out = run_single(args, dev) if args.config == "A" else run_other_config(args, dev)
+        # Everything is launched and timed on ONE NON-NULL stream.  On the null stream HIP orders every launch against the process's other
+        # streams: as soon as any other stream exists (the rows mode forks two, a framework always has some) back-to-back null-stream
+        # launches no longer overlap head to tail and a 74 us launch costs 79-87 us on the DEVICE (host time per call unchanged, 8 us;
+        # the same launches on a non-null stream stay at 74 us in every state: tests/perf_reorder_discrepancy.py host).
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            out = run_single(args, dev) if args.config == "A" else run_other_config(args, dev)
     if rank == 0 and out is not None:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

@@ -92,7 +92,14 @@ def big():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "big":
-        big()
-    else:
-        main()
+    # On ONE NON-NULL stream (round 6).  Rounds 2-5 timed on the null stream, where HIP orders every launch against the
+    # process's other streams: after oracle/_ref's kernels and the rows mode (which forks two streams) had run, back-to-back null-stream
+    # launches of the 74 us balanced kernel cost 79-87 us on the device -- exactly the locality reorder's gain, which is why this file
+    # showed 85.8 vs 86.2 us ("no gain") while bench.py, in a process that had only ever used the null stream, showed 85.2 -> 73.5 us
+    # (tests/perf_reorder_discrepancy.py host: null stream 74.5 -> 79.4 -> 82.3 us as streams appear, non-null stream 74.4-74.5 us in
+    # every state, host time per call 8 us throughout).
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        if len(sys.argv) > 1 and sys.argv[1] == "big":
+            big()
+        else:
+            main()

@@ -73,5 +73,128 @@ def main():
         case("after the hipified reference's kernels ran in this process", with_ref)
 
 
+def xcd_mapping():
+    """Second question: does the blockIdx -> XCD assignment the kernels' range mapping assumes (workgroup b runs on XCD b % 8) still hold
+    after the process has run the rows mode (forked streams -> more hardware queues)?  The instrumented launch (run_clock: s_memrealtime +
+    __smid per workgroup) answers it: share of workgroups whose XCC id equals (b + k) % 8 for the best constant k, before and after."""
+    ptr_t, idx_t = gnc.graph.dataset("arxiv")
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    rows, _ = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=8192)
+    rptr, ridx, _ = gnc.reorder_csr(ptr, idx, rows)
+    V, E, F = len(ptr) - 1, len(idx), 128
+    x = np.random.default_rng(123).standard_normal((V, F), dtype=np.float32)
+    dp, di = torch.from_numpy(rptr).to(dev), torch.from_numpy(ridx).to(dev)
+    dx, dy = torch.from_numpy(x).to(dev), torch.empty((V, F), device=dev)
+
+    def mapping(agg, tag):
+        t = agg.run_clock(dx, dy, 64, 0).cpu().numpy()
+        smid = t[:, 2].astype(np.int64)
+        b = np.arange(len(smid))
+        best = {}
+        for shift in range(4, 12):
+            xcc = (smid >> shift) & 7
+            if len(np.unique(xcc)) < 8:
+                continue
+            best[shift] = max(float(np.mean(xcc == (b + k) % 8)) for k in range(8))
+        print(json.dumps({"state": tag, "workgroups": int(len(smid)), "distinct_smid": int(len(np.unique(smid))),
+                          "share_on_xcd_b_mod_8_by_shift": best}), flush=True)
+
+    agg = gnc.Aggregator_GCN(dp, di, torch.ones(E, device=dev), F, F)
+    agg.schedule_balanced(0)
+    print(json.dumps({"state": "fresh process", "balanced_us": round(ours(lambda: agg.run(dx, dy, 512, "balanced")), 2)}), flush=True)
+    mapping(agg, "fresh process")
+    print(json.dumps({"state": "after run_clock", "balanced_us": round(ours(lambda: agg.run(dx, dy, 512, "balanced")), 2)}), flush=True)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        torch.zeros(16, device=dev).add_(1)
+    torch.cuda.synchronize()
+    print(json.dumps({"state": "after a second torch stream ran a kernel", "balanced_us": round(ours(lambda: agg.run(dx, dy, 512, "balanced")), 2)}), flush=True)
+    ours(lambda: agg.run(dx, dy, 512, 0))
+    print(json.dumps({"state": "after 60 rows-mode runs", "balanced_us": round(ours(lambda: agg.run(dx, dy, 512, "balanced")), 2)}), flush=True)
+    mapping(agg, "after 60 rows-mode runs")
+    agg2 = gnc.Aggregator_GCN(dp, di, torch.ones(E, device=dev), F, F)
+    agg2.schedule_balanced(0)
+    print(json.dumps({"state": "a NEW handle after the rows-mode runs", "balanced_us": round(ours(lambda: agg2.run(dx, dy, 512, "balanced")), 2)}), flush=True)
+    torch.cuda.synchronize()
+    import time
+    time.sleep(2.0)
+    print(json.dumps({"state": "after 2 s of idling", "balanced_us": round(ours(lambda: agg2.run(dx, dy, 512, "balanced")), 2)}), flush=True)
+    for it in (200, 1000):
+        print(json.dumps({"state": "%d back-to-back launches" % it, "balanced_us": round(ours(lambda: agg2.run(dx, dy, 512, "balanced"), 10, it), 2)}), flush=True)
+
+
+def host_or_device():
+    """Third question: is the slow state a slower KERNEL or a slower LAUNCH?  Per state: host seconds per call (no synchronise inside the
+    loop), device seconds per launch from one event pair around 200 launches, the kernel alone from a captured HIP graph of 20 launches
+    (no host between them), and the same launches issued on a non-null stream."""
+    import time
+    ptr_t, idx_t = gnc.graph.dataset("arxiv")
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    rows, _ = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=8192)
+    rptr, ridx, _ = gnc.reorder_csr(ptr, idx, rows)
+    V, E, F = len(ptr) - 1, len(idx), 128
+    x = np.random.default_rng(123).standard_normal((V, F), dtype=np.float32)
+    dp, di = torch.from_numpy(rptr).to(dev), torch.from_numpy(ridx).to(dev)
+    dx, dy = torch.from_numpy(x).to(dev), torch.empty((V, F), device=dev)
+    agg = gnc.Aggregator_GCN(dp, di, torch.ones(E, device=dev), F, F)
+    agg.schedule_balanced(0)
+    fn = lambda: agg.run(dx, dy, 512, "balanced")  # noqa: E731
+
+    def host_us(n=300):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        t = (time.perf_counter() - t0) / n * 1e6
+        torch.cuda.synchronize()
+        return round(t, 2)
+
+    def graph_us():
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            fn()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(20):
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                g.replay()
+            b.record()
+            torch.cuda.synchronize()
+        return round(a.elapsed_time(b) * 1e3 / 100, 2)
+
+    def side_stream_us():
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            return round(ours(fn, 10, 200), 2)
+
+    def state(tag, with_graph=True):
+        out = {"state": tag, "null_stream_device_us": round(ours(fn, 10, 200), 2), "null_stream_host_us_per_call": host_us()}
+        print(json.dumps(out), flush=True)
+
+    state("fresh process: only the null stream has ever been used")
+    out = {"state": "same process, launches on a NON-null stream", "side_stream_device_us": side_stream_us()}
+    print(json.dumps(out), flush=True)
+    state("after that side stream existed")
+    print(json.dumps({"state": "captured HIP graph of 20 launches (no host between them)", "graph_device_us": graph_us()}), flush=True)
+    ours(lambda: agg.run(dx, dy, 512, 0))
+    state("after 60 rows-mode runs (the library forks two more streams)")
+    print(json.dumps({"state": "after the rows-mode runs: NON-null stream", "side_stream_device_us": side_stream_us()}), flush=True)
+    print(json.dumps({"state": "after the rows-mode runs: captured graph", "graph_device_us": graph_us()}), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "xcd":
+        xcd_mapping()
+    elif len(sys.argv) > 1 and sys.argv[1] == "host":
+        host_or_device()
+    else:
+        main()
