@@ -610,7 +610,15 @@ def measure_config(cfg, args, dev, graph=None):
 
 
 def run_other_config(args, dev):
-    return measure_config(args.config, args, dev)
+    rec = measure_config(args.config, args, dev)
+    r = rec["roofline"]
+    rec["summary"] = {"fields": ["ms_per_step", "roofline.frac", "frac_vs_gather_ceiling", "verified_rows"],
+                      args.config: [round(rec["ms_per_step"], 5), round(r["frac"], 4), round(r["frac_vs_gather_ceiling"], 4), rec["verified_rows"]],
+                      "edges_per_s": round(rec["value"]), "verified": rec["verified_against_oracle"] is True}
+    if rec.get("no_reorder"):
+        nr = rec["no_reorder"]
+        rec["summary"][args.config + "_no_reorder"] = [round(nr["ms_per_step"], 5), round(nr["frac"], 4), round(nr["frac_vs_gather_ceiling"], 4), nr["verified_rows"]]
+    return rec
 
 
 def measure_rows_mode(args, dev, nptr, nidx, val, x_rows, ceil):

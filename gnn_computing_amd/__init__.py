@@ -12,5 +12,5 @@ from .aggregator import (  # noqa: F401
 )
 from . import graph  # noqa: F401
 from . import probe  # noqa: F401
-from . import autograd  # noqa: F401
-from .autograd import gat_aggregate, gcn_aggregate  # noqa: F401
+# (gnn_computing_amd.extras -- torch.autograd wrappers over the backward entry points -- needs libgnnagg_extras.so: out of scope per
+# SURVEY 2.2, not imported here)

@@ -73,8 +73,6 @@ SIGNATURES = {
     "gnnagg_gat_run_u_add_v": (c_int, [c_int64, c_void_p, c_void_p]),
     "gnnagg_gat_run_add_to_center": (c_int, [c_int64, c_void_p, c_void_p]),
     "gnnagg_gat_run_div_each": (c_int, [c_int64, c_void_p, c_void_p]),
-    "gnnagg_gcn_run_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_int]),
-    "gnnagg_gat_run_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int]),
     "gnnagg_spmm_naive": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gnnagg_validate": (c_int, [c_void_p, c_void_p, c_int, P_INT, c_void_p]),
     "gnnagg_validate_reordered": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, P_INT, c_void_p]),
@@ -114,7 +112,14 @@ SIGNATURES = {
                                      c_void_p]),
 }
 
+# Section E of the header: only libgnnagg_extras.so (-DGNNAGG_EXTRAS; GNNAGG_LIB=.../libgnnagg_extras.so) exports these
+EXTRA_SIGNATURES = {
+    "gnnagg_gcn_run_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_int]),
+    "gnnagg_gat_run_bwd": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int]),
+}
+
 _lib = None
+_has_extras = False
 
 
 class GnnAggError(RuntimeError):
@@ -136,9 +141,22 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        global _has_extras
+        _has_extras = all(hasattr(L, name) for name in EXTRA_SIGNATURES)
+        if _has_extras:
+            for name, (res, args) in EXTRA_SIGNATURES.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
         L.gnnagg_set_abort_on_error(0)  # Python callers get exceptions, not exit(1)
         _lib = L
     return _lib
+
+
+def has_extras():
+    """True when the loaded library is libgnnagg_extras.so (backward entry points, the older kernel forms): second-tier tests only."""
+    lib()
+    return _has_extras
 
 
 def check(rc):

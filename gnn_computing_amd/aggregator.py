@@ -47,6 +47,13 @@ def _dev_ptr(t, dtype, name):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _need_extras(what):
+    """the backward entry points are out of scope and ship in libgnnagg_extras.so only"""
+    if not _lib.has_extras():
+        raise RuntimeError("%s: the loaded libgnnagg.so has no backward entry points (SURVEY.md 2.2: out of scope); build "
+                           "`make -C gnn_computing_amd/csrc extras` and load it with GNNAGG_LIB=.../libgnnagg_extras.so" % what)
+
+
 def _mode(scheduled):
     if isinstance(scheduled, str):
         return MODE[scheduled]
@@ -228,6 +235,7 @@ class Aggregator_GCN(Aggregator):
     def run_bwd(self, doutput, dinput):
         """d(input) = A^T . d(output) for the sum aggregation with this aggregator's edge values (extension: the reference
         is forward-only).  Deterministic gather over the transposed CSR."""
+        _need_extras("Aggregator_GCN.run_bwd")
         self._use_current_stream()
         check(lib().gnnagg_gcn_run_bwd(self._h, _dev_ptr(doutput, torch.float32, "doutput"),
                                        _dev_ptr(dinput, torch.float32, "dinput"), int(doutput.shape[1])))
@@ -311,6 +319,7 @@ class Aggregator_GAT(Aggregator):
         d_a_b [V,2] (centre / source attention terms) are overwritten.  See gnnagg_gat_run_bwd for what the reference
         kernel leaves out."""
         self._use_current_stream()
+        _need_extras("Aggregator_GAT.run_bwd")
         check(lib().gnnagg_gat_run_bwd(self._h, _dev_ptr(output, torch.float32, "output"),
                                        _dev_ptr(doutput, torch.float32, "doutput"), _dev_ptr(newval, torch.float32, "newval"),
                                        _dev_ptr(div, torch.float32, "div"), _dev_ptr(infeat, torch.float32, "infeat"),

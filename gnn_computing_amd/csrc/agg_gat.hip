@@ -529,6 +529,22 @@ int launch_gat_plan(const GatPlanLaunch &L, void *stream_v)
     return GNNAGG_OK;
 }
 
+// edge values follow a permuted edge list (val_t[e'] = val[perm[e']]): the partitioned orders re-gather them before every run
+__global__ void k_permute_val(const int *__restrict__ perm, const float *__restrict__ val, float *__restrict__ val_t, int E)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) val_t[e] = val ? val[perm[e]] : 1.0f;
+}
+
+int launch_permute_val(const int *perm, const float *val, float *val_t, int E, void *stream_v)
+{
+    if (E <= 0) return GNNAGG_OK;
+    hipLaunchKernelGGL(k_permute_val, dim3(ceil_div(E, 256)), dim3(256), 0, (hipStream_t)stream_v, perm, val, val_t, E);
+    HIP_TRY(hipGetLastError());
+    return GNNAGG_OK;
+}
+
+#ifdef GNNAGG_EXTRAS   // the backward kernels ship in libgnnagg_extras.so only (api_extras.hip)
 // ------------------------------------------------------------ backward of the single-head fused aggregation
 // Reference: aggr_gat_fine_bwd (aggr_gat.h:222-296, marked "Experiment"; run_bwd :426-434).  With w_e = newval[e] and
 // D_r = div[r] saved by the forward pass, p_e = w_e / D_r:
@@ -657,12 +673,6 @@ __global__ void k_gat_bwd_permute(const int *__restrict__ perm, const int *__res
 }
 
 // val_t[e'] = val[perm[e']] (1 when the aggregator has implicit unit weights): the edge values of the transposed graph
-__global__ void k_permute_val(const int *__restrict__ perm, const float *__restrict__ val, float *__restrict__ val_t, int E)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < E) val_t[e] = val ? val[perm[e]] : 1.0f;
-}
-
 __global__ void k_interleave2(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -706,14 +716,6 @@ int launch_gat_bwd_permute(const int *perm, const int *idx_t, const float *dz, c
     return GNNAGG_OK;
 }
 
-int launch_permute_val(const int *perm, const float *val, float *val_t, int E, void *stream_v)
-{
-    if (E <= 0) return GNNAGG_OK;
-    hipLaunchKernelGGL(k_permute_val, dim3(ceil_div(E, 256)), dim3(256), 0, (hipStream_t)stream_v, perm, val, val_t, E);
-    HIP_TRY(hipGetLastError());
-    return GNNAGG_OK;
-}
-
 int launch_interleave2(const float *a, const float *b, float *out, int n, void *stream_v)
 {
     if (n <= 0) return GNNAGG_OK;
@@ -721,5 +723,7 @@ int launch_interleave2(const float *a, const float *b, float *out, int n, void *
     HIP_TRY(hipGetLastError());
     return GNNAGG_OK;
 }
+
+#endif  // GNNAGG_EXTRAS
 
 }  // namespace gnnagg

@@ -14,8 +14,7 @@
 #include <set>
 #include <vector>
 
-#include "common.h"
-#include "devbuf.h"
+#include "api_internal.h"
 
 namespace gnnagg {
 
@@ -28,188 +27,17 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
-// One schedule = the reference's (d_ptr_scheduled, d_idx_scheduled, d_target_scheduled,
-// d_val_scheduled, num_target) of aggregator.h:130-133 plus what the deterministic combine needs.
-struct Schedule {
-    bool valid = false;
-    int kind = GNNAGG_SCHED_NOP;
-    int num_target = 0;
-    bool permuted = false;  // locality schedules permute idx/val; neighbor grouping aliases them
-    bool gpu_built = false; // library-built blocked order made on the device (plan_gpu.hip): per-edge arrays exist on the device only
-                            // (idx_f, eperm), the descriptor form (slot, mrow_*, idx_s) does not exist at all
-    int n_edges_perm = 0;   // ... and its edge count
-    int total_cols = 0;     // locality schedules: the column count the ranges were cut from
-    int par_num = 0;        // locality schedules: the number of column ranges
-    std::vector<int> h_ptr_s, h_target, h_idx_s, h_slot, h_empty;
-    std::vector<int> h_eperm;  // library-built permuted schedules: host copy of eperm while a plan is being cut from it (build_rows_blocked)
-    std::vector<float> h_val_s;
-    DevBuf<int> ptr_s, target, slot, empty_rows, mrow_id, mrow_ptr, idx_s, big_rows;
-    DevBuf<int> eperm;      // library-built permuted schedules: original edge of every permuted position (val follows its edges)
-    // segmented-stream form of a library-built partitioned order (agg_span.hip)
-    DevBuf<int> idx_f, span_g, crows, rg_ptr, rg_idx;
-    int n_spans = 0, n_crows = 0;
-    std::vector<long> span_cost_prefix;
-    int n_big = 0;
-    DevBuf<float> val_s;
-    int n_empty = 0, n_mrows = 0, n_slots = 0;
-    std::vector<long> cost_prefix;  // per work item (groups then empty-row items), for the XCD ranges
+std::mutex g_mu;
+std::set<Ctx *> g_live;
 
-    void reset()
-    {
-        valid = false;
-        ptr_s.release(); target.release(); slot.release(); empty_rows.release();
-        mrow_id.release(); mrow_ptr.release(); idx_s.release(); val_s.release(); big_rows.release(); eperm.release(); n_big = 0;
-        idx_f.release(); span_g.release(); crows.release(); rg_ptr.release(); rg_idx.release(); n_spans = n_crows = 0;
-        span_cost_prefix.clear();
-        h_ptr_s.clear(); h_target.clear(); h_idx_s.clear(); h_val_s.clear(); h_slot.clear(); h_empty.clear(); h_eperm.clear();
-        cost_prefix.clear();
-        num_target = n_empty = n_mrows = n_slots = 0;
-        permuted = gpu_built = false;
-        n_edges_perm = 0;
-    }
-    WorkList worklist() const
-    {
-        WorkList w;
-        w.ptr = ptr_s.p; w.target = target.p; w.slot = slot.p; w.empty_rows = empty_rows.p;
-        w.n_items = num_target; w.n_empty = n_empty;
-        w.mrow_id = mrow_id.p; w.mrow_ptr = mrow_ptr.p; w.n_mrows = n_mrows; w.n_slots = n_slots;
-        w.big_rows = big_rows.p; w.n_big = n_big;
-        return w;
-    }
-};
-
-// GNNAGG_MODE_BALANCED plan of a GCN aggregator (k_gcn_plan): short rows, long-row segments, hub slots.
-struct BalancedPlan {
-    bool valid = false;
-    int chunk = 64;
-    int n0 = 0, n1 = 0, n_mrows = 0, n_slots = 0, n_big = 0;
-    DevBuf<int> t0, t1, mrow_id, mrow_ptr, big_rows, slot_hub;
-    std::vector<long> t0_cost_prefix;
-    // the same short-row descriptors, degree-sorted inside windows (built on first use by a narrow-feature run)
-    std::vector<int> h_t0;
-    DevBuf<int> t0_sorted;
-    std::vector<long> t0s_cost_prefix;
-    void reset()
-    {
-        valid = false;
-        t0.release(); t1.release(); mrow_id.release(); mrow_ptr.release(); big_rows.release(); slot_hub.release();
-        t0_cost_prefix.clear(); h_t0.clear(); t0_sorted.release(); t0s_cost_prefix.clear();
-        n0 = n1 = n_mrows = n_slots = n_big = 0;
-    }
-};
-static constexpr int kSegChunksHost = 16;  // kSegChunks in kernel_util.cuh
-
-// GNNAGG_MODE_ROWS plan of a GCN aggregator: short rows per lane group (r0), hub rows per 512-thread workgroup (r1), the rows
-// between the two per 128-thread workgroup (r2: "medium").  r1_rows lists the rows of r1 then r2 (products of the fused GEMM).
-struct RowsPlan {
-    bool valid = false;
-    bool medium_ok = true;   // false: built without the medium class (a GAT head width the long-row kernel cannot serve)
-    int n0 = 0, n1 = 0, n2 = 0, long_deg = 256, med_deg = 256;
-    DevBuf<int> r0, r1, r2, r1_rows;
-    std::vector<long> r0_cost_prefix;
-};
-
-static constexpr int kItemCost = 2;  // fixed per-item overhead in edge-equivalents (XCD range balancing)
-
-struct Ctx {
-    enum Kind { GCN, GAT } kind;
-    int V = 0, E = 0;
-    const int *d_ptr = nullptr;
-    const int *d_idx = nullptr;
-    const float *d_val = nullptr;
-    const int *row_aux = nullptr;  // gnnagg_set_row_aux (row-partitioned mean / max: see finish_gcn_row)
-    hipStream_t stream = nullptr;
-    std::vector<int> h_ptr;  // host mirror, fetched on first schedule (reference ctor: aggregator.h:50)
-    Schedule sched[2];       // [0] user schedule (MODE_SCHEDULED), [1] balanced (MODE_BALANCED; GAT, and the
-                             //     host arrays that describe the GCN plan's summation order)
-    BalancedPlan plan;       // balanced mode
-    BalancedPlan plan_sched; // `scheduled = 1` with a neighbor-grouping schedule, when the plan kernel suits that NG
-    BalancedPlan plan_part;  // source-partitioned balanced mode: one short-row descriptor per group of sched[1]
-    // canonical rows mode on the blocked order (option "rows_blocked"; build_rows_blocked / run_rows_blocked)
-    struct RowsBlocked {
-        bool tried = false, ok = false;
-        Schedule sched;                          // the reference's locality_schedule arrays: one group per (row, range)
-        DevBuf<int> span_g, idx_f;
-        DevBuf<int> r1;                          // rows with a sub-row too long for one lane group: {beg, end, row, 0} for k_gcn_rows_long
-        DevBuf<unsigned char> hub_mask;          // [V] 1 for those rows (the un-tiling pass leaves their rows of y alone)
-        int n1 = 0;
-        std::vector<int> span0;                  // [ranges + 1] first span of every range
-        std::vector<std::vector<long>> cost;     // per range: edges before every span of the range
-        void reset() { tried = ok = false; sched.reset(); span_g.release(); idx_f.release(); r1.release(); hub_mask.release(); n1 = 0; span0.clear(); cost.clear(); }
-    } rb;
-    bool keep_h_eperm = false;   // build_locality keeps the host copy of eperm (the plan being built filters its groups)
-    DevBuf<float> yt;        // tiled image of Y the chains of that mode pass through
-    DevBuf<float> den_t;     // ... and, GAT, the per-tile image of the softmax denominators
-    int opt_rows_blocked = 1;
-    int opt_hub_tile = 0;       // "rows_hub_tile": column-tile width of the 512-thread long-row form, GCN flavours (0: the launcher's rule; 32; 64)
-    int opt_rows_medium = 0;    // "rows_medium_edges": rows above this many edges (up to the hub threshold) take the 128-thread workgroups (0: library rule, -1: none)
-    int opt_rb_hub_edges = 0;   // "rows_hub_edges": rows with a (row, range) sub-row above this many edges leave the chained launches (0: library rule)
-    RowsPlan rows_plan;      // GCN rows mode
-    hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    Schedule sched_edges;    // chunked work items of the edge kernels (run_att, u_add_v, add_to_center, div_each)
-    DevBuf<float> den;       // [V,heads] row sums of run_att
-    DevBuf<float> partial, partial_den;
-    DevBuf<float> xt;      // 2-D blocked mode: column-tiled image of X, rebuilt by every run (k_tile_x)
-    DevBuf<float> att_t;   // 2-D blocked GAT: compact source / centre attention terms per head group, rebuilt by every run (k_tile_att)
-    int tiled = 1;         // source-partitioned balanced mode runs tile-major on the tiled image (GNNAGG_TILED=0: r01 order)
-    // gnnagg_set_option knobs (defaults from the environment, see create())
-    int opt_partitions = -1;   // -1: library decides (avg degree >= opt_part_min_deg), 0: never partition, N: N source ranges
-    int opt_part_min_deg = 96;   // measured crossover of the blocked order against the chunked plan (profiles/r02/partition_threshold.txt)
-    int opt_tile_w = 64;       // floats per column tile of the 2-D blocked mode
-    int opt_slice_kb = 4096;   // target size of the X slice one XCD's L2 holds (measured optimum 4-6 MB on the reddit-shaped F=602 case)
-    int opt_retile = 1;        // 0: gather from the caller's X when its rows are 128-byte aligned
-    int opt_scratch_limit_mb = 0;  // > 0: the blocked order may not take more scratch than this (else: half of the free memory)
-    int use_spans = 1;         // GCN, tiled: the segmented-stream kernel (agg_span.hip); 0: one descriptor per lane group
-    // `scheduled = 0` (GNNAGG_MODE_ROWS): 0 = canonical CSR-order chains, bit-exact against a sequential loop -- the default of
-    // the status-returning API; 1 = the balanced order (within 1e-5 of it) -- the default of the reference-facing surfaces
-    // (flat *_impl API, class shim, pybind names: gnnagg_set_option "reference_defaults").  GNNAGG_FAST_ROWS overrides both.
-    int fast_rows = 0;
-    bool fast_rows_from_env = false;
-    // `scheduled = 1`: 1 (default) = the balanced order -- the reference's scheduled kernels add their group partials with
-    // atomicAdd (aggr_gcn.h:112, aggr_gat.h:196-203), so ANY association is one of its legal results; num_target /
-    // get_schedule / mode_params(SCHEDULED) keep describing the user's groups, the order that runs is the one
-    // get_schedule(BALANCED) / balanced_params describe.  0 = the user's groups folded in the restated order (what the
-    // bit-exact parity tests of the scheduled mode pin).  GNNAGG_FAST_SCHEDULED / option "fast_scheduled".
-    int fast_scheduled = 1;
-    int use_aux_stream = 1;    // rows mode: hub rows on a second stream beside the short rows (0: same stream, one after the other)
-    DevBuf<int> edgelist;  // runEdgeWise cache (aggr_gcn.h:452-453)
-    int xcd_remap = 2;         // 0 identity, 1 equal-count XCD ranges, 2 work-balanced XCD ranges
-    DevBuf<int> hub_count;  // arrival counters of the in-kernel hub fold (zero between launches)
-    int inkernel_combine = 1;  // GNNAGG_INKERNEL_COMBINE=0: hubs through k_combine (A/B)
-    int sort_window = 2048;    // narrow features: short-row descriptors degree-sorted inside windows of this many rows
-    int use_plan = 1;          // GCN balanced mode runs k_gcn_plan (0: items + combine, the round-1 first design)
-    int partitions = 0;        // > 0: the balanced mode is SOURCE-PARTITIONED (high-degree graphs, see auto_partitions)
-    int part_descriptors = 1;  // run it on the plan kernels' descriptor path (GNNAGG_PART_DESC=0: item kernels)
-    int no_auto_partition = 0; // set when a run found the partial-row scratch too large: the handle stays on the chunked plan
-    int force_host_plan = 0;   // set when a run needed the descriptor form of the blocked order (GAT head widths the span kernel does not tile,
-                               // "spans" / "tiled" = 0): the order is then built by the host builder, which makes both forms
-    double rb_plan_seconds = 0.0;   // ... of the chain plan of the rows mode (build_rows_blocked)
-    double plan_seconds = 0.0; // wall time of the last library-chosen plan construction (gnnagg_plan_info)
-    size_t plan_bytes = 0;     // device bytes the plan's arrays hold
-    std::vector<long> row_cost_prefix;  // MODE_ROWS work items
-    // GAT backward (run_bwd): the transposed graph -- row s of A^T lists the destination rows of the edges whose source is
-    // s, in ascending original edge order; perm[e'] = original edge id -- and a GCN aggregator over it
-    struct Transposed {
-        bool valid = false;
-        DevBuf<int> ptr_t, idx_t, perm;
-        DevBuf<float> val_t, dz, dz_t, rowdot, da, db;
-        gnnagg_handle agg = 0;
-    } tr;
-    int avg_deg() const { return V > 0 ? (int)((long)E / V) : 0; }
-};
-
-static std::mutex g_mu;
-static std::set<Ctx *> g_live;
-
-static Ctx *lookup(gnnagg_handle h)
+Ctx *lookup(gnnagg_handle h)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     Ctx *c = reinterpret_cast<Ctx *>(h);
     return g_live.count(c) ? c : nullptr;
 }
 
-static int fetch_host_ptr(Ctx *c)
+int fetch_host_ptr(Ctx *c)
 {
     if (!c->h_ptr.empty()) return GNNAGG_OK;
     c->h_ptr.resize((size_t)c->V + 1);
@@ -822,17 +650,14 @@ static int reserve_hub_counters(Ctx *c, int n_mrows, int feat, int *stride_out)
     if (c->hub_count.n < want) {
         int rc = c->hub_count.reserve(want);
         if (rc) return rc;
-        HIP_TRY(hipMemset(c->hub_count.p, 0, c->hub_count.n * sizeof(int)));
+        // stream-ordered with the launch that uses them: a null-stream hipMemset is NOT ordered against a caller's non-blocking stream
+        // (round 6: one first step in ~12 folded its hubs on counters that were not zero yet)
+        HIP_TRY(hipMemsetAsync(c->hub_count.p, 0, c->hub_count.n * sizeof(int), c->stream));
     }
     *stride_out = stride;
     return GNNAGG_OK;
 }
 
-struct NnRequest {  // run_with_nn: transformed[V, cols] = y . weight[feat, cols]
-    const float *weight;
-    float *out;
-    int cols;
-};
 
 // Canonical rows mode (GNNAGG_MODE_ROWS: one sequential chain per (row, column) in CSR order, aggr_gcn.h:13-35) on the 2-D blocked
 // order.  If every row lists its neighbors in ascending order, the row's sub-rows per source range, taken range after range, ARE the
@@ -1169,8 +994,7 @@ static int run_rows_blocked_gat(Ctx *c, const float *x, const float *att, float 
     return GNNAGG_OK;
 }
 
-static int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags = 0, const NnRequest *nn = nullptr,
-                   int probe = 0)
+int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, int flags, const NnRequest *nn, int probe)
 {
     if ((flags & GNNAGG_FLAG_ACCUMULATE) && (mode != GNNAGG_MODE_BALANCED || (reduce != GNNAGG_REDUCE_SUM && !c->row_aux) || !c->use_plan))
         return fail(GNNAGG_ERR_ARG, "GNNAGG_FLAG_ACCUMULATE needs GNNAGG_MODE_BALANCED and GNNAGG_REDUCE_SUM (mean / max: gnnagg_set_row_aux first)");
@@ -1540,7 +1364,7 @@ static int edge_items(Ctx *c, Schedule **out)
     return GNNAGG_OK;
 }
 
-static int edge_launch(Ctx *c, EdgeItemLaunch &L, int heads)
+int edge_launch(Ctx *c, EdgeItemLaunch &L, int heads)
 {
     Schedule *s = nullptr;
     int rc = edge_items(c, &s);
@@ -1556,7 +1380,7 @@ static int edge_launch(Ctx *c, EdgeItemLaunch &L, int heads)
     return GNNAGG_OK;
 }
 
-static int do_schedule(Ctx *c, int kind, const int *param, int total_v)
+int do_schedule(Ctx *c, int kind, const int *param, int total_v)
 {
     if (!param) return fail(GNNAGG_ERR_ARG, "null schedule parameter array");
     switch (kind) {
@@ -1588,7 +1412,7 @@ static int do_schedule(Ctx *c, int kind, const int *param, int total_v)
     }
 }
 
-static void die_if_abort(int rc, const char *where)
+void die_if_abort(int rc, const char *where)
 {
     if (rc == GNNAGG_OK || !g_abort_on_error) return;
     // reference FatalError, include/util.h:82-92
@@ -1601,9 +1425,6 @@ static void die_if_abort(int rc, const char *where)
 
 using namespace gnnagg;
 
-#define GET_CTX(h)                                                      \
-    Ctx *c = lookup(h);                                                 \
-    if (!c) return fail(GNNAGG_ERR_ARG, "invalid or destroyed handle")
 
 #pragma GCC visibility push(default)
 extern "C" {
@@ -1626,7 +1447,9 @@ static int create(Ctx::Kind kind, const int *d_ptr, const int *d_idx, const floa
     Ctx *c = new Ctx;
     c->kind = kind; c->V = V; c->E = E; c->d_ptr = d_ptr; c->d_idx = d_idx; c->d_val = d_val;
     if (const char *e = getenv("GNNAGG_XCD_REMAP")) c->xcd_remap = atoi(e);
+#ifdef GNNAGG_EXTRAS
     if (const char *e = getenv("GNNAGG_PLAN")) c->use_plan = atoi(e);
+#endif
     if (const char *e = getenv("GNNAGG_PARTITIONS")) c->opt_partitions = atoi(e);
     if (const char *e = getenv("GNNAGG_FAST_ROWS")) { c->fast_rows = atoi(e); c->fast_rows_from_env = true; }
     if (const char *e = getenv("GNNAGG_FAST_SCHEDULED")) c->fast_scheduled = atoi(e);
@@ -1660,7 +1483,9 @@ int gnnagg_destroy(gnnagg_handle h)
         g_live.erase(c);
     }
     (void)hipStreamSynchronize(c->stream);
+#ifdef GNNAGG_EXTRAS
     if (c->tr.agg) (void)gnnagg_destroy(c->tr.agg);
+#endif
     if (c->aux_stream) {
         (void)hipStreamSynchronize(c->aux_stream);
         (void)hipStreamDestroy(c->aux_stream);
@@ -1685,12 +1510,17 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     const std::string n(name);
     bool replan = false;  // the library-chosen balanced order depends on it: rebuilt on the next use
     if (n == "partitions") { if (value < -1) return fail(GNNAGG_ERR_ARG, "partitions: -1 (auto), 0 (never) or a count"); c->opt_partitions = value; c->no_auto_partition = 0; replan = true; }
+#ifdef GNNAGG_EXTRAS
     else if (n == "partition_min_degree") { c->opt_part_min_deg = value; replan = true; }
+    else if (n == "retile") c->opt_retile = value;
+    else if (n == "tiled") c->tiled = value;
+    else if (n == "spans") { c->use_spans = value; replan = true; }
+    else if (n == "inkernel_combine") c->inkernel_combine = value;
+    else if (n == "host_plan") replan = true;
+#endif
     else if (n == "tile_width") { if (value != 32 && value != 64 && value != 128 && value != 256) return fail(GNNAGG_ERR_ARG, "tile_width: 32, 64, 128 or 256"); c->opt_tile_w = value; replan = true; }
     else if (n == "slice_kb") { if (value < 1) return fail(GNNAGG_ERR_ARG, "slice_kb must be >= 1"); c->opt_slice_kb = value; replan = true; }
-    else if (n == "retile") c->opt_retile = value;
     else if (n == "scratch_limit_mb") c->opt_scratch_limit_mb = value;
-    else if (n == "tiled") c->tiled = value;
     else if (n == "fast_rows") c->fast_rows = value;
     else if (n == "reference_defaults") {
         // what a handle made through a reference-facing surface starts with: run(vin, vout, B, 0) takes the balanced order
@@ -1699,10 +1529,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
     }
     else if (n == "fast_scheduled") c->fast_scheduled = value;
     else if (n == "aux_stream") c->use_aux_stream = value;
-    else if (n == "spans") { c->use_spans = value; replan = true; }
-    else if (n == "inkernel_combine") c->inkernel_combine = value;
     else if (n == "rows_blocked") c->opt_rows_blocked = value;
-    else if (n == "host_plan") replan = true;
     else if (n == "rows_hub_edges") { c->opt_rb_hub_edges = std::max(0, value); replan = true; }
     else if (n == "rows_hub_tile") {
         if (value != 0 && value != 32 && value != 64) return fail(GNNAGG_ERR_ARG, "rows_hub_tile: 0, 32 or 64");
@@ -2038,88 +1865,6 @@ int gnnagg_gat_run_add_to_center(gnnagg_handle h, const float *d_in_val, float *
     return launch_edge_items_sum(L, 1, c->stream);
 }
 
-static int build_transposed(Ctx *c)
-{
-    if (c->tr.valid) return GNNAGG_OK;
-    int rc = fetch_host_ptr(c);
-    if (rc) return rc;
-    const int V = c->V, E = c->E;
-    std::vector<int> h_idx((size_t)E);
-    if (E > 0) HIP_TRY(hipMemcpy(h_idx.data(), c->d_idx, (size_t)E * sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<int> ptr_t((size_t)V + 1, 0), idx_t((size_t)E), perm((size_t)E);
-    for (int e = 0; e < E; ++e) {
-        if (h_idx[e] < 0 || h_idx[e] >= V) return fail(GNNAGG_ERR_ARG, "run_bwd: neighbor id outside [0, num_v)");
-        ++ptr_t[(size_t)h_idx[e] + 1];
-    }
-    for (int v = 0; v < V; ++v) ptr_t[v + 1] += ptr_t[v];
-    std::vector<int> fill(ptr_t.begin(), ptr_t.end() - 1);
-    for (int r = 0; r < V; ++r)
-        for (int e = c->h_ptr[r]; e < c->h_ptr[r + 1]; ++e) {  // counting sort: stable in the original edge order
-            const int pos = fill[h_idx[e]]++;
-            idx_t[pos] = r;
-            perm[pos] = e;
-        }
-    Ctx::Transposed &t = c->tr;
-    if ((rc = t.ptr_t.upload(ptr_t)) || (rc = t.idx_t.upload(idx_t)) || (rc = t.perm.upload(perm))) return rc;
-    if ((rc = t.val_t.reserve((size_t)std::max(E, 1))) || (rc = t.dz.reserve((size_t)std::max(E, 1))) ||
-        (rc = t.dz_t.reserve((size_t)std::max(E, 1))) || (rc = t.rowdot.reserve((size_t)std::max(V, 1))) ||
-        (rc = t.da.reserve((size_t)std::max(V, 1))) || (rc = t.db.reserve((size_t)std::max(V, 1))))
-        return rc;
-    if ((rc = gnnagg_gcn_create(t.ptr_t.p, t.idx_t.p, t.val_t.p, V, E, &t.agg))) return rc;
-    t.valid = true;
-    return GNNAGG_OK;
-}
-
-int gnnagg_gat_run_bwd(gnnagg_handle h, const float *d_output, const float *d_doutput, const float *d_newval, const float *d_div,
-                       const float *d_infeat, float *d_a_b_grad, float *d_feat_grad, float relu_slope, int feat)
-{
-    GET_CTX(h);
-    if (c->kind != Ctx::GAT) return fail(GNNAGG_ERR_ARG, "handle is not a GAT aggregator");
-    if (feat <= 0 || !d_output || !d_doutput || !d_div || !d_infeat || !d_a_b_grad || !d_feat_grad || (!d_newval && c->E > 0))
-        return fail(GNNAGG_ERR_ARG, "bad run_bwd arguments");
-    int rc = build_transposed(c);
-    if (rc) return rc;
-    Ctx::Transposed &t = c->tr;
-    Ctx *ct = lookup(t.agg);
-    if (!ct) return fail(GNNAGG_ERR_ARG, "run_bwd: transposed aggregator lost");
-    ct->stream = c->stream;
-    // 1. per-edge dz on the chunked work items of this graph
-    EdgeItemLaunch L;
-    if ((rc = edge_launch(c, L, 1))) return rc;
-    GatBwdLaunch B;
-    B.wl = L.wl; B.idx = c->d_idx; B.out = d_output; B.dout = d_doutput; B.newval = d_newval; B.div = d_div; B.x = d_infeat;
-    B.rowdot = t.rowdot.p; B.dz = t.dz.p; B.V = c->V; B.feat = feat; B.slope = relu_slope;
-    if ((rc = launch_gat_bwd_edges(B, c->stream))) return rc;
-    // 2. centre-term gradient: row sums of dz (the hub-safe, ordered add_to_center)
-    L.in = t.dz.p; L.den = t.da.p;
-    if ((rc = launch_edge_items_sum(L, 1, c->stream))) return rc;
-    // 3. the source side runs on the transposed graph
-    if ((rc = launch_gat_bwd_permute(t.perm.p, t.idx_t.p, t.dz.p, d_newval, d_div, t.dz_t.p, t.val_t.p, c->E, c->stream))) return rc;
-    EdgeItemLaunch LT;
-    if ((rc = edge_launch(ct, LT, 1))) return rc;
-    LT.in = t.dz_t.p; LT.den = t.db.p;
-    if ((rc = launch_edge_items_sum(LT, 1, c->stream))) return rc;
-    if ((rc = launch_interleave2(t.da.p, t.db.p, d_a_b_grad, c->V, c->stream))) return rc;
-    // 4. d_feat = A^T-aggregation of dout with edge values p (balanced GCN kernels)
-    return gcn_run(ct, d_doutput, d_feat_grad, feat, GNNAGG_MODE_BALANCED, GNNAGG_REDUCE_SUM);
-}
-
-int gnnagg_gcn_run_bwd(gnnagg_handle h, const float *d_doutput, float *d_dinput, int feat)
-{
-    GET_CTX(h);
-    if (c->kind != Ctx::GCN) return fail(GNNAGG_ERR_ARG, "handle is not a GCN aggregator");
-    if (feat <= 0 || !d_doutput || !d_dinput) return fail(GNNAGG_ERR_ARG, "bad gcn_run_bwd arguments");
-    int rc = build_transposed(c);
-    if (rc) return rc;
-    Ctx::Transposed &t = c->tr;
-    Ctx *ct = lookup(t.agg);
-    if (!ct) return fail(GNNAGG_ERR_ARG, "gcn_run_bwd: transposed aggregator lost");
-    ct->stream = c->stream;
-    // the edge values follow their edges (re-gathered every call: updateval may have re-aliased them)
-    if ((rc = launch_permute_val(t.perm.p, c->d_val, t.val_t.p, c->E, c->stream))) return rc;
-    return gcn_run(ct, d_doutput, d_dinput, feat, GNNAGG_MODE_BALANCED, GNNAGG_REDUCE_SUM);
-}
-
 int gnnagg_gat_run_div_each(gnnagg_handle h, const float *d_in_att, float *d_inout_val)
 {
     GET_CTX(h);
@@ -2166,181 +1911,6 @@ int gnnagg_validate_reordered(const float *d_ref, const float *d_ans, const int 
     int rc = launch_validate_reordered(d_ref, d_ans, d_map, num_v, feat, d_diff, hip_stream);
     if (rc) { (void)hipFree(d_diff); return rc; }
     return count_result(d_diff, h_diff, hip_stream);
-}
-
-// ------------------------------------------------------------------------------- Section A
-int64_t GCN_init_impl(int *ptr, int *idx, float *val, int num_v, int num_e)
-{
-    gnnagg_handle h = 0;
-    die_if_abort(gnnagg_gcn_create(ptr, idx, val, num_v, num_e, &h), "GCN_init_impl");
-    if (h) (void)gnnagg_set_option(h, "reference_defaults", 1);
-    return h;
-}
-
-void GCN_update_val_impl(int64_t at, float *val) { die_if_abort(gnnagg_update_val(at, val), "GCN_update_val_impl"); }
-
-void GCN_run_impl(int64_t at, float *feat, float *out_feat, int blocksize, int scheduled, int featlen)
-{
-    (void)blocksize;
-    die_if_abort(gnnagg_gcn_run(at, feat, out_feat, featlen, scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS,
-                                GNNAGG_REDUCE_SUM),
-                 "GCN_run_impl");
-}
-
-static int schedule_ng(int64_t at, int *arr)
-{
-    GET_CTX(at);
-    return do_schedule(c, GNNAGG_SCHED_NEIGHBOR_GROUPING, arr, c->V);
-}
-
-void GCN_schedule_impl(int64_t at, int *arr) { die_if_abort(schedule_ng(at, arr), "GCN_schedule_impl"); }
-
-int64_t GAT_init_impl(int *ptr, int *idx, int num_v, int num_e)
-{
-    gnnagg_handle h = 0;
-    die_if_abort(gnnagg_gat_create(ptr, idx, num_v, num_e, &h), "GAT_init_impl");
-    if (h) (void)gnnagg_set_option(h, "reference_defaults", 1);
-    return h;
-}
-
-void GAT_run_impl(int64_t at, float *feat, float *att, float *out_feat, int blocksize, int scheduled, int featlen)
-{
-    (void)blocksize;
-    die_if_abort(gnnagg_gat_run(at, feat, att, out_feat, featlen, 1, 0.2f,
-                                scheduled ? GNNAGG_MODE_SCHEDULED : GNNAGG_MODE_ROWS, nullptr),
-                 "GAT_run_impl");
-}
-
-void GAT_run_u_add_v_impl(int64_t at, float *att, float *outval, int blocksize)
-{
-    (void)blocksize;
-    die_if_abort(gnnagg_gat_run_u_add_v(at, att, outval), "GAT_run_u_add_v_impl");
-}
-
-void GAT_run_add_to_center_impl(int64_t at, float *inval, float *outatt, int blocksize)
-{
-    (void)blocksize;
-    die_if_abort(gnnagg_gat_run_add_to_center(at, inval, outatt), "GAT_run_add_to_center_impl");
-}
-
-void GAT_run_div_each_impl(int64_t at, float *inatt, float *inoutval, int blocksize)
-{
-    (void)blocksize;
-    die_if_abort(gnnagg_gat_run_div_each(at, inatt, inoutval), "GAT_run_div_each_impl");
-}
-
-void GAT_schedule_impl(int64_t at, int *arr) { die_if_abort(schedule_ng(at, arr), "GAT_schedule_impl"); }
-
-// ------------------------------------------------------------------------------- Section C
-int gnnagg_load_graph(const char *datadir, const char *dset, const char *reorder_suffix, int shuffle, int *num_v,
-                      int *num_e, int **h_ptr, int **h_idx, int **h_rows, int **h_reverse_rows)
-{
-    if (!dset || !num_v || !num_e || !h_ptr || !h_idx) return fail(GNNAGG_ERR_ARG, "bad load_graph arguments");
-    if (h_rows) *h_rows = nullptr;
-    if (h_reverse_rows) *h_reverse_rows = nullptr;
-    return load_graph(datadir, dset, reorder_suffix, shuffle, num_v, num_e, h_ptr, h_idx, h_rows, h_reverse_rows);
-}
-
-void gnnagg_free_host(void *p) { free(p); }
-
-int gnnagg_reorder_csr(const int *h_ptr, const int *h_idx, const int *h_map, const int *h_reverse_map, int num_v,
-                       int num_e, int *h_newptr, int *h_newidx)
-{
-    if (!h_ptr || !h_map || !h_reverse_map || !h_newptr || num_v < 0 || num_e < 0 || (num_e > 0 && (!h_idx || !h_newidx)))
-        return fail(GNNAGG_ERR_ARG, "bad reorder_csr arguments");
-    reorder_csr(h_ptr, h_idx, h_map, h_reverse_map, num_v, h_newptr, h_newidx);
-    return GNNAGG_OK;
-}
-
-int gnnagg_neighbor_grouping_schedule(const int *h_ptr, int neighbor_num, int num_v, int *h_ptr_out,
-                                      int *h_target_out, int *num_groups)
-{
-    if (!h_ptr || neighbor_num <= 0 || num_v < 0 || !num_groups)
-        return fail(GNNAGG_ERR_ARG, "bad neighbor_grouping_schedule arguments");
-    *num_groups = neighbor_grouping(h_ptr, neighbor_num, num_v, h_ptr_out, h_target_out);
-    return GNNAGG_OK;
-}
-
-int gnnagg_locality_schedule(const int *h_ptr, const int *h_idx, const float *h_val, int par_num, int neighbor_num,
-                             int num_v, int total_num_v, int *h_ptr_out, int *h_idx_out, float *h_val_out,
-                             int *h_target_out, int *num_groups)
-{
-    if (!h_ptr || !h_idx || par_num <= 0 || num_v < 0 || !h_ptr_out || !h_idx_out || !h_target_out || !num_groups)
-        return fail(GNNAGG_ERR_ARG, "bad locality_schedule arguments");
-    *num_groups = locality_schedule(h_ptr, h_idx, h_val, par_num, neighbor_num, num_v, total_num_v, h_ptr_out,
-                                    h_idx_out, h_val_out, h_target_out);
-    return GNNAGG_OK;
-}
-
-int gnnagg_cluster_reorder(const int *h_ptr, const int *h_idx, int num_v, float threshold, int num_perm, int cluster_cap,
-                           unsigned long long seed, int *h_rows_out, int *num_clusters)
-{
-    if (!h_ptr || !h_rows_out || num_v < 0 || (h_ptr[num_v] > 0 && !h_idx))
-        return fail(GNNAGG_ERR_ARG, "bad cluster_reorder arguments");
-    return cluster_reorder(h_ptr, h_idx, num_v, threshold > 0 ? threshold : 0.2, num_perm > 0 ? num_perm : 64,
-                           cluster_cap > 0 ? cluster_cap : 64, seed, 8, h_rows_out, num_clusters);
-}
-
-int gnnagg_cluster_reorder_ex(const int *h_ptr, const int *h_idx, int num_v, float threshold, int num_perm, int cluster_cap,
-                              unsigned long long seed, int order_mode, int cache_rows, int *h_rows_out, int *num_clusters)
-{
-    if (!h_ptr || !h_rows_out || num_v < 0 || (h_ptr[num_v] > 0 && !h_idx))
-        return fail(GNNAGG_ERR_ARG, "bad cluster_reorder arguments");
-    return cluster_reorder(h_ptr, h_idx, num_v, threshold > 0 ? threshold : 0.2, num_perm > 0 ? num_perm : 64,
-                           cluster_cap > 0 ? cluster_cap : 64, seed, 8, h_rows_out, num_clusters, order_mode,
-                           cache_rows > 0 ? cache_rows : 4096);
-}
-
-// ------------------------------------------------------------------------------- Section D
-int gnnagg_partition_rows(const int *h_ptr, int num_v, int nparts, int *h_bounds)
-{
-    if (!h_ptr || !h_bounds || nparts <= 0 || num_v < 0) return fail(GNNAGG_ERR_ARG, "bad partition_rows arguments");
-    partition_rows(h_ptr, num_v, nparts, h_bounds);
-    return GNNAGG_OK;
-}
-
-int gnnagg_halo_plan(const int *h_ptr, const int *h_idx, int num_v, const int *h_bounds, int nparts, int rank,
-                     int *h_local_ptr, int *h_local_idx, int **h_halo_ids, int *h_halo_counts, int *num_halo)
-{
-    if (!h_ptr || !h_idx || !h_bounds || nparts <= 0 || rank < 0 || rank >= nparts || !h_local_ptr || !h_local_idx ||
-        !h_halo_ids || !h_halo_counts || !num_halo)
-        return fail(GNNAGG_ERR_ARG, "bad halo_plan arguments");
-    return halo_plan(h_ptr, h_idx, num_v, h_bounds, nparts, rank, h_local_ptr, h_local_idx, h_halo_ids, h_halo_counts,
-                     num_halo);
-}
-
-int gnnagg_halo_plan_slice(const int *h_ptr_slice, const int *h_idx_slice, int num_cols, const int *h_bounds, int nparts, int rank,
-                           int *h_local_ptr, int *h_local_idx, int **h_halo_ids, int *h_halo_counts, int *num_halo)
-{
-    if (!h_ptr_slice || !h_idx_slice || !h_bounds || nparts <= 0 || rank < 0 || rank >= nparts || num_cols < 0 || !h_local_ptr ||
-        !h_local_idx || !h_halo_ids || !h_halo_counts || !num_halo)
-        return fail(GNNAGG_ERR_ARG, "bad halo_plan_slice arguments");
-    return halo_plan_slice(h_ptr_slice, h_idx_slice, num_cols, h_bounds, nparts, rank, h_local_ptr, h_local_idx, h_halo_ids,
-                           h_halo_counts, num_halo);
-}
-
-int gnnagg_halo_stage_plan(const long long *h_recv_rows, const long long *h_send_rows, int world, int rank, int mode, int k, int *n_stages,
-                           long long *h_stage_recv, int *h_new_of_old, long long *h_stage_send, int *h_send_order)
-{
-    if (world <= 0 || rank < 0 || rank >= world || (mode != GNNAGG_STAGES_STRIPE && mode != GNNAGG_STAGES_OWNER) || (mode == GNNAGG_STAGES_STRIPE && (k < 1 || k > 64)) ||
-        (mode == GNNAGG_STAGES_OWNER && world > 65) || !n_stages)
-        return fail(GNNAGG_ERR_ARG, "bad halo_stage_plan arguments (stripe: 1 <= k <= 64; owner: world <= 65)");
-    *n_stages = halo_stage_count(world, mode, k);
-    if (h_recv_rows) {
-        if (!h_stage_recv) return fail(GNNAGG_ERR_ARG, "halo_stage_plan: null stage_recv");
-        halo_stage_plan_recv(h_recv_rows, world, rank, mode, k, h_stage_recv, h_new_of_old);
-    }
-    if (h_send_rows) {
-        if (!h_stage_send) return fail(GNNAGG_ERR_ARG, "halo_stage_plan: null stage_send");
-        halo_stage_plan_send(h_send_rows, world, rank, mode, k, h_stage_send, h_send_order);
-    }
-    return GNNAGG_OK;
-}
-
-int gnnagg_pack_rows(const float *d_x, const int *d_ids, int n, int feat, float *d_out, void *hip_stream)
-{
-    if (n < 0 || feat <= 0 || (n > 0 && (!d_x || !d_ids || !d_out))) return fail(GNNAGG_ERR_ARG, "bad pack_rows arguments");
-    return launch_pack_rows(d_x, d_ids, n, feat, d_out, hip_stream);
 }
 
 }  // extern "C"

@@ -78,7 +78,12 @@ public:
                  float relu_l, int BLOCK_SIZE)
     {
         (void)BLOCK_SIZE;
+#ifdef GNNAGG_EXTRAS
         checkGnnagg(gnnagg_gat_run_bwd(handle, output, doutput, newval, div, infeat, d_a_b, d_feat, relu_l, feat_in));
+#else
+        (void)output; (void)doutput; (void)newval; (void)div; (void)infeat; (void)d_a_b; (void)d_feat; (void)relu_l;
+        FatalError("run_bwd (aggr_gat.h:426-434, \"Experiment\", no caller in the reference) needs libgnnagg_extras.so and -DGNNAGG_EXTRAS");
+#endif
     }
 
 private:

@@ -151,7 +151,12 @@ public:
     void run_bwd(float *doutput, float *dinput, int BLOCK_SIZE)
     {
         (void)BLOCK_SIZE;
+#ifdef GNNAGG_EXTRAS
         checkGnnagg(gnnagg_gcn_run_bwd(handle, doutput, dinput, feat_in));
+#else
+        (void)doutput; (void)dinput;
+        FatalError("run_bwd needs libgnnagg_extras.so and -DGNNAGG_EXTRAS (the shipped library is forward-only, like the reference's drivers)");
+#endif
     }
 
 private:

@@ -95,17 +95,14 @@ int gnnagg_gat_create(const int *d_ptr, const int *d_idx, int num_v, int num_e, 
 int gnnagg_destroy(gnnagg_handle h);
 /* hipStream_t as void*; NULL = default stream.  Work of later calls is enqueued there. */
 int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
-/* Per-handle knobs.  Every knob is an option; the SIX a C++ driver linked against the class shim cannot reach through code also
+/* Per-handle knobs.  Every knob is an option; the four a C++ driver linked against the class shim cannot reach through code also
  * read an environment variable (in brackets) when the handle is made.  INTEGRATION.md section 5 is the table of all of them.
- *   "partitions" [GNNAGG_PARTITIONS]      -1 the library decides, 0 never, N > 0: N source ranges for the balanced mode
- *   "partition_min_degree"                average degree from which the library partitions (96)
+ *   "partitions" [GNNAGG_PARTITIONS]      -1 the library decides (average degree >= 96), 0 never, N > 0: N source ranges for the balanced mode
  *   "tile_width"                          floats per column tile of the 2-D blocked balanced mode: 32 / 64 / 128 / 256 (64)
  *   "slice_kb"                            target size of the X slice an XCD's L2 holds (4096)
  *   "scratch_limit_mb"                    > 0: cap on the scratch (partial rows + tiled image of X) the blocked order may take;
  *                                         a handle that would need more -- or more than half of the free device memory, or
  *                                         whose allocation fails -- moves to the chunked plan for good
- *   "retile", "tiled", "spans", "inkernel_combine"   older forms of the blocked order / the hub fold, kept because parity tests
- *                                         compare them bit for bit with the default form (tests/test_gpu_blocked.py)
  *   "fast_rows" [GNNAGG_FAST_ROWS]        1: GNNAGG_MODE_ROWS (`scheduled = 0`) runs the balanced order -- results within the
  *                                         1e-5 bound instead of bit-exact CSR-order chains; 0: canonical order.  Default 0 for
  *                                         handles made through this section, 1 for the reference-facing surfaces (see
@@ -126,9 +123,6 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *   "aux_stream" [GNNAGG_AUX_STREAM]      0: GNNAGG_MODE_ROWS runs its hub rows on the handle's stream, before the short rows, instead of
  *                                         beside them on an auxiliary stream (slower by the hub rows' duration, but the process keeps
  *                                         a single queue); 1 (default)
- *   "host_plan"                           1: the blocked orders are built by the host builders of rounds 2-3 (host_graph.cpp: D2H copy of the
- *                                         CSR, 2-3 GB of uploads) instead of on the device (plan_gpu.hip); the same arrays either way (tests
- *                                         compare them), 5-10 x the construction time.  0 (default)
  *   "rows_blocked"                        1 (default): GNNAGG_MODE_ROWS runs its canonical chains on the 2-D blocked order where the
  *                                         graph allows it (gnnagg_rows_blocked_ranges); 0: always the row kernels.  Same bits either way
  *   "rows_medium_edges"                   GNNAGG_MODE_ROWS on the row kernels: rows above this many edges, up to the hub threshold
@@ -139,8 +133,10 @@ int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
  *                                         kernel; 0 (default): 64 where the launch has more (row, tile) items than twice the CUs.  Same bits
  *   "rows_hub_edges"                      chained rows mode: rows with a (row, range) sub-row above this many edges leave the chained
  *                                         launches for the long-row kernel (0: the library's rule)
- * [GNNAGG_XCD_REMAP] 0 / 1 / 2 (workgroup -> XCD mapping: identity / equal-count / work-balanced ranges, default 2) and [GNNAGG_PLAN] 0
- * (the round-1 item kernels + k_combine instead of the plan kernels) are environment-only measurement switches (scripts/history/tune_gcn.py).
+ * Twelve options.  [GNNAGG_XCD_REMAP] 0 / 1 / 2 (workgroup -> XCD mapping: identity / equal-count / work-balanced ranges, default 2) is an
+ * environment-only measurement switch.  libgnnagg_extras.so (-DGNNAGG_EXTRAS, Section E) additionally knows "partition_min_degree",
+ * the older forms "retile", "tiled", "spans", "inkernel_combine", "host_plan" and [GNNAGG_PLAN]: second-tier A / B material, constants in
+ * the shipped library.
  * Options that change the library-chosen order drop it; it is rebuilt on the next use. */
 int gnnagg_set_option(gnnagg_handle h, const char *name, int value);
 /* What the library-chosen blocked order cost to build and holds (the reference prints its schedule time, graph_schedule.h:125-127):
@@ -272,21 +268,6 @@ int gnnagg_gat_run_part(gnnagg_handle h, const float *d_x, const float *d_att, f
                         float *d_den_io);
 /* Aggregator_GAT::run_att, aggr_gat.h:395-401 (attGat :5-31): out_val[E,heads] = softmax weights */
 int gnnagg_gat_run_att(gnnagg_handle h, const float *d_att, float *d_out_val, int heads, float slope);
-/* Backward of the GCN / SAGE sum aggregation y = A.x (no reference counterpart: the reference is forward-only):
- * d_dinput[V, feat] = A^T . d_doutput with the aggregator's edge values, as a deterministic gather over the
- * transposed CSR (built once per handle) on the balanced kernels.  Square graphs (neighbor ids < num_v). */
-int gnnagg_gcn_run_bwd(gnnagg_handle h, const float *d_doutput, float *d_dinput, int feat);
-/* Aggregator_GAT::run_bwd, aggr_gat.h:426-434 (kernel aggr_gat_fine_bwd :222-296, marked "Experiment" in the reference and
- * called by none of its drivers).  Backward of the single-head fused aggregation out_r = sum_e w_e x_s / D_r given the
- * forward pass's un-normalised edge weights newval[E] (w_e) and denominators div[V] (D_r):
- *   d_feat_grad[V,feat]  = gradient w.r.t. the input features through the aggregation (attention held constant)
- *   d_a_b_grad[V,2]      = gradient w.r.t. att: [.,0] centre term, [.,1] source term
- * Differences from the reference kernel, which stops short of its own comments: all `feat` columns (not 32), the
- * leaky-ReLU slope applied where z_e < 0 (the reference tests newval < 0, never true), the centre-term gradient is
- * produced, and both outputs are OVERWRITTEN with deterministic sums (the reference atomically accumulates into
- * caller-zeroed buffers).  heads == 1 only. */
-int gnnagg_gat_run_bwd(gnnagg_handle h, const float *d_output, const float *d_doutput, const float *d_newval, const float *d_div,
-                       const float *d_infeat, float *d_a_b_grad, float *d_feat_grad, float relu_slope, int feat);
 /* aggr_gat.h:402-425, single head as in the reference */
 int gnnagg_gat_run_u_add_v(gnnagg_handle h, const float *d_att, float *d_out_val);
 int gnnagg_gat_run_add_to_center(gnnagg_handle h, const float *d_in_val, float *d_out_att);
@@ -450,6 +431,28 @@ int gnnagg_dist_step_gcn(gnnagg_dist_step_t step, const float *d_x_local, float 
                          void *hip_stream);
 int gnnagg_dist_step_gat(gnnagg_dist_step_t step, float *d_x_ext, float *d_att_ext, int n_local, float *d_send_buf, float *d_recv_buf,
                          float *d_den, float *d_y, int feat, int heads, float slope, void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * E. Extras: libgnnagg_extras.so only (`make -C gnn_computing_amd/csrc extras`, -DGNNAGG_EXTRAS).  NOT in the shipped library:
+ *    the reference is forward-only and SURVEY 2.2 marks its one backward kernel ("Experiment", no caller) out of scope.
+ * ------------------------------------------------------------------------------------------- */
+#ifdef GNNAGG_EXTRAS
+/* Backward of the GCN / SAGE sum aggregation y = A.x (no reference counterpart: the reference is forward-only):
+ * d_dinput[V, feat] = A^T . d_doutput with the aggregator's edge values, as a deterministic gather over the
+ * transposed CSR (built once per handle) on the balanced kernels.  Square graphs (neighbor ids < num_v). */
+int gnnagg_gcn_run_bwd(gnnagg_handle h, const float *d_doutput, float *d_dinput, int feat);
+/* Aggregator_GAT::run_bwd, aggr_gat.h:426-434 (kernel aggr_gat_fine_bwd :222-296, marked "Experiment" in the reference and
+ * called by none of its drivers).  Backward of the single-head fused aggregation out_r = sum_e w_e x_s / D_r given the
+ * forward pass's un-normalised edge weights newval[E] (w_e) and denominators div[V] (D_r):
+ *   d_feat_grad[V,feat]  = gradient w.r.t. the input features through the aggregation (attention held constant)
+ *   d_a_b_grad[V,2]      = gradient w.r.t. att: [.,0] centre term, [.,1] source term
+ * Differences from the reference kernel, which stops short of its own comments: all `feat` columns (not 32), the
+ * leaky-ReLU slope applied where z_e < 0 (the reference tests newval < 0, never true), the centre-term gradient is
+ * produced, and both outputs are OVERWRITTEN with deterministic sums (the reference atomically accumulates into
+ * caller-zeroed buffers).  heads == 1 only. */
+int gnnagg_gat_run_bwd(gnnagg_handle h, const float *d_output, const float *d_doutput, const float *d_newval, const float *d_div,
+                       const float *d_infeat, float *d_a_b_grad, float *d_feat_grad, float relu_slope, int feat);
+#endif /* GNNAGG_EXTRAS */
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,9 @@
 """ISA lint for a hazard the gfx950 code generator left open once (aux_kernels.hip, k_dense_nn_lean, round 5): a VMEM / LDS store of more
 than 8 bytes reads its upper data registers a cycle after it issues, so a VALU write of one of those registers needs wait states in
 between.  The compiler inserts them inside a basic block; when the store is the LAST instruction of a block and the next block starts
-with such a write, nothing separated them.  usage: check_store_hazard.py file.s [...]   (hipcc --save-temps=obj ... gives the .s files)
+with such a write, nothing separated them.  usage: check_store_hazard.py [--require kernel[,kernel...]] file.s [...]
+(hipcc --cuda-device-only -S gives the .s files; --require fails the run when a named kernel is in none of them: an assembly file that
+did not compile, or a stale one, must not pass as "0 suspicious places" -- ADVICE r5)
 Prints every place where a >8-byte store is followed, within two instructions and across labels only, by a VALU write of its data."""
 import re
 import sys
@@ -22,9 +24,23 @@ def data_regs(op, args):
     return set(range(lo, hi + 1)) if hi - lo >= 2 else set()
 
 
+require = []
+if len(sys.argv) > 2 and sys.argv[1] == "--require":
+    require = [k for k in sys.argv[2].split(",") if k]
+    del sys.argv[1:3]
+if len(sys.argv) < 2:
+    sys.exit("usage: check_store_hazard.py [--require kernel[,kernel...]] file.s [...]")
+texts = {path: open(path).read() for path in sys.argv[1:]}
+empty = [p for p, t in texts.items() if ".amdhsa_kernel" not in t]
+if empty:
+    sys.exit("no kernel in %s: the file did not compile (or is not device assembly)" % ", ".join(empty))
+missing = [k for k in require if not any(re.search(r"^_Z\w*%s\w*:" % re.escape(k), t, re.M) for t in texts.values())]
+if missing:
+    sys.exit("required kernel(s) not found in the assembly: %s" % ", ".join(missing))
+
 bad = 0
 for path in sys.argv[1:]:
-    lines = open(path).read().split("\n")
+    lines = texts[path].split("\n")
     func = "?"
     code = []   # (line number, text, is_label)
     for n, l in enumerate(lines, 1):
@@ -70,7 +86,7 @@ VREG = re.compile(r"\bv\[?(\d+)(?::(\d+))?\]?")
 fixed_bad = 0
 for path in sys.argv[1:]:
     func, inasm = None, False
-    for n, l in enumerate(open(path).read().split("\n"), 1):
+    for n, l in enumerate(texts[path].split("\n"), 1):
         m = re.match(r"^(_Z\w*k_dense_nn_ahead\w*):", l)
         if m:
             func, inasm = m.group(1), False
