@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256) SPAN_WAVES_ATTR void k_gcn_span(const SpanArgs
                     continue;
                 }
                 // Every lane accumulates, also the lanes beyond the last feature column: they did not gather, their xv is whatever the
-                // register held, and their acc is never stored (every store below is behind col_ok).  With an `if (col_ok)` here the compiler
+                // register held, and their acc is never stored (every store below is behind col_ok).  INVARIANT this relies on:
+                // `acc` and `xv` of a !col_ok lane never reach another lane or memory -- no shuffle, DPP move or reduction reads them (the
+                // only cross-lane traffic in this kernel is ids / values / targets: my_s, my_w, tw), and making those lanes gather instead
+                // would cost address cycles for 38 of the 64 lanes of F = 602's last tile.  Pinned by tests/test_gpu_blocked.py::
+                // test_blocked_gcn_matches_the_restated_order (F = 602, 100, 30, 33: sum, mean AND max, bit-exact).  With an `if (col_ok)` here the compiler
                 // adds unconditionally anyway and then SELECTS -- four v_cndmask per gathered value, a third of this kernel's vector
                 // instructions (12.9 per gather instruction, profiles/r05/summary_R_sq.txt); without them R runs 15.40 -> 15.27 ms.
 #pragma unroll

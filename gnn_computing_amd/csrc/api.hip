@@ -293,7 +293,7 @@ static int build_rows_plan(Ctx *c, bool medium_ok = true)
 {
     int rc = fetch_host_ptr(c);
     if (rc) return rc;
-    RowsPlan &p = c->rows_plan;
+    RowsPlan &p = medium_ok ? c->rows_plan : c->rows_plan_nomed;
     p.valid = false;
     p.medium_ok = medium_ok;
     // The workgroup-per-row kernel finishes a long chain sooner (parallel gathers, one lane per column consuming), but a CU
@@ -1292,8 +1292,8 @@ static int gat_run(Ctx *c, const float *x, const float *att, float *y, int feat,
         // canonical order: short rows on the descriptor path of k_gat_plan, isolated hub rows on the long-row kernel
         // (auxiliary stream) when a 32-column tile lies inside one head
         const bool tile_in_head = ((feat / heads) % 32) == 0;
-        if ((!c->rows_plan.valid || c->rows_plan.medium_ok != tile_in_head) && (rc = build_rows_plan(c, tile_in_head))) return rc;
-        RowsPlan &p = c->rows_plan;
+        RowsPlan &p = tile_in_head ? c->rows_plan : c->rows_plan_nomed;
+        if (!p.valid && (rc = build_rows_plan(c, tile_in_head))) return rc;
         const bool long_ok = p.n1 > 0 && tile_in_head;
         if (p.n1 + p.n2 == 0 || tile_in_head) {
             const bool fork = long_ok && c->use_aux_stream;
@@ -1535,7 +1535,7 @@ int gnnagg_set_option(gnnagg_handle h, const char *name, int value)
         if (value != 0 && value != 32 && value != 64) return fail(GNNAGG_ERR_ARG, "rows_hub_tile: 0, 32 or 64");
         c->opt_hub_tile = value;
     }
-    else if (n == "rows_medium_edges") { c->opt_rows_medium = value; c->rows_plan.valid = false; }
+    else if (n == "rows_medium_edges") { c->opt_rows_medium = value; c->rows_plan.valid = false; c->rows_plan_nomed.valid = false; }
     else return fail(GNNAGG_ERR_ARG, "unknown option: " + n);
     if (replan) {
         c->force_host_plan = (n == "host_plan") ? (value != 0) : 0;

@@ -135,7 +135,9 @@ struct Ctx {
     int opt_hub_tile = 0;       // "rows_hub_tile": column-tile width of the 512-thread long-row form, GCN flavours (0: the launcher's rule; 32; 64)
     int opt_rows_medium = 0;    // "rows_medium_edges": rows above this many edges (up to the hub threshold) take the 128-thread workgroups (0: library rule, -1: none)
     int opt_rb_hub_edges = 0;   // "rows_hub_edges": rows with a (row, range) sub-row above this many edges leave the chained launches (0: library rule)
-    RowsPlan rows_plan;      // GCN rows mode
+    RowsPlan rows_plan;      // rows mode (GCN; GAT head widths a 32-column tile fits in)
+    RowsPlan rows_plan_nomed; // ... built WITHOUT the medium class (GAT head widths the long-row kernel cannot serve): a handle whose
+                             // calls alternate between the two keeps both instead of rebuilding on every call
     hipStream_t aux_stream = nullptr;  // long rows of the rows mode run here, overlapping the short rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     Schedule sched_edges;    // chunked work items of the edge kernels (run_att, u_add_v, add_to_center, div_each)

@@ -18,6 +18,6 @@ done
 python3 scripts/collect_profiles.py $OUT $OUT/pmc_traffic.json
 ROUND=${ROUND:-r03}; mkdir -p profiles/$ROUND && cp $OUT/pmc_traffic.json profiles/$ROUND/pmc_traffic.json
 python3 bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
-for cfg in ${CONFIGS:-R G P1}; do [ "$cfg" = "A_rows" ] && continue; BENCH_P1_REORDER=1 python3 bench.py --config $cfg --no-cpu >> $OUT/bench_configs.jsonl 2>> $OUT/bench.err; done
+for cfg in ${CONFIGS:-R G P1}; do case $cfg in A_rows|P1_reorder) continue;; esac; python3 bench.py --config $cfg --no-cpu >> $OUT/bench_configs.jsonl 2>> $OUT/bench.err; done
 rm -rf $OUT/trace_* $OUT/pmc_[A-Z]*_*
 ls $OUT
