@@ -104,6 +104,23 @@ def time_steps(step_fn, steps, warmup, barrier):
     # left idle between the warm-up and the first timed launch -- even for the few milliseconds of a gc.collect() -- starts
     # the K steps cold (scripts/history/exp_timed_region.py, K = 20: 80.3 us per step with the idle period after the warm-up, 75.2 us
     # with the warm-up after it).
+    # The launches run on ONE NON-NULL stream made for them; inputs, plans and oracle checks stay on the default stream (round 6,
+    # tests/perf_reorder_discrepancy.py, tests/perf_side_stream_alloc.py).  On the null stream HIP orders every launch
+    # against the process's other streams: once any exists (the rows mode forks two, a framework always has some) back-to-back null-stream
+    # launches no longer overlap head to tail and a 74 us launch costs 79-87 us on the device; a dedicated stream keeps 73.8 us.  (Putting
+    # EVERYTHING under a side stream -- allocations and uploads too -- measured 78.7 us: more active streams, the same loss.)
+    if not getattr(time_steps, "_inside", False) and os.environ.get("BENCH_STREAM", "side") != "null":
+        time_steps._inside = True
+        try:
+            s_ = getattr(time_steps, "_stream", None) or torch.cuda.Stream()
+            time_steps._stream = s_
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_):
+                r_ = time_steps(step_fn, steps, warmup, barrier)
+            torch.cuda.current_stream().wait_stream(s_)
+            return r_
+        finally:
+            time_steps._inside = False
     import gc
     gc.collect()
     time.sleep(0.15)
@@ -1177,8 +1194,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        with torch.cuda.stream(torch.cuda.Stream(device=dev)):   # (a non-null stream: see below)
-            out = run_multi(args, dev, rank, world, dog)
+        out = run_multi(args, dev, rank, world, dog)
         dist.barrier()
         dist.destroy_process_group()
     else:
@@ -1186,12 +1202,7 @@ def main():
             raise SystemExit("--gpus %d: WORLD_SIZE is 1 in the environment" % args.gpus)
         if args.config == "P":
             args.config = "P1"
-        # Everything is launched and timed on ONE NON-NULL stream.  On the null stream HIP orders every launch against the process's other
-        # streams: as soon as any other stream exists (the rows mode forks two, a framework always has some) back-to-back null-stream
-        # launches no longer overlap head to tail and a 74 us launch costs 79-87 us on the DEVICE (host time per call unchanged, 8 us;
-        # the same launches on a non-null stream stay at 74 us in every state: tests/perf_reorder_discrepancy.py host).
-        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-            out = run_single(args, dev) if args.config == "A" else run_other_config(args, dev)
+        out = run_single(args, dev) if args.config == "A" else run_other_config(args, dev)
     if rank == 0 and out is not None:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

@@ -11,5 +11,5 @@ for f in agg_gcn agg_gat agg_span aux_kernels plan_gpu; do
   objs="$objs build/ab/${f}_$1.o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ab/libgnnagg_$1.so $objs build/api.o build/host_graph.o build/reorder.o build/dist_rccl.o -lgomp -ldl -Wl,--exclude-libs,ALL
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ab/libgnnagg_$1.so $objs build/api.o build/api_flat.o build/api_extras.o build/host_graph.o build/reorder.o build/dist_rccl.o -lgomp -ldl -Wl,--exclude-libs,ALL
 echo build/ab/libgnnagg_$1.so

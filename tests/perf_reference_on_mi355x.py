@@ -16,7 +16,25 @@ from oracle import ref  # noqa: E402
 dev = torch.device("cuda", 0)
 
 
+RUN_STREAM = None
+
+
 def ours(fn, warm=10, iters=50):
+    """On ONE NON-NULL stream made for the launches (round 6); inputs stay on the default stream.  Rounds 2-5 timed on
+    the null stream, where HIP orders every launch against the process's other streams: after oracle/_ref's kernels and the rows mode
+    (which forks two streams) had run, back-to-back null-stream launches of the 74 us balanced kernel cost 79-87 us on the device --
+    exactly the locality reorder's gain, which is why this file showed 85.8 vs 86.2 us ("no gain") while bench.py, in a process that had
+    only ever used the null stream, showed 85.2 -> 73.5 us (tests/perf_reorder_discrepancy.py host: null stream 74.5 -> 79.4 -> 82.3 us as
+    streams appear, a dedicated non-null stream 74.4-74.5 us in every state, host time per call 8 us throughout)."""
+    global RUN_STREAM
+    if RUN_STREAM is None:
+        RUN_STREAM = torch.cuda.Stream()
+    RUN_STREAM.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(RUN_STREAM):
+        return _ours(fn, warm, iters)
+
+
+def _ours(fn, warm, iters):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -92,14 +110,7 @@ def big():
 
 
 if __name__ == "__main__":
-    # On ONE NON-NULL stream (round 6).  Rounds 2-5 timed on the null stream, where HIP orders every launch against the
-    # process's other streams: after oracle/_ref's kernels and the rows mode (which forks two streams) had run, back-to-back null-stream
-    # launches of the 74 us balanced kernel cost 79-87 us on the device -- exactly the locality reorder's gain, which is why this file
-    # showed 85.8 vs 86.2 us ("no gain") while bench.py, in a process that had only ever used the null stream, showed 85.2 -> 73.5 us
-    # (tests/perf_reorder_discrepancy.py host: null stream 74.5 -> 79.4 -> 82.3 us as streams appear, non-null stream 74.4-74.5 us in
-    # every state, host time per call 8 us throughout).
-    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-        if len(sys.argv) > 1 and sys.argv[1] == "big":
-            big()
-        else:
-            main()
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        big()
+    else:
+        main()
