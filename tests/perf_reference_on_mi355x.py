@@ -35,19 +35,30 @@ def ours(fn, warm=10, iters=50):
 
 
 def _ours(fn, warm, iters):
+    """median of 5 bursts of iters / 5 launches (one event pair each): a host thread descheduled for tens of milliseconds -- the GPU boxes run
+    in a CPU-quota'd container -- must not land in the number (round 6: one burst of 50 once read 1.5 ms per launch)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) * 1e3 / iters
+    per, n = [], max(1, iters // 5)
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        per.append(a.elapsed_time(b) * 1e3 / n)
+    return sorted(per)[2]
 
 
 def main():
+    """Two passes: FIRST every measurement of this library (balanced before scheduled before rows: the rows mode forks two streams), THEN
+    the reference's kernels.  Round 6: the state of the PROCESS decides what a 74 us launch costs.  oracle/_ref
+    initialises hipBLAS / hipSPARSE / hipRAND (each with queues of its own) and the rows mode forks streams; after them the same balanced
+    launch measured 82-87 us here -- on the null stream and on a dedicated stream alike, as kernel time, not as gaps between launches --
+    which swallowed the locality reorder's gain (85.8 vs 86.2 us in rounds 2-5) while bench.py, whose process holds nothing but this
+    library, showed 85.2 -> 73.5 us.  Measured in this order the two harnesses agree (tests/perf_reorder_discrepancy.py isolates the states)."""
     ptr_t, idx_t = gnc.graph.dataset("arxiv")
     ptr, idx = ptr_t.numpy(), idx_t.numpy()
     rows, _ = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=8192)
@@ -56,33 +67,49 @@ def main():
     rng = np.random.default_rng(123)
     val = np.ones(E, np.float32)
     att = (rng.standard_normal((V, 2)) * 0.3).astype(np.float32)
-    for name, (p, i) in (("no reorder", (ptr, idx)), ("locality reorder on load", (rptr, ridx))):
+    arms = (("no reorder", (ptr, idx)), ("locality reorder on load", (rptr, ridx)))
+    xs = {F: rng.standard_normal((V, F), dtype=np.float32) for F in (128, 32)}
+    out = {}
+    for name, (p, i) in arms:                       # ---- pass 1: this library
         dp, di = torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev)
-        for F, block in ((128, 512), (32, 512)):
-            x = rng.standard_normal((V, F), dtype=np.float32)
-            dx, dy = torch.from_numpy(x).to(dev), torch.empty((V, F), device=dev)
+        for F in (128, 32):
+            dx, dy = torch.from_numpy(xs[F]).to(dev), torch.empty((V, F), device=dev)
             agg = gnc.Aggregator_GCN(dp, di, torch.from_numpy(val).to(dev), F, F)
             agg.schedule(gnc.Schedule.neighbor_grouping, [16])
-            out = dict(workload="arxiv-shaped %dx%d GCN sum F=%d, %s" % (V, E, F, name),
-                       reference_aggr_gcn_us=ref.time_run("gcn", p, i, val, x, block, False),
-                       reference_neighbor_grouping16_us=ref.time_run("gcn", p, i, val, x, block, True, 16),
-                       reference_neighbor_grouping32_us=ref.time_run("gcn", p, i, val, x, block, True, 32),
-                       ours_rows_us=ours(lambda: agg.run(dx, dy, 512, 0)),
-                       ours_neighbor_grouping16_us=ours(lambda: agg.run(dx, dy, 512, 1)),
-                       ours_balanced_us=ours(lambda: agg.run(dx, dy, 512, "balanced")))
-            print(json.dumps(out), flush=True)
-        F = 128
-        x = rng.standard_normal((V, F), dtype=np.float32)
-        dx, dy, datt = torch.from_numpy(x).to(dev), torch.empty((V, F), device=dev), torch.from_numpy(att).to(dev)
-        gat = gnc.Aggregator_GAT(dp, di, F, F)
+            o = out.setdefault(("gcn", F, name), dict(workload="arxiv-shaped %dx%d GCN sum F=%d, %s" % (V, E, F, name)))
+            o["ours_balanced_us"] = ours(lambda: agg.run(dx, dy, 512, "balanced"))
+            o["ours_neighbor_grouping16_us"] = ours(lambda: agg.run(dx, dy, 512, 1))
+        dx, dy, datt = torch.from_numpy(xs[128]).to(dev), torch.empty((V, 128), device=dev), torch.from_numpy(att).to(dev)
+        gat = gnc.Aggregator_GAT(dp, di, 128, 128)
         gat.schedule(gnc.Schedule.neighbor_grouping, [32])
-        out = dict(workload="arxiv-shaped GAT (1 head) F=128, %s" % name,
-                   reference_aggr_gat_us=ref.time_run("gat", p, i, att, x, 128, False),
-                   reference_neighbor_grouping32_us=ref.time_run("gat", p, i, att, x, 128, True, 32),
-                   ours_rows_us=ours(lambda: gat.run(dx, datt, dy, 128, 0)),
-                   ours_neighbor_grouping32_us=ours(lambda: gat.run(dx, datt, dy, 128, 1)),
-                   ours_balanced_us=ours(lambda: gat.run(dx, datt, dy, 128, "balanced")))
-        print(json.dumps(out), flush=True)
+        o = out.setdefault(("gat", 128, name), dict(workload="arxiv-shaped GAT (1 head) F=128, %s" % name))
+        o["ours_balanced_us"] = ours(lambda: gat.run(dx, datt, dy, 128, "balanced"))
+        o["ours_neighbor_grouping32_us"] = ours(lambda: gat.run(dx, datt, dy, 128, 1))
+    for name, (p, i) in arms:                       # (the rows mode last: it forks streams)
+        dp, di = torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev)
+        for F in (128, 32):
+            dx, dy = torch.from_numpy(xs[F]).to(dev), torch.empty((V, F), device=dev)
+            agg = gnc.Aggregator_GCN(dp, di, torch.from_numpy(val).to(dev), F, F)
+            out[("gcn", F, name)]["ours_rows_us"] = ours(lambda: agg.run(dx, dy, 512, 0))
+        dx, dy, datt = torch.from_numpy(xs[128]).to(dev), torch.empty((V, 128), device=dev), torch.from_numpy(att).to(dev)
+        gat = gnc.Aggregator_GAT(dp, di, 128, 128)
+        out[("gat", 128, name)]["ours_rows_us"] = ours(lambda: gat.run(dx, datt, dy, 128, 0))
+    for name, (p, i) in arms:                       # ---- pass 2: the reference's kernels (oracle/_ref)
+        for F, block in ((128, 512), (32, 512)):
+            o = out[("gcn", F, name)]
+            o["reference_aggr_gcn_us"] = ref.time_run("gcn", p, i, val, xs[F], block, False)
+            o["reference_neighbor_grouping16_us"] = ref.time_run("gcn", p, i, val, xs[F], block, True, 16)
+            o["reference_neighbor_grouping32_us"] = ref.time_run("gcn", p, i, val, xs[F], block, True, 32)
+        o = out[("gat", 128, name)]
+        o["reference_aggr_gat_us"] = ref.time_run("gat", p, i, att, xs[128], 128, False)
+        o["reference_neighbor_grouping32_us"] = ref.time_run("gat", p, i, att, xs[128], 128, True, 32)
+    # ---- and once more this library's balanced launch, now that the process holds the reference's libraries and forked streams
+    dp, di = torch.from_numpy(rptr).to(dev), torch.from_numpy(ridx).to(dev)
+    dx, dy = torch.from_numpy(xs[128]).to(dev), torch.empty((V, 128), device=dev)
+    agg = gnc.Aggregator_GCN(dp, di, torch.from_numpy(val).to(dev), 128, 128)
+    out[("gcn", 128, "locality reorder on load")]["ours_balanced_us_after_the_reference_ran_in_this_process"] = ours(lambda: agg.run(dx, dy, 512, "balanced"))
+    for o in out.values():
+        print(json.dumps(o), flush=True)
 
 
 def big():

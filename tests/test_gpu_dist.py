@@ -162,7 +162,7 @@ def _worker_late_peer(rank, world, port, q, stages, delay_us, late_ranks, graph)
         from gnn_computing_amd.dist import PartitionedGAT, PartitionedGCN
         from oracle import oracle as orc
         torch.cuda.set_device(0)
-        V, E, F, H, FG = 6000, 150000, 128, 8, 256
+        V, E, F, H, FG = 5000, 100000, 128, 4, 64    # (sizes: the float64 error scale of the GAT check is the test's host cost)
         ptr_t, idx_t = gnc.graph.powerlaw_csr(V, E, seed=11)
         ptr, idx = ptr_t.numpy(), idx_t.numpy()
         rng = np.random.default_rng(17)          # the same stream on every rank: the ranks agree on every step's global input
