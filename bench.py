@@ -71,8 +71,9 @@ def pmc_traffic(tag):
             if d:
                 label = d.get("_label", "")
                 build = d.get("build") or (label.split("build ")[1].split(";")[0].strip() if "build " in label else None)
+                # (the file's own `_label` says how the counters were collected and corrected; the line only names the file and the build)
                 return (d.get("hbm_bytes_per_launch"), d.get("all_kernels_bytes_per_step"),
-                        "profiles/%s/pmc_traffic.json: %s" % (rnd, label), build != lib_md5())
+                        "profiles/%s/pmc_traffic.json [%s], build %s" % (rnd, tag, build), build != lib_md5())
     return None, None, None, None
 
 
