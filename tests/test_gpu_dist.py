@@ -1,7 +1,8 @@
-"""GPU, 2 processes sharing cuda:0, gloo transport: the complete row-partitioned step (plan exchange, HIP pack kernel,
-asynchronous all-to-all, local-source aggregation overlapped with it, halo-source aggregation with the accumulate
-flag) end to end.  RCCL needs one GPU per rank, so on the single-GPU test box the collective itself runs over gloo
-(which moves CUDA tensors through the host); everything else is the production path."""
+"""GPU, 2 - 4 processes sharing cuda:0: the complete row-partitioned step (plan exchange, HIP pack kernel, asynchronous all-to-all,
+local-source aggregation overlapped with it, halo-source aggregation with the accumulate flag) end to end.  RCCL needs one GPU per rank, so
+on the single-GPU test box the collective itself runs over gloo (which moves CUDA tensors through the host) for the torch transport, and over
+tests/fake_rccl -- a stream-ordered, asynchronous double of the eight nccl* entry points the library binds -- for the C-ABI step; everything
+else is the production path."""
 import os
 import socket
 
@@ -119,8 +120,8 @@ def test_cabi_step_with_several_peers_on_one_gpu(world, stages):
     """The ONE-CALL step of the C-ABI (gnnagg_dist_step_gcn / _gat: pack kernel, per stage a grouped ncclSend / ncclRecv to every
     peer of the stage, events, local-source pass beside the exchange, halo-source pass per stage) with 2, 3 and 4 ranks.  RCCL
     needs a GPU per rank and the box has one, so the eight nccl entry points the library binds are served by a test double
-    (tests/fake_rccl: ranks are processes sharing cuda:0, a message is a mailbox file in /dev/shm; matched per pair in posting
-    order, sizes checked on both ends).  Everything on the library's side of ncclSend / ncclRecv is the production code: the
+    (tests/fake_rccl: ranks are processes sharing cuda:0, a message is a stream-ordered device-to-device copy through an IPC-shared
+    staging arena, ordered between the processes by counters in device memory; matched per pair in posting order, sizes checked on both ends).  Everything on the library's side of ncclSend / ncclRecv is the production code: the
     offsets of several peers inside a stage, the stage-major buffers, owner and stripe plans, GCN sum / mean / max and the GAT
     numerator / denominator passes -- all against the oracle on the global graph."""
     if not os.path.exists(FAKE_RCCL):
