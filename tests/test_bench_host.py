@@ -52,6 +52,25 @@ def test_agreement_is_per_node():
     assert bench.agree_on_outcome(0, 1, 99, 0, timeout_s=5.0, need_port=False) == (0, None)
 
 
+def test_a_job_that_spans_nodes_does_not_wait_for_files_it_cannot_see():
+    """with WORLD_SIZE = 4 and LOCAL_WORLD_SIZE = 2 the old agreement waited 420 s for rank files of the other node and then
+    failed a successful run.  Now a supervisor of a multi-node job runs the first transport only and reports its own child at once.  (The
+    child here has no GPU and exits 1: what matters is that the supervisor returns that code within seconds, without a fallback.)"""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU: the rank child must fail fast")
+    code = ("import os, sys, time; sys.path.insert(0, %r); import bench, argparse; "
+            "sys.argv = ['bench.py', '--gpus', '4', '--steps', '1', '--warmup', '0', '--no-cpu']; "
+            "t0 = time.time(); rc = bench.supervise_rank(argparse.Namespace(gpus=4), os.dup(1)); print('RC', rc, round(time.time() - t0, 1))" % ROOT)
+    env = dict(os.environ, WORLD_SIZE="4", LOCAL_WORLD_SIZE="2", RANK="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RC ")]
+    assert line and line[0].split()[1] != "0" and time.time() - t0 < 120, (r.stdout[-500:], r.stderr[-800:])
+
+
 def test_summary_is_compact_and_complete():
     """the last key of the line, <= 1 KB, every record's numbers"""
     sys.path.insert(0, ROOT)
