@@ -84,6 +84,8 @@ class Aggregator:
             pass
 
     def _use_current_stream(self):
+        """work of the following call is enqueued on torch's current stream; host-synchronous reads of the caller's arrays (plan
+        construction) are ordered behind it too (gnnagg.h: copy_to_host)"""
         check(lib().gnnagg_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def set_option(self, name, value):
@@ -93,6 +95,7 @@ class Aggregator:
     # -- aggregator.h:67-99
     def schedule(self, s, param, total_num_v=None):
         arr = (ctypes.c_int * 2)(*(list(param) + [0])[:2])
+        self._use_current_stream()   # (plan construction reads the CSR: ordered behind the stream that may still be writing it)
         check(lib().gnnagg_schedule(self._h, int(s), arr, self.num_v if total_num_v is None else int(total_num_v)))
 
     def plan_info(self):
@@ -102,6 +105,7 @@ class Aggregator:
         return {"plan_s": a.value, "rows_plan_s": b.value, "plan_bytes": pb.value, "scratch_bytes": sb.value}
 
     def schedule_balanced(self, chunk=0):
+        self._use_current_stream()
         check(lib().gnnagg_schedule_balanced(self._h, int(chunk)))
 
     def balanced_params(self):

@@ -37,11 +37,19 @@ Ctx *lookup(gnnagg_handle h)
     return g_live.count(c) ? c : nullptr;
 }
 
+int copy_to_host(Ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return GNNAGG_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GNNAGG_OK;
+}
+
 int fetch_host_ptr(Ctx *c)
 {
     if (!c->h_ptr.empty()) return GNNAGG_OK;
     c->h_ptr.resize((size_t)c->V + 1);
-    HIP_TRY(hipMemcpy(c->h_ptr.data(), c->d_ptr, ((size_t)c->V + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (int rc_ = copy_to_host(c, c->h_ptr.data(), c->d_ptr, ((size_t)c->V + 1) * sizeof(int))) { c->h_ptr.clear(); return rc_; }
     if (c->h_ptr[0] != 0 || c->h_ptr[c->V] != c->E) {
         c->h_ptr.clear();
         return fail(GNNAGG_ERR_ARG, "CSR ptr[0] != 0 or ptr[num_v] != num_e");
@@ -136,10 +144,10 @@ static int build_locality(Ctx *c, Schedule &s, int par_num, int ng, int total_v,
     if (rc) return rc;
     std::vector<int> h_idx((size_t)c->E);
     std::vector<float> h_val;
-    if (c->E > 0) HIP_TRY(hipMemcpy(h_idx.data(), c->d_idx, (size_t)c->E * sizeof(int), hipMemcpyDeviceToHost));
+    if (int rc_ = copy_to_host(c, h_idx.data(), c->d_idx, (size_t)c->E * sizeof(int))) return rc_;
     if (c->d_val && c->E > 0) {
         h_val.resize((size_t)c->E);
-        HIP_TRY(hipMemcpy(h_val.data(), c->d_val, (size_t)c->E * sizeof(float), hipMemcpyDeviceToHost));
+        if (int rc_ = copy_to_host(c, h_val.data(), c->d_val, (size_t)c->E * sizeof(float))) return rc_;
     }
     if (total_v < 0) {  // library-chosen partitioning: the ranges must cover every column that occurs (the CSR need not be
                         // square: a rank's local graph indexes [X_local ; X_halo])
@@ -728,7 +736,7 @@ static int build_rows_blocked_host(Ctx *c, int ntiles_hint)
     int rc;
     {   // neighbors ascending in every row?
         std::vector<int> h_idx((size_t)c->E);
-        HIP_TRY(hipMemcpy(h_idx.data(), c->d_idx, (size_t)c->E * sizeof(int), hipMemcpyDeviceToHost));
+        if (int rc_ = copy_to_host(c, h_idx.data(), c->d_idx, (size_t)c->E * sizeof(int))) return rc_;
         int unsorted = 0;
 #pragma omp parallel for schedule(static) reduction(| : unsorted)
         for (int r = 0; r < c->V; ++r)
@@ -1673,7 +1681,7 @@ int gnnagg_get_schedule(gnnagg_handle h, int mode, int *h_ptr_s, int *h_idx_s, i
     if (h_target && G > 0) memcpy(h_target, s->h_target.data(), (size_t)G * sizeof(int));
     const size_t ne = s->gpu_built ? (size_t)s->n_edges_perm : s->permuted ? s->h_idx_s.size() : (size_t)c->E;
     if (h_idx_s && ne > 0) {
-        HIP_TRY(hipMemcpy(h_idx_s, s->gpu_built ? s->idx_f.p : s->permuted ? s->idx_s.p : c->d_idx, ne * sizeof(int), hipMemcpyDeviceToHost));
+        if (int rc_ = copy_to_host(c, h_idx_s, s->gpu_built ? s->idx_f.p : s->permuted ? s->idx_s.p : c->d_idx, ne * sizeof(int))) return rc_;
         if (s->gpu_built)   // the device holds the ids with the span kernel's two flag bits
             for (size_t e = 0; e < ne; ++e) h_idx_s[e] &= 0x3fffffff;
     }
@@ -1684,7 +1692,7 @@ int gnnagg_get_schedule(gnnagg_handle h, int mode, int *h_ptr_s, int *h_idx_s, i
         }
         const float *src = s->permuted ? s->val_s.p : c->d_val;
         if (!src) return fail(GNNAGG_ERR_STATE, "aggregator has no edge values");
-        HIP_TRY(hipMemcpy(h_val_s, src, ne * sizeof(float), hipMemcpyDeviceToHost));
+        if (int rc_ = copy_to_host(c, h_val_s, src, ne * sizeof(float))) return rc_;
     }
     return GNNAGG_OK;
 }

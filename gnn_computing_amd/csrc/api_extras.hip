@@ -17,7 +17,7 @@ static int build_transposed(Ctx *c)
     if (rc) return rc;
     const int V = c->V, E = c->E;
     std::vector<int> h_idx((size_t)E);
-    if (E > 0) HIP_TRY(hipMemcpy(h_idx.data(), c->d_idx, (size_t)E * sizeof(int), hipMemcpyDeviceToHost));
+    if (int rc_ = copy_to_host(c, h_idx.data(), c->d_idx, (size_t)E * sizeof(int))) return rc_;
     std::vector<int> ptr_t((size_t)V + 1, 0), idx_t((size_t)E), perm((size_t)E);
     for (int e = 0; e < E; ++e) {
         if (h_idx[e] < 0 || h_idx[e] >= V) return fail(GNNAGG_ERR_ARG, "run_bwd: neighbor id outside [0, num_v)");

@@ -212,6 +212,10 @@ int gcn_run(Ctx *c, const float *x, float *y, int feat, int mode, int reduce, in
 int edge_launch(Ctx *c, EdgeItemLaunch &L, int heads);
 int do_schedule(Ctx *c, int kind, const int *param, int total_v);
 int fetch_host_ptr(Ctx *c);
+// Device -> host copy of a CALLER's array, ordered behind the work on the handle's stream and complete on return.  (A blocking hipMemcpy
+// runs on the null stream, which a caller's non-blocking stream is not ordered against: a CSR that stream was still writing came back
+// half-written -- round 6, the GPU suite run with a non-null stream current, GNNAGG_TEST_STREAM=side.)
+int copy_to_host(Ctx *c, void *dst, const void *src, size_t bytes);
 
 }  // namespace gnnagg
 

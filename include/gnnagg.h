@@ -93,7 +93,9 @@ int gnnagg_gcn_create(const int *d_ptr, const int *d_idx, const float *d_val, in
 int gnnagg_gat_create(const int *d_ptr, const int *d_idx, int num_v, int num_e, gnnagg_handle *out);
 /* Frees what the handle allocated (schedules, scratch).  Never frees caller pointers. */
 int gnnagg_destroy(gnnagg_handle h);
-/* hipStream_t as void*; NULL = default stream.  Work of later calls is enqueued there. */
+/* hipStream_t as void*; NULL = default stream.  Work of later calls is enqueued there, and whatever the library reads of the caller's
+ * arrays on the HOST (the CSR, when a schedule or plan is built) is copied on that stream and waited for -- i.e. ordered behind the
+ * caller's work on it.  Set it before schedule() / the first run when the arrays were produced on a non-null stream. */
 int gnnagg_set_stream(gnnagg_handle h, void *hip_stream);
 /* Per-handle knobs.  Every knob is an option; the four a C++ driver linked against the class shim cannot reach through code also
  * read an environment variable (in brackets) when the handle is made.  INTEGRATION.md section 5 is the table of all of them.

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "null_stream: the test drives an entry point that launches on the null stream by design (the flat reference API); "
+                                       "GNNAGG_TEST_STREAM=side leaves it on the null stream")
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -20,3 +22,22 @@ def _built():
     orc = os.path.join(ROOT, "oracle", "liboracle.so")
     if not (os.path.exists(so) and os.path.exists(orc)):
         ge.build()
+
+
+@pytest.fixture(autouse=True)
+def _caller_stream(request):
+    """GNNAGG_TEST_STREAM=side (second tier): every test body runs with a NON-NULL torch stream current, so that library-internal work
+    that is only ordered against the null stream -- like round 6's hipMemset of the hub-fold counters -- races where it can be seen.
+    Default: the null stream, as a reference driver uses it."""
+    if os.environ.get("GNNAGG_TEST_STREAM") != "side" or request.node.get_closest_marker("null_stream"):
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        yield
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()   # (the caching allocator keeps a pool per stream: a new stream per test must not strand the previous one's blocks)

@@ -318,6 +318,7 @@ def test_error_behaviour():
         gat.run(x, dev(rand((V, 3, 2), 2)), y, 128, 0, heads=3)  # 32 % 3 != 0
 
 
+@pytest.mark.null_stream
 def test_flat_reference_api():
     """The Section-A entry points (reference Figure7/kernel.cpp:15-35), called the way the reference's
     kernel.cpp wrappers call them: raw device pointers + sizes."""
