@@ -33,4 +33,5 @@ python3 examples/forward_3layer.py --model our_GCN --dataset arxiv > $OUT/forwar
 #    reference's kernels, the plain several-peer cases and the 8-rank spawn
 GNNAGG_LIB=$PWD/gnn_computing_amd/libgnnagg_extras.so GNNAGG_TEST_TIER=2 python3 -m pytest tests/test_gpu_blocked.py tests/test_gpu_parity.py tests/test_cabi.py -q > $OUT/second_tier_extras.txt 2>&1
 REF_FUZZ=600 GNNAGG_TEST_TIER=2 python3 -m pytest tests/test_gpu_reference.py::test_reference_fuzz tests/test_gpu_dist.py tests/test_gpu_bench_contract.py::test_failed_nccl_backend_falls_back_to_gloo_in_fresh_processes -q > $OUT/second_tier.txt 2>&1
+GNNAGG_TEST_STREAM=side python3 -m pytest tests -m gpu -q -p no:cacheprovider --deselect tests/test_gpu_bench_contract.py > $OUT/second_tier_side_stream.txt 2>&1
 ls -la $OUT
