@@ -191,8 +191,50 @@ def host_or_device():
     print(json.dumps({"state": "after the rows-mode runs: captured graph", "graph_device_us": graph_us()}), flush=True)
 
 
+def l2_between_launches():
+    """Fourth question: is what a multi-queue process loses the L2 CONTENT one launch leaves for the next?  (With several hardware queues
+    the runtime may fence every dispatch at a wider scope -- an L2 invalidate at kernel start.)  Per-launch time of the headline kernel,
+    one event pair per launch, (a) launches back to back and (b) with a kernel between them that reads 48 MB of other memory -- more than
+    the 32 MB of L2, far less than the Infinity Cache -- for the reordered graph, the original numbering and uniform-random ids."""
+    ptr_t, idx_t = gnc.graph.dataset("arxiv")
+    ptr, idx = ptr_t.numpy(), idx_t.numpy()
+    rows, _ = gnc.cluster_reorder(ptr, idx, order="cache_greedy", cluster_cap=1, cache_rows=8192)
+    rptr, ridx, _ = gnc.reorder_csr(ptr, idx, rows)
+    V, E, F = len(ptr) - 1, len(idx), 128
+    x = np.random.default_rng(123).standard_normal((V, F), dtype=np.float32)
+    uid = np.random.default_rng(7).integers(0, V, E).astype(np.int32)
+    dx, dy = torch.from_numpy(x).to(dev), torch.empty((V, F), device=dev)
+    other = torch.ones(48 << 18, device=dev)          # 48 MB
+    sink = torch.zeros(1, device=dev)
+    run_stream = torch.cuda.Stream()
+    for name, (p, i) in (("locality reorder", (rptr, ridx)), ("no reorder", (ptr, idx)), ("uniform-random ids", (ptr, uid))):
+        agg = gnc.Aggregator_GCN(torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev), torch.ones(E, device=dev), F, F)
+        agg.schedule_balanced(0)
+        out = {"input": name}
+        run_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(run_stream):
+            for label, between in (("back_to_back_us", False), ("with_48MB_read_between_us", True), ("back_to_back_again_us", False)):
+                for _ in range(10):
+                    agg.run(dx, dy, 512, "balanced")
+                ts = []
+                for _ in range(60):
+                    if between:
+                        sink += other.sum()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    agg.run(dx, dy, 512, "balanced")
+                    b.record()
+                    ts.append((a, b))
+                torch.cuda.synchronize()
+                per = sorted(a.elapsed_time(b) * 1e3 for a, b in ts)
+                out[label] = round(per[len(per) // 2], 2)
+        print(json.dumps(out), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "xcd":
+    if len(sys.argv) > 1 and sys.argv[1] == "l2":
+        l2_between_launches()
+    elif len(sys.argv) > 1 and sys.argv[1] == "xcd":
         xcd_mapping()
     elif len(sys.argv) > 1 and sys.argv[1] == "host":
         host_or_device()
